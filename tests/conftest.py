@@ -1,0 +1,46 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+class Golden:
+    def __init__(self):
+        d = os.path.join(ROOT, "tests", "golden")
+        self.npz = np.load(os.path.join(d, "world_golden.npz"))
+        with open(os.path.join(d, "world_golden.json")) as f:
+            self.meta = json.load(f)
+
+    def __getitem__(self, k):
+        return self.npz[k]
+
+    def case(self, name):
+        m = dict(self.meta["cases"][name])
+        m["x"] = self.npz[name + "/x_i16"].astype(np.float64) / 32768.0
+        for k in ("tpos", "f0", "sp_rows", "ap_rows", "sp_rowsum", "ap_rowsum", "y"):
+            m[k] = self.npz[name + "/" + k]
+        return m
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return Golden()
+
+
+@pytest.fixture(scope="session")
+def port():
+    from oracle import port as _port
+    return _port.Port()
+
+
+PIPELINE_CASES = ["c1_16k_2s_floor71", "c1_16k_2s_floor40", "m48k_1s", "m24k_1s_1ms"]

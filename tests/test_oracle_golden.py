@@ -1,0 +1,129 @@
+"""CPU tests: our restatement (oracle/wc_oracle.cpp) against the golden vectors generated from the real
+reference (oracle/gen_golden.py), and against the real reference itself when oracle/_ref is present.
+These pin the oracle that the -m gpu parity tests then use as the checker."""
+import numpy as np
+import pytest
+
+from conftest import PIPELINE_CASES
+from world_class_amd.synth import make_utterance
+
+# tolerances of the restatement vs the reference (FP64; only the FFT rounding differs)
+F0_ABS, SP_REL, AP_ABS, Y_ABS = 1e-9, 1e-9, 1e-10, 1e-9
+
+
+def test_synth_generator_is_pinned(golden):
+    for name in PIPELINE_CASES:
+        c = golden.case(name)
+        x = make_utterance(c["fs"], c["seconds"], c["seed"])
+        assert np.array_equal(x, c["x"])
+
+
+def test_randn_stream(golden, port):
+    port.rng_reset()
+    assert np.array_equal(port.randn(4096), golden["randn/first4096"])
+    port.rng_seek(1000)
+    assert np.array_equal(port.randn(96), golden["randn/first4096"][1000:1096])
+    assert port.rng_position() == 1096
+    port.rng_reset()
+
+
+@pytest.mark.parametrize("n", [128, 1024, 2048, 4096])
+def test_fft_conventions(golden, port, n):
+    x = golden[f"fft/r2c_in_{n}"]
+    X = golden[f"fft/r2c_out_{n}"]
+    Xc = X[:, 0] + 1j * X[:, 1]
+    got = port.fft_r2c(x)
+    assert np.abs(got - Xc).max() < 1e-11 * n
+    # reference "forward" is e^{+i}: conj of numpy's rfft
+    assert np.abs(Xc - np.conj(np.fft.rfft(x))).max() < 1e-10
+    assert np.abs(port.fft_c2r(Xc * (1 + 0.5j), n) - golden[f"fft/c2r_out_{n}"]).max() < 1e-10 * n
+
+
+def test_fft_c2c_and_minimum_phase(golden, port):
+    z = golden["fft/c2c_in_1024"]
+    z = z[:, 0] + 1j * z[:, 1]
+    for s in (1, 2):
+        Z = golden[f"fft/c2c_out_1024_sign{s}"]
+        assert np.abs(port.fft_c2c(z, s) - (Z[:, 0] + 1j * Z[:, 1])).max() < 1e-10
+    M = golden["minphase/out_1024"]
+    got = port.minimum_phase(golden["minphase/in_1024"], 1024)
+    assert np.abs(got - (M[:, 0] + 1j * M[:, 1])).max() < 1e-12
+
+
+def test_matlab_helpers(golden, port):
+    xs, ys, xi = golden["interp1/x"], golden["interp1/y"], golden["interp1/xi"]
+    assert np.array_equal(port.histc(xs, xi), golden["interp1/histc"])
+    assert np.array_equal(port.interp1(xs, ys, xi), golden["interp1/yi"])
+    assert np.array_equal(port.interp1Q(0.5, 0.25, golden["interp1Q/y"], golden["interp1Q/xi"]), golden["interp1Q/yi"])
+    for r in (2, 3, 6, 12):
+        assert np.array_equal(port.decimate(golden["decimate/x"], r), golden[f"decimate/y_r{r}"])
+    spec = golden["spec/in_1025"]
+    assert np.array_equal(port.dc_correction(spec, 200.0, 48000, 2048), golden["spec/dc_f200_48k_2048"])
+    assert np.array_equal(port.linear_smoothing(spec, 400.0 / 3.0, 48000, 2048), golden["spec/ls_w133_48k_2048"])
+    assert np.array_equal(port.nuttall(769), golden["nuttall/769"])
+    for k, v in golden.meta["matlab_round"].items():
+        assert port.matlab_round(float(k)) == v
+    for k, v in golden.meta["suitable_fft_size"].items():
+        assert port.suitable_fft_size(int(k)) == v
+    for k, v in golden.meta["cheaptrick_fft_size"].items():
+        assert port.cheaptrick_fft_size(int(k)) == v
+    for k, v in golden.meta["get_samples"].items():
+        fs, n, fp = k.split(":")
+        assert port.get_samples(int(fs), int(n), float(fp)) == v
+
+
+@pytest.mark.parametrize("name", PIPELINE_CASES)
+def test_pipeline_against_golden(golden, port, name):
+    c = golden.case(name)
+    r = port.pipeline(c["x"], c["fs"], harvest_floor=c["harvest_floor"], frame_period=c["frame_period"])
+    assert np.array_equal(r["tpos"], c["tpos"])
+    assert np.array_equal(r["f0"] == 0, c["f0"] == 0)
+    assert np.abs(r["f0"] - c["f0"]).max() < F0_ABS
+    s = c["stride"]
+    assert (np.abs(r["sp"][::s] - c["sp_rows"]) / c["sp_rows"]).max() < SP_REL
+    assert np.abs(r["ap"][::s] - c["ap_rows"]).max() < AP_ABS
+    assert (np.abs(r["sp"].sum(1) - c["sp_rowsum"]) / c["sp_rowsum"]).max() < SP_REL
+    assert np.abs(r["ap"].sum(1) - c["ap_rowsum"]).max() < AP_ABS * r["ap"].shape[1]
+    assert np.abs(r["y"] - c["y"]).max() < Y_ABS
+
+
+def test_synthesis_only_against_golden(golden, port):
+    from oracle.gen_golden import synth_params
+    m = golden.meta["synth_only"]
+    f0, sp, ap = synth_params(m["fs"], m["fft_size"], m["n_frames"], m["seed"])
+    port.rng_reset()
+    y = port.synthesis(f0, sp, ap, m["fs"], m["frame_period"])
+    assert np.abs(y - golden["synth_only/y"]).max() < Y_ABS
+
+
+def test_threaded_oracle_is_bit_identical_to_serial(golden, port):
+    c = golden.case("m48k_1s")
+    a = port.pipeline(c["x"], c["fs"])
+    port.set_threads(4)
+    try:
+        b = port.pipeline(c["x"], c["fs"])
+    finally:
+        port.set_threads(0)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_draw_count_contract(golden, port):
+    c = golden.case("c1_16k_2s_floor71")
+    port.rng_reset()
+    port.cheaptrick(c["x"], c["fs"], c["tpos"], c["f0"])
+    assert port.rng_position() == port.cheaptrick_draws(c["fs"], c["f0"])
+
+
+def test_port_against_live_reference(golden, port):
+    """When the real reference is built here (oracle/_ref), check a case that is NOT in the goldens."""
+    from oracle import ref
+    if not ref.available():
+        pytest.skip("oracle/_ref not built in this environment")
+    x = make_utterance(16000, 1.0, 1234)
+    r = ref.run_fresh("pipeline", x, 16000, harvest_floor=40.0)
+    p = port.pipeline(x, 16000, harvest_floor=40.0)
+    assert np.abs(r["f0"] - p["f0"]).max() < F0_ABS
+    assert (np.abs(r["sp"] - p["sp"]) / r["sp"]).max() < SP_REL
+    assert np.abs(r["ap"] - p["ap"]).max() < AP_ABS
+    assert np.abs(r["y"] - p["y"]).max() < Y_ABS
