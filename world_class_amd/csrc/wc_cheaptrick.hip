@@ -1,0 +1,422 @@
+// CheapTrick spectral-envelope estimation on gfx950: one workgroup per analysis frame, the whole
+// frame resident in LDS from the windowed gather to the final exp().
+//
+// Restates reference src/cheaptrick.cpp:48-276 (compute, generalBody, getWindowedWaveform,
+// getPowerSpectrum, addInfinitesimalNoise, smoothingWithRecovery) with DCCorrection and
+// LinearSmoothing of reference src/world_common.cpp:27-116.  Differences from the reference are
+// confined to summation order (block reductions / block scan instead of sequential loops), our own
+// FFT, and device libm; the noise draws come from the exact stream positions the reference's serial
+// order would use (see wc_core.hip).
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "wc_device.hpp"
+#include "wc_internal.hpp"
+
+namespace wc {
+
+struct CtArgs {
+	const double *x;
+	const UttDesc *utts;
+	int n_utt;
+	const double *tpos, *f0;
+	const unsigned long long *rng_off;  // absolute stream position of each frame's first draw
+	const uint32_t *rng_table;
+	unsigned long long rng_base;
+	const double2 *tw;
+	double *sp;
+	long long total_frames;
+	int fs;
+	double q1, f0_floor;  // f0_floor = 3 fs / (N - 3)
+};
+
+__device__ __forceinline__ double randn_at(const uint32_t *__restrict__ table, unsigned long long idx) {
+	return table[idx] / 268435456.0 - 6.0;
+}
+__device__ __forceinline__ int find_utt(const UttDesc *__restrict__ utts, int n_utt, long long frame) {
+	int lo = 0, hi = n_utt - 1;
+	while (lo < hi) {
+		int mid = (lo + hi + 1) >> 1;
+		if (utts[mid].f_off <= frame) lo = mid; else hi = mid - 1;
+	}
+	return lo;
+}
+// blockIdx -> frame so that each XCD (block b runs on XCD b % 8) walks one contiguous range of
+// frames: neighbouring frames share almost all of their input samples, which then stay in that
+// XCD's L2.
+__device__ __forceinline__ long long xcd_frame(long long b, long long total) {
+	long long per = (total + 7) / 8;
+	return (b & 7) * per + (b >> 3);
+}
+
+// per-frame number of draws: window (2 hw + 1) then one per bin (reference :153, :227)
+__global__ void ct_count_kernel(const double *__restrict__ f0, long long total, int fs, double f0_floor,
+								int bins, uint32_t *__restrict__ cnt) {
+	long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= total) return;
+	double f = f0[g];
+	double f0c = (f <= f0_floor) ? 500.0 : f;
+	cnt[g] = (uint32_t)(2 * mround(1.5 * fs / f0c) + 1 + bins);
+}
+
+// one block per utterance: off[frame] = utt.rng_pos + exclusive prefix of cnt; total[u] = end position
+__global__ void utt_scan_kernel(const uint32_t *__restrict__ cnt, const UttDesc *__restrict__ utts,
+								unsigned long long *__restrict__ off, unsigned long long *__restrict__ end_pos) {
+	__shared__ unsigned long long s[256];
+	const UttDesc u = utts[blockIdx.x];
+	unsigned long long carry = u.rng_pos;
+	int tid = threadIdx.x;
+	for (int base = 0; base < u.f_len; base += 256) {
+		int i = base + tid;
+		unsigned long long v = (i < u.f_len) ? cnt[u.f_off + i] : 0ull;
+		s[tid] = v;
+		__syncthreads();
+		for (int o = 1; o < 256; o <<= 1) {
+			unsigned long long t = (tid >= o) ? s[tid - o] : 0ull;
+			__syncthreads();
+			s[tid] += t;
+			__syncthreads();
+		}
+		if (i < u.f_len) off[u.f_off + i] = carry + s[tid] - v;
+		carry += s[255];
+		__syncthreads();
+	}
+	if (tid == 0) end_pos[blockIdx.x] = carry;
+}
+
+template <int N, int T>
+__global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
+	constexpr int M = N / 2;
+	constexpr int EPT = (N + T - 1) / T;       // window elements per thread
+	constexpr int BPT = (M + 1 + T - 1) / T;   // bins per thread
+	__shared__ double2 A[M];
+	__shared__ double P[M + 2];
+	__shared__ double red[2 * (T / 64) + 2];
+	double *Ar = reinterpret_cast<double *>(A);
+
+	const int tid = threadIdx.x;
+	long long g = xcd_frame(blockIdx.x, a.total_frames);
+	if (g >= a.total_frames) return;
+	const int u = find_utt(a.utts, a.n_utt, g);
+	const UttDesc ud = a.utts[u];
+	const double *__restrict__ x = a.x + ud.x_off;
+	const int fs = a.fs;
+	const double f0v = a.f0[g];
+	const double f0c = (f0v <= a.f0_floor) ? 500.0 : f0v;  // reference :77
+	const double pos = a.tpos[g];
+	const unsigned long long roff = a.rng_off[g] - a.rng_base;
+
+	// ---- F0-adaptive window (reference :137-196) ----
+	const int hw = mround(1.5 * fs / f0c);
+	const int wl = 2 * hw + 1;
+	const int origin = mround(pos * fs + 0.001);
+	double w[EPT];
+	double ssq = 0.0;
+#pragma unroll
+	for (int e = 0; e < EPT; ++e) {
+		int i = tid + e * T;
+		w[e] = 0.0;
+		if (i < wl) {
+			double position = (i - hw) / 1.5 / fs;
+			w[e] = 0.5 * cos(kPi * position * f0c) + 0.5;
+			ssq += w[e] * w[e];
+		}
+	}
+	ssq = block_sum<T>(ssq, red, tid);
+	const double norm = sqrt(ssq);
+	double s1 = 0.0, s2 = 0.0;
+	double wv[EPT];
+#pragma unroll
+	for (int e = 0; e < EPT; ++e) {
+		int i = tid + e * T;
+		wv[e] = 0.0;
+		if (i < wl) {
+			w[e] = w[e] / norm;
+			int si = clampi(origin + i - hw, 0, ud.x_len - 1);
+			wv[e] = x[si] * w[e] + randn_at(a.rng_table, roff + i) * 0.000000000000001;
+			s1 += wv[e];
+			s2 += w[e];
+		}
+	}
+	block_sum2<T>(s1, s2, red, tid);
+	const double wc = s1 / s2;
+#pragma unroll
+	for (int e = 0; e < EPT; ++e) {
+		int i = tid + e * T;
+		if (i < N) Ar[i] = (i < wl) ? wv[e] - w[e] * wc : 0.0;
+	}
+	__syncthreads();
+
+	// ---- power spectrum (reference :198-218) ----
+	fft_lds<M, T, +1>(A, a.tw, tid);
+	r2c_post<M, T>(A, a.tw, tid);
+	for (int k = tid; k <= M; k += T) {
+		double2 v = A[k == M ? 0 : k];
+		double p;
+		if (k == 0) p = v.x * v.x;
+		else if (k == M) p = v.y * v.y;
+		else p = v.x * v.x + v.y * v.y;
+		P[k] = p;
+	}
+	__syncthreads();
+	// DC correction (reference src/world_common.cpp:61-80)
+	{
+		const int upper = 2 + (int)(f0c * N / fs);
+		const double dx = -(double)fs / N;
+		double rep[2];
+#pragma unroll
+		for (int e = 0; e < 2; ++e) {
+			int i = tid + e * T;
+			rep[e] = 0.0;
+			if (i < upper - 1 && i <= M) {
+				double axis = (double)i * fs / N;
+				rep[e] = interp1q(f0c, dx, [&](int b) { return P[min(max(b, 0), M)]; }, upper + 1, axis);
+			}
+		}
+		__syncthreads();
+#pragma unroll
+		for (int e = 0; e < 2; ++e) {
+			int i = tid + e * T;
+			if (i < upper - 1 && i <= M) P[i] += rep[e];
+		}
+		__syncthreads();
+	}
+
+	// ---- linear smoothing, width 2 f0 / 3 (reference src/world_common.cpp:27-52, :82-116) ----
+	double lp[BPT];
+	{
+		const double width = f0c * 2.0 / 3.0;
+		int b = (int)(width * N / fs) + 1;
+		if (M + 2 * b + 1 > N) b = (N - M - 1) / 2;  // cannot happen for f0 < 3 fs / 8
+		const int len = M + 2 * b + 1;
+		auto mir = [&](int i) -> double {
+			if (i < b) return P[b - i];
+			if (i < M + b) return P[i - b];
+			return P[M - (i - (M + b))];
+		};
+		const int ch = (len + T - 1) / T;
+		const int lo = tid * ch, hi = min(len, lo + ch);
+		double loc = 0.0;
+		for (int i = lo; i < hi; ++i) loc += mir(i) * fs / N;
+		double base = block_excl_scan<T>(loc, red, tid);
+		// Ar is free (the spectrum has been consumed): it now holds the cumulative segment
+		__syncthreads();
+		double run = base;
+		for (int i = lo; i < hi; ++i) {
+			run = mir(i) * fs / N + run;
+			Ar[i] = run;
+		}
+		__syncthreads();
+		const double origin_axis = -(b - 0.5) * fs / N;
+		const double step = (double)fs / N;
+		auto seg = [&](int i) -> double { return Ar[min(max(i, 0), len - 1)]; };
+#pragma unroll
+		for (int e = 0; e < BPT; ++e) {
+			int k = tid + e * T;
+			lp[e] = 0.0;
+			if (k <= M) {
+				double lo_axis = (double)k / N * fs - width / 2.0;
+				double hi_axis = lo_axis + width;
+				double lo_v = interp1q(origin_axis, step, seg, len, lo_axis);
+				double hi_v = interp1q(origin_axis, step, seg, len, hi_axis);
+				double sm = (hi_v - lo_v) / width;
+				// infinitesimal noise (reference :220-228) then log (reference :251-252)
+				sm += fabs(randn_at(a.rng_table, roff + wl + k)) * 0.00000000000000022204460492503131;
+				lp[e] = log(sm);
+			}
+		}
+		__syncthreads();  // all reads of the segment are done; Ar becomes the mirrored log spectrum
+	}
+#pragma unroll
+	for (int e = 0; e < BPT; ++e) {
+		int k = tid + e * T;
+		if (k <= M) {
+			Ar[k] = lp[e];
+			if (k > 0 && k < M) Ar[N - k] = lp[e];
+		}
+	}
+	__syncthreads();
+
+	// ---- smoothing + recovery lifters in the cepstral domain (reference :230-276) ----
+	fft_lds<M, T, +1>(A, a.tw, tid);
+	r2c_post<M, T>(A, a.tw, tid);
+	{
+		const double q1 = a.q1;
+		for (int k = tid; k <= M; k += T) {
+			double sl, cl;
+			if (k == 0) {
+				sl = 1.0;
+				cl = (1.0 - 2.0 * q1) + 2.0 * q1;
+			} else {
+				double q = (double)k / fs;
+				sl = sin(kPi * f0c * q) / (kPi * f0c * q);
+				cl = (1.0 - 2.0 * q1) + 2.0 * q1 * cos(2.0 * kPi * q * f0c);
+			}
+			if (k == M) {
+				P[M] = A[0].y * sl * cl / N;  // parked until every thread has read its own bin
+			} else {
+				double re = (k == 0) ? A[0].x : A[k].x;
+				P[k] = re * sl * cl / N;
+			}
+		}
+		__syncthreads();
+		for (int k = tid; k < M; k += T) A[k] = make_double2(P[k], k == 0 ? P[M] : 0.0);
+		__syncthreads();
+	}
+	c2r_pre<M, T>(A, a.tw, tid);
+	fft_lds<M, T, -1>(A, a.tw, tid);
+	double *__restrict__ out = a.sp + g * (long long)(M + 1);
+	for (int k = tid; k <= M; k += T) out[k] = exp(Ar[k]);
+}
+
+}  // namespace wc
+
+using namespace wc;
+
+struct wc_cheaptrick {
+	int fs, fft_size;
+	double q1, f0_floor_opt, f0_floor;
+	Device *dev;
+	DevBuf utts, cnt, off, endpos, d_x, d_tpos, d_f0, d_sp;
+	HostBuf h_stage;
+};
+
+template <int N>
+static void launch_ct(const CtArgs &a, hipStream_t s) {
+	long long blocks = ((a.total_frames + 7) / 8) * 8;
+	hipLaunchKernelGGL((ct_frames_kernel<N, 256>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+}
+
+static int ct_run_device(wc_cheaptrick *c, int n_utt, const double *d_x, const int *x_length, const double *d_tpos,
+						 const double *d_f0, const int *f0_length, double *d_sp, uint64_t *rng_pos) {
+	Device *dev = c->dev;
+	hipStream_t s = dev->stream;
+	const int bins = c->fft_size / 2 + 1;
+	std::vector<UttDesc> utts(n_utt);
+	long long xo = 0, fo = 0;
+	uint64_t min_pos = ~0ull, max_end = 0;
+	const uint64_t per_frame_max = (uint64_t)(2 * (c->fft_size / 2) + 1 + bins);
+	for (int u = 0; u < n_utt; ++u) {
+		if (x_length[u] <= 0 || f0_length[u] < 0) return fail(WC_ERR_INVALID, "cheaptrick: non-positive length");
+		UttDesc &d = utts[u];
+		d.x_off = xo; d.f_off = fo; d.y_off = 0;
+		d.x_len = x_length[u]; d.f_len = f0_length[u]; d.y_len = 0; d.pad = 0;
+		d.rng_pos = rng_pos ? rng_pos[u] : 0ull;
+		xo += x_length[u];
+		fo += f0_length[u];
+		if (d.rng_pos < min_pos) min_pos = d.rng_pos;
+		uint64_t e = d.rng_pos + per_frame_max * (uint64_t)d.f_len;
+		if (e > max_end) max_end = e;
+	}
+	const long long total = fo;
+	if (total == 0) return WC_OK;
+	int rc;
+	if ((rc = dev->ensure_rng(min_pos, max_end))) return rc;
+	if ((rc = c->utts.reserve(sizeof(UttDesc) * n_utt))) return rc;
+	if ((rc = c->cnt.reserve(sizeof(uint32_t) * total))) return rc;
+	if ((rc = c->off.reserve(sizeof(uint64_t) * total))) return rc;
+	if ((rc = c->endpos.reserve(sizeof(uint64_t) * n_utt))) return rc;
+	if ((rc = c->h_stage.reserve(sizeof(UttDesc) * n_utt + sizeof(uint64_t) * n_utt))) return rc;
+	std::memcpy(c->h_stage.p, utts.data(), sizeof(UttDesc) * n_utt);
+	WC_HIP(hipMemcpyAsync(c->utts.p, c->h_stage.p, sizeof(UttDesc) * n_utt, hipMemcpyHostToDevice, s));
+	hipLaunchKernelGGL(ct_count_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_f0, total, c->fs,
+					   c->f0_floor, bins, c->cnt.as<uint32_t>());
+	hipLaunchKernelGGL(utt_scan_kernel, dim3(n_utt), dim3(256), 0, s, c->cnt.as<uint32_t>(), c->utts.as<UttDesc>(),
+					   c->off.as<unsigned long long>(), c->endpos.as<unsigned long long>());
+	CtArgs a;
+	a.x = d_x; a.utts = c->utts.as<UttDesc>(); a.n_utt = n_utt; a.tpos = d_tpos; a.f0 = d_f0;
+	a.rng_off = c->off.as<unsigned long long>(); a.rng_table = dev->rng_table.as<uint32_t>();
+	a.rng_base = dev->rng_base; a.tw = dev->twiddle; a.sp = d_sp; a.total_frames = total; a.fs = c->fs;
+	a.q1 = c->q1; a.f0_floor = c->f0_floor;
+	if ((rc = dev->time_begin("cheaptrick_frames"))) return rc;
+	switch (c->fft_size) {
+		case 512: launch_ct<512>(a, s); break;
+		case 1024: launch_ct<1024>(a, s); break;
+		case 2048: launch_ct<2048>(a, s); break;
+		case 4096: launch_ct<4096>(a, s); break;
+		default: return fail(WC_ERR_UNSUPPORTED, "cheaptrick: fft_size must be 512, 1024, 2048 or 4096");
+	}
+	WC_HIP(hipGetLastError());
+	if ((rc = dev->time_end("cheaptrick_frames"))) return rc;
+	if (rng_pos) {
+		uint64_t *h_end = reinterpret_cast<uint64_t *>(static_cast<char *>(c->h_stage.p) + sizeof(UttDesc) * n_utt);
+		WC_HIP(hipMemcpyAsync(h_end, c->endpos.p, sizeof(uint64_t) * n_utt, hipMemcpyDeviceToHost, s));
+		WC_HIP(hipStreamSynchronize(s));
+		for (int u = 0; u < n_utt; ++u) rng_pos[u] = h_end[u];
+	}
+	return WC_OK;
+}
+
+extern "C" {
+
+wc_cheaptrick *wc_cheaptrick_create(int fs, double q1, double f0_floor, int fft_size) {
+	if (fs <= 0 || f0_floor <= 0) {
+		set_error("cheaptrick: fs and f0_floor must be positive");
+		return nullptr;
+	}
+	Device *dev = current_device();
+	if (!dev) return nullptr;
+	wc_cheaptrick *c = new wc_cheaptrick();
+	c->fs = fs;
+	c->q1 = q1;
+	c->f0_floor_opt = f0_floor;
+	c->fft_size = fft_size ? fft_size : wc_cheaptrick_fft_size(fs, f0_floor);  // reference :36-41
+	c->f0_floor = wc_cheaptrick_f0_floor(fs, c->fft_size);                      // reference :44
+	c->dev = dev;
+	if (c->fft_size != 512 && c->fft_size != 1024 && c->fft_size != 2048 && c->fft_size != 4096) {
+		set_error("cheaptrick: fft_size must be 512, 1024, 2048 or 4096 (fs between 8 kHz and 96 kHz)");
+		delete c;
+		return nullptr;
+	}
+	return c;
+}
+void wc_cheaptrick_destroy(wc_cheaptrick *c) {
+	if (!c) return;
+	(void)hipStreamSynchronize(c->dev->stream);
+	c->utts.release(); c->cnt.release(); c->off.release(); c->endpos.release();
+	c->d_x.release(); c->d_tpos.release(); c->d_f0.release(); c->d_sp.release();
+	c->h_stage.release();
+	delete c;
+}
+int wc_cheaptrick_get_fft_size(const wc_cheaptrick *c) { return c ? c->fft_size : WC_ERR_INVALID; }
+
+int wc_cheaptrick_compute_device(wc_cheaptrick *c, int n_utt, const double *d_x, const int *x_length,
+								 const double *d_tpos, const double *d_f0, const int *f0_length, double *d_sp,
+								 uint64_t *rng_pos) {
+	if (!c || n_utt <= 0 || !d_x || !x_length || !d_tpos || !d_f0 || !f0_length || !d_sp)
+		return fail(WC_ERR_INVALID, "cheaptrick: null argument");
+	WC_HIP(hipSetDevice(c->dev->id));
+	return ct_run_device(c, n_utt, d_x, x_length, d_tpos, d_f0, f0_length, d_sp, rng_pos);
+}
+
+// host-pointer, single utterance, reference argument meaning (rows of `spectrogram` need not be contiguous)
+int wc_cheaptrick_compute(wc_cheaptrick *c, const double *x, int x_length, const double *temporal_positions,
+						  const double *f0, int f0_length, double **spectrogram) {
+	if (!c || !x || !temporal_positions || !f0 || !spectrogram) return fail(WC_ERR_INVALID, "cheaptrick: null argument");
+	if (x_length <= 0 || f0_length < 0) return fail(WC_ERR_INVALID, "cheaptrick: bad length");
+	if (f0_length == 0) return WC_OK;
+	WC_HIP(hipSetDevice(c->dev->id));
+	hipStream_t s = c->dev->stream;
+	const int bins = c->fft_size / 2 + 1;
+	int rc;
+	if ((rc = c->d_x.reserve(sizeof(double) * x_length))) return rc;
+	if ((rc = c->d_tpos.reserve(sizeof(double) * f0_length))) return rc;
+	if ((rc = c->d_f0.reserve(sizeof(double) * f0_length))) return rc;
+	if ((rc = c->d_sp.reserve(sizeof(double) * (size_t)f0_length * bins))) return rc;
+	WC_HIP(hipMemcpyAsync(c->d_x.p, x, sizeof(double) * x_length, hipMemcpyHostToDevice, s));
+	WC_HIP(hipMemcpyAsync(c->d_tpos.p, temporal_positions, sizeof(double) * f0_length, hipMemcpyHostToDevice, s));
+	WC_HIP(hipMemcpyAsync(c->d_f0.p, f0, sizeof(double) * f0_length, hipMemcpyHostToDevice, s));
+	uint64_t pos = global_rng_position();
+	rc = ct_run_device(c, 1, c->d_x.as<double>(), &x_length, c->d_tpos.as<double>(), c->d_f0.as<double>(), &f0_length,
+					   c->d_sp.as<double>(), &pos);
+	if (rc) return rc;
+	global_rng_position() = pos;
+	std::vector<double> host((size_t)f0_length * bins);
+	WC_HIP(hipMemcpyAsync(host.data(), c->d_sp.p, sizeof(double) * host.size(), hipMemcpyDeviceToHost, s));
+	WC_HIP(hipStreamSynchronize(s));
+	for (int i = 0; i < f0_length; ++i) std::memcpy(spectrogram[i], &host[(size_t)i * bins], sizeof(double) * bins);
+	return WC_OK;
+}
+
+}  // extern "C"

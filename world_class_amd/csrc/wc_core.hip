@@ -1,0 +1,350 @@
+// Library-wide plumbing of the C-ABI: error state, per-device state (stream, twiddle table, RNG draw
+// table), device buffers, size helpers.  No signal-path arithmetic lives here except the RNG table.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+
+#include "wc_device.hpp"
+#include "wc_internal.hpp"
+
+namespace wc {
+
+static thread_local std::string g_error;
+void set_error(const std::string &msg) { g_error = msg; }
+int fail(int code, const std::string &msg) {
+	g_error = msg;
+	return code;
+}
+
+int DevBuf::reserve(size_t bytes) {
+	if (bytes <= cap) return WC_OK;
+	if (p) (void)hipFree(p);
+	p = nullptr;
+	cap = 0;
+	size_t want = bytes + bytes / 4 + 256;
+	WC_HIP(hipMalloc(&p, want));
+	cap = want;
+	return WC_OK;
+}
+void DevBuf::release() {
+	if (p) (void)hipFree(p);
+	p = nullptr;
+	cap = 0;
+}
+int HostBuf::reserve(size_t bytes) {
+	if (bytes <= cap) return WC_OK;
+	if (p) (void)hipHostFree(p);
+	p = nullptr;
+	cap = 0;
+	size_t want = bytes + bytes / 4 + 256;
+	WC_HIP(hipHostMalloc(&p, want, hipHostMallocDefault));
+	cap = want;
+	return WC_OK;
+}
+void HostBuf::release() {
+	if (p) (void)hipHostFree(p);
+	p = nullptr;
+	cap = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RNG: xorshift128 with the reference's draw structure (reference
+// src/world_matlabfunctions.cpp:243-264): per draw one shift-only step (w not updated), then 12
+// full steps; the draw is the sum of (w >> 4) over the 12 steps.  The state transition of one draw
+// is linear over GF(2), so stream position p is reachable by multiplying the seed state with the
+// binary matrix T^p (host side, below); the device then fills the table in independent chunks.
+// ------------------------------------------------------------------------------------------------
+struct XorShift {
+	uint32_t x, y, z, w;
+	__host__ __device__ uint32_t draw() {
+		uint32_t t = x ^ (x << 11);
+		x = y; y = z; z = w;
+		uint32_t acc = 0;
+#pragma unroll
+		for (int i = 0; i < 12; ++i) {
+			t = x ^ (x << 11);
+			x = y; y = z; z = w;
+			w = (w ^ (w >> 19)) ^ (t ^ (t >> 8));
+			acc += w >> 4;
+		}
+		return acc;
+	}
+};
+
+struct BitMat { uint32_t col[128][4]; };
+static void matvec(const BitMat &m, const uint32_t s[4], uint32_t o[4]) {
+	o[0] = o[1] = o[2] = o[3] = 0;
+	for (int j = 0; j < 128; ++j)
+		if ((s[j >> 5] >> (j & 31)) & 1u)
+			for (int k = 0; k < 4; ++k) o[k] ^= m.col[j][k];
+}
+static std::vector<BitMat> build_jump() {
+	std::vector<BitMat> tab(64);
+	for (int j = 0; j < 128; ++j) {
+		uint32_t s[4] = {0, 0, 0, 0};
+		s[j >> 5] = 1u << (j & 31);
+		XorShift r{s[0], s[1], s[2], s[3]};
+		r.draw();
+		tab[0].col[j][0] = r.x; tab[0].col[j][1] = r.y; tab[0].col[j][2] = r.z; tab[0].col[j][3] = r.w;
+	}
+	for (int k = 1; k < 64; ++k)
+		for (int j = 0; j < 128; ++j) matvec(tab[k - 1], tab[k - 1].col[j], tab[k].col[j]);
+	return tab;
+}
+static const std::vector<BitMat> &jump() {
+	static const std::vector<BitMat> tab = build_jump();
+	return tab;
+}
+void rng_state_at(uint64_t position, uint32_t s[4]) {
+	s[0] = 123456789u; s[1] = 362436069u; s[2] = 521288629u; s[3] = 88675123u;
+	const std::vector<BitMat> &tab = jump();
+	uint32_t o[4];
+	for (int k = 0; k < 64; ++k)
+		if ((position >> k) & 1ull) { matvec(tab[k], s, o); std::memcpy(s, o, sizeof(o)); }
+}
+
+constexpr int kRngChunk = 256;  // draws per device thread
+__global__ void rng_fill_kernel(const uint4 *__restrict__ seeds, uint32_t *__restrict__ table, int n_chunks) {
+	int c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= n_chunks) return;
+	uint4 s = seeds[c];
+	XorShift r{s.x, s.y, s.z, s.w};
+	uint4 *out = reinterpret_cast<uint4 *>(table + (size_t)c * kRngChunk);
+	for (int i = 0; i < kRngChunk / 4; ++i) {
+		uint4 v;
+		v.x = r.draw(); v.y = r.draw(); v.z = r.draw(); v.w = r.draw();
+		out[i] = v;
+	}
+}
+
+int launch_rng_fill(Device *dev, uint32_t *table, uint64_t first, uint64_t count) {
+	// first and count are multiples of kRngChunk
+	int n_chunks = (int)(count / kRngChunk);
+	if (n_chunks == 0) return WC_OK;
+	std::vector<uint32_t> seeds((size_t)n_chunks * 4);
+	uint32_t s[4], o[4];
+	rng_state_at(first, s);
+	const BitMat &step = jump()[8];  // T^256
+	for (int c = 0; c < n_chunks; ++c) {
+		std::memcpy(&seeds[(size_t)c * 4], s, sizeof(s));
+		matvec(step, s, o);
+		std::memcpy(s, o, sizeof(o));
+	}
+	uint4 *d_seeds = nullptr;
+	WC_HIP(hipMalloc(&d_seeds, seeds.size() * sizeof(uint32_t)));
+	hipError_t e = hipMemcpyAsync(d_seeds, seeds.data(), seeds.size() * sizeof(uint32_t), hipMemcpyHostToDevice, dev->stream);
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(rng_fill_kernel, dim3((n_chunks + 255) / 256), dim3(256), 0, dev->stream, d_seeds, table, n_chunks);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);  // seeds vector must outlive the copy
+	(void)hipFree(d_seeds);
+	if (e != hipSuccess) return fail(WC_ERR_DEVICE, std::string("rng_fill: ") + hipGetErrorString(e));
+	return WC_OK;
+}
+
+int Device::ensure_rng(uint64_t first, uint64_t last) {
+	if (last <= first) return WC_OK;
+	if (rng_count > 0 && first >= rng_base && last <= rng_base + rng_count) return WC_OK;
+	uint64_t nb = (first / kRngChunk) * kRngChunk;
+	// keep what a typical reference process would also have consumed before `first`
+	if (rng_count > 0 && nb >= rng_base && nb - rng_base < (1ull << 26)) nb = rng_base;
+	uint64_t ne = ((last + kRngChunk - 1) / kRngChunk) * kRngChunk;
+	uint64_t cnt = ne - nb;
+	cnt += cnt / 8;  // slack so slightly longer batches do not regenerate
+	cnt = ((cnt + kRngChunk - 1) / kRngChunk) * kRngChunk;
+	if (cnt > (1ull << 33)) return fail(WC_ERR_UNSUPPORTED, "RNG table request too large");
+	WC_HIP(hipStreamSynchronize(stream));  // previous kernels may still read the old table
+	rng_count = 0;
+	int rc = rng_table.reserve(cnt * sizeof(uint32_t));
+	if (rc) return rc;
+	rc = launch_rng_fill(this, rng_table.as<uint32_t>(), nb, cnt);
+	if (rc) return rc;
+	rng_base = nb;
+	rng_count = cnt;
+	return WC_OK;
+}
+
+int Device::time_begin(const char *name) {
+	if (!timing) return WC_OK;
+	auto it = events.find(name);
+	if (it == events.end()) {
+		hipEvent_t a, b;
+		WC_HIP(hipEventCreate(&a));
+		WC_HIP(hipEventCreate(&b));
+		it = events.emplace(name, std::make_pair(a, b)).first;
+	}
+	WC_HIP(hipEventRecord(it->second.first, stream));
+	return WC_OK;
+}
+int Device::time_end(const char *name) {
+	if (!timing) return WC_OK;
+	auto it = events.find(name);
+	if (it == events.end()) return WC_OK;
+	WC_HIP(hipEventRecord(it->second.second, stream));
+	return WC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+static std::mutex g_mu;
+static std::map<int, std::unique_ptr<Device>> g_devices;
+static thread_local int g_device_id = 0;
+static thread_local void *g_user_stream = nullptr;
+static thread_local bool g_has_user_stream = false;
+static uint64_t g_rng_position = 0;
+
+uint64_t &global_rng_position() { return g_rng_position; }
+
+Device *current_device() {
+	std::lock_guard<std::mutex> lk(g_mu);
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess || n <= 0) {
+		set_error(std::string("no usable HIP device (hipGetDeviceCount: ") + hipGetErrorString(e) +
+				  "); this library has no CPU fallback");
+		return nullptr;
+	}
+	if (g_device_id < 0 || g_device_id >= n) {
+		set_error("wc_set_device: device index out of range");
+		return nullptr;
+	}
+	if (hipSetDevice(g_device_id) != hipSuccess) {
+		set_error("hipSetDevice failed");
+		return nullptr;
+	}
+	auto it = g_devices.find(g_device_id);
+	if (it == g_devices.end()) {
+		std::unique_ptr<Device> d(new Device);
+		d->id = g_device_id;
+		if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) {
+			set_error("hipStreamCreate failed");
+			return nullptr;
+		}
+		std::vector<double2> tw(kTwiddleN);
+		for (int k = 0; k < kTwiddleN; ++k) {
+			double a = 2.0 * 3.14159265358979323846 * k / kTwiddleN;
+			tw[k] = make_double2(std::cos(a), std::sin(a));
+		}
+		// exact values on the axes / diagonals keep symmetric spectra symmetric
+		tw[0] = make_double2(1.0, 0.0);
+		tw[kTwiddleN / 4] = make_double2(0.0, 1.0);
+		tw[kTwiddleN / 2] = make_double2(-1.0, 0.0);
+		tw[3 * kTwiddleN / 4] = make_double2(0.0, -1.0);
+		if (hipMalloc(&d->twiddle, sizeof(double2) * kTwiddleN) != hipSuccess ||
+			hipMemcpy(d->twiddle, tw.data(), sizeof(double2) * kTwiddleN, hipMemcpyHostToDevice) != hipSuccess) {
+			set_error("twiddle table upload failed");
+			return nullptr;
+		}
+		it = g_devices.emplace(g_device_id, std::move(d)).first;
+	}
+	Device *d = it->second.get();
+	if (g_has_user_stream) {
+		d->stream = (hipStream_t)g_user_stream;
+		d->user_stream = true;
+	}
+	return d;
+}
+
+}  // namespace wc
+
+using namespace wc;
+
+extern "C" {
+
+const char *wc_last_error(void) { return g_error.c_str(); }
+const char *wc_version(void) { return "world_class_amd 0.1 (gfx950)"; }
+int wc_device_count(void) {
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess) return fail(WC_ERR_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+	return n;
+}
+int wc_set_device(int device) {
+	if (device < 0) return fail(WC_ERR_INVALID, "negative device index");
+	g_device_id = device;
+	return WC_OK;
+}
+int wc_get_device(void) { return g_device_id; }
+int wc_set_stream(void *hip_stream) {
+	g_user_stream = hip_stream;
+	g_has_user_stream = hip_stream != nullptr;
+	if (!g_has_user_stream) {
+		std::lock_guard<std::mutex> lk(g_mu);
+		auto it = g_devices.find(g_device_id);
+		if (it != g_devices.end() && it->second->user_stream) {
+			it->second->user_stream = false;
+			if (hipStreamCreateWithFlags(&it->second->stream, hipStreamNonBlocking) != hipSuccess)
+				return fail(WC_ERR_DEVICE, "hipStreamCreate failed");
+		}
+	}
+	return WC_OK;
+}
+int wc_synchronize(void) {
+	Device *d = current_device();
+	if (!d) return WC_ERR_DEVICE;
+	WC_HIP(hipStreamSynchronize(d->stream));
+	return WC_OK;
+}
+uint64_t wc_rng_get_position(void) { return g_rng_position; }
+void wc_rng_set_position(uint64_t position) { g_rng_position = position; }
+
+// reference src/harvest.cpp:173-181
+int wc_get_samples(int fs, int x_length, double frame_period) {
+	return static_cast<int>(1000.0 * x_length / fs / frame_period) + 1;
+}
+// reference src/cheaptrick.cpp:97-105
+int wc_cheaptrick_fft_size(int fs, double f0_floor) {
+	return static_cast<int>(std::pow(2.0, 1.0 + static_cast<int>(std::log(3.0 * fs / f0_floor + 1) / 0.69314718055994529)));
+}
+double wc_cheaptrick_f0_floor(int fs, int fft_size) { return 3 * fs / (fft_size - 3.0); }
+// reference test/test.cpp:362-363
+int wc_synthesis_out_length(int f0_length, double frame_period, int fs) {
+	return static_cast<int>((f0_length - 1) * frame_period / 1000.0 * fs) + 1;
+}
+
+void *wc_device_malloc(uint64_t bytes) {
+	if (!current_device()) return nullptr;
+	void *p = nullptr;
+	hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+	if (e != hipSuccess) {
+		set_error(std::string("hipMalloc: ") + hipGetErrorString(e));
+		return nullptr;
+	}
+	return p;
+}
+void wc_device_free(void *p) {
+	if (p) (void)hipFree(p);
+}
+int wc_memcpy_h2d(void *dst, const void *src, uint64_t bytes) {
+	Device *d = current_device();
+	if (!d) return WC_ERR_DEVICE;
+	WC_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, d->stream));
+	WC_HIP(hipStreamSynchronize(d->stream));
+	return WC_OK;
+}
+int wc_memcpy_d2h(void *dst, const void *src, uint64_t bytes) {
+	Device *d = current_device();
+	if (!d) return WC_ERR_DEVICE;
+	WC_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, d->stream));
+	WC_HIP(hipStreamSynchronize(d->stream));
+	return WC_OK;
+}
+int wc_set_kernel_timing(int enable) {
+	Device *d = current_device();
+	if (!d) return WC_ERR_DEVICE;
+	d->timing = enable != 0;
+	return WC_OK;
+}
+float wc_last_kernel_ms(const char *kernel_name) {
+	Device *d = current_device();
+	if (!d) return -1.f;
+	auto it = d->events.find(kernel_name);
+	if (it == d->events.end()) return -1.f;
+	if (hipEventSynchronize(it->second.second) != hipSuccess) return -1.f;
+	float ms = -1.f;
+	if (hipEventElapsedTime(&ms, it->second.first, it->second.second) != hipSuccess) return -1.f;
+	return ms;
+}
+
+}  // extern "C"

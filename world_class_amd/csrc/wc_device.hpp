@@ -1,0 +1,230 @@
+// Device-side building blocks shared by the stage kernels (gfx950, wave64, FP64).
+//   * block reductions / scans built on 64-lane wave shuffles
+//   * LDS-resident Stockham FFT (radix-4 passes, optional leading radix-2) on interleaved complex
+//     doubles, plus the real<->half-size-complex pre/post passes
+//   * the reference's small arithmetic helpers (matlab_round, interp1Q) as __device__ inlines
+//
+// FFT conventions are the reference's (reference src/world_fft.cpp:31-77 over Ooura):
+//   r2c  X[k] = sum x[n] e^{+2 pi i k n / N}            (SIGN = +1, "forward")
+//   c2r  y[n] = sum_k Yh[k] e^{-2 pi i k n / N}, Yh = Hermitian extension, imag of bins 0, N/2 ignored
+//   c2c  forward e^{+i}, backward e^{-i}; nothing is normalised.
+// Compiled with -ffp-contract=off: every fused multiply-add below is an explicit fma().
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace wc {
+
+constexpr double kPi = 3.1415926535897932384;
+constexpr int kTwiddleN = 4096;  // table W[k] = e^{+2 pi i k / 4096}, k < 4096
+
+// reference src/world_matlabfunctions.cpp:212-214
+__device__ __forceinline__ int mround(double x) { return x > 0 ? (int)(x + 0.5) : (int)(x - 0.5); }
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return max(lo, min(hi, v)); }
+
+// reference src/world_matlabfunctions.cpp:220-241 for one abscissa (y indexed by a functor so the
+// table may live in LDS or be a mirrored view)
+template <class F>
+__device__ __forceinline__ double interp1q(double x0, double dx, F y, int n, double xi) {
+	double q = (xi - x0) / dx;
+	int b = (int)q;
+	double frac = q - b;
+	double y0 = y(b);
+	double dy = (b == n - 1) ? 0.0 : y(b + 1) - y0;
+	return y0 + dy * frac;
+}
+
+// ---- wave / block collectives ------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+	return v;  // valid in lane 0
+}
+__device__ __forceinline__ double wave_incl_scan(double v, int lane) {
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		double t = __shfl_up(v, o, 64);
+		if (lane >= o) v += t;
+	}
+	return v;
+}
+// Sum over the block; result broadcast to every thread.  scratch: >= T/64 doubles of LDS.
+template <int T>
+__device__ __forceinline__ double block_sum(double v, double *scratch, int tid) {
+	v = wave_sum(v);
+	__syncthreads();
+	if ((tid & 63) == 0) scratch[tid >> 6] = v;
+	__syncthreads();
+	double s = 0.0;
+#pragma unroll
+	for (int w = 0; w < T / 64; ++w) s += scratch[w];
+	return s;
+}
+// Two sums at once.
+template <int T>
+__device__ __forceinline__ void block_sum2(double &a, double &b, double *scratch, int tid) {
+	a = wave_sum(a);
+	b = wave_sum(b);
+	__syncthreads();
+	if ((tid & 63) == 0) { scratch[tid >> 6] = a; scratch[T / 64 + (tid >> 6)] = b; }
+	__syncthreads();
+	double sa = 0.0, sb = 0.0;
+#pragma unroll
+	for (int w = 0; w < T / 64; ++w) { sa += scratch[w]; sb += scratch[T / 64 + w]; }
+	a = sa;
+	b = sb;
+}
+// Exclusive scan of one value per thread across the block.  scratch: >= T/64 doubles.
+template <int T>
+__device__ __forceinline__ double block_excl_scan(double v, double *scratch, int tid) {
+	int lane = tid & 63, w = tid >> 6;
+	double inc = wave_incl_scan(v, lane);
+	__syncthreads();
+	if (lane == 63) scratch[w] = inc;
+	__syncthreads();
+	double base = 0.0;
+#pragma unroll
+	for (int k = 0; k < T / 64; ++k) if (k < w) base += scratch[k];
+	return base + inc - v;
+}
+
+// ---- complex helpers ----------------------------------------------------------------------------
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
+	return make_double2(fma(a.x, b.x, -(a.y * b.y)), fma(a.x, b.y, a.y * b.x));
+}
+__device__ __forceinline__ double2 cconj(double2 a) { return make_double2(a.x, -a.y); }
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+// multiply by +i (S=+1) or -i (S=-1)
+template <int S>
+__device__ __forceinline__ double2 cmul_i(double2 a) {
+	return S > 0 ? make_double2(-a.y, a.x) : make_double2(a.y, -a.x);
+}
+template <int S>
+__device__ __forceinline__ double2 twiddle(const double2 *__restrict__ tw, int idx) {
+	double2 w = tw[idx];
+	return S > 0 ? w : cconj(w);
+}
+
+// ---- in-LDS complex FFT of M points by T threads, sign S (+1: e^{+i}) -------------------------------
+// a: M interleaved complex doubles in LDS (natural order in, natural order out).
+// tw: global twiddle table of kTwiddleN entries.  Ends with a __syncthreads().
+template <int M, int T, int S>
+__device__ void fft_lds(double2 *a, const double2 *__restrict__ tw, int tid) {
+	static_assert((M & (M - 1)) == 0 && M >= 16 && M <= kTwiddleN, "M must be a power of two in [16, 4096]");
+	constexpr int LOG2 = __builtin_ctz(M);
+	constexpr bool LEAD2 = (LOG2 & 1) != 0;
+	int Ns = 1;
+	if (LEAD2) {  // radix-2 pass with Ns = 1: no twiddles
+		constexpr int NB = M / 2;
+		constexpr int BPT = (NB + T - 1) / T;
+		double2 v0[BPT], v1[BPT];
+#pragma unroll
+		for (int b = 0; b < BPT; ++b) {
+			int j = tid + b * T;
+			if (j < NB) { v0[b] = a[j]; v1[b] = a[j + NB]; }
+		}
+		__syncthreads();
+#pragma unroll
+		for (int b = 0; b < BPT; ++b) {
+			int j = tid + b * T;
+			if (j < NB) { a[2 * j] = cadd(v0[b], v1[b]); a[2 * j + 1] = csub(v0[b], v1[b]); }
+		}
+		__syncthreads();
+		Ns = 2;
+	}
+	constexpr int NB4 = M / 4;
+	constexpr int BPT4 = (NB4 + T - 1) / T;
+#pragma unroll 1
+	for (; Ns < M; Ns <<= 2) {
+		double2 v[BPT4][4];
+#pragma unroll
+		for (int b = 0; b < BPT4; ++b) {
+			int j = tid + b * T;
+			if (j < NB4) {
+#pragma unroll
+				for (int r = 0; r < 4; ++r) v[b][r] = a[j + r * NB4];
+			}
+		}
+		__syncthreads();
+		const int tstride = (kTwiddleN / 4) / Ns;  // (M / (Ns*4)) * (kTwiddleN / M)
+#pragma unroll
+		for (int b = 0; b < BPT4; ++b) {
+			int j = tid + b * T;
+			if (j < NB4) {
+				int k = j & (Ns - 1);
+				double2 x0 = v[b][0], x1 = v[b][1], x2 = v[b][2], x3 = v[b][3];
+				if (Ns > 1) {
+					int idx = k * tstride;
+					x1 = cmul(x1, twiddle<S>(tw, idx));
+					x2 = cmul(x2, twiddle<S>(tw, 2 * idx));
+					x3 = cmul(x3, twiddle<S>(tw, 3 * idx));
+				}
+				double2 s02 = cadd(x0, x2), d02 = csub(x0, x2);
+				double2 s13 = cadd(x1, x3), d13 = cmul_i<S>(csub(x1, x3));
+				int j0 = ((j - k) << 2) + k;
+				a[j0] = cadd(s02, s13);
+				a[j0 + Ns] = cadd(d02, d13);
+				a[j0 + 2 * Ns] = csub(s02, s13);
+				a[j0 + 3 * Ns] = csub(d02, d13);
+			}
+		}
+		__syncthreads();
+	}
+}
+
+// ---- real FFT of N = 2M points held as M interleaved complex (x[2k], x[2k+1]) -----------------------
+// After fft_lds<M,T,+1> on that array, unpack to the spectrum X[0..M] (reference r2c convention).
+// Packed in place: a[0] = (X[0].re, X[M].re); a[k] = X[k] for 0 < k < M.  Ends with a __syncthreads().
+template <int M, int T>
+__device__ void r2c_post(double2 *a, const double2 *__restrict__ tw, int tid) {
+	constexpr int TS = kTwiddleN / (2 * M);  // W_N^k = tw[k * TS]
+	// pairs (k, M-k), k = 1 .. M/2-1 ; k = 0 and k = M/2 handled apart
+	for (int k = tid; k <= M / 2; k += T) {
+		if (k == 0) {
+			double2 z = a[0];
+			a[0] = make_double2(z.x + z.y, z.x - z.y);
+		} else if (k == M / 2) {
+			// X[M/2] = Z[M/2] for the e^{+i} convention
+		} else {
+			double2 zk = a[k], zm = a[M - k];
+			double2 e = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));   // (Zk + conj Zm)/2
+			double2 o = make_double2(0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x));  // (Zk - conj Zm)/(2i)
+			double2 w = tw[k * TS];
+			double2 wo = cmul(w, o);
+			a[k] = cadd(e, wo);
+			// X[M-k] = conj(E) + W^{M-k} conj(O),  W^{M-k} = -conj(W^k)  =>  X[M-k] = conj(E - W O)
+			a[M - k] = cconj(csub(e, wo));
+		}
+	}
+	__syncthreads();
+}
+// Inverse of the above: a holds the packed spectrum Y (a[0] = (Y[0].re, Y[M].re)); produce Z so that
+// fft_lds<M,T,-1> yields the real signal y[n] interleaved (reference c2r convention, unnormalised).
+template <int M, int T>
+__device__ void c2r_pre(double2 *a, const double2 *__restrict__ tw, int tid) {
+	constexpr int TS = kTwiddleN / (2 * M);
+	for (int k = tid; k <= M / 2; k += T) {
+		if (k == 0) {
+			double2 y = a[0];
+			// E0 = Y0 + YM, O0 = Y0 - YM (both real) ; Z0 = E0 + i O0
+			a[0] = make_double2(y.x + y.y, y.x - y.y);
+		} else if (k == M / 2) {
+			// E = Y + conj Y = 2 Re, O = (Y - conj Y) * conj(W^{M/2}) = 2i Im * (-i) = 2 Im ; Z = E + iO
+			double2 y = a[k];
+			a[k] = make_double2(2.0 * y.x, 2.0 * y.y);
+		} else {
+			double2 yk = a[k], ym = a[M - k];
+			double2 e = make_double2(yk.x + ym.x, yk.y - ym.y);  // Yk + conj Ym
+			double2 d = make_double2(yk.x - ym.x, yk.y + ym.y);  // Yk - conj Ym
+			double2 w = cconj(tw[k * TS]);
+			double2 o = cmul(d, w);
+			a[k] = make_double2(e.x - o.y, e.y + o.x);  // E + i O
+			// index M-k: E' = conj(E), D' = -conj(D), conj(W^{M-k}) = -W^k ... O' = conj(D) W^k = conj(D conj W) = conj(O)
+			a[M - k] = make_double2(e.x + o.y, -e.y + o.x);  // conj(E) + i conj(O)
+		}
+	}
+	__syncthreads();
+}
+
+}  // namespace wc

@@ -1,0 +1,81 @@
+// Host-side internals shared by the C-ABI translation units: per-device state (stream, twiddle
+// table, RNG draw table), grow-only device buffers, error reporting, kernel timing.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/world_class_c.h"
+
+namespace wc {
+
+void set_error(const std::string &msg);
+int fail(int code, const std::string &msg);
+
+#define WC_HIP(expr)                                                                              \
+	do {                                                                                          \
+		hipError_t _e = (expr);                                                                   \
+		if (_e != hipSuccess)                                                                     \
+			return ::wc::fail(WC_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));  \
+	} while (0)
+
+// Grow-only device buffer.
+struct DevBuf {
+	void *p = nullptr;
+	size_t cap = 0;
+	int reserve(size_t bytes);  // 0 on success
+	void release();
+	template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+// Pinned host staging buffer (grow-only).
+struct HostBuf {
+	void *p = nullptr;
+	size_t cap = 0;
+	int reserve(size_t bytes);
+	void release();
+	template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+// Per-device shared state.
+struct Device {
+	int id = 0;
+	hipStream_t stream = nullptr;  // library-owned non-blocking stream (or user stream)
+	bool user_stream = false;
+	std::mutex mu;
+	double2 *twiddle = nullptr;  // kTwiddleN entries, e^{+2 pi i k / kTwiddleN}
+	// RNG draw table: raw 12-step sums (uint32) of the reference's randn() for stream positions
+	// [rng_base, rng_base + rng_count)
+	DevBuf rng_table;
+	uint64_t rng_base = 0, rng_count = 0;
+	int ensure_rng(uint64_t first, uint64_t last_exclusive);  // makes [first, last) available
+	// timing
+	bool timing = false;
+	std::map<std::string, std::pair<hipEvent_t, hipEvent_t>> events;
+	int time_begin(const char *name);
+	int time_end(const char *name);
+};
+
+Device *current_device();  // creates the state on first use; nullptr + error on failure
+uint64_t &global_rng_position();
+
+// utterance descriptors uploaded per batch call
+struct UttDesc {
+	long long x_off;   // first sample in the packed sample array
+	long long f_off;   // first frame (row) in the packed frame arrays
+	long long y_off;   // first output sample (synthesis)
+	int x_len, f_len, y_len, pad;
+	unsigned long long rng_pos;  // stream position at which this utterance starts the stage
+};
+
+// host-side RNG jump-ahead (GF(2) linear algebra on the xorshift128 state)
+void rng_state_at(uint64_t position, uint32_t state[4]);
+
+// device entry points implemented in the .hip files
+int launch_rng_fill(Device *dev, uint32_t *table, uint64_t first, uint64_t count);
+
+}  // namespace wc

@@ -24,7 +24,7 @@ def make_utterance(fs: int, seconds: float, seed: int) -> np.ndarray:
         x += keep * np.sin(h * phase + ph_h) / h
     gate = (np.sin(2.0 * np.pi * 1.5 * t + psi) > -0.3).astype(np.float64)
     box = np.ones(200, dtype=np.float64) / 200.0
-    gate = np.convolve(gate, box, mode="same")
+    gate = np.convolve(gate, box, mode="full")[99:99 + n]  # == mode="same" for n >= 200
     x *= gate
     peak = np.max(np.abs(x))
     if peak > 0:
@@ -39,3 +39,19 @@ def make_utterance(fs: int, seconds: float, seed: int) -> np.ndarray:
 def make_batch(fs: int, seconds: float, n_utt: int, config: int = 0, first: int = 0):
     """List of utterances with seeds 1000*config + u (u = first .. first+n_utt-1)."""
     return [make_utterance(fs, seconds, 1000 * config + u) for u in range(first, first + n_utt)]
+
+
+def true_f0(fs: int, seconds: float, seed: int, frame_period: float = 5.0):
+    """(temporal_positions, f0) of the generator's own contour on the analysis grid (0 where the
+    voicing gate is closed).  Used by the stage micro-benchmarks, which need a plausible contour
+    without running F0 estimation first."""
+    rng = np.random.default_rng(seed)
+    n = int(round(fs * seconds))
+    f_c = rng.uniform(120.0, 300.0)
+    phi = rng.uniform(0.0, 2.0 * np.pi)
+    psi = rng.uniform(0.0, 2.0 * np.pi)
+    n_frames = int(1000.0 * n / fs / frame_period) + 1
+    tpos = np.arange(n_frames) * frame_period / 1000.0
+    f0 = f_c + 40.0 * np.sin(2.0 * np.pi * 0.7 * tpos + phi)
+    voiced = np.sin(2.0 * np.pi * 1.5 * tpos + psi) > -0.3
+    return tpos, np.where(voiced, f0, 0.0)
