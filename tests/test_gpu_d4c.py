@@ -1,0 +1,92 @@
+"""-m gpu parity tests of the HIP D4C path (through the C-ABI) against the golden vectors from the real
+reference and against the CPU oracle on seeded inputs."""
+import numpy as np
+import pytest
+
+from conftest import PIPELINE_CASES
+from world_class_amd.synth import make_utterance
+
+pytestmark = pytest.mark.gpu
+
+# aperiodicity lives in (0, 1]; absolute tolerance (1e-7)
+AP_ABS = 1e-7
+
+
+@pytest.fixture(scope="module")
+def wca():
+    import world_class_amd as w
+    w.lib()
+    return w
+
+
+@pytest.mark.parametrize("name", PIPELINE_CASES)
+def test_d4c_golden(golden, wca, port, name):
+    c = golden.case(name)
+    d = wca.D4C(c["fs"])
+    # the reference process had consumed CheapTrick's draws before D4C started
+    wca.rng_set_position(port.cheaptrick_draws(c["fs"], c["f0"]))
+    ap = d.compute(c["x"], c["tpos"], c["f0"], c["fft_size"])
+    s = c["stride"]
+    assert np.isfinite(ap).all()
+    assert np.abs(ap[::s] - c["ap_rows"]).max() < AP_ABS
+    assert np.abs(ap.sum(1) - c["ap_rowsum"]).max() < AP_ABS * ap.shape[1]
+
+
+def test_d4c_vs_oracle_and_rng_position(wca, port):
+    fs = 48000
+    x = make_utterance(fs, 0.7, 78)
+    tpos, f0 = port.harvest(x, fs)
+    port.rng_seek(999)
+    ref = port.d4c(x, fs, tpos, f0, 2048)
+    end = port.rng_position()
+    d = wca.D4C(fs)
+    wca.rng_set_position(999)
+    ap = d.compute(x, tpos, f0, 2048)
+    assert wca.rng_get_position() == end
+    assert np.abs(ap - ref).max() < AP_ABS
+    # gate decisions identical: rows at the 1 - 1e-12 sentinel are exactly the same rows
+    assert np.array_equal(ap[:, 0] == 1.0 - 1e-12, ref[:, 0] == 1.0 - 1e-12)
+    port.rng_reset()
+
+
+def test_d4c_ragged_batch_threshold_and_other_grid(wca, port):
+    fs = 16000
+    xs = [make_utterance(fs, sec, 700 + i) for i, sec in enumerate((0.4, 1.0, 0.08))]
+    tf = [port.harvest(x, fs) for x in xs]
+    d = wca.D4C(fs, threshold=0.5)
+    start = [0, 77, 123456]
+    outs, pos = d.compute_batch(xs, [t for t, _ in tf], [f for _, f in tf], 512, rng_pos=start)
+    for x, (t, f), ap, p0, p1 in zip(xs, tf, outs, start, pos):
+        port.rng_seek(p0)
+        ref = port.d4c(x, fs, t, f, 512, threshold=0.5)
+        assert port.rng_position() == p1
+        assert np.abs(ap - ref).max() < AP_ABS
+    port.rng_reset()
+
+
+@pytest.mark.parametrize("fs", [8000, 22050, 44100])
+def test_d4c_other_rates(wca, port, fs):
+    x = make_utterance(fs, 0.3, fs + 1)
+    tpos, f0 = port.harvest(x, fs)
+    n = port.cheaptrick_fft_size(fs)
+    d = wca.D4C(fs)
+    wca.rng_set_position(0)
+    port.rng_reset()
+    assert np.abs(d.compute(x, tpos, f0, n) - port.d4c(x, fs, tpos, f0, n)).max() < AP_ABS
+    port.rng_reset()
+
+
+def test_d4c_edges(wca, port):
+    fs = 16000
+    d = wca.D4C(fs)
+    x = make_utterance(fs, 0.2, 9)
+    # all unvoiced -> every row is the sentinel; low f0 is floored at 47 Hz; frames off both ends
+    ap = d.compute(x, [0.0, 0.1], [0.0, 0.0], 1024)
+    assert np.array_equal(ap, np.full((2, 513), 1.0 - 1e-12))
+    tpos = np.array([0.0, 0.05, 0.1995, 0.3])
+    f0 = np.array([30.0, 45.0, 200.0, 150.0])
+    wca.rng_set_position(0)
+    port.rng_reset()
+    assert np.abs(d.compute(x, tpos, f0, 1024) - port.d4c(x, fs, tpos, f0, 1024)).max() < AP_ABS
+    assert d.compute(x, [], [], 1024).shape == (0, 513)
+    port.rng_reset()

@@ -242,3 +242,47 @@ class CheapTrick:
                 self._h = None
         except Exception:
             pass
+
+
+class D4C:
+    """reference include/d4c.hpp:16-36 (D4COption default threshold 0.85)"""
+
+    def __init__(self, fs, threshold=0.85):
+        self.fs = fs
+        self._h = _handle(lib().wc_d4c_create(fs, threshold))
+
+    def compute(self, x, temporal_positions, f0, fft_size):
+        x, t, f = _c(x), _c(temporal_positions), _c(f0)
+        ap = np.empty((len(f), fft_size // 2 + 1))
+        _check(lib().wc_d4c_compute(self._h, _p(x), len(x), _p(t), _p(f), len(f), fft_size, _rows(ap)))
+        return ap
+
+    def compute_device(self, d_x, x_lengths, d_tpos, d_f0, f0_lengths, fft_size, d_ap, rng_pos=None):
+        n = len(x_lengths)
+        arr, arg = _rng_arg(rng_pos, n)
+        _check(lib().wc_d4c_compute_device(self._h, n, _ptr(d_x), _ints(x_lengths), _ptr(d_tpos), _ptr(d_f0),
+                                           _ints(f0_lengths), fft_size, _ptr(d_ap), arg))
+        return list(arr) if arr is not None else None
+
+    def compute_batch(self, xs, tposs, f0s, fft_size, rng_pos=None):
+        bins = fft_size // 2 + 1
+        d_x = DeviceArray.from_host(np.concatenate([_c(v) for v in xs]))
+        d_t = DeviceArray.from_host(np.concatenate([_c(v) for v in tposs]))
+        d_f = DeviceArray.from_host(np.concatenate([_c(v) for v in f0s]))
+        fl = [len(v) for v in f0s]
+        d_ap = DeviceArray(sum(fl) * bins)
+        pos = self.compute_device(d_x, [len(v) for v in xs], d_t, d_f, fl, fft_size, d_ap, rng_pos)
+        ap = d_ap.to_host((sum(fl), bins))
+        out, o = [], 0
+        for n in fl:
+            out.append(ap[o:o + n])
+            o += n
+        return (out, pos) if rng_pos is not None else out
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().wc_d4c_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass

@@ -13,6 +13,7 @@
 
 #include "wc_device.hpp"
 #include "wc_internal.hpp"
+#include "wc_frames.hpp"
 
 namespace wc {
 
@@ -31,25 +32,6 @@ struct CtArgs {
 	double q1, f0_floor;  // f0_floor = 3 fs / (N - 3)
 };
 
-__device__ __forceinline__ double randn_at(const uint32_t *__restrict__ table, unsigned long long idx) {
-	return table[idx] / 268435456.0 - 6.0;
-}
-__device__ __forceinline__ int find_utt(const UttDesc *__restrict__ utts, int n_utt, long long frame) {
-	int lo = 0, hi = n_utt - 1;
-	while (lo < hi) {
-		int mid = (lo + hi + 1) >> 1;
-		if (utts[mid].f_off <= frame) lo = mid; else hi = mid - 1;
-	}
-	return lo;
-}
-// blockIdx -> frame so that each XCD (block b runs on XCD b % 8) walks one contiguous range of
-// frames: neighbouring frames share almost all of their input samples, which then stay in that
-// XCD's L2.
-__device__ __forceinline__ long long xcd_frame(long long b, long long total) {
-	long long per = (total + 7) / 8;
-	return (b & 7) * per + (b >> 3);
-}
-
 // per-frame number of draws: window (2 hw + 1) then one per bin (reference :153, :227)
 __global__ void ct_count_kernel(const double *__restrict__ f0, long long total, int fs, double f0_floor,
 								int bins, uint32_t *__restrict__ cnt) {
@@ -58,31 +40,6 @@ __global__ void ct_count_kernel(const double *__restrict__ f0, long long total, 
 	double f = f0[g];
 	double f0c = (f <= f0_floor) ? 500.0 : f;
 	cnt[g] = (uint32_t)(2 * mround(1.5 * fs / f0c) + 1 + bins);
-}
-
-// one block per utterance: off[frame] = utt.rng_pos + exclusive prefix of cnt; total[u] = end position
-__global__ void utt_scan_kernel(const uint32_t *__restrict__ cnt, const UttDesc *__restrict__ utts,
-								unsigned long long *__restrict__ off, unsigned long long *__restrict__ end_pos) {
-	__shared__ unsigned long long s[256];
-	const UttDesc u = utts[blockIdx.x];
-	unsigned long long carry = u.rng_pos;
-	int tid = threadIdx.x;
-	for (int base = 0; base < u.f_len; base += 256) {
-		int i = base + tid;
-		unsigned long long v = (i < u.f_len) ? cnt[u.f_off + i] : 0ull;
-		s[tid] = v;
-		__syncthreads();
-		for (int o = 1; o < 256; o <<= 1) {
-			unsigned long long t = (tid >= o) ? s[tid - o] : 0ull;
-			__syncthreads();
-			s[tid] += t;
-			__syncthreads();
-		}
-		if (i < u.f_len) off[u.f_off + i] = carry + s[tid] - v;
-		carry += s[255];
-		__syncthreads();
-	}
-	if (tid == 0) end_pos[blockIdx.x] = carry;
 }
 
 template <int N, int T>
@@ -323,7 +280,7 @@ static int ct_run_device(wc_cheaptrick *c, int n_utt, const double *d_x, const i
 	hipLaunchKernelGGL(ct_count_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_f0, total, c->fs,
 					   c->f0_floor, bins, c->cnt.as<uint32_t>());
 	hipLaunchKernelGGL(utt_scan_kernel, dim3(n_utt), dim3(256), 0, s, c->cnt.as<uint32_t>(), c->utts.as<UttDesc>(),
-					   c->off.as<unsigned long long>(), c->endpos.as<unsigned long long>());
+					   (const unsigned long long *)nullptr, c->off.as<unsigned long long>(), c->endpos.as<unsigned long long>());
 	CtArgs a;
 	a.x = d_x; a.utts = c->utts.as<UttDesc>(); a.n_utt = n_utt; a.tpos = d_tpos; a.f0 = d_f0;
 	a.rng_off = c->off.as<unsigned long long>(); a.rng_table = dev->rng_table.as<uint32_t>();

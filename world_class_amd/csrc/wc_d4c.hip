@@ -1,0 +1,607 @@
+// D4C band-aperiodicity estimation on gfx950.
+//
+// Restates reference src/d4c.cpp:113-503.  Two per-frame kernels, one workgroup per frame:
+//   d4c_lovetrain_kernel  the "Love Train" voiced/unvoiced gate (reference :181-240): Blackman 3 T0
+//                         window, one real FFT, ratio of cumulative powers; also writes the
+//                         1 - 1e-12 rows of frames that fail the gate (reference :127-132)
+//   d4c_frames_kernel     for gated frames (reference :308-503): two energy centroids (2 real FFTs
+//                         each), smoothed power spectrum, static group delay (three prefix-sum
+//                         smoothings), per 3 kHz band a Nuttall-windowed FFT whose power spectrum is
+//                         ranked by an in-LDS radix select instead of std::sort (the reference only
+//                         needs the sum of the bins-boundary-1 smallest values), dB -> linear.
+// The noise draws come from the exact stream positions of the reference's serial order: all
+// LoveTrain frames first, then the gated frames (RNG draw-count contract).
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "wc_device.hpp"
+#include "wc_internal.hpp"
+#include "wc_frames.hpp"
+
+namespace wc {
+
+constexpr double kSafe = 0.000000000001;
+constexpr int kMaxBands = 5;  // min(15000, fs/2 - 3000) / 3000
+
+struct D4cArgs {
+	const double *x;
+	const UttDesc *utts;
+	int n_utt;
+	const double *tpos, *f0;
+	const unsigned long long *rng_off;
+	const uint32_t *rng_table;
+	unsigned long long rng_base;
+	const double2 *tw;
+	double *ap;        // [total_frames][bins_out]
+	double *ap0;       // [total_frames] LoveTrain result
+	uint32_t *cnt;     // [total_frames] draws of the main pass (written by LoveTrain)
+	const double *nuttall;  // window_length_ entries
+	long long total_frames;
+	int fs, fft_size_out, n_ap, window_length;
+	double threshold;
+};
+
+// F0-adaptive window of reference src/d4c.cpp:246-303 for the calling block; each thread keeps its
+// N/T samples in registers.  type 1 = Hanning, 2 = Blackman.  Returns the window length.
+template <int N, int T>
+__device__ __forceinline__ int d4c_windowed(const double *__restrict__ x, int x_len, int fs, double f0, double pos,
+											int type, double ratio, const uint32_t *__restrict__ rng,
+											unsigned long long roff, double (&wave)[N / T], double *red, int tid) {
+	constexpr int EPT = N / T;
+	const int hw = mround(ratio * fs / f0 / 2.0);
+	const int wl = 2 * hw + 1;
+	const int origin = mround(pos * fs + 0.001);
+	const double c1 = 2.0 / ratio / fs;
+	const double c2 = kPi * f0;
+	double w[EPT];
+	double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+	for (int e = 0; e < EPT; ++e) {
+		int i = tid + e * T;
+		w[e] = 0.0;
+		wave[e] = 0.0;
+		if (i < wl) {
+			double position = c1 * (i - hw);
+			if (type == 1) w[e] = 0.5 * cos(c2 * position) + 0.5;
+			else w[e] = 0.42 + 0.5 * cos(c2 * position) + 0.08 * cos(c2 * position * 2);
+			int si = clampi(origin + i - hw, 0, x_len - 1);
+			wave[e] = x[si] * w[e] + randn_at(rng, roff + i) * kSafe;
+			s1 += wave[e];
+			s2 += w[e];
+		}
+	}
+	block_sum2<T>(s1, s2, red, tid);
+	const double wc = s1 / s2;
+#pragma unroll
+	for (int e = 0; e < EPT; ++e) {
+		int i = tid + e * T;
+		if (i < wl) wave[e] -= w[e] * wc;
+	}
+	return wl;
+}
+
+// DCCorrection of reference src/world_common.cpp:61-80, in place on P[0..M] in LDS.
+template <int M, int T>
+__device__ __forceinline__ void dc_correction_lds(double *P, double f0, int fs, int tid) {
+	constexpr int N = 2 * M;
+	const int upper = 2 + (int)(f0 * N / fs);
+	const double dx = -(double)fs / N;
+	double rep[2];
+#pragma unroll
+	for (int e = 0; e < 2; ++e) {
+		int i = tid + e * T;
+		rep[e] = 0.0;
+		if (i < upper - 1 && i <= M) {
+			double axis = (double)i * fs / N;
+			rep[e] = interp1q(f0, dx, [&](int b) { return P[min(max(b, 0), M)]; }, upper + 1, axis);
+		}
+	}
+	__syncthreads();
+#pragma unroll
+	for (int e = 0; e < 2; ++e) {
+		int i = tid + e * T;
+		if (i < upper - 1 && i <= M) P[i] += rep[e];
+	}
+	__syncthreads();
+}
+
+// LinearSmoothing of reference src/world_common.cpp:27-52, :82-116.  P[0..M] in LDS is the input,
+// S (>= N doubles of LDS) receives the mirrored cumulative segment, out(k, value) is called for
+// every bin once the segment is complete (it may overwrite P[k]).  Ends with a __syncthreads().
+template <int M, int T, class Out>
+__device__ __forceinline__ void linear_smoothing_lds(const double *P, double *S, double width, int fs, double *red,
+													 int tid, Out out) {
+	constexpr int N = 2 * M;
+	int b = (int)(width * N / fs) + 1;
+	if (M + 2 * b + 1 > N) b = (N - M - 1) / 2;
+	const int len = M + 2 * b + 1;
+	auto mir = [&](int i) -> double {
+		if (i < b) return P[b - i];
+		if (i < M + b) return P[i - b];
+		return P[M - (i - (M + b))];
+	};
+	const int ch = (len + T - 1) / T;
+	const int lo = tid * ch, hi = min(len, lo + ch);
+	double loc = 0.0;
+	for (int i = lo; i < hi; ++i) loc += mir(i) * fs / N;
+	double run = block_excl_scan<T>(loc, red, tid);
+	for (int i = lo; i < hi; ++i) {
+		run = mir(i) * fs / N + run;
+		S[i] = run;
+	}
+	__syncthreads();
+	const double origin_axis = -(b - 0.5) * fs / N;
+	const double step = (double)fs / N;
+	auto seg = [&](int i) -> double { return S[min(max(i, 0), len - 1)]; };
+	for (int k = tid; k <= M; k += T) {
+		double lo_axis = (double)k / N * fs - width / 2.0;
+		double hi_axis = lo_axis + width;
+		double lo_v = interp1q(origin_axis, step, seg, len, lo_axis);
+		double hi_v = interp1q(origin_axis, step, seg, len, hi_axis);
+		out(k, (hi_v - lo_v) / width);
+	}
+	__syncthreads();
+}
+
+// number of draws of one frame's LoveTrain window / of its three D4C windows
+__global__ void d4c_lt_count_kernel(const double *__restrict__ f0, long long total, int fs, uint32_t *__restrict__ cnt) {
+	long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= total) return;
+	double f = f0[g];
+	cnt[g] = (f == 0.0) ? 0u : (uint32_t)(2 * mround(3.0 * fs / fmax(f, 40.0) / 2.0) + 1);
+}
+
+template <int N, int T>
+__global__ __launch_bounds__(T) void d4c_lovetrain_kernel(D4cArgs a) {
+	constexpr int M = N / 2;
+	constexpr int EPT = N / T;
+	__shared__ double2 A[M];
+	__shared__ double red[2 * (T / 64) + 2];
+	double *Ar = reinterpret_cast<double *>(A);
+	const int tid = threadIdx.x;
+	long long g = xcd_frame(blockIdx.x, a.total_frames);
+	if (g >= a.total_frames) return;
+	const int bins_out = a.fft_size_out / 2 + 1;
+	double *__restrict__ row = a.ap + g * (long long)bins_out;
+	const double f0v = a.f0[g];
+	double ap0 = 0.0;
+	if (f0v != 0.0) {
+		const int u = find_utt(a.utts, a.n_utt, g);
+		const UttDesc ud = a.utts[u];
+		const int fs = a.fs;
+		const double f0c = fmax(f0v, 40.0);
+		double wave[EPT];
+		const int wl = d4c_windowed<N, T>(a.x + ud.x_off, ud.x_len, fs, f0c, a.tpos[g], 2, 3.0, a.rng_table,
+										  a.rng_off[g] - a.rng_base, wave, red, tid);
+#pragma unroll
+		for (int e = 0; e < EPT; ++e) {
+			int i = tid + e * T;
+			Ar[i] = (i < wl) ? wave[e] : 0.0;
+		}
+		__syncthreads();
+		fft_lds<M, T, +1>(A, a.tw, tid);
+		r2c_post<M, T>(A, a.tw, tid);
+		// cumulative powers above 100 Hz up to 4000 Hz and 7900 Hz (reference :184-186, :226-235)
+		const int b0 = (int)ceil(100.0 * N / fs);
+		const int b1 = (int)ceil(4000.0 * N / fs);
+		const int b2 = (int)ceil(7900.0 * N / fs);
+		double p1 = 0.0, p2 = 0.0;
+		for (int k = b0 + 1 + tid; k <= min(b2, M); k += T) {
+			double2 v = A[k == M ? 0 : k];
+			double p = (k == M) ? v.y * v.y : v.x * v.x + v.y * v.y;
+			p2 += p;
+			if (k <= b1) p1 += p;
+		}
+		block_sum2<T>(p1, p2, red, tid);
+		ap0 = p1 / p2;
+	}
+	const bool gate = !(f0v == 0.0 || ap0 <= a.threshold);  // reference :147
+	if (tid == 0) {
+		a.ap0[g] = ap0;
+		a.cnt[g] = gate ? (uint32_t)(3 * (2 * mround(4.0 * a.fs / fmax(47.0, f0v) / 2.0) + 1)) : 0u;
+	}
+	if (!gate) {
+		const double init_val = 1.0 - kSafe;
+		for (int k = tid; k < bins_out; k += T) row[k] = init_val;
+	}
+}
+
+template <int N, int T>
+__global__ __launch_bounds__(T) void d4c_frames_kernel(D4cArgs a) {
+	constexpr int M = N / 2;
+	constexpr int EPT = N / T;
+	constexpr int KPT = (M + 1 + T - 1) / T;  // power-spectrum keys per thread
+	// LDS: 32 KB + 2 x 16 KB at N = 4096 -> two workgroups per CU
+	__shared__ double2 A[M];      // FFT workspace / cumulative segment / radix-select histograms
+	__shared__ double Br[M + 2];  // smoothed power spectrum, scratch of the last smoothing
+	__shared__ double Cc[M + 2];  // centroid -> static group delay
+	__shared__ double red[2 * (T / 64) + 2];
+	__shared__ unsigned long long sel_prefix[kMaxBands];
+	__shared__ unsigned int sel_k[kMaxBands];
+	__shared__ double coarse[kMaxBands + 2];
+	double *Ar = reinterpret_cast<double *>(A);
+	unsigned int(*hist)[256] = reinterpret_cast<unsigned int(*)[256]>(A);
+	static_assert(sizeof(double2) * M >= sizeof(unsigned int) * 256 * kMaxBands, "histograms must fit in A");
+
+	const int tid = threadIdx.x;
+	long long g = xcd_frame(blockIdx.x, a.total_frames);
+	if (g >= a.total_frames) return;
+	const double f0v = a.f0[g];
+	if (f0v == 0.0 || a.ap0[g] <= a.threshold) return;  // reference :147
+	const int u = find_utt(a.utts, a.n_utt, g);
+	const UttDesc ud = a.utts[u];
+	const double *__restrict__ x = a.x + ud.x_off;
+	const int fs = a.fs;
+	const double f0 = fmax(47.0, f0v);
+	const double pos = a.tpos[g];
+	const unsigned long long roff = a.rng_off[g] - a.rng_base;
+
+	// ---- static centroid (reference :339-405) ----
+	int wl = 0;
+	for (int c = 0; c < 2; ++c) {
+		double wave[EPT];
+		const double p = (c == 0) ? pos - 0.25 / f0 : pos + 0.25 / f0;
+		wl = d4c_windowed<N, T>(x, ud.x_len, fs, f0, p, 2, 4.0, a.rng_table, roff + (unsigned long long)c * wl, wave, red, tid);
+		double pw = 0.0;
+#pragma unroll
+		for (int e = 0; e < EPT; ++e) pw += wave[e] * wave[e];
+		pw = sqrt(block_sum<T>(pw, red, tid));
+#pragma unroll
+		for (int e = 0; e < EPT; ++e) {
+			int i = tid + e * T;
+			wave[e] = (i < wl) ? wave[e] / pw : 0.0;
+			Ar[i] = wave[e];
+		}
+		__syncthreads();
+		fft_lds<M, T, +1>(A, a.tw, tid);
+		r2c_post<M, T>(A, a.tw, tid);
+		double2 s1[KPT];  // spectrum of the plain windowed signal, kept in registers
+#pragma unroll
+		for (int e = 0; e < KPT; ++e) {
+			int k = tid + e * T;
+			s1[e] = make_double2(0.0, 0.0);
+			if (k < M) s1[e] = A[k];
+			else if (k == M) s1[e] = make_double2(A[0].y, 0.0);
+		}
+		__syncthreads();
+#pragma unroll
+		for (int e = 0; e < EPT; ++e) {
+			int i = tid + e * T;
+			Ar[i] = wave[e] * (i + 1.0);
+		}
+		__syncthreads();
+		fft_lds<M, T, +1>(A, a.tw, tid);
+		r2c_post<M, T>(A, a.tw, tid);
+#pragma unroll
+		for (int e = 0; e < KPT; ++e) {
+			int k = tid + e * T;
+			if (k <= M) {
+				double v;
+				if (k == 0) v = A[0].x * s1[e].x;
+				else if (k == M) v = A[0].y * s1[e].x;
+				else v = A[k].x * s1[e].x + s1[e].y * A[k].y;
+				Cc[k] = (c == 0) ? v : Cc[k] + v;
+			}
+		}
+		__syncthreads();
+	}
+	dc_correction_lds<M, T>(Cc, f0, fs, tid);
+
+	// ---- smoothed power spectrum (reference :411-434) ----
+	{
+		double wave[EPT];
+		wl = d4c_windowed<N, T>(x, ud.x_len, fs, f0, pos, 1, 4.0, a.rng_table, roff + 2ull * wl, wave, red, tid);
+#pragma unroll
+		for (int e = 0; e < EPT; ++e) {
+			int i = tid + e * T;
+			Ar[i] = (i < wl) ? wave[e] : 0.0;
+		}
+		__syncthreads();
+		fft_lds<M, T, +1>(A, a.tw, tid);
+		r2c_post<M, T>(A, a.tw, tid);
+		for (int k = tid; k <= M; k += T) {
+			double2 v = A[k == M ? 0 : k];
+			Br[k] = (k == 0) ? v.x * v.x : (k == M) ? v.y * v.y : v.x * v.x + v.y * v.y;
+		}
+		__syncthreads();
+		dc_correction_lds<M, T>(Br, f0, fs, tid);
+		linear_smoothing_lds<M, T>(Br, Ar, f0, fs, red, tid, [&](int k, double v) { Br[k] = v; });
+	}
+	// ---- static group delay (reference :440-460) ----
+	for (int k = tid; k <= M; k += T) Cc[k] = Cc[k] / Br[k];
+	__syncthreads();
+	linear_smoothing_lds<M, T>(Cc, Ar, f0 / 2.0, fs, red, tid, [&](int k, double v) { Cc[k] = v; });
+	linear_smoothing_lds<M, T>(Cc, Ar, f0, fs, red, tid, [&](int k, double v) { Br[k] = v; });
+	for (int k = tid; k <= M; k += T) Cc[k] -= Br[k];
+	__syncthreads();
+
+	// ---- coarse aperiodicity (reference :466-503) ----
+	const int n_ap = a.n_ap;
+	const int wln = a.window_length;
+	const int hwl = wln / 2;
+	const int boundary = mround(N * 8.0 / wln);
+	const int bins = M + 1;
+	const unsigned int K = (unsigned int)(bins - boundary - 1);  // sum of the K smallest powers
+	double key[kMaxBands][KPT];
+	for (int bnd = 0; bnd < n_ap; ++bnd) {
+		const int center = (int)(3000.0 * (bnd + 1) * N / fs);
+#pragma unroll
+		for (int e = 0; e < EPT; ++e) {
+			int i = tid + e * T;
+			Ar[i] = (i < wln) ? Cc[center - hwl + i] * a.nuttall[i] : 0.0;
+		}
+		__syncthreads();
+		fft_lds<M, T, +1>(A, a.tw, tid);
+		r2c_post<M, T>(A, a.tw, tid);
+#pragma unroll
+		for (int e = 0; e < KPT; ++e) {
+			int k = tid + e * T;
+			double p = 0.0;
+			if (k <= M) {
+				double2 v = A[k == M ? 0 : k];
+				p = (k == 0) ? v.x * v.x : (k == M) ? v.y * v.y : v.x * v.x + v.y * v.y;
+			}
+#pragma unroll
+			for (int bb = 0; bb < kMaxBands; ++bb) if (bb == bnd) key[bb][e] = p;
+		}
+		__syncthreads();
+	}
+	// radix select (8 bits per pass, most significant first) of the K-th smallest power of every band at
+	// once; non-negative doubles order like their bit patterns.
+	if (tid < kMaxBands) { sel_prefix[tid] = 0ull; sel_k[tid] = K; }
+	for (int pass = 0; pass < 8; ++pass) {
+		const int shift = 56 - 8 * pass;
+		for (int i = tid; i < kMaxBands * 256; i += T) (&hist[0][0])[i] = 0u;
+		__syncthreads();
+#pragma unroll
+		for (int bb = 0; bb < kMaxBands; ++bb) {
+			if (bb < n_ap) {
+				const unsigned long long pre = sel_prefix[bb];
+#pragma unroll
+				for (int e = 0; e < KPT; ++e) {
+					int k = tid + e * T;
+					if (k <= M) {
+						unsigned long long bits = (unsigned long long)__double_as_longlong(key[bb][e]);
+						bool match = (pass == 0) || ((bits >> (shift + 8)) == (pre >> (shift + 8)));
+						if (match) atomicAdd(&hist[bb][(bits >> shift) & 255ull], 1u);
+					}
+				}
+			}
+		}
+		__syncthreads();
+		if (tid < n_ap) {
+			unsigned int need = sel_k[tid], acc = 0;
+			int d = 0;
+			for (; d < 256; ++d) {
+				unsigned int h = hist[tid][d];
+				if (acc + h >= need) break;
+				acc += h;
+			}
+			sel_k[tid] = need - acc;  // rank inside the chosen digit bucket
+			sel_prefix[tid] |= ((unsigned long long)d) << shift;
+		}
+		__syncthreads();
+	}
+	// sum of the K smallest = sum(values < v*) + (remaining rank) * v*, and the total
+	for (int bb = 0; bb < n_ap; ++bb) {
+		const unsigned long long tb = sel_prefix[bb];
+		const double thr = __longlong_as_double((long long)tb);
+		double low = 0.0, tot = 0.0;
+#pragma unroll
+		for (int e = 0; e < KPT; ++e) {
+			int k = tid + e * T;
+			if (k <= M) {
+				double p = 0.0;
+#pragma unroll
+				for (int b2 = 0; b2 < kMaxBands; ++b2) if (b2 == bb) p = key[b2][e];
+				tot += p;
+				if (p < thr) low += p;
+			}
+		}
+		block_sum2<T>(low, tot, red, tid);
+		if (tid == 0) {
+			double part = low + (double)sel_k[bb] * thr;
+			double cv = 10 * log10(part / tot);
+			coarse[bb + 1] = fmin(0.0, cv + (f0 - 100) / 50.0);  // reference :326-328
+		}
+		__syncthreads();
+	}
+	if (tid == 0) { coarse[0] = -60.0; coarse[n_ap + 1] = -kSafe; }
+	__syncthreads();
+	// ---- interp1 onto the output grid + dB -> linear (reference :162-168) ----
+	const int bins_out = a.fft_size_out / 2 + 1;
+	double *__restrict__ row = a.ap + g * (long long)bins_out;
+	const int na = n_ap + 2;
+	for (int k = tid; k < bins_out; k += T) {
+		double f = (double)k * fs / a.fft_size_out;
+		int c = 1;  // histc semantics: clamp(#{j : axis[j] <= f}, 1, n-1)
+		while (c < na && f >= ((c == na - 1) ? fs / 2.0 : c * 3000.0)) ++c;
+		c = min(c, na - 1);
+		double x0 = (c - 1) * 3000.0;
+		double x1 = (c == na - 1) ? fs / 2.0 : c * 3000.0;
+		double s = (f - x0) / (x1 - x0);
+		double v = coarse[c - 1] + s * (coarse[c] - coarse[c - 1]);
+		row[k] = pow(10.0, v / 20.0);
+	}
+}
+
+}  // namespace wc
+
+using namespace wc;
+
+struct wc_d4c {
+	int fs, fft_size_d4c, fft_size_lt, n_ap, window_length;
+	double threshold;
+	Device *dev;
+	DevBuf nuttall, utts, cnt, off, endpos, endpos2, ap0, d_x, d_tpos, d_f0, d_ap;
+	HostBuf h_stage;
+};
+
+template <int N>
+static void launch_lt(const D4cArgs &a, hipStream_t s) {
+	long long blocks = ((a.total_frames + 7) / 8) * 8;
+	hipLaunchKernelGGL((d4c_lovetrain_kernel<N, 256>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+}
+template <int N>
+static void launch_main(const D4cArgs &a, hipStream_t s) {
+	long long blocks = ((a.total_frames + 7) / 8) * 8;
+	hipLaunchKernelGGL((d4c_frames_kernel<N, 256>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+}
+
+static int d4c_run_device(wc_d4c *d, int n_utt, const double *d_x, const int *x_length, const double *d_tpos,
+						  const double *d_f0, const int *f0_length, int fft_size, double *d_ap, uint64_t *rng_pos) {
+	Device *dev = d->dev;
+	hipStream_t s = dev->stream;
+	if (fft_size < 2 || (fft_size & 1)) return fail(WC_ERR_INVALID, "d4c: fft_size must be even and positive");
+	std::vector<UttDesc> utts(n_utt);
+	long long xo = 0, fo = 0;
+	uint64_t min_pos = ~0ull, max_end = 0;
+	const uint64_t lt_max = (uint64_t)(2 * (int)(3.0 * d->fs / 40.0 / 2.0 + 1.0) + 1);
+	const uint64_t main_max = 3ull * (uint64_t)(2 * (int)(4.0 * d->fs / 47.0 / 2.0 + 1.0) + 1);
+	for (int u = 0; u < n_utt; ++u) {
+		if (x_length[u] <= 0 || f0_length[u] < 0) return fail(WC_ERR_INVALID, "d4c: non-positive length");
+		UttDesc &t = utts[u];
+		t.x_off = xo; t.f_off = fo; t.y_off = 0;
+		t.x_len = x_length[u]; t.f_len = f0_length[u]; t.y_len = 0; t.pad = 0;
+		t.rng_pos = rng_pos ? rng_pos[u] : 0ull;
+		xo += x_length[u];
+		fo += f0_length[u];
+		if (t.rng_pos < min_pos) min_pos = t.rng_pos;
+		uint64_t e = t.rng_pos + (lt_max + main_max) * (uint64_t)t.f_len;
+		if (e > max_end) max_end = e;
+	}
+	const long long total = fo;
+	if (total == 0) return WC_OK;
+	int rc;
+	if ((rc = dev->ensure_rng(min_pos, max_end))) return rc;
+	if ((rc = d->utts.reserve(sizeof(UttDesc) * n_utt))) return rc;
+	if ((rc = d->cnt.reserve(sizeof(uint32_t) * total))) return rc;
+	if ((rc = d->off.reserve(sizeof(uint64_t) * total))) return rc;
+	if ((rc = d->ap0.reserve(sizeof(double) * total))) return rc;
+	if ((rc = d->endpos.reserve(sizeof(uint64_t) * n_utt))) return rc;
+	if ((rc = d->endpos2.reserve(sizeof(uint64_t) * n_utt))) return rc;
+	if ((rc = d->h_stage.reserve(sizeof(UttDesc) * n_utt + sizeof(uint64_t) * n_utt))) return rc;
+	std::memcpy(d->h_stage.p, utts.data(), sizeof(UttDesc) * n_utt);
+	WC_HIP(hipMemcpyAsync(d->utts.p, d->h_stage.p, sizeof(UttDesc) * n_utt, hipMemcpyHostToDevice, s));
+	const unsigned grid1 = (unsigned)((total + 255) / 256);
+	hipLaunchKernelGGL(d4c_lt_count_kernel, dim3(grid1), dim3(256), 0, s, d_f0, total, d->fs, d->cnt.as<uint32_t>());
+	hipLaunchKernelGGL(utt_scan_kernel, dim3(n_utt), dim3(256), 0, s, d->cnt.as<uint32_t>(), d->utts.as<UttDesc>(),
+					   (const unsigned long long *)nullptr, d->off.as<unsigned long long>(), d->endpos.as<unsigned long long>());
+	D4cArgs a;
+	a.x = d_x; a.utts = d->utts.as<UttDesc>(); a.n_utt = n_utt; a.tpos = d_tpos; a.f0 = d_f0;
+	a.rng_off = d->off.as<unsigned long long>(); a.rng_table = dev->rng_table.as<uint32_t>(); a.rng_base = dev->rng_base;
+	a.tw = dev->twiddle; a.ap = d_ap; a.ap0 = d->ap0.as<double>(); a.cnt = d->cnt.as<uint32_t>();
+	a.nuttall = d->nuttall.as<double>(); a.total_frames = total; a.fs = d->fs; a.fft_size_out = fft_size;
+	a.n_ap = d->n_ap; a.window_length = d->window_length; a.threshold = d->threshold;
+	if ((rc = dev->time_begin("d4c_lovetrain"))) return rc;
+	switch (d->fft_size_lt) {
+		case 1024: launch_lt<1024>(a, s); break;
+		case 2048: launch_lt<2048>(a, s); break;
+		case 4096: launch_lt<4096>(a, s); break;
+		default: return fail(WC_ERR_UNSUPPORTED, "d4c: unsupported LoveTrain FFT size (fs must be 8..48 kHz)");
+	}
+	WC_HIP(hipGetLastError());
+	if ((rc = dev->time_end("d4c_lovetrain"))) return rc;
+	// offsets of the main pass start where the LoveTrain draws of the utterance end
+	hipLaunchKernelGGL(utt_scan_kernel, dim3(n_utt), dim3(256), 0, s, d->cnt.as<uint32_t>(), d->utts.as<UttDesc>(),
+					   d->endpos.as<unsigned long long>(), d->off.as<unsigned long long>(), d->endpos2.as<unsigned long long>());
+	if ((rc = dev->time_begin("d4c_frames"))) return rc;
+	switch (d->fft_size_d4c) {
+		case 1024: launch_main<1024>(a, s); break;
+		case 2048: launch_main<2048>(a, s); break;
+		case 4096: launch_main<4096>(a, s); break;
+		default: return fail(WC_ERR_UNSUPPORTED, "d4c: unsupported FFT size (fs must be 8..48 kHz)");
+	}
+	WC_HIP(hipGetLastError());
+	if ((rc = dev->time_end("d4c_frames"))) return rc;
+	if (rng_pos) {
+		uint64_t *h_end = reinterpret_cast<uint64_t *>(static_cast<char *>(d->h_stage.p) + sizeof(UttDesc) * n_utt);
+		WC_HIP(hipMemcpyAsync(h_end, d->endpos2.p, sizeof(uint64_t) * n_utt, hipMemcpyDeviceToHost, s));
+		WC_HIP(hipStreamSynchronize(s));
+		for (int u = 0; u < n_utt; ++u) rng_pos[u] = h_end[u];
+	}
+	return WC_OK;
+}
+
+extern "C" {
+
+wc_d4c *wc_d4c_create(int fs, double threshold) {
+	if (fs <= 0) { set_error("d4c: fs must be positive"); return nullptr; }
+	Device *dev = current_device();
+	if (!dev) return nullptr;
+	wc_d4c *d = new wc_d4c();
+	d->fs = fs;
+	d->threshold = threshold;
+	d->dev = dev;
+	// reference src/d4c.cpp:60-111
+	d->fft_size_d4c = static_cast<int>(std::pow(2.0, 1.0 + static_cast<int>(std::log(4.0 * fs / 47.0 + 1) / 0.69314718055994529)));
+	d->n_ap = static_cast<int>(std::fmin(15000.0, fs / 2.0 - 3000.0) / 3000.0);
+	d->window_length = static_cast<int>(3000.0 * d->fft_size_d4c / fs) * 2 + 1;
+	d->fft_size_lt = static_cast<int>(std::pow(2.0, 1.0 + static_cast<int>(std::log(3.0 * fs / 40.0 + 1) / 0.69314718055994529)));
+	if (d->n_ap < 0) d->n_ap = 0;
+	if (d->n_ap > kMaxBands || (d->fft_size_d4c != 1024 && d->fft_size_d4c != 2048 && d->fft_size_d4c != 4096) ||
+		(d->fft_size_lt != 1024 && d->fft_size_lt != 2048 && d->fft_size_lt != 4096)) {
+		set_error("d4c: unsupported sampling rate (supported: 8 kHz .. 48 kHz)");
+		delete d;
+		return nullptr;
+	}
+	std::vector<double> win(d->window_length);
+	for (int i = 0; i < d->window_length; ++i) {  // NuttallWindow, reference src/world_common.cpp:118-126
+		double t = i / (d->window_length - 1.0);
+		win[i] = 0.355768 - 0.487396 * std::cos(2.0 * 3.1415926535897932384 * t) +
+				 0.144232 * std::cos(4.0 * 3.1415926535897932384 * t) - 0.012604 * std::cos(6.0 * 3.1415926535897932384 * t);
+	}
+	if (d->nuttall.reserve(sizeof(double) * win.size()) ||
+		hipMemcpy(d->nuttall.p, win.data(), sizeof(double) * win.size(), hipMemcpyHostToDevice) != hipSuccess) {
+		set_error("d4c: window upload failed");
+		delete d;
+		return nullptr;
+	}
+	return d;
+}
+void wc_d4c_destroy(wc_d4c *d) {
+	if (!d) return;
+	(void)hipStreamSynchronize(d->dev->stream);
+	d->nuttall.release(); d->utts.release(); d->cnt.release(); d->off.release(); d->endpos.release(); d->endpos2.release();
+	d->ap0.release(); d->d_x.release(); d->d_tpos.release(); d->d_f0.release(); d->d_ap.release(); d->h_stage.release();
+	delete d;
+}
+
+int wc_d4c_compute_device(wc_d4c *d, int n_utt, const double *d_x, const int *x_length, const double *d_tpos,
+						  const double *d_f0, const int *f0_length, int fft_size, double *d_ap, uint64_t *rng_pos) {
+	if (!d || n_utt <= 0 || !d_x || !x_length || !d_tpos || !d_f0 || !f0_length || !d_ap)
+		return fail(WC_ERR_INVALID, "d4c: null argument");
+	WC_HIP(hipSetDevice(d->dev->id));
+	return d4c_run_device(d, n_utt, d_x, x_length, d_tpos, d_f0, f0_length, fft_size, d_ap, rng_pos);
+}
+
+int wc_d4c_compute(wc_d4c *d, const double *x, int x_length, const double *temporal_positions, const double *f0,
+				   int f0_length, int fft_size, double **aperiodicity) {
+	if (!d || !x || !temporal_positions || !f0 || !aperiodicity) return fail(WC_ERR_INVALID, "d4c: null argument");
+	if (x_length <= 0 || f0_length < 0) return fail(WC_ERR_INVALID, "d4c: bad length");
+	if (f0_length == 0) return WC_OK;
+	WC_HIP(hipSetDevice(d->dev->id));
+	hipStream_t s = d->dev->stream;
+	const int bins = fft_size / 2 + 1;
+	int rc;
+	if ((rc = d->d_x.reserve(sizeof(double) * x_length))) return rc;
+	if ((rc = d->d_tpos.reserve(sizeof(double) * f0_length))) return rc;
+	if ((rc = d->d_f0.reserve(sizeof(double) * f0_length))) return rc;
+	if ((rc = d->d_ap.reserve(sizeof(double) * (size_t)f0_length * bins))) return rc;
+	WC_HIP(hipMemcpyAsync(d->d_x.p, x, sizeof(double) * x_length, hipMemcpyHostToDevice, s));
+	WC_HIP(hipMemcpyAsync(d->d_tpos.p, temporal_positions, sizeof(double) * f0_length, hipMemcpyHostToDevice, s));
+	WC_HIP(hipMemcpyAsync(d->d_f0.p, f0, sizeof(double) * f0_length, hipMemcpyHostToDevice, s));
+	uint64_t pos = global_rng_position();
+	rc = d4c_run_device(d, 1, d->d_x.as<double>(), &x_length, d->d_tpos.as<double>(), d->d_f0.as<double>(), &f0_length,
+						fft_size, d->d_ap.as<double>(), &pos);
+	if (rc) return rc;
+	global_rng_position() = pos;
+	std::vector<double> host((size_t)f0_length * bins);
+	WC_HIP(hipMemcpyAsync(host.data(), d->d_ap.p, sizeof(double) * host.size(), hipMemcpyDeviceToHost, s));
+	WC_HIP(hipStreamSynchronize(s));
+	for (int i = 0; i < f0_length; ++i) std::memcpy(aperiodicity[i], &host[(size_t)i * bins], sizeof(double) * bins);
+	return WC_OK;
+}
+
+}  // extern "C"
