@@ -33,6 +33,7 @@ const double kUpperLimit = 15000.0;
 const double kFloorF0D4C = 47.0;
 
 int g_threads = 0;
+int g_only_pulse = -1;  // debugging aid: synthesise only this pulse (-1 = all)
 
 // ------------------------------------------------------------------------------------------
 // RNG: xorshift128, one shift-only step then 12 full steps per draw
@@ -740,6 +741,7 @@ static void synthesis(const double *f0, int L, const double *sp, const double *a
 		if (g_threads > 0) { rng_seek(local, st[i]); r = &local; }
 		double *rp = g_threads > 0 ? resp.data() + static_cast<size_t>(N) * i : resp.data();
 		synth_pulse(sp, ap, L, N, fs, fp, P.vuv[P.index[i]], ns[i], P.time[i], P.shift[i], dcr.data(), *r, rp);
+		if (g_only_pulse >= 0 && i != g_only_pulse) continue;
 		if (g_threads > 0) continue;
 		int index = P.index[i] - N / 2;  // overlap-add (:156-168)
 		if (index + N < 0 || index + 1 >= out_len) continue;
@@ -1240,6 +1242,7 @@ void wco_minimum_phase(int n, const double *log_spectrum, double *out) {
 	for (int i = 0; i <= n / 2; ++i) { out[2 * i] = m[i].real(); out[2 * i + 1] = m[i].imag(); }
 }
 void wco_set_threads(int threads) { g_threads = threads; }
+void wco_debug_only_pulse(int p) { g_only_pulse = p; }
 int wco_get_samples(int fs, int x_length, double frame_period) { return get_samples(fs, x_length, frame_period); }
 void wco_harvest(const double *x, int x_length, int fs, double f0_floor, double f0_ceil, double frame_period,
 				 double *tpos, double *f0) { harvest(x, x_length, fs, f0_floor, f0_ceil, frame_period, tpos, f0); }

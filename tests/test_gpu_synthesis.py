@@ -1,0 +1,84 @@
+"""-m gpu parity tests of the HIP Synthesis path (through the C-ABI): golden waveforms from the real
+reference (exact noise stream position included) and the CPU oracle on seeded inputs."""
+import numpy as np
+import pytest
+
+from world_class_amd.synth import make_utterance
+
+pytestmark = pytest.mark.gpu
+
+# waveform parity, absolute (signals are O(0.5)); SURVEY.md section 8(c) proposes 1e-8 with exact RNG
+Y_ABS = 1e-8
+
+
+@pytest.fixture(scope="module")
+def wca():
+    import world_class_amd as w
+    w.lib()
+    return w
+
+
+def test_synthesis_only_golden(golden, wca):
+    from oracle.gen_golden import synth_params
+    m = golden.meta["synth_only"]
+    f0, sp, ap = synth_params(m["fs"], m["fft_size"], m["n_frames"], m["seed"])
+    s = wca.Synthesis(m["fs"], m["fft_size"], m["frame_period"])
+    wca.rng_set_position(0)
+    y = s.compute(f0, sp, ap)
+    assert np.abs(y - golden["synth_only/y"]).max() < Y_ABS
+
+
+@pytest.mark.parametrize("fs,sec,seed,fp", [(16000, 1.0, 41, 5.0), (48000, 0.6, 42, 5.0), (24000, 0.5, 5006, 1.0),
+                                           (8000, 0.5, 43, 5.0)])
+def test_synthesis_vs_oracle(wca, port, fs, sec, seed, fp):
+    x = make_utterance(fs, sec, seed)
+    r = port.pipeline(x, fs, frame_period=fp)
+    n = (r["sp"].shape[1] - 1) * 2
+    s = wca.Synthesis(fs, n, fp)
+    start = 31337
+    port.rng_seek(start)
+    ref = port.synthesis(r["f0"], r["sp"], r["ap"], fs, fp)
+    end = port.rng_position()
+    wca.rng_set_position(start)
+    y = s.compute(r["f0"], r["sp"], r["ap"])
+    assert wca.rng_get_position() == end
+    assert np.abs(y - ref).max() < Y_ABS
+    port.rng_reset()
+
+
+def test_synthesis_batch_ragged_and_unvoiced(wca, port):
+    fs, n = 16000, 1024
+    from oracle.gen_golden import synth_params
+    cases = []
+    for i, nfr in enumerate((40, 101, 7)):
+        f0, sp, ap = synth_params(fs, n, nfr, 600 + i)
+        cases.append((f0, sp, ap))
+    # an all-unvoiced utterance (the reference divides by max_f0 == 0 here; we define it as noise only)
+    f0, sp, ap = synth_params(fs, n, 30, 610)
+    cases.append((np.zeros_like(f0), sp, np.full_like(ap, 1.0 - 1e-12)))
+    s = wca.Synthesis(fs, n, 5.0)
+    start = [0, 10, 0, 5]
+    ys, pos = s.compute_batch([c[0] for c in cases], [c[1] for c in cases], [c[2] for c in cases], rng_pos=start)
+    for (f0, sp, ap), y, p0, p1 in zip(cases, ys, start, pos):
+        port.rng_seek(p0)
+        ref = port.synthesis(f0, sp, ap, fs, 5.0)
+        assert port.rng_position() == p1
+        assert np.abs(y - ref).max() < Y_ABS
+    port.rng_reset()
+
+
+def test_synthesis_short_output_and_errors(wca, port):
+    fs, n = 16000, 1024
+    from oracle.gen_golden import synth_params
+    f0, sp, ap = synth_params(fs, n, 20, 620)
+    s = wca.Synthesis(fs, n, 5.0)
+    for out_len in (1, 100, 3000):  # shorter than / longer than the contour
+        wca.rng_set_position(0)
+        port.rng_reset()
+        y = s.compute(f0, sp, ap, out_length=out_len)
+        assert np.abs(y - port.synthesis(f0, sp, ap, fs, 5.0, out_length=out_len)).max() < Y_ABS
+    with pytest.raises(wca.WorldClassError):
+        s.compute(f0[:1], sp[:1], ap[:1])
+    with pytest.raises(wca.WorldClassError):
+        wca.Synthesis(fs, 1000, 5.0)
+    port.rng_reset()

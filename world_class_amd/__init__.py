@@ -286,3 +286,6 @@ class D4C:
                 self._h = None
         except Exception:
             pass
+
+
+from ._synthesis import Synthesis  # noqa: E402,F401

@@ -1,0 +1,59 @@
+"""Synthesis stage wrapper (reference include/synthesis.hpp:29-51) over the C-ABI."""
+import ctypes as C
+
+import numpy as np
+
+from . import (DeviceArray, _c, _check, _handle, _ints, _p, _ptr, _rng_arg, _rows, lib,
+               synthesis_out_length)
+
+
+class Synthesis:
+    """Synthesis(fs, fft_size, frame_period_ms); compute(f0, spectrogram, aperiodicity, out_length)"""
+
+    def __init__(self, fs, fft_size, frame_period=5.0):
+        self.fs, self.fft_size, self.frame_period = fs, fft_size, frame_period
+        self.bins = fft_size // 2 + 1
+        self._h = _handle(lib().wc_synthesis_create(fs, fft_size, frame_period))
+
+    def out_length(self, f0_length):
+        return synthesis_out_length(f0_length, self.frame_period, self.fs)  # reference test/test.cpp:362-363
+
+    def compute(self, f0, spectrogram, aperiodicity, out_length=None):
+        f = _c(f0)
+        sp, ap = _c(spectrogram), _c(aperiodicity)
+        if out_length is None:
+            out_length = self.out_length(len(f))
+        out = np.zeros(out_length)
+        _check(lib().wc_synthesis_compute(self._h, _p(f), len(f), _rows(sp), _rows(ap), out_length, _p(out)))
+        return out
+
+    def compute_device(self, d_f0, f0_lengths, d_sp, d_ap, out_lengths, d_out, rng_pos=None):
+        n = len(f0_lengths)
+        arr, arg = _rng_arg(rng_pos, n)
+        _check(lib().wc_synthesis_compute_device(self._h, n, _ptr(d_f0), _ints(f0_lengths), _ptr(d_sp), _ptr(d_ap),
+                                                 _ints(out_lengths), _ptr(d_out), arg))
+        return list(arr) if arr is not None else None
+
+    def compute_batch(self, f0s, sps, aps, out_lengths=None, rng_pos=None):
+        fl = [len(v) for v in f0s]
+        if out_lengths is None:
+            out_lengths = [self.out_length(n) for n in fl]
+        d_f = DeviceArray.from_host(np.concatenate([_c(v) for v in f0s]))
+        d_sp = DeviceArray.from_host(np.concatenate([_c(v) for v in sps]))
+        d_ap = DeviceArray.from_host(np.concatenate([_c(v) for v in aps]))
+        d_y = DeviceArray(sum(out_lengths))
+        pos = self.compute_device(d_f, fl, d_sp, d_ap, out_lengths, d_y, rng_pos)
+        y = d_y.to_host()
+        out, o = [], 0
+        for n in out_lengths:
+            out.append(y[o:o + n])
+            o += n
+        return (out, pos) if rng_pos is not None else out
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().wc_synthesis_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass

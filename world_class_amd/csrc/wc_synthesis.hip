@@ -1,0 +1,654 @@
+// Pulse-by-pulse overlap-add synthesis on gfx950.
+//
+// Restates reference src/synthesis.cpp:77-530 and MinimumPhaseAnalysis of
+// src/world_common.cpp:196-233.
+//   syn_timebase_kernel  one workgroup per utterance walks the output samples in chunks: sample-rate
+//                        F0 / VUV interpolation (reference :180-243), phase accumulation as a
+//                        chunked block prefix sum (the reference's running sum, :245-288), wrap
+//                        detection and an ordered stream compaction of the pulses
+//   syn_pulse_kernel     one workgroup per pulse (reference :308-530): sp/ap row blend, two
+//                        minimum-phase analyses (r2c + c2c in LDS), fractional delay, DC removal,
+//                        noise excitation from the exact stream position, overlap-add with FP64
+//                        atomics (reference :118-139)
+// The sum order of the phase accumulation and of the overlap-add differs from the reference's
+// sequential loops (documented in DESIGN.md); everything else is the same arithmetic.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "wc_device.hpp"
+#include "wc_internal.hpp"
+#include "wc_frames.hpp"
+
+namespace wc {
+
+constexpr double kSafe = 0.000000000001;
+
+struct PulseBuf {
+	int *index;       // sample index of the pulse
+	double *shift;    // fractional time shift (s)
+	int *noise_size;  // samples to the next pulse (0 for the last pulse)
+	int *vuv;         // interpolated VUV at the pulse
+};
+
+struct TbArgs {
+	const UttDesc *utts;
+	const double *f0;          // packed frames
+	const long long *cap_off;  // per-utterance first slot in the pulse arrays
+	const int *cap;            // per-utterance capacity
+	PulseBuf p;
+	int *count;                // per-utterance number of pulses (may exceed cap: overflow)
+	int *first_index;          // per-utterance index of the first pulse (for RNG offsets)
+	int fs, fft_size;
+	double frame_period;       // seconds
+};
+
+// interp1 of a coarse contour given on the uniform axis j * fp (j = 0 .. L) at time t, with the
+// reference's histc semantics (reference src/world_matlabfunctions.cpp:136-182): k = clamp(#{j : j fp <= t}, 1, L)
+struct Coarse {
+	const double *f0;
+	int L;
+	double lowest_f0, fp;
+	__device__ __forceinline__ double cf_in(int j) const {  // reference :232-236
+		double v = f0[j];
+		return (v < lowest_f0) ? 0.0 : v;
+	}
+	__device__ __forceinline__ double cv_in(int j) const { return (cf_in(j) == 0.0) ? 0.0 : 1.0; }
+	// one extrapolated point at j == L (reference :239-242)
+	__device__ __forceinline__ double cf(int j) const { return j < L ? cf_in(j) : cf_in(L - 1) * 2 - cf_in(L - 2); }
+	__device__ __forceinline__ double cv(int j) const { return j < L ? cv_in(j) : cv_in(L - 1) * 2 - cv_in(L - 2); }
+	__device__ __forceinline__ void at(double t, double &f, double &v) const {
+		int j = (int)(t / fp);
+		j = max(0, min(j, L));
+		while (j < L && t >= (j + 1) * fp) ++j;
+		while (j > 0 && t < j * fp) --j;
+		int k = min(max(j + 1, 1), L);
+		double x0 = (k - 1) * fp, x1 = k * fp;
+		double s = (t - x0) / (x1 - x0);
+		double f_a = cf(k - 1), f_b = cf(k), v_a = cv(k - 1), v_b = cv(k);
+		f = f_a + s * (f_b - f_a);
+		v = v_a + s * (v_b - v_a);
+	}
+};
+
+// Phase increment of every output sample (reference :211-216, :255-262): 2 pi f0_i / fs with the
+// sample-rate F0 (500 Hz where the interpolated VUV is <= 0.5).  Stored into the output buffer itself
+// (it is cleared again before the overlap-add); the sign carries the VUV: negative = unvoiced.
+__global__ void syn_increment_kernel(TbArgs a, int n_utt, long long total_out, double *__restrict__ inc) {
+	long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= total_out) return;
+	int lo = 0, hi = n_utt - 1;
+	while (lo < hi) {
+		int mid = (lo + hi + 1) >> 1;
+		if (a.utts[mid].y_off <= g) lo = mid; else hi = mid - 1;
+	}
+	const UttDesc ud = a.utts[lo];
+	const int i = (int)(g - ud.y_off);
+	Coarse co{a.f0 + ud.f_off, ud.f_len, a.fs / a.fft_size + 1.0, a.frame_period};  // integer division (reference :97)
+	double f, v;
+	co.at(i / (double)a.fs, f, v);
+	const bool voiced = v > 0.5;
+	f = voiced ? f : 500.0;
+	const double cval = 2.0 * kPi / a.fs;
+	const double d = f * cval;
+	inc[g] = voiced ? d : -d;
+}
+
+// One wavefront per utterance.  The reference accumulates the phase with a sequential running sum
+// (reference :255-262) and places a pulse wherever the wrapped phase jumps by more than pi.  During
+// unvoiced stretches (500 Hz) at the usual sampling rates the phase hits multiples of 2 pi exactly at
+// sample instants, so the pulse positions depend on the rounding of that very sum: a re-associated
+// (parallel) prefix sum moves pulses by one sample.  The sum is therefore evaluated in the
+// reference's order -- every lane runs the same 64-step dependent chain on values broadcast with
+// v_readlane -- and only the wrap / compare / compaction part is lane-parallel.
+__global__ __launch_bounds__(64) void syn_timebase_kernel(TbArgs a, const double *__restrict__ inc_all) {
+	const UttDesc ud = a.utts[blockIdx.x];
+	const int lane = threadIdx.x;
+	const int n = ud.y_len;
+	const double *__restrict__ inc_g = inc_all + ud.y_off;
+	const double two_pi = 2.0 * kPi;
+	const long long slot0 = a.cap_off[blockIdx.x];
+	const int cap = a.cap[blockIdx.x];
+	double run = 0.0;        // total phase so far (identical in every lane)
+	double prev_wrap = 0.0;  // wrapped phase / VUV of the previous sample
+	double prev_vu = 0.0;
+	int n_pulses = 0;
+	double nxt = (lane < n) ? inc_g[lane] : 0.0;
+	for (int base = 0; base < n; base += 64) {
+		const int i = base + lane;
+		const double sv = nxt;
+		{  // prefetch the next chunk while the serial chain runs
+			int j = i + 64;
+			nxt = (j < n) ? inc_g[j] : 0.0;
+		}
+		const double vu = sv > 0.0 ? 1.0 : 0.0;
+		const double inc = fabs(sv);
+		double mine = 0.0;
+#pragma unroll
+		for (int k = 0; k < 64; ++k) {
+			double v = __shfl(inc, k, 64);
+			run = run + v;
+			if (lane == k) mine = run;
+		}
+		const double wrap = fmod(mine, two_pi);
+		double w_prev = __shfl_up(wrap, 1, 64);
+		double v_prev = __shfl_up(vu, 1, 64);
+		if (lane == 0) { w_prev = prev_wrap; v_prev = prev_vu; }
+		// pulse between samples i-1 and i  <=>  |wrap[i] - wrap[i-1]| > pi ; the pulse sits at i-1
+		const bool is_pulse = (i < n) && (i >= 1) && (fabs(wrap - w_prev) > kPi);
+		const unsigned long long mask = __ballot(is_pulse);
+		if (is_pulse) {
+			const int slot = n_pulses + __popcll(mask & ((1ull << lane) - 1ull));
+			if (slot < cap) {
+				const double y1 = w_prev - two_pi, y2 = wrap;
+				const double xx = -y1 / (y2 - y1);
+				a.p.index[slot0 + slot] = i - 1;
+				a.p.shift[slot0 + slot] = xx / a.fs;
+				a.p.vuv[slot0 + slot] = v_prev > 0.5 ? 1 : 0;
+			}
+		}
+		n_pulses += __popcll(mask);
+		prev_wrap = __shfl(wrap, 63, 64);
+		prev_vu = __shfl(vu, 63, 64);
+	}
+	if (lane == 0) a.count[blockIdx.x] = n_pulses;
+}
+
+// noise_size of every pulse and the first pulse index of the utterance
+__global__ void syn_noise_size_kernel(const long long *__restrict__ cap_off, const int *__restrict__ count,
+									  const int *__restrict__ cap, PulseBuf p, int *__restrict__ first_index,
+									  int *__restrict__ last_index) {
+	const int u = blockIdx.y;
+	const int np = min(count[u], cap[u]);
+	const long long s0 = cap_off[u];
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		first_index[u] = np > 0 ? p.index[s0] : 0;
+		last_index[u] = np > 0 ? p.index[s0 + np - 1] : 0;
+	}
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < np; i += gridDim.x * blockDim.x) {
+		int nxt = p.index[s0 + min(np - 1, i + 1)];
+		p.noise_size[s0 + i] = nxt - p.index[s0 + i];
+	}
+}
+
+struct SynArgs {
+	const UttDesc *utts;
+	int n_utt;
+	const long long *pulse_prefix;  // exclusive prefix of the per-utterance pulse counts (n_utt + 1)
+	const long long *cap_off;
+	const int *first_index;
+	PulseBuf p;
+	const double *f0, *sp, *ap;
+	const uint32_t *rng_table;
+	unsigned long long rng_base;
+	const double2 *tw;
+	const double *dc_remover;
+	double *out;
+	long long total_pulses;
+	long long only_pulse;  // debugging aid (env WC_DEBUG_ONLY_PULSE): synthesise only this pulse, -1 = all
+	int fs;
+	double frame_period;
+};
+
+// MinimumPhaseAnalysis::compute (reference src/world_common.cpp:196-233) for the block.
+// ls[BPT]: log spectrum of this thread's bins k = tid + e T (k <= M).  On return A[0..M] holds the
+// minimum-phase spectrum (full complex, M+1 entries).  Ends with a __syncthreads().
+template <int N, int T>
+__device__ __forceinline__ void minimum_phase_lds(double2 *A, const double (&ls)[(N / 2 + T) / T],
+												  const double2 *__restrict__ tw, int tid) {
+	constexpr int M = N / 2;
+	constexpr int BPT = (M + T) / T;
+	double *Ar = reinterpret_cast<double *>(A);
+#pragma unroll
+	for (int e = 0; e < BPT; ++e) {
+		int k = tid + e * T;
+		if (k <= M) {
+			Ar[k] = ls[e];
+			if (k > 0 && k < M) Ar[N - k] = ls[e];  // mirroring (reference :199-200)
+		}
+	}
+	__syncthreads();
+	fft_lds<M, T, +1>(A, tw, tid);
+	r2c_post<M, T>(A, tw, tid);
+	// cepstrum folding (reference :207-217): bins 1..M-1 doubled and conjugated, upper half zeroed
+	double2 c[BPT];
+#pragma unroll
+	for (int e = 0; e < BPT; ++e) {
+		int k = tid + e * T;
+		c[e] = make_double2(0.0, 0.0);
+		if (k == 0) c[e] = make_double2(A[0].x, 0.0);
+		else if (k == M) c[e] = make_double2(A[0].y, 0.0);
+		else if (k < M) c[e] = make_double2(A[k].x * 2.0, A[k].y * -2.0);
+	}
+	__syncthreads();
+#pragma unroll
+	for (int e = 0; e < BPT; ++e) {
+		int k = tid + e * T;
+		if (k <= M) A[k] = c[e];
+		if (k >= 1 && k < M) A[M + k] = make_double2(0.0, 0.0);
+	}
+	__syncthreads();
+	fft_lds<N, T, +1>(A, tw, tid);
+#pragma unroll
+	for (int e = 0; e < BPT; ++e) {
+		int k = tid + e * T;
+		if (k <= M) {
+			double2 m = A[k];
+			double t = exp(m.x / N);
+			c[e] = make_double2(t * cos(m.y / N), t * sin(m.y / N));
+		}
+	}
+	__syncthreads();
+#pragma unroll
+	for (int e = 0; e < BPT; ++e) {
+		int k = tid + e * T;
+		if (k <= M) A[k] = c[e];
+	}
+	__syncthreads();
+}
+
+__device__ __forceinline__ double safe_ap(double v) { return fmax(0.001, fmin(0.999999999999, v)); }
+
+template <int N, int T>
+__global__ __launch_bounds__(T) void syn_pulse_kernel(SynArgs a) {
+	constexpr int M = N / 2;
+	constexpr int BPT = (M + T) / T;  // bins per thread (k <= M)
+	constexpr int EPT = N / T;        // time samples per thread
+	__shared__ double2 A[N];
+	__shared__ double red[2 * (T / 64) + 2];
+	double *Ar = reinterpret_cast<double *>(A);
+	const int tid = threadIdx.x;
+	const long long gp = blockIdx.x;
+	if (gp >= a.total_pulses) return;
+	if (a.only_pulse >= 0 && gp != a.only_pulse) return;
+	// utterance of this pulse
+	int lo = 0, hi = a.n_utt - 1;
+	while (lo < hi) {
+		int mid = (lo + hi + 1) >> 1;
+		if (a.pulse_prefix[mid] <= gp) lo = mid; else hi = mid - 1;
+	}
+	const int u = lo;
+	const UttDesc ud = a.utts[u];
+	const long long slot = a.cap_off[u] + (gp - a.pulse_prefix[u]);
+	const int pidx = a.p.index[slot];
+	const double shift = a.p.shift[slot];
+	const int noise_size = a.p.noise_size[slot];
+	const double vuv = (double)a.p.vuv[slot];
+	const int fs = a.fs, L = ud.f_len;
+	const double fp = a.frame_period;
+	const double t = pidx / (double)fs;  // time_axis[ii] (reference :227)
+
+	// ---- spectral envelope / aperiodic ratio at the pulse (reference :346-393) ----
+	const int fl = min(L - 1, (int)floor(t / fp));
+	const int ce = min(L - 1, (int)ceil(t / fp));
+	const double ipol = t / fp - fl;
+	const double *__restrict__ sf = a.sp + (ud.f_off + fl) * (long long)(M + 1);
+	const double *__restrict__ sc = a.sp + (ud.f_off + ce) * (long long)(M + 1);
+	const double *__restrict__ af = a.ap + (ud.f_off + fl) * (long long)(M + 1);
+	const double *__restrict__ ac = a.ap + (ud.f_off + ce) * (long long)(M + 1);
+	double env[BPT], ar[BPT], ls[BPT];
+#pragma unroll
+	for (int e = 0; e < BPT; ++e) {
+		int k = tid + e * T;
+		env[e] = 1.0;
+		ar[e] = 0.5;
+		if (k <= M) {
+			if (fl == ce) {
+				env[e] = fabs(sf[k]);
+				double s = safe_ap(af[k]);
+				ar[e] = s * s;
+			} else {
+				env[e] = (1.0 - ipol) * fabs(sf[k]) + ipol * fabs(sc[k]);
+				double s = (1.0 - ipol) * safe_ap(af[k]) + ipol * safe_ap(ac[k]);
+				ar[e] = s * s;
+			}
+		}
+	}
+	// aperiodic_ratio[0] decides whether there is a periodic response (reference :410)
+	if (tid == 0) red[2 * (T / 64)] = ar[0];
+	__syncthreads();
+	const double ar0 = red[2 * (T / 64)];
+	__syncthreads();
+
+	// ---- periodic response (reference :403-474) ----
+	double periodic[EPT];
+#pragma unroll
+	for (int e = 0; e < EPT; ++e) periodic[e] = 0.0;
+	if (!(vuv <= 0.5 || ar0 > 0.999)) {
+#pragma unroll
+		for (int e = 0; e < BPT; ++e) ls[e] = log(env[e] * (1.0 - ar[e]) + kSafe) / 2.0;
+		minimum_phase_lds<N, T>(A, ls, a.tw, tid);
+		// fractional time shift (reference :443-457), then pack for c2r
+		const double coef = 2.0 * kPi * shift * fs / N;
+		double2 sp_[BPT];
+#pragma unroll
+		for (int e = 0; e < BPT; ++e) {
+			int k = tid + e * T;
+			sp_[e] = make_double2(0.0, 0.0);
+			if (k <= M) {
+				double2 m = A[k];
+				double re2 = cos(coef * k);
+				double im2 = sqrt(1.0 - re2 * re2);
+				sp_[e] = make_double2(m.x * re2 - m.y * im2, m.x * im2 + m.y * re2);
+			}
+		}
+		__syncthreads();
+#pragma unroll
+		for (int e = 0; e < BPT; ++e) {
+			int k = tid + e * T;
+			if (k > 0 && k < M) A[k] = sp_[e];
+			else if (k == 0) Ar[0] = sp_[e].x;   // A[0] = (Y[0].re, Y[M].re)
+			else if (k == M) Ar[1] = sp_[e].x;
+		}
+		__syncthreads();
+		c2r_pre<M, T>(A, a.tw, tid);
+		fft_lds<M, T, -1>(A, a.tw, tid);
+		// fftshift + DC removal (reference :459-474): dc = sum of the shifted second half = sum wave[0..M)
+		double part = 0.0;
+		for (int i = tid; i < M; i += T) part += Ar[i];
+		const double dc = block_sum<T>(part, red, tid);
+#pragma unroll
+		for (int e = 0; e < EPT; ++e) {
+			int j = tid + e * T;  // index in the shifted response
+			if (j < M) periodic[e] = -dc * a.dc_remover[j];
+			else periodic[e] = Ar[j - M] + (-dc * a.dc_remover[j - M]);
+		}
+		__syncthreads();
+	}
+
+	// ---- aperiodic response (reference :479-530) ----
+	{
+		const unsigned long long roff = ud.rng_pos + (unsigned long long)(pidx - a.first_index[u]) - a.rng_base;
+		double nz[EPT];
+		double s = 0.0;
+#pragma unroll
+		for (int e = 0; e < EPT; ++e) {
+			int i = tid + e * T;
+			nz[e] = 0.0;
+			if (i < noise_size) { nz[e] = randn_at(a.rng_table, roff + i); s += nz[e]; }
+		}
+		s = block_sum<T>(s, red, tid);
+		const double avg = s / noise_size;
+#pragma unroll
+		for (int e = 0; e < EPT; ++e) {
+			int i = tid + e * T;
+			Ar[i] = (i < noise_size) ? nz[e] - avg : 0.0;
+		}
+		__syncthreads();
+		fft_lds<M, T, +1>(A, a.tw, tid);
+		r2c_post<M, T>(A, a.tw, tid);
+		double2 ns[BPT];
+#pragma unroll
+		for (int e = 0; e < BPT; ++e) {
+			int k = tid + e * T;
+			ns[e] = make_double2(0.0, 0.0);
+			if (k == 0) ns[e] = make_double2(A[0].x, 0.0);
+			else if (k == M) ns[e] = make_double2(A[0].y, 0.0);
+			else if (k < M) ns[e] = A[k];
+		}
+		__syncthreads();
+		if (vuv != 0.0) {
+#pragma unroll
+			for (int e = 0; e < BPT; ++e) ls[e] = log(env[e] * ar[e]) / 2.0;
+		} else {
+#pragma unroll
+			for (int e = 0; e < BPT; ++e) ls[e] = log(env[e]) / 2.0;
+		}
+		minimum_phase_lds<N, T>(A, ls, a.tw, tid);
+		double2 pr[BPT];
+#pragma unroll
+		for (int e = 0; e < BPT; ++e) {
+			int k = tid + e * T;
+			pr[e] = make_double2(0.0, 0.0);
+			if (k <= M) {
+				double2 m = A[k];
+				pr[e] = make_double2(m.x * ns[e].x - m.y * ns[e].y, m.x * ns[e].y + m.y * ns[e].x);
+			}
+		}
+		__syncthreads();
+#pragma unroll
+		for (int e = 0; e < BPT; ++e) {
+			int k = tid + e * T;
+			if (k > 0 && k < M) A[k] = pr[e];
+			else if (k == 0) Ar[0] = pr[e].x;
+			else if (k == M) Ar[1] = pr[e].x;
+		}
+		__syncthreads();
+		c2r_pre<M, T>(A, a.tw, tid);
+		fft_lds<M, T, -1>(A, a.tw, tid);
+	}
+	// ---- mix + overlap-add (reference :339-343, :118-139) ----
+	const double sq = sqrt((double)noise_size);
+	double *__restrict__ out = a.out + ud.y_off;
+	const int index = pidx - M;
+#pragma unroll
+	for (int e = 0; e < EPT; ++e) {
+		int j = tid + e * T;
+		double aper = (j < M) ? Ar[j + M] : Ar[j - M];  // fftshift
+		double r = (periodic[e] * sq + aper) / N;
+		int o = index + 1 + j;
+		if (o >= 0 && o < ud.y_len) atomicAdd(&out[o], r);
+	}
+}
+
+}  // namespace wc
+
+using namespace wc;
+
+struct wc_synthesis {
+	int fs, fft_size;
+	double frame_period;  // seconds
+	Device *dev;
+	DevBuf dc_remover, utts, meta, pulses, d_f0, d_sp, d_ap, d_out;
+	HostBuf h_stage;
+};
+
+template <int N>
+static void launch_pulses(const SynArgs &a, hipStream_t s) {
+	hipLaunchKernelGGL((syn_pulse_kernel<N, 256>), dim3((unsigned)a.total_pulses), dim3(256), 0, s, a);
+}
+
+static int syn_run_device(wc_synthesis *sy, int n_utt, const double *d_f0, const int *f0_length, const double *d_sp,
+						  const double *d_ap, const int *out_length, double *d_out, uint64_t *rng_pos) {
+	Device *dev = sy->dev;
+	hipStream_t s = dev->stream;
+	std::vector<UttDesc> utts(n_utt);
+	long long fo = 0, yo = 0;
+	uint64_t min_pos = ~0ull, max_end = 0;
+	for (int u = 0; u < n_utt; ++u) {
+		if (f0_length[u] < 2) return fail(WC_ERR_INVALID, "synthesis: f0_length must be at least 2 (reference src/synthesis.cpp:241-242)");
+		if (out_length[u] < 0) return fail(WC_ERR_INVALID, "synthesis: negative out_length");
+		UttDesc &t = utts[u];
+		t.x_off = 0; t.f_off = fo; t.y_off = yo; t.x_len = 0; t.f_len = f0_length[u]; t.y_len = out_length[u]; t.pad = 0;
+		t.rng_pos = rng_pos ? rng_pos[u] : 0ull;
+		fo += f0_length[u];
+		yo += out_length[u];
+		if (t.rng_pos < min_pos) min_pos = t.rng_pos;
+		uint64_t e = t.rng_pos + (uint64_t)out_length[u];
+		if (e > max_end) max_end = e;
+	}
+	const long long total_out = yo;
+	if (total_out == 0) return WC_OK;
+	int rc;
+	if ((rc = dev->ensure_rng(min_pos, max_end))) return rc;
+	// meta layout (device): cap_off[n] (i64) | pulse_prefix[n+1] (i64) | cap[n] | count[n] | first_index[n] | last_index[n]
+	const size_t meta_bytes = sizeof(long long) * (2 * (size_t)n_utt + 1) + sizeof(int) * 4 * (size_t)n_utt;
+	if ((rc = sy->utts.reserve(sizeof(UttDesc) * n_utt))) return rc;
+	if ((rc = sy->meta.reserve(meta_bytes))) return rc;
+	if ((rc = sy->h_stage.reserve(sizeof(UttDesc) * n_utt + meta_bytes))) return rc;
+	char *hs = static_cast<char *>(sy->h_stage.p);
+	std::memcpy(hs, utts.data(), sizeof(UttDesc) * n_utt);
+	long long *h_cap_off = reinterpret_cast<long long *>(hs + sizeof(UttDesc) * n_utt);
+	long long *h_prefix = h_cap_off + n_utt;
+	int *h_cap = reinterpret_cast<int *>(h_prefix + n_utt + 1);
+	int *h_count = h_cap + n_utt;
+	char *dm = static_cast<char *>(sy->meta.p);
+	long long *d_cap_off = reinterpret_cast<long long *>(dm);
+	long long *d_prefix = d_cap_off + n_utt;
+	int *d_cap = reinterpret_cast<int *>(d_prefix + n_utt + 1);
+	int *d_count = d_cap + n_utt;
+	int *d_first = d_count + n_utt;
+	int *d_last = d_first + n_utt;
+
+	bool full = false;
+	long long total_pulses = 0;
+	for (int attempt = 0; attempt < 2; ++attempt) {
+		long long co = 0;
+		for (int u = 0; u < n_utt; ++u) {
+			// pulses <= samples; normally f0 < fs / 10, so start with a tenth and retry with the bound
+			int cap = full ? out_length[u] + 1 : out_length[u] / 10 + 16;
+			h_cap_off[u] = co;
+			h_cap[u] = cap;
+			co += cap;
+		}
+		if ((rc = sy->pulses.reserve((size_t)co * (sizeof(int) * 3 + sizeof(double))))) return rc;
+		PulseBuf pb;
+		pb.shift = sy->pulses.as<double>();
+		pb.index = reinterpret_cast<int *>(pb.shift + co);
+		pb.noise_size = pb.index + co;
+		pb.vuv = pb.noise_size + co;
+		WC_HIP(hipMemcpyAsync(sy->utts.p, hs, sizeof(UttDesc) * n_utt, hipMemcpyHostToDevice, s));
+		WC_HIP(hipMemcpyAsync(d_cap_off, h_cap_off, sizeof(long long) * n_utt, hipMemcpyHostToDevice, s));
+		WC_HIP(hipMemcpyAsync(d_cap, h_cap, sizeof(int) * n_utt, hipMemcpyHostToDevice, s));
+		TbArgs ta;
+		ta.utts = sy->utts.as<UttDesc>(); ta.f0 = d_f0; ta.cap_off = d_cap_off; ta.cap = d_cap; ta.p = pb;
+		ta.count = d_count; ta.first_index = d_first; ta.fs = sy->fs; ta.fft_size = sy->fft_size;
+		ta.frame_period = sy->frame_period;
+		if ((rc = dev->time_begin("synthesis_timebase"))) return rc;
+		hipLaunchKernelGGL(syn_increment_kernel, dim3((unsigned)((total_out + 255) / 256)), dim3(256), 0, s, ta, n_utt,
+						   total_out, d_out);
+		hipLaunchKernelGGL(syn_timebase_kernel, dim3(n_utt), dim3(64), 0, s, ta, (const double *)d_out);
+		WC_HIP(hipGetLastError());
+		if ((rc = dev->time_end("synthesis_timebase"))) return rc;
+		WC_HIP(hipMemcpyAsync(h_count, d_count, sizeof(int) * n_utt, hipMemcpyDeviceToHost, s));
+		WC_HIP(hipStreamSynchronize(s));
+		bool overflow = false;
+		total_pulses = 0;
+		for (int u = 0; u < n_utt; ++u) {
+			if (h_count[u] > h_cap[u]) overflow = true;
+			h_prefix[u] = total_pulses;
+			total_pulses += h_count[u];
+		}
+		h_prefix[n_utt] = total_pulses;
+		if (!overflow) {
+			WC_HIP(hipMemsetAsync(d_out, 0, sizeof(double) * total_out, s));  // it held the phase increments
+			if (total_pulses > 0) {
+				hipLaunchKernelGGL(syn_noise_size_kernel, dim3(8, n_utt), dim3(256), 0, s, d_cap_off, d_count, d_cap, pb, d_first, d_last);
+				WC_HIP(hipMemcpyAsync(d_prefix, h_prefix, sizeof(long long) * (n_utt + 1), hipMemcpyHostToDevice, s));
+				SynArgs a;
+				a.utts = sy->utts.as<UttDesc>(); a.n_utt = n_utt; a.pulse_prefix = d_prefix; a.cap_off = d_cap_off;
+				a.first_index = d_first; a.p = pb; a.f0 = d_f0; a.sp = d_sp; a.ap = d_ap;
+				a.rng_table = dev->rng_table.as<uint32_t>(); a.rng_base = dev->rng_base; a.tw = dev->twiddle;
+				a.dc_remover = sy->dc_remover.as<double>(); a.out = d_out; a.total_pulses = total_pulses; a.fs = sy->fs;
+				a.frame_period = sy->frame_period;
+				{
+					const char *dbg = getenv("WC_DEBUG_ONLY_PULSE");
+					a.only_pulse = dbg ? atoll(dbg) : -1;
+				}
+				if ((rc = dev->time_begin("synthesis_pulses"))) return rc;
+				switch (sy->fft_size) {
+					case 512: launch_pulses<512>(a, s); break;
+					case 1024: launch_pulses<1024>(a, s); break;
+					case 2048: launch_pulses<2048>(a, s); break;
+					default: return fail(WC_ERR_UNSUPPORTED, "synthesis: fft_size must be 512, 1024 or 2048");
+				}
+				WC_HIP(hipGetLastError());
+				if ((rc = dev->time_end("synthesis_pulses"))) return rc;
+			}
+			break;
+		}
+		if (full) return fail(WC_ERR_DEVICE, "synthesis: pulse buffer overflow");
+		full = true;
+	}
+	if (rng_pos) {
+		// total draws = index_last - index_first (reference :106-107, :519-521)
+		std::vector<int> fl(2 * (size_t)n_utt, 0);
+		if (total_pulses > 0) {
+			WC_HIP(hipMemcpyAsync(fl.data(), d_first, sizeof(int) * 2 * n_utt, hipMemcpyDeviceToHost, s));
+			WC_HIP(hipStreamSynchronize(s));
+		}
+		for (int u = 0; u < n_utt; ++u) rng_pos[u] += (uint64_t)(fl[n_utt + u] - fl[u]);
+	}
+	return WC_OK;
+}
+
+extern "C" {
+
+wc_synthesis *wc_synthesis_create(int fs, int fft_size, double frame_period_ms) {
+	if (fs <= 0 || frame_period_ms <= 0) { set_error("synthesis: fs and frame_period must be positive"); return nullptr; }
+	if (fft_size != 512 && fft_size != 1024 && fft_size != 2048) {
+		set_error("synthesis: fft_size must be 512, 1024 or 2048");
+		return nullptr;
+	}
+	Device *dev = current_device();
+	if (!dev) return nullptr;
+	wc_synthesis *s = new wc_synthesis();
+	s->fs = fs;
+	s->fft_size = fft_size;
+	s->frame_period = frame_period_ms / 1000.;  // reference :31
+	s->dev = dev;
+	// getDCRemover, reference :290-303
+	std::vector<double> d(fft_size);
+	const double cv = 2.0 * 3.1415926535897932384 / (1.0 + fft_size);
+	for (int i = 0; i < fft_size / 2; ++i) d[i] = 0.5 - 0.5 * std::cos(cv * (i + 1.0));
+	double dc = 0.0;
+	for (int i = 0; i < fft_size / 2; ++i) dc += d[i];
+	dc *= 2;
+	for (int i = 0; i < fft_size / 2; ++i) { d[i] /= dc; d[fft_size - i - 1] = d[i]; }
+	if (s->dc_remover.reserve(sizeof(double) * fft_size) ||
+		hipMemcpy(s->dc_remover.p, d.data(), sizeof(double) * fft_size, hipMemcpyHostToDevice) != hipSuccess) {
+		set_error("synthesis: table upload failed");
+		delete s;
+		return nullptr;
+	}
+	return s;
+}
+void wc_synthesis_destroy(wc_synthesis *s) {
+	if (!s) return;
+	(void)hipStreamSynchronize(s->dev->stream);
+	s->dc_remover.release(); s->utts.release(); s->meta.release(); s->pulses.release();
+	s->d_f0.release(); s->d_sp.release(); s->d_ap.release(); s->d_out.release(); s->h_stage.release();
+	delete s;
+}
+
+int wc_synthesis_compute_device(wc_synthesis *s, int n_utt, const double *d_f0, const int *f0_length, const double *d_sp,
+								const double *d_ap, const int *out_length, double *d_out, uint64_t *rng_pos) {
+	if (!s || n_utt <= 0 || !d_f0 || !f0_length || !d_sp || !d_ap || !out_length || !d_out)
+		return fail(WC_ERR_INVALID, "synthesis: null argument");
+	WC_HIP(hipSetDevice(s->dev->id));
+	return syn_run_device(s, n_utt, d_f0, f0_length, d_sp, d_ap, out_length, d_out, rng_pos);
+}
+
+int wc_synthesis_compute(wc_synthesis *s, const double *f0, int f0_length, const double *const *spectrogram,
+						 const double *const *aperiodicity, int out_length, double *out) {
+	if (!s || !f0 || !spectrogram || !aperiodicity || !out) return fail(WC_ERR_INVALID, "synthesis: null argument");
+	if (f0_length < 2) return fail(WC_ERR_INVALID, "synthesis: f0_length must be at least 2");
+	if (out_length <= 0) return WC_OK;
+	WC_HIP(hipSetDevice(s->dev->id));
+	hipStream_t st = s->dev->stream;
+	const int bins = s->fft_size / 2 + 1;
+	int rc;
+	if ((rc = s->d_f0.reserve(sizeof(double) * f0_length))) return rc;
+	if ((rc = s->d_sp.reserve(sizeof(double) * (size_t)f0_length * bins))) return rc;
+	if ((rc = s->d_ap.reserve(sizeof(double) * (size_t)f0_length * bins))) return rc;
+	if ((rc = s->d_out.reserve(sizeof(double) * out_length))) return rc;
+	std::vector<double> hsp((size_t)f0_length * bins), hap((size_t)f0_length * bins);
+	for (int i = 0; i < f0_length; ++i) {
+		std::memcpy(&hsp[(size_t)i * bins], spectrogram[i], sizeof(double) * bins);
+		std::memcpy(&hap[(size_t)i * bins], aperiodicity[i], sizeof(double) * bins);
+	}
+	WC_HIP(hipMemcpyAsync(s->d_f0.p, f0, sizeof(double) * f0_length, hipMemcpyHostToDevice, st));
+	WC_HIP(hipMemcpyAsync(s->d_sp.p, hsp.data(), sizeof(double) * hsp.size(), hipMemcpyHostToDevice, st));
+	WC_HIP(hipMemcpyAsync(s->d_ap.p, hap.data(), sizeof(double) * hap.size(), hipMemcpyHostToDevice, st));
+	uint64_t pos = global_rng_position();
+	rc = syn_run_device(s, 1, s->d_f0.as<double>(), &f0_length, s->d_sp.as<double>(), s->d_ap.as<double>(), &out_length,
+						s->d_out.as<double>(), &pos);
+	if (rc) return rc;
+	global_rng_position() = pos;
+	WC_HIP(hipMemcpyAsync(out, s->d_out.p, sizeof(double) * out_length, hipMemcpyDeviceToHost, st));
+	WC_HIP(hipStreamSynchronize(st));
+	return WC_OK;
+}
+
+}  // extern "C"
