@@ -289,3 +289,4 @@ class D4C:
 
 
 from ._synthesis import Synthesis  # noqa: E402,F401
+from ._harvest import Harvest  # noqa: E402,F401

@@ -1,0 +1,64 @@
+"""Harvest stage wrapper (reference include/harvest.hpp:16-44) over the C-ABI."""
+import ctypes as C
+
+import numpy as np
+
+from . import DeviceArray, _c, _check, _handle, _ints, _p, _ptr, get_samples, lib
+
+
+class Harvest:
+    """HarvestOption defaults of reference src/harvest.cpp:52-56: f0_floor 71, f0_ceil 800, frame_period 5,
+    target_fs 8000, channels_in_octave 40, use_cos_table False (accepted, ignored)."""
+
+    def __init__(self, fs, f0_floor=71.0, f0_ceil=800.0, frame_period=5.0, target_fs=8000.0,
+                 channels_in_octave=40.0, use_cos_table=False):
+        self.fs, self.frame_period = fs, frame_period
+        self._h = _handle(lib().wc_harvest_create(fs, f0_floor, f0_ceil, frame_period, target_fs,
+                                                  channels_in_octave, int(use_cos_table)))
+
+    def get_samples(self, x_length):
+        return get_samples(self.fs, x_length, self.frame_period)
+
+    def compute(self, x):
+        x = _c(x)
+        n = self.get_samples(len(x))
+        tpos, f0 = np.zeros(n), np.zeros(n)
+        _check(lib().wc_harvest_compute(self._h, _p(x), len(x), _p(tpos), _p(f0)))
+        return tpos, f0
+
+    def compute_device(self, d_x, x_lengths, d_tpos, d_f0):
+        _check(lib().wc_harvest_compute_device(self._h, len(x_lengths), _ptr(d_x), _ints(x_lengths), _ptr(d_tpos),
+                                               _ptr(d_f0)))
+
+    def compute_batch(self, xs):
+        fl = [self.get_samples(len(x)) for x in xs]
+        d_x = DeviceArray.from_host(np.concatenate([_c(v) for v in xs]))
+        d_t, d_f = DeviceArray(sum(fl)), DeviceArray(sum(fl))
+        self.compute_device(d_x, [len(x) for x in xs], d_t, d_f)
+        t, f = d_t.to_host(), d_f.to_host()
+        out, o = [], 0
+        for n in fl:
+            out.append((t[o:o + n], f[o:o + n]))
+            o += n
+        return out
+
+    def debug_fetch(self, name, utt=0):
+        """Development hook: an intermediate of the most recent call (y, raw, cand0, cand1, cand, score, base,
+        s1, s2, s3, fixed, f0_1ms) as a flat float64 array."""
+        fn = lib().wc_harvest_debug_fetch
+        fn.restype = C.c_longlong
+        fn.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p]
+        n = fn(self._h, name.encode(), utt, None)
+        if n < 0:
+            _check(int(n))
+        out = np.zeros(n)
+        _check(min(0, int(fn(self._h, name.encode(), utt, out.ctypes.data))))
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().wc_harvest_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass

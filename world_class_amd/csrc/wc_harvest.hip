@@ -1,0 +1,1190 @@
+// Harvest F0 estimation on gfx950.
+//
+// Restates reference src/harvest.cpp:183-1453 (compute, generalBody and everything they reach) and
+// decimate/FilterForDecimate of src/world_matlabfunctions.cpp:27-125, :184-210 as a chain of kernels:
+//
+//   hv_decimate_kernel   zero-phase order-3 IIR decimation (reference :213-248).  The recursion is
+//                        split into independent chunks that warm up on the preceding samples (the
+//                        filter's impulse response is below 1e-20 after 768 samples), two passes.
+//   hv_dc_kernel         the reference's int-typed "DC removal" (:239) -- a no-op unless abs(y) >= 1
+//   hv_bandpass_kernel   one workgroup per (utterance, band): the band-pass of reference :1261-1305
+//                        evaluated as the equivalent linear FIR (<= 2*512+1 Nuttall*cos taps, register
+//                        tiled, signal tile + taps in LDS) fused with the four zero-crossing detectors
+//                        of :1179-1255; fine edge positions are stream-compacted in time order
+//   hv_raw_kernel        interp1 of the four interval series onto the 1 ms grid (:1098-1143)
+//   hv_detect_kernel     per-frame candidate detection over bands (:1005-1083)
+//   hv_refine_kernel     one wavefront per (frame, candidate): overlap (:987-1000) folded into the
+//                        gather, Blackman / differentiated windows, and -- instead of the reference's two
+//                        full FFTs -- direct DFTs of the <= 6 harmonic bins fixF0 reads (:809-927)
+//   hv_unreliable_kernel (:708-744)
+//   hv_contour_kernel    one wavefront per utterance walks the sequential contour logic
+//                        (:254-634: base contour, fixStep1..4, extend, merge) with the candidate
+//                        searches spread over the lanes
+//   hv_smooth_kernel     zero-lag Butterworth per voiced section, one lane per section (:639-703)
+//   hv_output_kernel     1 ms contour -> frame_period grid (:199-204)
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "wc_device.hpp"
+#include "wc_internal.hpp"
+#include "wc_frames.hpp"
+
+namespace wc {
+
+constexpr double kSafeH = 0.000000000001;
+constexpr double kLog2H = 0.69314718055994529;
+constexpr int HL_MAX = 512;       // longest supported half filter length (f0_floor >= ~35 Hz at 8 kHz)
+constexpr int BP_T = 256;         // threads of the band-pass workgroup
+constexpr int BP_R = 8;           // consecutive outputs per thread
+constexpr int BP_TILE = BP_T * BP_R;
+constexpr int BP_ADV = BP_TILE - 2;  // the detectors look two samples ahead
+constexpr int MAX_SLOTS = 32;     // candidates per frame before overlap (reference: round(bands/10))
+
+struct HvUtt {
+	long long x_off;     // samples
+	long long dec_off;   // scratch of the decimator (x_len + 2 lag + 18 per utterance)
+	long long y_off;     // decimated signal
+	long long l1_off;    // 1 ms frames
+	long long out_off;   // output frames
+	long long ev_off;    // first event slot of this utterance
+	int x_len, y_len, L1, L;
+};
+
+struct HvParams {
+	int fs, decim, n_bands, S, n_cand;  // S = slots per overlap block, n_cand = 7 S
+	double fs_d, f0_floor, f0_ceil, frame_period;
+};
+
+__device__ __forceinline__ int hv_find(const HvUtt *__restrict__ u, int n, long long v, long long HvUtt::*field) {
+	int lo = 0, hi = n - 1;
+	while (lo < hi) {
+		int mid = (lo + hi + 1) >> 1;
+		if (u[mid].*field <= v) lo = mid; else hi = mid - 1;
+	}
+	return lo;
+}
+
+// ------------------------------------------------------------------------------------------------
+// decimation
+// ------------------------------------------------------------------------------------------------
+struct DecCoef { double a0, a1, a2, b0, b1; };
+constexpr int DEC_CHUNK = 1024, DEC_WARM = 768;
+
+// pass 0: forward over the edge-padded input; pass 1: forward over the reversed pass-0 output, storing
+// only the samples the decimated signal keeps.  Index algebra of reference
+// src/world_matlabfunctions.cpp:184-210 and src/harvest.cpp:222-235.
+template <int PASS>
+__global__ void hv_decimate_kernel(const HvUtt *__restrict__ utts, const double *__restrict__ x, double *__restrict__ buf,
+								   double *__restrict__ y, DecCoef c, int r, int lag) {
+	const HvUtt u = utts[blockIdx.y];
+	const int nn = u.x_len + 2 * lag;
+	const int len = nn + 18;
+	const int chunk = blockIdx.x * blockDim.x + threadIdx.x;
+	const int k0 = chunk * DEC_CHUNK;
+	if (k0 >= len) return;
+	const int k1 = min(len, k0 + DEC_CHUNK);
+	const int ks = max(0, k0 - DEC_WARM);
+	const double *__restrict__ xin = x + u.x_off;
+	double *__restrict__ b = buf + u.dec_off;
+	double w0 = 0.0, w1 = 0.0, w2 = 0.0;
+	// output bookkeeping of pass 1
+	const int nout = nn / r + 1;
+	const int nbeg = r - r * nout + nn;
+	const int first = nbeg + (lag / r) * r + 8;  // index (original order) of y[0]
+#pragma unroll 4
+	for (int k = ks; k < k1; ++k) {
+		double v;
+		if (PASS == 0) v = xin[clampi(k - 9 - lag, 0, u.x_len - 1)];
+		else v = b[len - 1 - k];
+		double wt = v + c.a0 * w0 + c.a1 * w1 + c.a2 * w2;
+		double o = c.b0 * wt + c.b1 * w0 + c.b1 * w1 + c.b0 * w2;
+		w2 = w1; w1 = w0; w0 = wt;
+		if (k >= k0) {
+			if (PASS == 0) {
+				b[k] = o;
+			} else {
+				int p = len - 1 - k;  // position in the original order
+				int d = p - first;
+				if (d >= 0 && d % r == 0) {
+					int i = d / r;
+					if (i < u.y_len) y[u.y_off + i] = o;
+				}
+			}
+		}
+	}
+}
+
+// reference src/harvest.cpp:237-241: accumulate(y, y + n, 0) with an int accumulator truncates after every
+// addition, so the "mean" is 0 unless some abs(y) reaches 1.  Emulated exactly.
+__global__ void hv_dc_kernel(const HvUtt *__restrict__ utts, double *__restrict__ y) {
+	__shared__ int flag;
+	__shared__ double mean;
+	const HvUtt u = utts[blockIdx.x];
+	double *__restrict__ yy = y + u.y_off;
+	if (threadIdx.x == 0) flag = 0;
+	__syncthreads();
+	int f = 0;
+	for (int i = threadIdx.x; i < u.y_len; i += blockDim.x) if (fabs(yy[i]) >= 1.0) f = 1;
+	if (f) flag = 1;
+	__syncthreads();
+	if (!flag) return;
+	if (threadIdx.x == 0) {
+		int acc = 0;
+		for (int i = 0; i < u.y_len; ++i) acc = (int)(acc + yy[i]);
+		double m = acc;
+		mean = m / u.y_len;
+	}
+	__syncthreads();
+	for (int i = threadIdx.x; i < u.y_len; i += blockDim.x) yy[i] -= mean;
+}
+__global__ void hv_copy_kernel(const HvUtt *__restrict__ utts, const double *__restrict__ x, double *__restrict__ y) {
+	const HvUtt u = utts[blockIdx.y];
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < u.y_len) y[u.y_off + i] = (i < u.x_len) ? x[u.x_off + i] : 0.0;  // decimation_ratio == 1 (reference :217-219)
+}
+
+// ------------------------------------------------------------------------------------------------
+// band-pass + four zero-crossing detectors
+// ------------------------------------------------------------------------------------------------
+struct BpArgs {
+	const HvUtt *utts;
+	const double *y;
+	const double *taps;       // per band, padded to a multiple of 8 with zeros
+	const int *tap_off;       // first tap of each band
+	const int *half_len;      // hl per band
+	const long long *ev_band_off;  // per band: first slot relative to the utterance's ev_off (4 types contiguous)
+	const int *ev_cap;        // per band capacity per type
+	double *events;           // fine edge positions
+	int *ev_count;            // [utt][band][4]
+	int *overflow;
+	int n_bands;
+};
+
+__device__ __forceinline__ int padidx(int m) { return m + (m >> 3); }
+
+__global__ __launch_bounds__(BP_T) void hv_bandpass_kernel(BpArgs a) {
+	__shared__ double Ys[(BP_TILE + 2 * HL_MAX + 32) * 9 / 8 + 16];
+	__shared__ double Tp[2 * HL_MAX + 16];
+	__shared__ double Ss[(BP_TILE + 8) * 9 / 8 + 16];
+	__shared__ unsigned long long scan_s[BP_T / 64];
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int band = blockIdx.x;
+	const HvUtt u = a.utts[blockIdx.y];
+	const int hl = a.half_len[band];
+	const int nt8 = ((2 * hl + 1 + 7) / 8) * 8;
+	const double *__restrict__ y = a.y + u.y_off;
+	const double *__restrict__ taps = a.taps + a.tap_off[band];
+	for (int i = tid; i < nt8; i += BP_T) Tp[i] = taps[i];
+	const int cap = a.ev_cap[band];
+	double *__restrict__ ev = a.events + u.ev_off + a.ev_band_off[band];
+	int run[4] = {0, 0, 0, 0};
+	const int t0 = tid * BP_R;
+	for (int ts = 0; ts < u.y_len; ts += BP_ADV) {
+		// Ys[m] = y[ts + 1 - hl + m], m in [0, TILE + nt8 + 8)
+		__syncthreads();
+		for (int m = tid; m < BP_TILE + nt8 + 8; m += BP_T) {
+			int g = ts + 1 - hl + m;
+			Ys[padidx(m)] = (g >= 0 && g < u.y_len) ? y[g] : 0.0;
+		}
+		__syncthreads();
+		// out[t0 + j] = sum_q tap[q] * Ys[t0 + j + q]  (the filter is symmetric)
+		double acc[BP_R];
+#pragma unroll
+		for (int j = 0; j < BP_R; ++j) acc[j] = 0.0;
+		double w[16];
+#pragma unroll
+		for (int c = 0; c < 8; ++c) w[c] = Ys[padidx(t0 + c)];
+		for (int q0 = 0; q0 < nt8; q0 += 8) {
+			double tp[8];
+#pragma unroll
+			for (int c = 0; c < 8; ++c) { w[8 + c] = Ys[padidx(t0 + q0 + 8 + c)]; tp[c] = Tp[q0 + c]; }
+#pragma unroll
+			for (int qq = 0; qq < 8; ++qq)
+#pragma unroll
+				for (int j = 0; j < BP_R; ++j) acc[j] = fma(tp[qq], w[qq + j], acc[j]);
+#pragma unroll
+			for (int c = 0; c < 8; ++c) w[c] = w[8 + c];
+		}
+#pragma unroll
+		for (int j = 0; j < BP_R; ++j) Ss[padidx(t0 + j)] = acc[j];
+		__syncthreads();
+		// detectors at positions i = ts + t, t in [0, BP_ADV)
+		double s[BP_R + 2];
+#pragma unroll
+		for (int j = 0; j < BP_R + 2; ++j) s[j] = (t0 + j < BP_TILE) ? Ss[padidx(t0 + j)] : 0.0;
+		unsigned int mask[4] = {0, 0, 0, 0};
+#pragma unroll
+		for (int j = 0; j < BP_R; ++j) {
+			const int t = t0 + j, i = ts + t;
+			if (t < BP_ADV) {
+				const double s0 = s[j], s1 = s[j + 1], s2 = s[j + 2];
+				if (i + 1 < u.y_len) {  // zeroCrossingEngine over y_length samples
+					if (0.0 < s0 && s1 <= 0.0) mask[0] |= 1u << j;    // positive -> negative
+					if (0.0 < -s0 && -s1 <= 0.0) mask[1] |= 1u << j;  // negative -> positive
+				}
+				if (i + 2 < u.y_len) {  // engine over the y_length - 1 first differences
+					const double d0 = s1 - s0, d1 = s2 - s1;  // = (-s[i]) - (-s[i+1])
+					if (0.0 < d0 && d1 <= 0.0) mask[2] |= 1u << j;    // peaks
+					if (0.0 < -d0 && -d1 <= 0.0) mask[3] |= 1u << j;  // dips
+				}
+			}
+		}
+		// ordered compaction: the four counts travel packed in one 64-bit word
+		unsigned long long packed = 0;
+#pragma unroll
+		for (int ty = 0; ty < 4; ++ty) packed |= (unsigned long long)__popc(mask[ty]) << (16 * ty);
+		unsigned long long inc = packed;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			unsigned long long t = __shfl_up(inc, o, 64);
+			if (lane >= o) inc += t;
+		}
+		if (lane == 63) scan_s[wv] = inc;
+		__syncthreads();
+		unsigned long long base = 0, total = 0;
+#pragma unroll
+		for (int k = 0; k < BP_T / 64; ++k) {
+			unsigned long long t = scan_s[k];
+			if (k < wv) base += t;
+			total += t;
+		}
+		const unsigned long long excl = base + inc - packed;
+#pragma unroll
+		for (int ty = 0; ty < 4; ++ty) {
+			int slot = run[ty] + (int)((excl >> (16 * ty)) & 0xffffull);
+#pragma unroll
+			for (int j = 0; j < BP_R; ++j) {
+				if (mask[ty] & (1u << j)) {
+					const int i = ts + t0 + j;
+					double v0, v1;
+					if (ty < 2) { v0 = s[j]; v1 = s[j + 1]; }
+					else { v0 = s[j + 1] - s[j]; v1 = s[j + 2] - s[j + 1]; }
+					// edges[e] - sig[e-1] / (sig[e] - sig[e-1]) with edges = i + 1 (reference :1206-1208);
+					// the value is the same for a signal and its negation
+					const double fine = (i + 1) - v0 / (v1 - v0);
+					if (slot < cap) ev[(long long)ty * cap + slot] = fine;
+					++slot;
+				}
+			}
+			run[ty] += (int)((total >> (16 * ty)) & 0xffffull);
+		}
+	}
+	if (tid < 4) {
+		int cnt = run[tid];
+		a.ev_count[((long long)blockIdx.y * a.n_bands + band) * 4 + tid] = cnt;
+		if (cnt > cap) atomicExch(a.overflow, 1);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// raw candidates on the 1 ms grid
+// ------------------------------------------------------------------------------------------------
+struct RawArgs {
+	const HvUtt *utts;
+	const double *events;
+	const long long *ev_band_off;
+	const int *ev_cap;
+	const int *ev_count;
+	const double *band_f0;
+	double *raw;  // [utt: l1_off * n_bands][band][L1]
+	int n_bands;
+	double fs_d, f0_floor, f0_ceil;
+};
+
+// interp1 (reference src/world_matlabfunctions.cpp:157-182) of intervals fs/(e[k+1]-e[k]) located at
+// (e[k]+e[k+1])/2/fs, k < n, evaluated at time t
+__device__ __forceinline__ double hv_interp_events(const double *__restrict__ e, int n, double fs, double t) {
+	// c = #{k < n : loc[k] <= t} by binary search, then clamp to [1, n-1]
+	int lo = 0, hi = n;
+	while (lo < hi) {
+		int mid = (lo + hi) >> 1;
+		double loc = (e[mid] + e[mid + 1]) / 2.0 / fs;
+		if (loc <= t) lo = mid + 1; else hi = mid;
+	}
+	int k = min(max(lo, 1), n - 1);
+	double e0 = e[k - 1], e1 = e[k], e2 = e[k + 1];
+	double x0 = (e0 + e1) / 2.0 / fs, x1 = (e1 + e2) / 2.0 / fs;
+	double y0 = fs / (e1 - e0), y1 = fs / (e2 - e1);
+	double s = (t - x0) / (x1 - x0);
+	return y0 + s * (y1 - y0);
+}
+
+__global__ void hv_raw_kernel(RawArgs a) {
+	const int band = blockIdx.y;
+	const HvUtt u = a.utts[blockIdx.z];
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= u.L1) return;
+	const int *cnt = a.ev_count + ((long long)blockIdx.z * a.n_bands + band) * 4;
+	const int cap = a.ev_cap[band];
+	const double *__restrict__ ev = a.events + u.ev_off + a.ev_band_off[band];
+	double *__restrict__ out = a.raw + u.l1_off * a.n_bands + (long long)band * u.L1;
+	// number of intervals = edges - 1 (0 when fewer than 2 edges); all four need more than 2 (reference :1101-1107)
+	int n[4];
+	bool ok = true;
+#pragma unroll
+	for (int ty = 0; ty < 4; ++ty) {
+		n[ty] = cnt[ty] < 2 ? 0 : cnt[ty] - 1;
+		ok = ok && n[ty] > 2;
+	}
+	double v = 0.0;
+	if (ok) {
+		const double t = i * 1 / 1000.0;
+		double s = 0.0;
+		// (a + b + c + d) in the reference's order: negative-going, positive-going, peaks, dips
+		s = hv_interp_events(ev, n[0], a.fs_d, t);
+		s = s + hv_interp_events(ev + cap, n[1], a.fs_d, t);
+		s = s + hv_interp_events(ev + 2ll * cap, n[2], a.fs_d, t);
+		s = s + hv_interp_events(ev + 3ll * cap, n[3], a.fs_d, t);
+		v = s / 4.0;
+		const double fb = a.band_f0[band];
+		if (v > fb * 1.1 || v < fb * 0.9 || v > a.f0_ceil || v < a.f0_floor) v = 0.0;
+	}
+	out[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-frame candidate detection (reference :1005-1083)
+// ------------------------------------------------------------------------------------------------
+__global__ void hv_detect_kernel(const HvUtt *__restrict__ utts, const double *__restrict__ raw, double *__restrict__ cand0,
+								 int n_bands, int S) {
+	const HvUtt u = utts[blockIdx.y];
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= u.L1) return;
+	const double *__restrict__ r = raw + u.l1_off * n_bands + i;
+	double *__restrict__ out = cand0 + (u.l1_off + i) * S;
+	int nc = 0, st = 0;
+	int prev = 0;
+	double sum = 0.0;
+	for (int j = 1; j < n_bands; ++j) {
+		const double v = r[(long long)j * u.L1];
+		const int cur = (j == n_bands - 1) ? 0 : (v > 0 ? 1 : 0);
+		if (cur - prev == 1) { st = j; sum = 0.0; }
+		if (cur - prev == -1) {
+			const int ed = j;
+			if (ed - st >= 10 && nc < S) out[nc++] = sum / (ed - st);
+		}
+		if (cur) sum += v;
+		prev = cur;
+	}
+	for (int k = nc; k < S; ++k) out[k] = 0.0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// refinement by instantaneous frequency (reference :750-982), one wavefront per candidate
+// ------------------------------------------------------------------------------------------------
+struct RefArgs {
+	const HvUtt *utts;
+	int n_utt;
+	const double *y;
+	const double *cand0;
+	const double2 *tw;
+	double *cand1, *score1;
+	long long total_frames;
+	HvParams p;
+};
+
+constexpr int RF_MAXW = 2 * 320 + 1;  // longest window (f0 = 37.5 Hz at 8 kHz)
+
+__global__ __launch_bounds__(256) void hv_refine_kernel(RefArgs a) {
+	__shared__ double MW[4][RF_MAXW + 3];
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const long long g = blockIdx.x;
+	if (g >= a.total_frames) return;
+	const int ui = hv_find(a.utts, a.n_utt, g, &HvUtt::l1_off);
+	const HvUtt u = a.utts[ui];
+	const int i = (int)(g - u.l1_off);
+	const double pos = i * 1 / 1000.0;
+	const double fs = a.p.fs_d;
+	const int S = a.p.S;
+	const double *__restrict__ y = a.y + u.y_off;
+	double *mw = MW[wv];
+	for (int slot = wv; slot < a.p.n_cand; slot += 4) {
+		const int blk = slot / S, j = slot - blk * S;
+		const int src = (blk == 0) ? i : (blk <= 3 ? i - blk : i + (blk - 3));  // overlap (reference :987-1000)
+		double f = 0.0;
+		if (src >= 0 && src < u.L1) f = a.cand0[(u.l1_off + src) * S + j];
+		double rf = 0.0, rs = 0.0;
+		if (f > 0.0) {
+			const int hw = (int)(1.5 * fs / f + 1.0);
+			const int bt = 2 * hw + 1;
+			if (bt <= RF_MAXW) {
+				const double wlt = (2.0 * hw + 1.0) / fs;
+				const int fft_index = 2 + (int)(log(hw * 2 + 1.0) / kLog2H);
+				const int N = 1 << fft_index;
+				const double bt0 = (-hw) / fs;
+				const int basic = mround((pos + bt0) * fs + 0.001);
+				// main window (reference :762-788)
+				for (int n = lane; n < bt; n += 64) {
+					double tmp = (basic + n - 1.0) / fs - pos;
+					double tmp2 = 2.0 * kPi * tmp / wlt;
+					mw[n] = 0.42 + 0.5 * cos(tmp2) + 0.08 * cos(2 * tmp2);
+				}
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+				__builtin_amdgcn_wave_barrier();
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+				const int nh = min((int)(fs / 2.0 / f), 6);
+				int idx[6];
+#pragma unroll
+				for (int h = 0; h < 6; ++h) idx[h] = mround(f * N / fs * (h + 1));
+				double mr[6], mi[6], dr[6], di[6];
+#pragma unroll
+				for (int h = 0; h < 6; ++h) mr[h] = mi[h] = dr[h] = di[h] = 0.0;
+				const int tsh = kTwiddleN / N;
+				for (int n = lane; n < bt; n += 64) {
+					const double m = mw[n];
+					double d;  // differentiated window (reference :794-803)
+					if (n == 0) d = -mw[1] / 2.0;
+					else if (n == bt - 1) d = mw[bt - 2] / 2.0;
+					else d = -(mw[n + 1] - mw[n - 1]) / 2.0;
+					const double yv = y[clampi(basic + n - 1, 0, u.y_len - 1)];
+					const double xm = m * yv, xd = d * yv;
+#pragma unroll
+					for (int h = 0; h < 6; ++h) {
+						if (h < nh) {
+							const double2 t = a.tw[((idx[h] * n) & (N - 1)) * tsh];  // e^{+i th}; the DFT uses e^{-i th}
+							mr[h] = fma(xm, t.x, mr[h]);
+							mi[h] = fma(-xm, t.y, mi[h]);
+							dr[h] = fma(xd, t.x, dr[h]);
+							di[h] = fma(-xd, t.y, di[h]);
+						}
+					}
+				}
+#pragma unroll
+				for (int h = 0; h < 6; ++h) {
+#pragma unroll
+					for (int o = 32; o > 0; o >>= 1) {
+						mr[h] += __shfl_xor(mr[h], o, 64);
+						mi[h] += __shfl_xor(mi[h], o, 64);
+						dr[h] += __shfl_xor(dr[h], o, 64);
+						di[h] += __shfl_xor(di[h], o, 64);
+					}
+				}
+				// fixF0 (reference :844-878)
+				double num = 0.0, den = 0.0, sc = 0.0;
+#pragma unroll
+				for (int h = 0; h < 6; ++h) {
+					if (h < nh) {
+						const double pw = mr[h] * mr[h] + mi[h] * mi[h];
+						const double ni = mr[h] * di[h] - mi[h] * dr[h];
+						const double inst = (pw == 0.0) ? 0.0 : (double)idx[h] * fs / N + ni / pw * fs / 2.0 / kPi;
+						const double amp = sqrt(pw);
+						num += amp * inst;
+						den += amp * (h + 1.0);
+						sc += fabs((inst / (h + 1.0) - f) / f);
+					}
+				}
+				rf = num / (den + kSafeH);
+				rs = 1.0 / (sc / nh + kSafeH);
+				if (rf < a.p.f0_floor || rf > a.p.f0_ceil || rs < 2.5) { rf = 0.0; rs = 0.0; }  // reference :974-979
+				__builtin_amdgcn_wave_barrier();
+			}
+		}
+		if (lane == 0) {
+			a.cand1[g * a.p.n_cand + slot] = rf;
+			a.score1[g * a.p.n_cand + slot] = rs;
+		}
+	}
+}
+
+// reference :708-744
+__global__ void hv_unreliable_kernel(const HvUtt *__restrict__ utts, int n_utt, const double *__restrict__ c1,
+									 const double *__restrict__ s1, double *__restrict__ c2, double *__restrict__ s2,
+									 long long total_frames, int nc) {
+	const long long g = blockIdx.x;
+	if (g >= total_frames) return;
+	const int ui = hv_find(utts, n_utt, g, &HvUtt::l1_off);
+	const HvUtt u = utts[ui];
+	const int i = (int)(g - u.l1_off);
+	for (int j = threadIdx.x; j < nc; j += blockDim.x) {
+		double ref = c1[g * nc + j], sc = s1[g * nc + j];
+		if (ref != 0 && i >= 1 && i < u.L1 - 1) {
+			double e1 = 1.0, e2 = 1.0;  // selectBestF0(..., allowed_range 1.0, error) keeps the smallest error <= 1
+			const double *__restrict__ nx = c1 + (g + 1) * nc;
+			const double *__restrict__ pv = c1 + (g - 1) * nc;
+			for (int k = 0; k < nc; ++k) {
+				double t1 = fabs(ref - nx[k]) / ref;
+				if (!(t1 > e1)) e1 = t1;
+				double t2 = fabs(ref - pv[k]) / ref;
+				if (!(t2 > e2)) e2 = t2;
+			}
+			if (fmin(e1, e2) > 0.05) { ref = 0; sc = 0; }
+		}
+		c2[g * nc + j] = ref;
+		s2[g * nc + j] = sc;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// contour fixing: one wavefront per utterance
+// ------------------------------------------------------------------------------------------------
+struct CtrArgs {
+	const HvUtt *utts;
+	const double *cand, *score;  // after removeUnreliableCandidates
+	double *base, *s1, *s2, *s3, *fixed;  // [total L1 frames] work contours
+	int *sec;         // [utt][2 * max_sec] section boundaries (st, ed)
+	double *chan;     // channel storage
+	long long chan_stride;  // doubles per utterance
+	int max_sec;
+	int nc;
+	int *ibuf;        // [utt][4 * max_sec] position bookkeeping of fixStep3
+};
+
+__device__ __forceinline__ void wave_sync() {
+	__syncthreads();  // 64-thread workgroup: waitcnt + barrier
+}
+
+// argmin_k |ref - c[k]| / ref over the lanes with the reference's tie rule (the last smallest error that
+// does not exceed `allowed` wins), reference :347-365
+__device__ __forceinline__ double hv_select_best(double ref, const double *__restrict__ c, int nc, double allowed, int lane) {
+	double best_err = allowed;
+	int best_k = -1;
+	for (int k = lane; k < nc; k += 64) {
+		double t = fabs(ref - c[k]) / ref;
+		if (!(t > best_err)) { best_err = t; best_k = k; }
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		double oe = __shfl_xor(best_err, o, 64);
+		int ok = __shfl_xor(best_k, o, 64);
+		if (ok >= 0 && (best_k < 0 || oe < best_err || (oe == best_err && ok > best_k))) { best_err = oe; best_k = ok; }
+	}
+	return best_k >= 0 ? c[best_k] : 0.0;
+}
+// reference :463-470
+__device__ __forceinline__ double hv_search_score(double f0, const double *__restrict__ c, const double *__restrict__ s, int nc) {
+	double score = 0.0;
+	for (int k = 0; k < nc; ++k)
+		if (f0 == c[k] && score < s[k]) score = s[k];
+	return score;
+}
+
+// boundaries of the voiced sections of f0[0..n) (reference :296-314): returns the number of sections;
+// sec[2k] = first frame, sec[2k+1] = last frame.  Executed by all 64 lanes, ordered by ballot.
+__device__ int hv_sections(const double *__restrict__ f0, int n, int *__restrict__ sec, int max_sec, int lane) {
+	int nb = 0;  // boundaries so far (wave-uniform)
+	for (int base = 1; base < n; base += 64) {
+		int i = base + lane;
+		int cur = 0, prv = 0;
+		if (i < n) {
+			cur = (i >= 1 && i < n - 1 && f0[i] > 0) ? 1 : 0;
+			prv = (i - 1 >= 1 && i - 1 < n - 1 && f0[i - 1] > 0) ? 1 : 0;
+		}
+		const bool ch = (i < n) && (cur != prv);
+		const unsigned long long m = __ballot(ch);
+		if (ch) {
+			int k = nb + __popcll(m & ((1ull << lane) - 1ull));
+			if (k < 2 * max_sec) sec[k] = i - (k & 1);
+		}
+		nb += __popcll(m);
+	}
+	return nb / 2;
+}
+
+__global__ __launch_bounds__(64) void hv_contour_kernel(CtrArgs a) {
+	const HvUtt u = a.utts[blockIdx.x];
+	const int lane = threadIdx.x;
+	const int L = u.L1, nc = a.nc;
+	const double *__restrict__ cand = a.cand + u.l1_off * nc;
+	const double *__restrict__ score = a.score + u.l1_off * nc;
+	double *__restrict__ base = a.base + u.l1_off;
+	double *__restrict__ s1 = a.s1 + u.l1_off;
+	double *__restrict__ s2 = a.s2 + u.l1_off;
+	double *__restrict__ s3 = a.s3 + u.l1_off;
+	double *__restrict__ s4 = a.fixed + u.l1_off;
+	int *__restrict__ sec = a.sec + (long long)blockIdx.x * 2 * a.max_sec;
+	double *__restrict__ chan = a.chan + (long long)blockIdx.x * a.chan_stride;
+
+	// searchF0Base (reference :254-272)
+	for (int i = lane; i < L; i += 64) {
+		double b = 0.0, bs = 0.0;
+		for (int j = 0; j < nc; ++j) {
+			double sc = score[(long long)i * nc + j];
+			if (sc > bs) { b = cand[(long long)i * nc + j]; bs = sc; }
+		}
+		base[i] = b;
+	}
+	wave_sync();
+	// fixStep1 (reference :277-291; entries the reference never writes are 0)
+	for (int i = lane; i < L; i += 64) {
+		double v = 0.0;
+		if (i >= 2 && base[i] != 0.0) {
+			double ref = base[i - 1] * 2 - base[i - 2];
+			v = (fabs((base[i] - ref) / ref) > 0.008 && fabs((base[i] - base[i - 1])) / base[i - 1] > 0.008) ? 0.0 : base[i];
+		}
+		s1[i] = v;
+		s2[i] = v;
+	}
+	wave_sync();
+	// fixStep2 (reference :319-334)
+	int ns = hv_sections(s1, L, sec, a.max_sec, lane);
+	wave_sync();
+	ns = min(ns, a.max_sec);
+	for (int k = 0; k < ns; ++k) {
+		int st = sec[2 * k], ed = sec[2 * k + 1];
+		if (ed - st >= 6) continue;
+		for (int j = st + lane; j <= ed; j += 64) s2[j] = 0.0;
+	}
+	wave_sync();
+	// fixStep3 (reference :560-585)
+	for (int i = lane; i < L; i += 64) s3[i] = s2[i];
+	ns = hv_sections(s2, L, sec, a.max_sec, lane);
+	wave_sync();
+	ns = min(ns, a.max_sec);
+	// channel k keeps frames [clo_k, clo_k + clen_k) around its section (extension moves at most 101 frames);
+	// the reference's full-length rows are zero outside that window
+	int *__restrict__ clo = reinterpret_cast<int *>(chan);
+	int *__restrict__ clen = clo + a.max_sec;
+	int *__restrict__ coff = clen + a.max_sec;
+	int *__restrict__ perm = a.ibuf + (long long)blockIdx.x * 4 * a.max_sec;  // position -> channel
+	int *__restrict__ bl = perm + a.max_sec;                                    // boundaries by position
+	int *__restrict__ order = bl + 2 * a.max_sec;
+	double *__restrict__ cdata = chan + 2 * a.max_sec;  // 3 * max_sec ints fit in 2 * max_sec doubles
+	{
+		int off = 0;
+		for (int k = 0; k < ns; ++k) {
+			const int st = sec[2 * k], ed = sec[2 * k + 1];
+			const int lo = max(0, st - 104), hi = min(L - 1, ed + 104);
+			if (lane == 0) { clo[k] = lo; clen[k] = hi - lo + 1; coff[k] = off; perm[k] = k; bl[2 * k] = st; bl[2 * k + 1] = ed; }
+			// getMultiChannelF0 (reference :542-555)
+			for (int j = lo + lane; j <= hi; j += 64) cdata[off + (j - lo)] = (j >= st && j <= ed) ? s2[j] : 0.0;
+			off += hi - lo + 1;
+		}
+	}
+	wave_sync();
+	auto CH = [&](int k, int j) -> double & { return cdata[coff[k] + (j - clo[k])]; };
+	auto chv = [&](int k, int j) -> double {  // value of the full-length row
+		const int d = j - clo[k];
+		return (d >= 0 && d < clen[k]) ? cdata[coff[k] + d] : 0.0;
+	};
+	// extend (reference :427-458) with extendF0 (:371-403)
+	for (int k = 0; k < ns; ++k) {
+		for (int dir = 0; dir < 2; ++dir) {
+			const int shift = dir == 0 ? 1 : -1;
+			const int origin = dir == 0 ? bl[2 * k + 1] : bl[2 * k];
+			const int last_point = dir == 0 ? min(L - 2, origin + 100) : max(1, origin - 100);
+			double tmp_f0 = CH(k, origin);
+			int shifted_origin = origin;
+			const int distance = abs(last_point - origin);
+			int miss = 0;
+			for (int t = 0; t <= distance; ++t) {
+				const int idx = origin + shift * t + shift;
+				const double sel = hv_select_best(tmp_f0, cand + (long long)idx * nc, nc, 0.18, lane);
+				if (lane == 0) CH(k, idx) = sel;
+				if (sel == 0.0) {
+					miss++;
+				} else {
+					tmp_f0 = sel;
+					miss = 0;
+					shifted_origin = idx;
+				}
+				if (miss == 4) break;
+			}
+			wave_sync();
+			if (lane == 0) bl[dir == 0 ? 2 * k + 1 : 2 * k] = shifted_origin;
+			wave_sync();
+		}
+	}
+	// extendSub: keep the sections that are long enough for their mean F0 (reference :441-455; mean_f0 is
+	// deliberately not reset between sections)
+	int count = 0;
+	{
+		double mean_f0 = 0.0;
+		for (int k = 0; k < ns; ++k) {
+			const int st = bl[2 * k], ed = bl[2 * k + 1];
+			const int ch = perm[k];
+			for (int j = st; j < ed; ++j) mean_f0 += CH(ch, j);
+			mean_f0 /= ed - st;
+			if (2200.0 / mean_f0 < ed - st) {
+				wave_sync();
+				if (lane == 0) {  // swapArray (reference :409-422)
+					int t = perm[count]; perm[count] = perm[k]; perm[k] = t;
+					t = bl[2 * count]; bl[2 * count] = bl[2 * k]; bl[2 * k] = t;
+					t = bl[2 * count + 1]; bl[2 * count + 1] = bl[2 * k + 1]; bl[2 * k + 1] = t;
+				}
+				wave_sync();
+				count++;
+			}
+		}
+	}
+	// mergeF0 (reference :502-536) with mergeF0Sub (:475-497)
+	if (ns > 0) {
+		// merged = the row at position 0, whatever its rank in time
+		const int ch0 = perm[0];
+		for (int i = lane; i < L; i += 64) s3[i] = chv(ch0, i);
+		// order[] = positions 0..count-1 sorted by start frame
+		if (lane == 0) {
+			for (int k = 0; k < count; ++k) order[k] = k;
+			for (int k = 1; k < count; ++k) {
+				int v = order[k], key = bl[2 * v], m = k - 1;
+				while (m >= 0 && bl[2 * order[m]] > key) { order[m + 1] = order[m]; --m; }
+				order[m + 1] = v;
+			}
+		}
+		wave_sync();
+		for (int q = 1; q < count; ++q) {
+			const int p = order[q];
+			const int ch = perm[p];
+			const int i1 = bl[2 * p], i2 = bl[2 * p + 1];
+			if (i1 - bl[1] > 0) {
+				for (int j = i1 + lane; j <= i2; j += 64) s3[j] = chv(ch, j);
+				wave_sync();
+				if (lane == 0) { bl[0] = i1; bl[1] = i2; }
+				wave_sync();
+			} else {
+				const int st1 = bl[0], ed1 = bl[1], st2 = i1, ed2 = i2;
+				int new_ed = ed1;
+				if (!(st1 <= st2 && ed1 >= ed2)) {
+					double sc1 = 0.0, sc2 = 0.0;
+					for (int j = st2 + lane; j <= ed1; j += 64) {
+						sc1 += hv_search_score(s3[j], cand + (long long)j * nc, score + (long long)j * nc, nc);
+						sc2 += hv_search_score(chv(ch, j), cand + (long long)j * nc, score + (long long)j * nc, nc);
+					}
+#pragma unroll
+					for (int o = 32; o > 0; o >>= 1) { sc1 += __shfl_xor(sc1, o, 64); sc2 += __shfl_xor(sc2, o, 64); }
+					wave_sync();
+					if (sc1 > sc2) { for (int j = ed1 + lane; j <= ed2; j += 64) s3[j] = chv(ch, j); }
+					else { for (int j = st2 + lane; j <= ed2; j += 64) s3[j] = chv(ch, j); }
+					new_ed = ed2;
+				}
+				wave_sync();
+				if (lane == 0) bl[1] = new_ed;
+				wave_sync();
+			}
+		}
+	}
+	wave_sync();
+	// fixStep4 (reference :590-614)
+	for (int i = lane; i < L; i += 64) s4[i] = s3[i];
+	ns = hv_sections(s3, L, sec, a.max_sec, lane);
+	wave_sync();
+	ns = min(ns, a.max_sec);
+	for (int k = 0; k + 1 < ns; ++k) {
+		const int e0 = sec[2 * k + 1], b1 = sec[2 * (k + 1)];
+		const int distance = b1 - e0 - 1;
+		if (distance >= 9) continue;
+		const double t0 = s3[e0] + 1, t1 = s3[b1] - 1;
+		const double coef = (t1 - t0) / (distance + 1.0);
+		for (int j = e0 + 1 + lane; j <= b1 - 1; j += 64) s4[j] = t0 + coef * (j - e0);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// zero-lag Butterworth smoothing per voiced section (reference :639-703), one lane per section
+// ------------------------------------------------------------------------------------------------
+struct SmArgs {
+	const HvUtt *utts;
+	const double *fixed;
+	double *f0_1ms;
+	int *sec;         // [utt][2 * max_sec]
+	double *scratch;  // [utt][(L1max + 600) * 64]
+	long long scratch_stride;
+	int max_sec;
+};
+
+__global__ __launch_bounds__(64) void hv_smooth_kernel(SmArgs a) {
+	const HvUtt u = a.utts[blockIdx.x];
+	const int lane = threadIdx.x;
+	const int L = u.L1, lag = 300, n = L + 2 * lag;
+	const double *__restrict__ f0 = a.fixed + u.l1_off;
+	double *__restrict__ out = a.f0_1ms + u.l1_off;
+	int *__restrict__ sec = a.sec + (long long)blockIdx.x * 2 * a.max_sec;
+	double *__restrict__ tmp = a.scratch + (long long)blockIdx.x * a.scratch_stride;
+	for (int i = lane; i < L; i += 64) out[i] = 0.0;
+	// sections of the padded contour: padding is unvoiced, so they are the sections of f0 with the ends
+	// (frames 0 and L-1) allowed to be voiced -- getBoundaryList on the padded array forces only ITS ends to 0
+	int nb = 0;
+	for (int base = 1; base < n; base += 64) {
+		int i = base + lane;
+		auto vu = [&](int q) { int fq = q - lag; return (q >= 1 && q < n - 1 && fq >= 0 && fq < L && f0[fq] > 0) ? 1 : 0; };
+		const bool ch = (i < n) && (vu(i) != vu(i - 1));
+		const unsigned long long m = __ballot(ch);
+		if (ch) {
+			int k = nb + __popcll(m & ((1ull << lane) - 1ull));
+			if (k < 2 * a.max_sec) sec[k] = i - (k & 1);
+		}
+		nb += __popcll(m);
+	}
+	__syncthreads();
+	const int ns = min(nb / 2, a.max_sec);
+	const double b0 = 0.0078202080334971724, b1 = 0.015640416066994345;
+	const double a0 = 1.7347257688092754, a1 = -0.76600660094326412;
+	for (int s0 = 0; s0 < ns; s0 += 64) {
+		const int k = s0 + lane;
+		if (k < ns) {
+			const int st = sec[2 * k], ed = sec[2 * k + 1];
+			const double xs = f0[st - lag], xe = f0[ed - lag];
+			double w0 = 0.0, w1 = 0.0;
+			for (int i = 0; i < n; ++i) {
+				const double xv = (i < st) ? xs : (i > ed ? xe : f0[i - lag]);
+				const double wt = xv + a0 * w0 + a1 * w1;
+				tmp[(long long)(n - i - 1) * 64 + lane] = b0 * wt + b1 * w0 + b0 * w1;
+				w1 = w0; w0 = wt;
+			}
+			w0 = w1 = 0.0;
+			for (int i = 0; i < n; ++i) {
+				const double wt = tmp[(long long)i * 64 + lane] + a0 * w0 + a1 * w1;
+				const double yv = b0 * wt + b1 * w0 + b0 * w1;
+				w1 = w0; w0 = wt;
+				const int j = n - i - 1;
+				if (j >= st && j <= ed) out[j - lag] = yv;
+			}
+		}
+		__syncthreads();
+	}
+}
+
+// reference :183-208
+__global__ void hv_output_kernel(const HvUtt *__restrict__ utts, const double *__restrict__ f0_1ms, double *__restrict__ tpos,
+								 double *__restrict__ f0, double frame_period) {
+	const HvUtt u = utts[blockIdx.y];
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= u.L) return;
+	double t, v;
+	if (frame_period == 1.0) {
+		t = i * 1 / 1000.0;
+		v = f0_1ms[u.l1_off + i];
+	} else {
+		t = i * frame_period / 1000.0;
+		v = f0_1ms[u.l1_off + min(u.L1 - 1, mround(t * 1000.0))];
+	}
+	tpos[u.out_off + i] = t;
+	f0[u.out_off + i] = v;
+}
+
+}  // namespace wc
+
+using namespace wc;
+
+struct wc_harvest {
+	int fs, decim, n_bands, S, max_cand;
+	double fs_d, f0_floor, f0_ceil, frame_period, target_fs, channels_in_octave;
+	Device *dev;
+	std::vector<double> band_f0;
+	std::vector<int> half_len, tap_off;
+	DevBuf d_taps, d_tap_off, d_half_len, d_band_f0, d_ev_band_off, d_ev_cap;
+	DevBuf utts, dec, y, events, ev_count, overflow, raw, cand0, cand1, score1, cand2, score2;
+	DevBuf base, s1, s2, s3, fixed, f0_1ms, sec, chan, smooth, ibuf;
+	DevBuf d_x, d_tpos, d_f0;
+	HostBuf h_stage;
+	std::vector<HvUtt> last_utts;
+};
+
+static DecCoef dec_coef(int r) {
+	// FilterForDecimate coefficient sets, reference src/world_matlabfunctions.cpp:27-103
+	static const double A[13][3] = {
+		{0, 0, 0}, {0, 0, 0},
+		{0.041156734567757189, -0.42599112459189636, 0.041037215479961225},
+		{0.95039378983237421, -0.67429146741526791, 0.15412211621346475},
+		{1.4499664446880227, -0.98943497080950582, 0.24578252340690215},
+		{1.7610939654280557, -1.2554914843859768, 0.3237186507788215},
+		{1.9715352749512141, -1.4686795689225347, 0.3893908434965701},
+		{2.1225239019534703, -1.6395144861046302, 0.44469707800587366},
+		{2.2357462340187593, -1.7780899984041358, 0.49152555365968692},
+		{2.3236003491759578, -1.8921545617463598, 0.53148928133729068},
+		{2.3936475118069387, -1.9873904075111861, 0.5658879979027055},
+		{2.450743295230728, -2.06794904601978, 0.59574774438332101},
+		{2.4981398605924205, -2.1368928194784025, 0.62187513816221485}};
+	static const double B[13][2] = {
+		{0, 0}, {0, 0},
+		{0.16797464681802227, 0.50392394045406674},
+		{0.071221945171178636, 0.21366583551353591},
+		{0.036710750339322612, 0.11013225101796784},
+		{0.021334858522387423, 0.06400457556716227},
+		{0.013469181309343825, 0.040407543928031475},
+		{0.0090366882681608418, 0.027110064804482525},
+		{0.0063522763407111993, 0.019056829022133598},
+		{0.0046331164041389372, 0.013899349212416812},
+		{0.0034818622251927556, 0.010445586675578267},
+		{0.0026822508007163792, 0.0080467524021491377},
+		{0.0021097275904709001, 0.0063291827714127002}};
+	int i = (r >= 2 && r <= 12) ? r : 0;
+	return DecCoef{A[i][0], A[i][1], A[i][2], B[i][0], B[i][1]};
+}
+
+static inline int h_mround(double x) { return x > 0 ? static_cast<int>(x + 0.5) : static_cast<int>(x - 0.5); }
+
+static int hv_run_device(wc_harvest *h, int n_utt, const double *d_x, const int *x_length, double *d_tpos, double *d_f0) {
+	Device *dev = h->dev;
+	hipStream_t s = dev->stream;
+	const int r = h->decim;
+	const int lag = (r == 1) ? 0 : static_cast<int>(std::ceil(140.0 / r) * r);
+	std::vector<HvUtt> utts(n_utt);
+	long long xo = 0, deco = 0, yo = 0, l1o = 0, oo = 0;
+	int max_len = 0, max_ylen = 0, max_L1 = 0, max_L = 0;
+	for (int u = 0; u < n_utt; ++u) {
+		if (x_length[u] <= 0) return fail(WC_ERR_INVALID, "harvest: non-positive x_length");
+		HvUtt &t = utts[u];
+		t.x_off = xo; t.dec_off = deco; t.y_off = yo; t.l1_off = l1o; t.out_off = oo; t.ev_off = 0;
+		t.x_len = x_length[u];
+		t.y_len = 1 + x_length[u] / r;                              // reference :1400
+		t.L1 = wc_get_samples(h->fs, x_length[u], 1);                // reference :1411
+		t.L = (h->frame_period == 1.0) ? t.L1 : wc_get_samples(h->fs, x_length[u], h->frame_period);
+		if (t.L1 < 3) return fail(WC_ERR_INVALID, "harvest: signal shorter than 3 ms");
+		const int len = t.x_len + 2 * lag + 18;
+		xo += t.x_len; deco += len; yo += t.y_len; l1o += t.L1; oo += t.L;
+		max_len = std::max(max_len, len); max_ylen = std::max(max_ylen, t.y_len);
+		max_L1 = std::max(max_L1, t.L1); max_L = std::max(max_L, t.L);
+	}
+	const long long total_l1 = l1o;
+	const int nb = h->n_bands, S = h->S, nc = 7 * S;
+	const int max_sec = max_L1 / 2 + 8;
+	int rc;
+	// event capacities: per band and type; first try a rate bound, then the hard bound
+	bool full = false;
+	std::vector<long long> ev_band_off(nb);
+	std::vector<int> ev_cap(nb);
+	if ((rc = h->overflow.reserve(sizeof(int)))) return rc;
+	if ((rc = h->utts.reserve(sizeof(HvUtt) * n_utt))) return rc;
+	if ((rc = h->y.reserve(sizeof(double) * yo))) return rc;
+	if (r != 1 && (rc = h->dec.reserve(sizeof(double) * deco))) return rc;
+	if ((rc = h->ev_count.reserve(sizeof(int) * 4ll * nb * n_utt))) return rc;
+	if ((rc = h->raw.reserve(sizeof(double) * total_l1 * nb))) return rc;
+	if ((rc = h->cand0.reserve(sizeof(double) * total_l1 * S))) return rc;
+	if ((rc = h->cand1.reserve(sizeof(double) * total_l1 * nc))) return rc;
+	if ((rc = h->score1.reserve(sizeof(double) * total_l1 * nc))) return rc;
+	if ((rc = h->cand2.reserve(sizeof(double) * total_l1 * nc))) return rc;
+	if ((rc = h->score2.reserve(sizeof(double) * total_l1 * nc))) return rc;
+	for (DevBuf *b : {&h->base, &h->s1, &h->s2, &h->s3, &h->fixed, &h->f0_1ms})
+		if ((rc = b->reserve(sizeof(double) * total_l1))) return rc;
+	if ((rc = h->sec.reserve(sizeof(int) * 2ll * max_sec * n_utt))) return rc;
+	// after fixStep2 a section spans at least 7 frames plus one unvoiced frame
+	const long long chan_stride = 2ll * max_sec + (long long)max_L1 + 209ll * (max_L1 / 8 + 2) + 64;
+	if ((rc = h->ibuf.reserve(sizeof(int) * 4ll * max_sec * n_utt))) return rc;
+	if ((rc = h->chan.reserve(sizeof(double) * chan_stride * n_utt))) return rc;
+	const long long smooth_stride = (long long)(max_L1 + 600) * 64;
+	if ((rc = h->smooth.reserve(sizeof(double) * smooth_stride * n_utt))) return rc;
+
+	for (int attempt = 0; attempt < 2; ++attempt) {
+		long long per_utt = 0;
+		for (int b = 0; b < nb; ++b) {
+			int hard = max_ylen / 2 + 4;
+			int soft = static_cast<int>(2.5 * h->band_f0[b] * (max_ylen / h->fs_d)) + 64;
+			ev_cap[b] = full ? hard : std::min(hard, soft);
+			ev_band_off[b] = per_utt;
+			per_utt += 4ll * ev_cap[b];
+		}
+		for (int u = 0; u < n_utt; ++u) utts[u].ev_off = per_utt * u;
+		if ((rc = h->events.reserve(sizeof(double) * per_utt * n_utt))) return rc;
+		if ((rc = h->d_ev_band_off.reserve(sizeof(long long) * nb))) return rc;
+		if ((rc = h->d_ev_cap.reserve(sizeof(int) * nb))) return rc;
+		if ((rc = h->h_stage.reserve(sizeof(HvUtt) * n_utt + sizeof(long long) * nb + sizeof(int) * nb + 64))) return rc;
+		char *hs = static_cast<char *>(h->h_stage.p);
+		std::memcpy(hs, utts.data(), sizeof(HvUtt) * n_utt);
+		std::memcpy(hs + sizeof(HvUtt) * n_utt, ev_band_off.data(), sizeof(long long) * nb);
+		std::memcpy(hs + sizeof(HvUtt) * n_utt + sizeof(long long) * nb, ev_cap.data(), sizeof(int) * nb);
+		WC_HIP(hipMemcpyAsync(h->utts.p, hs, sizeof(HvUtt) * n_utt, hipMemcpyHostToDevice, s));
+		WC_HIP(hipMemcpyAsync(h->d_ev_band_off.p, hs + sizeof(HvUtt) * n_utt, sizeof(long long) * nb, hipMemcpyHostToDevice, s));
+		WC_HIP(hipMemcpyAsync(h->d_ev_cap.p, hs + sizeof(HvUtt) * n_utt + sizeof(long long) * nb, sizeof(int) * nb, hipMemcpyHostToDevice, s));
+		WC_HIP(hipMemsetAsync(h->overflow.p, 0, sizeof(int), s));
+		const HvUtt *du = h->utts.as<HvUtt>();
+		if (attempt == 0) {
+			WC_HIP(hipMemsetAsync(h->y.p, 0, sizeof(double) * yo, s));
+			if ((rc = dev->time_begin("harvest_decimate"))) return rc;
+			if (r == 1) {
+				hipLaunchKernelGGL(hv_copy_kernel, dim3((max_ylen + 255) / 256, n_utt), dim3(256), 0, s, du, d_x, h->y.as<double>());
+			} else {
+				const DecCoef c = dec_coef(r);
+				const int chunks = (max_len + DEC_CHUNK - 1) / DEC_CHUNK;
+				dim3 grid((chunks + 63) / 64, n_utt);
+				hipLaunchKernelGGL(hv_decimate_kernel<0>, grid, dim3(64), 0, s, du, d_x, h->dec.as<double>(), h->y.as<double>(), c, r, lag);
+				hipLaunchKernelGGL(hv_decimate_kernel<1>, grid, dim3(64), 0, s, du, d_x, h->dec.as<double>(), h->y.as<double>(), c, r, lag);
+			}
+			hipLaunchKernelGGL(hv_dc_kernel, dim3(n_utt), dim3(256), 0, s, du, h->y.as<double>());
+			WC_HIP(hipGetLastError());
+			if ((rc = dev->time_end("harvest_decimate"))) return rc;
+		}
+		BpArgs ba;
+		ba.utts = du; ba.y = h->y.as<double>(); ba.taps = h->d_taps.as<double>(); ba.tap_off = h->d_tap_off.as<int>();
+		ba.half_len = h->d_half_len.as<int>(); ba.ev_band_off = h->d_ev_band_off.as<long long>(); ba.ev_cap = h->d_ev_cap.as<int>();
+		ba.events = h->events.as<double>(); ba.ev_count = h->ev_count.as<int>(); ba.overflow = h->overflow.as<int>(); ba.n_bands = nb;
+		if ((rc = dev->time_begin("harvest_bandpass"))) return rc;
+		hipLaunchKernelGGL(hv_bandpass_kernel, dim3(nb, n_utt), dim3(BP_T), 0, s, ba);
+		WC_HIP(hipGetLastError());
+		if ((rc = dev->time_end("harvest_bandpass"))) return rc;
+		int ovf = 0;
+		WC_HIP(hipMemcpyAsync(&ovf, h->overflow.p, sizeof(int), hipMemcpyDeviceToHost, s));
+		WC_HIP(hipStreamSynchronize(s));
+		if (!ovf) break;
+		if (full) return fail(WC_ERR_DEVICE, "harvest: zero-crossing buffer overflow");
+		full = true;
+	}
+	const HvUtt *du = h->utts.as<HvUtt>();
+	RawArgs ra;
+	ra.utts = du; ra.events = h->events.as<double>(); ra.ev_band_off = h->d_ev_band_off.as<long long>(); ra.ev_cap = h->d_ev_cap.as<int>();
+	ra.ev_count = h->ev_count.as<int>(); ra.band_f0 = h->d_band_f0.as<double>(); ra.raw = h->raw.as<double>(); ra.n_bands = nb;
+	ra.fs_d = h->fs_d; ra.f0_floor = h->f0_floor; ra.f0_ceil = h->f0_ceil;
+	if ((rc = dev->time_begin("harvest_raw"))) return rc;
+	hipLaunchKernelGGL(hv_raw_kernel, dim3((max_L1 + 255) / 256, nb, n_utt), dim3(256), 0, s, ra);
+	hipLaunchKernelGGL(hv_detect_kernel, dim3((max_L1 + 255) / 256, n_utt), dim3(256), 0, s, du, h->raw.as<double>(), h->cand0.as<double>(), nb, S);
+	WC_HIP(hipGetLastError());
+	if ((rc = dev->time_end("harvest_raw"))) return rc;
+	RefArgs fa;
+	fa.utts = du; fa.n_utt = n_utt; fa.y = h->y.as<double>(); fa.cand0 = h->cand0.as<double>(); fa.tw = dev->twiddle;
+	fa.cand1 = h->cand1.as<double>(); fa.score1 = h->score1.as<double>(); fa.total_frames = total_l1;
+	fa.p.fs = h->fs; fa.p.decim = r; fa.p.n_bands = nb; fa.p.S = S; fa.p.n_cand = nc; fa.p.fs_d = h->fs_d;
+	fa.p.f0_floor = h->f0_floor; fa.p.f0_ceil = h->f0_ceil; fa.p.frame_period = h->frame_period;
+	if ((rc = dev->time_begin("harvest_refine"))) return rc;
+	hipLaunchKernelGGL(hv_refine_kernel, dim3((unsigned)total_l1), dim3(256), 0, s, fa);
+	WC_HIP(hipGetLastError());
+	if ((rc = dev->time_end("harvest_refine"))) return rc;
+	hipLaunchKernelGGL(hv_unreliable_kernel, dim3((unsigned)total_l1), dim3(128), 0, s, du, n_utt, h->cand1.as<double>(), h->score1.as<double>(),
+					   h->cand2.as<double>(), h->score2.as<double>(), total_l1, nc);
+	CtrArgs ca;
+	ca.utts = du; ca.cand = h->cand2.as<double>(); ca.score = h->score2.as<double>(); ca.base = h->base.as<double>();
+	ca.s1 = h->s1.as<double>(); ca.s2 = h->s2.as<double>(); ca.s3 = h->s3.as<double>(); ca.fixed = h->fixed.as<double>();
+	ca.sec = h->sec.as<int>(); ca.chan = h->chan.as<double>(); ca.chan_stride = chan_stride; ca.max_sec = max_sec; ca.nc = nc;
+	ca.ibuf = h->ibuf.as<int>();
+	if ((rc = dev->time_begin("harvest_contour"))) return rc;
+	hipLaunchKernelGGL(hv_contour_kernel, dim3(n_utt), dim3(64), 0, s, ca);
+	SmArgs sa;
+	sa.utts = du; sa.fixed = h->fixed.as<double>(); sa.f0_1ms = h->f0_1ms.as<double>(); sa.sec = h->sec.as<int>();
+	sa.scratch = h->smooth.as<double>(); sa.scratch_stride = smooth_stride; sa.max_sec = max_sec;
+	hipLaunchKernelGGL(hv_smooth_kernel, dim3(n_utt), dim3(64), 0, s, sa);
+	hipLaunchKernelGGL(hv_output_kernel, dim3((max_L + 255) / 256, n_utt), dim3(256), 0, s, du, h->f0_1ms.as<double>(), d_tpos, d_f0, h->frame_period);
+	WC_HIP(hipGetLastError());
+	if ((rc = dev->time_end("harvest_contour"))) return rc;
+	h->last_utts = utts;
+	return WC_OK;
+}
+
+extern "C" {
+
+wc_harvest *wc_harvest_create(int fs, double f0_floor, double f0_ceil, double frame_period, double target_fs,
+							  double channels_in_octave, int use_cos_table) {
+	(void)use_cos_table;  // reference-only approximation (src/harvest.cpp:152-170); exact cosines are always used
+	if (fs <= 0 || f0_floor <= 0 || f0_ceil <= f0_floor || frame_period <= 0 || target_fs <= 0 || channels_in_octave <= 0) {
+		set_error("harvest: invalid option");
+		return nullptr;
+	}
+	Device *dev = current_device();
+	if (!dev) return nullptr;
+	wc_harvest *h = new wc_harvest();
+	h->fs = fs; h->f0_floor = f0_floor; h->f0_ceil = f0_ceil; h->frame_period = frame_period; h->target_fs = target_fs;
+	h->channels_in_octave = channels_in_octave; h->dev = dev;
+	// reference src/harvest.cpp:82-84, :1388-1397, :1418-1419
+	h->decim = std::max(std::min(h_mround(fs / target_fs), 12), 1);
+	h->fs_d = static_cast<double>(fs) / h->decim;
+	const double adj_floor = f0_floor * 0.9, adj_ceil = f0_ceil * 1.1;
+	h->n_bands = 1 + static_cast<int>(std::log(adj_ceil / adj_floor) / 0.69314718055994529 * channels_in_octave);
+	h->max_cand = h_mround(h->n_bands / 10) * 7;
+	h->S = h->max_cand / 7;
+	if (h->S < 1 || h->S > MAX_SLOTS || h->n_bands < 12) {
+		set_error("harvest: unsupported f0_floor / f0_ceil / channels_in_octave combination");
+		delete h;
+		return nullptr;
+	}
+	h->band_f0.resize(h->n_bands);
+	h->half_len.resize(h->n_bands);
+	h->tap_off.resize(h->n_bands);
+	std::vector<double> taps;
+	const double pi = 3.1415926535897932384;
+	for (int b = 0; b < h->n_bands; ++b) {
+		const double fb = adj_floor * std::pow(2.0, static_cast<double>(b + 1) / channels_in_octave);
+		const int hl = h_mround(h->fs_d / fb * 2.0);  // reference :1264
+		if (hl > HL_MAX) {
+			set_error("harvest: f0_floor too low for the supported band-pass length (f0_floor >= 35 Hz at 8 kHz internal rate)");
+			delete h;
+			return nullptr;
+		}
+		h->band_f0[b] = fb;
+		h->half_len[b] = hl;
+		h->tap_off[b] = static_cast<int>(taps.size());
+		const int ylen = hl * 2 + 1;
+		const int nt8 = ((ylen + 7) / 8) * 8;
+		for (int i = 0; i < ylen; ++i) {  // NuttallWindow * cos (reference src/world_common.cpp:118-126, src/harvest.cpp:1266-1269)
+			const double t = i / (ylen - 1.0);
+			double w = 0.355768 - 0.487396 * std::cos(2.0 * pi * t) + 0.144232 * std::cos(4.0 * pi * t) - 0.012604 * std::cos(6.0 * pi * t);
+			w *= std::cos(2 * pi * fb * (i - hl) / h->fs_d);
+			taps.push_back(w);
+		}
+		for (int i = ylen; i < nt8; ++i) taps.push_back(0.0);
+	}
+	// longest refinement window must fit the kernel's LDS buffer
+	if (2 * static_cast<int>(1.5 * h->fs_d / f0_floor + 1.0) + 1 > RF_MAXW) {
+		set_error("harvest: f0_floor too low for the refinement window");
+		delete h;
+		return nullptr;
+	}
+	bool ok = h->d_taps.reserve(sizeof(double) * taps.size()) == 0 && h->d_tap_off.reserve(sizeof(int) * h->n_bands) == 0 &&
+			  h->d_half_len.reserve(sizeof(int) * h->n_bands) == 0 && h->d_band_f0.reserve(sizeof(double) * h->n_bands) == 0;
+	ok = ok && hipMemcpy(h->d_taps.p, taps.data(), sizeof(double) * taps.size(), hipMemcpyHostToDevice) == hipSuccess;
+	ok = ok && hipMemcpy(h->d_tap_off.p, h->tap_off.data(), sizeof(int) * h->n_bands, hipMemcpyHostToDevice) == hipSuccess;
+	ok = ok && hipMemcpy(h->d_half_len.p, h->half_len.data(), sizeof(int) * h->n_bands, hipMemcpyHostToDevice) == hipSuccess;
+	ok = ok && hipMemcpy(h->d_band_f0.p, h->band_f0.data(), sizeof(double) * h->n_bands, hipMemcpyHostToDevice) == hipSuccess;
+	if (!ok) {
+		set_error("harvest: table upload failed");
+		delete h;
+		return nullptr;
+	}
+	return h;
+}
+
+void wc_harvest_destroy(wc_harvest *h) {
+	if (!h) return;
+	(void)hipStreamSynchronize(h->dev->stream);
+	for (DevBuf *b : {&h->d_taps, &h->d_tap_off, &h->d_half_len, &h->d_band_f0, &h->d_ev_band_off, &h->d_ev_cap, &h->utts, &h->dec, &h->y,
+					  &h->events, &h->ev_count, &h->overflow, &h->raw, &h->cand0, &h->cand1, &h->score1, &h->cand2, &h->score2, &h->base,
+					  &h->s1, &h->s2, &h->s3, &h->fixed, &h->f0_1ms, &h->sec, &h->chan, &h->smooth, &h->ibuf, &h->d_x, &h->d_tpos, &h->d_f0})
+		b->release();
+	h->h_stage.release();
+	delete h;
+}
+
+int wc_harvest_compute_device(wc_harvest *h, int n_utt, const double *d_x, const int *x_length, double *d_tpos, double *d_f0) {
+	if (!h || n_utt <= 0 || !d_x || !x_length || !d_tpos || !d_f0) return fail(WC_ERR_INVALID, "harvest: null argument");
+	WC_HIP(hipSetDevice(h->dev->id));
+	return hv_run_device(h, n_utt, d_x, x_length, d_tpos, d_f0);
+}
+
+int wc_harvest_compute(wc_harvest *h, const double *x, int x_length, double *temporal_positions, double *f0) {
+	if (!h || !x || !temporal_positions || !f0) return fail(WC_ERR_INVALID, "harvest: null argument");
+	if (x_length <= 0) return fail(WC_ERR_INVALID, "harvest: bad length");
+	WC_HIP(hipSetDevice(h->dev->id));
+	hipStream_t s = h->dev->stream;
+	const int L = wc_get_samples(h->fs, x_length, h->frame_period);
+	int rc;
+	if ((rc = h->d_x.reserve(sizeof(double) * x_length))) return rc;
+	if ((rc = h->d_tpos.reserve(sizeof(double) * L))) return rc;
+	if ((rc = h->d_f0.reserve(sizeof(double) * L))) return rc;
+	WC_HIP(hipMemcpyAsync(h->d_x.p, x, sizeof(double) * x_length, hipMemcpyHostToDevice, s));
+	if ((rc = hv_run_device(h, 1, h->d_x.as<double>(), &x_length, h->d_tpos.as<double>(), h->d_f0.as<double>()))) return rc;
+	WC_HIP(hipMemcpyAsync(temporal_positions, h->d_tpos.p, sizeof(double) * L, hipMemcpyDeviceToHost, s));
+	WC_HIP(hipMemcpyAsync(f0, h->d_f0.p, sizeof(double) * L, hipMemcpyDeviceToHost, s));
+	WC_HIP(hipStreamSynchronize(s));
+	return WC_OK;
+}
+
+// Development hook (not part of include/world_class_c.h): copies an intermediate of the most recent call
+// for utterance `utt` to the host.  names: y, raw, cand, score, base, fixed, f0_1ms.  Returns the number of
+// doubles written (or needed when dst is NULL), <0 on error.
+long long wc_harvest_debug_fetch(wc_harvest *h, const char *name, int utt, double *dst) {
+	if (!h || !name || utt < 0 || utt >= (int)h->last_utts.size()) return fail(WC_ERR_INVALID, "harvest debug: bad argument");
+	const HvUtt &u = h->last_utts[utt];
+	const int nc = 7 * h->S;
+	const double *src = nullptr;
+	long long n = 0;
+	std::string nm(name);
+	if (nm == "y") { src = h->y.as<double>() + u.y_off; n = u.y_len; }
+	else if (nm == "raw") { src = h->raw.as<double>() + u.l1_off * h->n_bands; n = (long long)u.L1 * h->n_bands; }
+	else if (nm == "cand0") { src = h->cand0.as<double>() + u.l1_off * h->S; n = (long long)u.L1 * h->S; }
+	else if (nm == "cand1") { src = h->cand1.as<double>() + u.l1_off * nc; n = (long long)u.L1 * nc; }
+	else if (nm == "cand") { src = h->cand2.as<double>() + u.l1_off * nc; n = (long long)u.L1 * nc; }
+	else if (nm == "score") { src = h->score2.as<double>() + u.l1_off * nc; n = (long long)u.L1 * nc; }
+	else if (nm == "base") { src = h->base.as<double>() + u.l1_off; n = u.L1; }
+	else if (nm == "s1") { src = h->s1.as<double>() + u.l1_off; n = u.L1; }
+	else if (nm == "s2") { src = h->s2.as<double>() + u.l1_off; n = u.L1; }
+	else if (nm == "s3") { src = h->s3.as<double>() + u.l1_off; n = u.L1; }
+	else if (nm == "fixed") { src = h->fixed.as<double>() + u.l1_off; n = u.L1; }
+	else if (nm == "f0_1ms") { src = h->f0_1ms.as<double>() + u.l1_off; n = u.L1; }
+	else return fail(WC_ERR_INVALID, "harvest debug: unknown name");
+	if (dst) {
+		WC_HIP(hipMemcpyAsync(dst, src, sizeof(double) * n, hipMemcpyDeviceToHost, h->dev->stream));
+		WC_HIP(hipStreamSynchronize(h->dev->stream));
+	}
+	return n;
+}
+
+}  // extern "C"
