@@ -1,0 +1,88 @@
+"""-m gpu parity tests of the HIP Harvest path (through the C-ABI) against golden F0 contours from the real
+reference and against the CPU oracle (final contour and intermediates)."""
+import numpy as np
+import pytest
+
+from conftest import PIPELINE_CASES
+from world_class_amd.synth import make_utterance
+
+pytestmark = pytest.mark.gpu
+
+# F0 parity in Hz on every frame, voiced/unvoiced decisions identical (SURVEY.md section 8(c) asks for
+# 1e-6 Hz on 99.9 % of the frames and <= 0.1 % V/UV flips; these inputs meet the stricter bar)
+F0_ABS = 1e-6
+
+
+@pytest.fixture(scope="module")
+def wca():
+    import world_class_amd as w
+    w.lib()
+    return w
+
+
+def check_f0(f0, ref):
+    assert np.array_equal(f0 == 0, ref == 0), "voiced/unvoiced decisions differ"
+    assert np.abs(f0 - ref).max() < F0_ABS
+
+
+@pytest.mark.parametrize("name", PIPELINE_CASES)
+def test_harvest_golden(golden, wca, name):
+    c = golden.case(name)
+    h = wca.Harvest(c["fs"], f0_floor=c["harvest_floor"], frame_period=c["frame_period"])
+    tpos, f0 = h.compute(c["x"])
+    assert np.array_equal(tpos, c["tpos"])
+    check_f0(f0, c["f0"])
+
+
+def test_harvest_intermediates_vs_oracle(wca, port):
+    fs = 48000
+    x = make_utterance(fs, 1.5, 2024)
+    d = port.harvest_debug(x, fs, f0_floor=40.0)
+    h = wca.Harvest(fs, f0_floor=40.0)
+    h.compute(x)
+    L1 = len(d["f0_1ms"])
+    assert np.abs(h.debug_fetch("y") - d["y"]).max() < 1e-14
+    raw = h.debug_fetch("raw").reshape(d["raw"].shape)
+    assert np.array_equal(raw == 0, d["raw"] == 0)
+    assert np.abs(raw - d["raw"]).max() < 1e-7
+    gc = h.debug_fetch("cand").reshape(L1, -1)
+    for i in range(L1):
+        a, b = np.sort(gc[i][gc[i] != 0]), np.sort(d["cand"][i][d["cand"][i] != 0])
+        assert len(a) == len(b) and (len(a) == 0 or np.abs(a - b).max() < 1e-8)
+    for name, key in (("base", "f0_base"), ("fixed", "f0_fixed"), ("f0_1ms", "f0_1ms")):
+        check_f0(h.debug_fetch(name), d[key])
+
+
+def test_harvest_ragged_batch(wca, port):
+    fs = 16000
+    xs = [make_utterance(fs, sec, 300 + i) for i, sec in enumerate((0.5, 1.3, 0.05, 0.9))]
+    h = wca.Harvest(fs)
+    outs = h.compute_batch(xs)
+    for x, (t, f) in zip(xs, outs):
+        tr, fr = port.harvest(x, fs)
+        assert np.array_equal(t, tr)
+        check_f0(f, fr)
+
+
+@pytest.mark.parametrize("fs,fp", [(8000, 5.0), (22050, 5.0), (44100, 10.0), (16000, 1.0)])
+def test_harvest_other_rates(wca, port, fs, fp):
+    x = make_utterance(fs, 0.8, fs + 7)
+    t, f = wca.Harvest(fs, frame_period=fp).compute(x)
+    tr, fr = port.harvest(x, fs, frame_period=fp)
+    assert np.array_equal(t, tr)
+    check_f0(f, fr)
+
+
+def test_harvest_edges(wca, port):
+    fs = 16000
+    h = wca.Harvest(fs)
+    # noise only (no voiced section at all) and a loud signal that trips the int-typed "DC removal"
+    rng = np.random.default_rng(3)
+    for x in (rng.normal(0, 0.01, 8000), np.clip(make_utterance(fs, 0.5, 11) * 4.0, -1.5, 1.5)):
+        t, f = h.compute(x)
+        tr, fr = port.harvest(x, fs)
+        check_f0(f, fr)
+    with pytest.raises(wca.WorldClassError):
+        h.compute(np.zeros(10))          # shorter than 3 ms
+    with pytest.raises(wca.WorldClassError):
+        wca.Harvest(fs, f0_floor=10.0)   # band-pass longer than the kernel supports

@@ -1,0 +1,82 @@
+"""-m gpu: the whole hot path Harvest -> CheapTrick -> D4C -> Synthesis on the device, in the demo order of
+reference test/test.cpp:288-384, against the golden outputs of the real reference (noise stream included),
+plus size-independent properties at the benchmark's full utterance size."""
+import numpy as np
+import pytest
+
+from conftest import PIPELINE_CASES
+from world_class_amd.synth import make_utterance, true_f0
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def wca():
+    import world_class_amd as w
+    w.lib()
+    return w
+
+
+def run_pipeline(wca, x, fs, floor=71.0, fp=5.0):
+    wca.rng_set_position(0)
+    tpos, f0 = wca.Harvest(fs, f0_floor=floor, frame_period=fp).compute(x)
+    ct = wca.CheapTrick(fs)
+    sp = ct.compute(x, tpos, f0)
+    ap = wca.D4C(fs).compute(x, tpos, f0, ct.fft_size)
+    y = wca.Synthesis(fs, ct.fft_size, fp).compute(f0, sp, ap)
+    return tpos, f0, sp, ap, y
+
+
+@pytest.mark.parametrize("name", PIPELINE_CASES)
+def test_pipeline_golden(golden, wca, name):
+    c = golden.case(name)
+    tpos, f0, sp, ap, y = run_pipeline(wca, c["x"], c["fs"], c["harvest_floor"], c["frame_period"])
+    s = c["stride"]
+    assert np.array_equal(f0 == 0, c["f0"] == 0)
+    assert np.abs(f0 - c["f0"]).max() < 1e-6
+    assert (np.abs(sp[::s] - c["sp_rows"]) / c["sp_rows"]).max() < 1e-7
+    assert np.abs(ap[::s] - c["ap_rows"]).max() < 1e-7
+    assert np.abs(y - c["y"]).max() < 1e-8
+
+
+def test_device_batch_equals_single_calls(wca):
+    """Packed device API on a ragged batch == the host API utterance by utterance (fresh-process RNG each)."""
+    fs = 16000
+    xs = [make_utterance(fs, sec, 50 + i) for i, sec in enumerate((0.7, 0.3, 1.1))]
+    hv, ct, d4, = wca.Harvest(fs), wca.CheapTrick(fs), wca.D4C(fs)
+    sy = wca.Synthesis(fs, ct.fft_size, 5.0)
+    tf = hv.compute_batch(xs)
+    t, f = [a for a, _ in tf], [b for _, b in tf]
+    sps, pos = ct.compute_batch(xs, t, f, rng_pos=[0] * 3)
+    aps, pos = d4.compute_batch(xs, t, f, ct.fft_size, rng_pos=pos)
+    ys, pos = sy.compute_batch(f, sps, aps, rng_pos=pos)
+    for x, fb, spb, apb, yb in zip(xs, f, sps, aps, ys):
+        _, f0, sp, ap, y = run_pipeline(wca, x, fs)
+        assert np.array_equal(fb, f0) and np.array_equal(spb, sp) and np.array_equal(apb, ap)
+        assert np.abs(yb - y).max() < 1e-12  # overlap-add order is the only non-determinism
+
+
+def test_full_size_properties(wca):
+    """48 kHz, 10 s (the benchmark's utterance size): structural checks that need no oracle run."""
+    fs = 48000
+    x = make_utterance(fs, 10.0, 3000)
+    tpos, f0, sp, ap, y = run_pipeline(wca, x, fs)
+    assert len(f0) == 2001 and sp.shape == (2001, 1025) and ap.shape == (2001, 1025) and len(y) == 480001
+    assert np.isfinite(sp).all() and (sp > 0).all()
+    assert ((ap > 0) & (ap <= 1.0)).all()
+    assert np.array_equal(ap[f0 == 0], np.full_like(ap[f0 == 0], 1.0 - 1e-12))  # unvoiced rows are the sentinel
+    v = f0 > 0
+    assert (f0[v] >= 71.0).all() and (f0[v] <= 800.0).all()
+    # the estimator recovers the generator's own contour where both call the frame voiced
+    tt, tf = true_f0(fs, 10.0, 3000)
+    both = v & (tf > 0)
+    assert both.mean() > 0.5 and np.median(np.abs(f0[both] - tf[both]) / tf[both]) < 0.01
+    # analysis of a time-shifted copy is the shifted analysis (shift = 2 hops) away from the edges
+    x2 = np.concatenate([np.zeros(480) + x[0], x])[:len(x)]
+    _, f02, sp2, _, _ = run_pipeline(wca, x2, fs)
+    inner = slice(300, 1700)
+    a, b = f0[inner], f02[302:1702]
+    same = (a > 0) & (b > 0)
+    assert same.mean() > 0.5 and np.abs(a[same] - b[same]).max() < 0.5
+    # resynthesis has the energy of the input (same order of magnitude) and is finite
+    assert np.isfinite(y).all() and 0.3 < np.sqrt(np.mean(y ** 2)) / np.sqrt(np.mean(x ** 2)) < 3.0
