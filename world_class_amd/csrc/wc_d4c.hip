@@ -63,8 +63,12 @@ __device__ __forceinline__ int d4c_windowed(const double *__restrict__ x, int x_
 		wave[e] = 0.0;
 		if (i < wl) {
 			double position = c1 * (i - hw);
+#ifdef ABL_NOCOS
+			{ double t_ = c2 * position; w[e] = 0.5 + 0.4 * (1.0 - t_ * t_ * 0.1); }
+#else
 			if (type == 1) w[e] = 0.5 * cos(c2 * position) + 0.5;
 			else w[e] = 0.42 + 0.5 * cos(c2 * position) + 0.08 * cos(c2 * position * 2);
+#endif
 			int si = clampi(origin + i - hw, 0, x_len - 1);
 			wave[e] = x[si] * w[e] + randn_at(rng, roff + i) * kSafe;
 			s1 += wave[e];
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(T) void d4c_lovetrain_kernel(D4cArgs a) {
 }
 
 template <int N, int T>
-__global__ __launch_bounds__(T) void d4c_frames_kernel(D4cArgs a) {
+__global__ __launch_bounds__(T, 2) void d4c_frames_kernel(D4cArgs a) {
 	constexpr int M = N / 2;
 	constexpr int EPT = N / T;
 	constexpr int KPT = (M + 1 + T - 1) / T;  // power-spectrum keys per thread
@@ -370,16 +374,30 @@ __global__ __launch_bounds__(T) void d4c_frames_kernel(D4cArgs a) {
 			}
 		}
 		__syncthreads();
-		if (tid < n_ap) {
-			unsigned int need = sel_k[tid], acc = 0;
-			int d = 0;
-			for (; d < 256; ++d) {
-				unsigned int h = hist[tid][d];
-				if (acc + h >= need) break;
-				acc += h;
+		// digit search: wave w scans the 256-bin histograms of bands w, w + 4 (4 bins per lane)
+		for (int bb = tid >> 6; bb < n_ap; bb += T / 64) {
+			const int lane = tid & 63;
+			const unsigned int need = sel_k[bb];
+			const uint4 h4 = reinterpret_cast<const uint4 *>(&hist[bb][0])[lane];
+			const unsigned int own = h4.x + h4.y + h4.z + h4.w;
+			unsigned int inc = own;
+#pragma unroll
+			for (int o = 1; o < 64; o <<= 1) {
+				unsigned int t = __shfl_up(inc, o, 64);
+				if (lane >= o) inc += t;
 			}
-			sel_k[tid] = need - acc;  // rank inside the chosen digit bucket
-			sel_prefix[tid] |= ((unsigned long long)d) << shift;
+			const unsigned long long reach = __ballot(inc >= need);  // never empty: the total count >= need
+			const int first = __ffsll((long long)reach) - 1;
+			if (lane == first) {
+				unsigned int acc = inc - own;
+				int d = 4 * lane;
+				if (acc + h4.x >= need) { d += 0; }
+				else if (acc + h4.x + h4.y >= need) { acc += h4.x; d += 1; }
+				else if (acc + h4.x + h4.y + h4.z >= need) { acc += h4.x + h4.y; d += 2; }
+				else { acc += h4.x + h4.y + h4.z; d += 3; }
+				sel_k[bb] = need - acc;  // rank inside the chosen digit bucket
+				sel_prefix[bb] |= ((unsigned long long)d) << shift;
+			}
 		}
 		__syncthreads();
 	}

@@ -111,6 +111,10 @@ __device__ __forceinline__ double2 twiddle(const double2 *__restrict__ tw, int i
 // tw: global twiddle table of kTwiddleN entries.  Ends with a __syncthreads().
 template <int M, int T, int S>
 __device__ void fft_lds(double2 *a, const double2 *__restrict__ tw, int tid) {
+#ifdef ABL_NOFFT
+	__syncthreads();
+	return;
+#endif
 	static_assert((M & (M - 1)) == 0 && M >= 16 && M <= kTwiddleN, "M must be a power of two in [16, 4096]");
 	constexpr int LOG2 = __builtin_ctz(M);
 	constexpr bool LEAD2 = (LOG2 & 1) != 0;

@@ -381,16 +381,24 @@ struct RefArgs {
 	const double *y;
 	const double *cand0;
 	const double2 *tw;
+	const double2 *rot;  // per half window length hw: (cos, sin) of 2 pi / (2 hw + 1) and of 8 times that
 	double *cand1, *score1;
 	long long total_frames;
 	HvParams p;
 };
 
-constexpr int RF_MAXW = 2 * 320 + 1;  // longest window (f0 = 37.5 Hz at 8 kHz)
+constexpr int RF_MAXHW = 320;           // longest half window (f0 = 37.5 Hz at 8 kHz)
+constexpr int RF_MAXW = 2 * RF_MAXHW + 1;
 
+// One workgroup per 1 ms frame; a wavefront handles candidate slot j of all 7 overlap blocks at once:
+// lanes 8 b .. 8 b + 7 work on block b (the same slot of frames i-3 .. i+3, so the windows have similar
+// lengths) and split the window samples n = sub + 8 q among them.  The Blackman window and the DFT twiddles
+// advance by rotation recurrences from exact starting values (one sincos and 6 table twiddles per lane);
+// the 24 partial sums are reduced inside the 8-lane group by a halving butterfly that leaves harmonic h
+// in lane h.
 __global__ __launch_bounds__(256) void hv_refine_kernel(RefArgs a) {
-	__shared__ double MW[4][RF_MAXW + 3];
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const int blk = lane >> 3, sub = lane & 7;
 	const long long g = blockIdx.x;
 	if (g >= a.total_frames) return;
 	const int ui = hv_find(a.utts, a.n_utt, g, &HvUtt::l1_off);
@@ -400,91 +408,123 @@ __global__ __launch_bounds__(256) void hv_refine_kernel(RefArgs a) {
 	const double fs = a.p.fs_d;
 	const int S = a.p.S;
 	const double *__restrict__ y = a.y + u.y_off;
-	double *mw = MW[wv];
-	for (int slot = wv; slot < a.p.n_cand; slot += 4) {
-		const int blk = slot / S, j = slot - blk * S;
-		const int src = (blk == 0) ? i : (blk <= 3 ? i - blk : i + (blk - 3));  // overlap (reference :987-1000)
+	const int src = (blk == 0) ? i : (blk <= 3 ? i - blk : i + (blk - 3));  // overlap (reference :987-1000)
+	const bool src_ok = blk < 7 && src >= 0 && src < u.L1;
+	for (int j = wv; j < S; j += 4) {
 		double f = 0.0;
-		if (src >= 0 && src < u.L1) f = a.cand0[(u.l1_off + src) * S + j];
+		if (src_ok) f = a.cand0[(u.l1_off + src) * S + j];
+		const bool live = f > 0.0;
 		double rf = 0.0, rs = 0.0;
-		if (f > 0.0) {
-			const int hw = (int)(1.5 * fs / f + 1.0);
-			const int bt = 2 * hw + 1;
-			if (bt <= RF_MAXW) {
-				const double wlt = (2.0 * hw + 1.0) / fs;
-				const int fft_index = 2 + (int)(log(hw * 2 + 1.0) / kLog2H);
-				const int N = 1 << fft_index;
-				const double bt0 = (-hw) / fs;
-				const int basic = mround((pos + bt0) * fs + 0.001);
-				// main window (reference :762-788)
-				for (int n = lane; n < bt; n += 64) {
-					double tmp = (basic + n - 1.0) / fs - pos;
-					double tmp2 = 2.0 * kPi * tmp / wlt;
-					mw[n] = 0.42 + 0.5 * cos(tmp2) + 0.08 * cos(2 * tmp2);
-				}
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-				__builtin_amdgcn_wave_barrier();
-				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-				const int nh = min((int)(fs / 2.0 / f), 6);
-				int idx[6];
+		if (__ballot(live) != 0ull) {
+			// per-candidate constants (garbage-free defaults for idle groups)
+			const double fc = live ? f : 100.0;
+			const int hw = min((int)(1.5 * fs / fc + 1.0), RF_MAXHW);
+			const int bt = live ? 2 * hw + 1 : 0;
+			const double wlt = (2.0 * hw + 1.0) / fs;
+			const int fft_index = 2 + (int)(log(hw * 2 + 1.0) / kLog2H);
+			const int N = 1 << fft_index;
+			const int tsh = kTwiddleN / N;
+			const double bt0 = (-hw) / fs;
+			const int basic = mround((pos + bt0) * fs + 0.001);
+			const int nh = min((int)(fs / 2.0 / fc), 6);
+			int idx[6];
 #pragma unroll
-				for (int h = 0; h < 6; ++h) idx[h] = mround(f * N / fs * (h + 1));
-				double mr[6], mi[6], dr[6], di[6];
+			for (int h = 0; h < 6; ++h) idx[h] = mround(fc * N / fs * (h + 1));
+			// window phase at this lane's first sample, exactly as the reference evaluates it (:762-788)
+			double wc, ws;
+			{
+				const double tmp = (basic + sub - 1.0) / fs - pos;
+				const double tmp2 = 2.0 * kPi * tmp / wlt;
+				sincos(tmp2, &ws, &wc);
+			}
+			const double2 r1 = a.rot[2 * hw], r8 = a.rot[2 * hw + 1];  // (cos, sin) of beta and 8 beta, beta = 2 pi / (2 hw + 1)
+			double2 t[6], st[6];
 #pragma unroll
-				for (int h = 0; h < 6; ++h) mr[h] = mi[h] = dr[h] = di[h] = 0.0;
-				const int tsh = kTwiddleN / N;
-				for (int n = lane; n < bt; n += 64) {
-					const double m = mw[n];
+			for (int h = 0; h < 6; ++h) {
+				const double2 t0 = a.tw[((idx[h] * sub) & (N - 1)) * tsh];
+				const double2 s0 = a.tw[((idx[h] * 8) & (N - 1)) * tsh];
+				t[h] = make_double2(t0.x, -t0.y);   // e^{-i theta}
+				st[h] = make_double2(s0.x, -s0.y);
+			}
+			double v[32];
+#pragma unroll
+			for (int k = 0; k < 32; ++k) v[k] = 0.0;
+			for (int n = sub; __ballot(n < bt) != 0ull; n += 8) {
+				if (n < bt) {
+					const double cp = fma(wc, r1.x, ws * r1.y);    // cos(theta - beta)
+					const double cn = fma(wc, r1.x, -(ws * r1.y)); // cos(theta + beta)
+					const double m = 0.42 + 0.5 * wc + 0.08 * (2.0 * wc * wc - 1.0);
+					const double mp = 0.42 + 0.5 * cp + 0.08 * (2.0 * cp * cp - 1.0);
+					const double mn = 0.42 + 0.5 * cn + 0.08 * (2.0 * cn * cn - 1.0);
 					double d;  // differentiated window (reference :794-803)
-					if (n == 0) d = -mw[1] / 2.0;
-					else if (n == bt - 1) d = mw[bt - 2] / 2.0;
-					else d = -(mw[n + 1] - mw[n - 1]) / 2.0;
+					if (n == 0) d = -mn / 2.0;
+					else if (n == bt - 1) d = mp / 2.0;
+					else d = -(mn - mp) / 2.0;
 					const double yv = y[clampi(basic + n - 1, 0, u.y_len - 1)];
 					const double xm = m * yv, xd = d * yv;
 #pragma unroll
 					for (int h = 0; h < 6; ++h) {
-						if (h < nh) {
-							const double2 t = a.tw[((idx[h] * n) & (N - 1)) * tsh];  // e^{+i th}; the DFT uses e^{-i th}
-							mr[h] = fma(xm, t.x, mr[h]);
-							mi[h] = fma(-xm, t.y, mi[h]);
-							dr[h] = fma(xd, t.x, dr[h]);
-							di[h] = fma(-xd, t.y, di[h]);
-						}
+						v[4 * h + 0] = fma(xm, t[h].x, v[4 * h + 0]);
+						v[4 * h + 1] = fma(xm, t[h].y, v[4 * h + 1]);
+						v[4 * h + 2] = fma(xd, t[h].x, v[4 * h + 2]);
+						v[4 * h + 3] = fma(xd, t[h].y, v[4 * h + 3]);
+						t[h] = cmul(t[h], st[h]);
 					}
+					const double nc_ = fma(wc, r8.x, -(ws * r8.y));
+					ws = fma(ws, r8.x, wc * r8.y);
+					wc = nc_;
 				}
+			}
+			// halving butterfly inside the 8-lane group: afterwards lane `sub` holds v[4 sub .. 4 sub + 3]
 #pragma unroll
-				for (int h = 0; h < 6; ++h) {
+			for (int k = 0; k < 16; ++k) {
+				const bool up = (sub & 4) != 0;
+				const double send = up ? v[k] : v[16 + k];
+				const double keep = up ? v[16 + k] : v[k];
+				v[k] = keep + __shfl_xor(send, 4, 64);
+			}
 #pragma unroll
-					for (int o = 32; o > 0; o >>= 1) {
-						mr[h] += __shfl_xor(mr[h], o, 64);
-						mi[h] += __shfl_xor(mi[h], o, 64);
-						dr[h] += __shfl_xor(dr[h], o, 64);
-						di[h] += __shfl_xor(di[h], o, 64);
-					}
-				}
-				// fixF0 (reference :844-878)
-				double num = 0.0, den = 0.0, sc = 0.0;
+			for (int k = 0; k < 8; ++k) {
+				const bool up = (sub & 2) != 0;
+				const double send = up ? v[k] : v[8 + k];
+				const double keep = up ? v[8 + k] : v[k];
+				v[k] = keep + __shfl_xor(send, 2, 64);
+			}
 #pragma unroll
-				for (int h = 0; h < 6; ++h) {
-					if (h < nh) {
-						const double pw = mr[h] * mr[h] + mi[h] * mi[h];
-						const double ni = mr[h] * di[h] - mi[h] * dr[h];
-						const double inst = (pw == 0.0) ? 0.0 : (double)idx[h] * fs / N + ni / pw * fs / 2.0 / kPi;
-						const double amp = sqrt(pw);
-						num += amp * inst;
-						den += amp * (h + 1.0);
-						sc += fabs((inst / (h + 1.0) - f) / f);
-					}
-				}
+			for (int k = 0; k < 4; ++k) {
+				const bool up = (sub & 1) != 0;
+				const double send = up ? v[k] : v[4 + k];
+				const double keep = up ? v[4 + k] : v[k];
+				v[k] = keep + __shfl_xor(send, 1, 64);
+			}
+			// lane `sub` = harmonic h: instantaneous frequency and amplitude (fixF0, reference :844-878)
+			const int h = sub;
+			int myidx = 0;
+#pragma unroll
+			for (int q = 0; q < 6; ++q) if (q == h) myidx = idx[q];
+			const double mr = v[0], mi = v[1], dr = v[2], di = v[3];
+			const double pw = mr * mr + mi * mi;
+			const double ni = mr * di - mi * dr;
+			const double inst = (pw == 0.0) ? 0.0 : (double)myidx * fs / N + ni / pw * fs / 2.0 / kPi;
+			const double amp = sqrt(pw);
+			const double e_num = amp * inst, e_den = amp * (h + 1.0), e_sc = fabs((inst / (h + 1.0) - fc) / fc);
+			double num = 0.0, den = 0.0, sc = 0.0;
+#pragma unroll
+			for (int q = 0; q < 6; ++q) {  // the reference's summation order over harmonics
+				const double x1 = __shfl(e_num, (lane & 56) + q, 64);
+				const double x2 = __shfl(e_den, (lane & 56) + q, 64);
+				const double x3 = __shfl(e_sc, (lane & 56) + q, 64);
+				if (q < nh) { num += x1; den += x2; sc += x3; }
+			}
+			if (live) {
 				rf = num / (den + kSafeH);
 				rs = 1.0 / (sc / nh + kSafeH);
 				if (rf < a.p.f0_floor || rf > a.p.f0_ceil || rs < 2.5) { rf = 0.0; rs = 0.0; }  // reference :974-979
-				__builtin_amdgcn_wave_barrier();
 			}
 		}
-		if (lane == 0) {
-			a.cand1[g * a.p.n_cand + slot] = rf;
-			a.score1[g * a.p.n_cand + slot] = rs;
+		if (sub == 0 && blk < 7) {
+			a.cand1[g * a.p.n_cand + j + S * blk] = rf;
+			a.score1[g * a.p.n_cand + j + S * blk] = rs;
 		}
 	}
 }
@@ -864,7 +904,7 @@ struct wc_harvest {
 	Device *dev;
 	std::vector<double> band_f0;
 	std::vector<int> half_len, tap_off;
-	DevBuf d_taps, d_tap_off, d_half_len, d_band_f0, d_ev_band_off, d_ev_cap;
+	DevBuf d_taps, d_tap_off, d_half_len, d_band_f0, d_ev_band_off, d_ev_cap, d_rot;
 	DevBuf utts, dec, y, events, ev_count, overflow, raw, cand0, cand1, score1, cand2, score2;
 	DevBuf base, s1, s2, s3, fixed, f0_1ms, sec, chan, smooth, ibuf;
 	DevBuf d_x, d_tpos, d_f0;
@@ -1022,7 +1062,7 @@ static int hv_run_device(wc_harvest *h, int n_utt, const double *d_x, const int 
 	WC_HIP(hipGetLastError());
 	if ((rc = dev->time_end("harvest_raw"))) return rc;
 	RefArgs fa;
-	fa.utts = du; fa.n_utt = n_utt; fa.y = h->y.as<double>(); fa.cand0 = h->cand0.as<double>(); fa.tw = dev->twiddle;
+	fa.utts = du; fa.n_utt = n_utt; fa.y = h->y.as<double>(); fa.cand0 = h->cand0.as<double>(); fa.tw = dev->twiddle; fa.rot = h->d_rot.as<double2>();
 	fa.cand1 = h->cand1.as<double>(); fa.score1 = h->score1.as<double>(); fa.total_frames = total_l1;
 	fa.p.fs = h->fs; fa.p.decim = r; fa.p.n_bands = nb; fa.p.S = S; fa.p.n_cand = nc; fa.p.fs_d = h->fs_d;
 	fa.p.f0_floor = h->f0_floor; fa.p.f0_ceil = h->f0_ceil; fa.p.frame_period = h->frame_period;
@@ -1114,6 +1154,16 @@ wc_harvest *wc_harvest_create(int fs, double f0_floor, double f0_ceil, double fr
 	ok = ok && hipMemcpy(h->d_tap_off.p, h->tap_off.data(), sizeof(int) * h->n_bands, hipMemcpyHostToDevice) == hipSuccess;
 	ok = ok && hipMemcpy(h->d_half_len.p, h->half_len.data(), sizeof(int) * h->n_bands, hipMemcpyHostToDevice) == hipSuccess;
 	ok = ok && hipMemcpy(h->d_band_f0.p, h->band_f0.data(), sizeof(double) * h->n_bands, hipMemcpyHostToDevice) == hipSuccess;
+	{
+		std::vector<double2> rot(2 * (RF_MAXHW + 1));
+		for (int hw = 0; hw <= RF_MAXHW; ++hw) {
+			const double beta = 2.0 * pi / (2 * hw + 1);
+			rot[2 * hw] = make_double2(std::cos(beta), std::sin(beta));
+			rot[2 * hw + 1] = make_double2(std::cos(8 * beta), std::sin(8 * beta));
+		}
+		ok = ok && h->d_rot.reserve(sizeof(double2) * rot.size()) == 0 &&
+			 hipMemcpy(h->d_rot.p, rot.data(), sizeof(double2) * rot.size(), hipMemcpyHostToDevice) == hipSuccess;
+	}
 	if (!ok) {
 		set_error("harvest: table upload failed");
 		delete h;
@@ -1125,7 +1175,7 @@ wc_harvest *wc_harvest_create(int fs, double f0_floor, double f0_ceil, double fr
 void wc_harvest_destroy(wc_harvest *h) {
 	if (!h) return;
 	(void)hipStreamSynchronize(h->dev->stream);
-	for (DevBuf *b : {&h->d_taps, &h->d_tap_off, &h->d_half_len, &h->d_band_f0, &h->d_ev_band_off, &h->d_ev_cap, &h->utts, &h->dec, &h->y,
+	for (DevBuf *b : {&h->d_rot, &h->d_taps, &h->d_tap_off, &h->d_half_len, &h->d_band_f0, &h->d_ev_band_off, &h->d_ev_cap, &h->utts, &h->dec, &h->y,
 					  &h->events, &h->ev_count, &h->overflow, &h->raw, &h->cand0, &h->cand1, &h->score1, &h->cand2, &h->score2, &h->base,
 					  &h->s1, &h->s2, &h->s3, &h->fixed, &h->f0_1ms, &h->sec, &h->chan, &h->smooth, &h->ibuf, &h->d_x, &h->d_tpos, &h->d_f0})
 		b->release();
