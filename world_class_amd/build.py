@@ -33,6 +33,11 @@ def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "world_class_c.h"))
+    # objects depend on the flags too: a flags stamp forces a full rebuild when they change
+    stamp = os.path.join(OBJ, "flags.txt")
+    flags_now = " ".join(FLAGS)
+    if not os.path.exists(stamp) or open(stamp).read() != flags_now:
+        force = True
     jobs = []
     objs = []
     for src in sources():
@@ -54,6 +59,8 @@ def build(force=False, verbose=False):
                 print(out)
             if rc != 0:
                 raise RuntimeError("hipcc failed")
+    with open(stamp, "w") as f:
+        f.write(flags_now)
     if jobs or force or _stale(OUT, objs):
         rc, out = run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
         if out.strip():

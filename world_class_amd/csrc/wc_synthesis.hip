@@ -40,6 +40,7 @@ struct TbArgs {
 	PulseBuf p;
 	int *count;                // per-utterance number of pulses (may exceed cap: overflow)
 	int *first_index;          // per-utterance index of the first pulse (for RNG offsets)
+	const long long *inc_off;  // per-utterance first slot in the padded increment scratch
 	int fs, fft_size;
 	double frame_period;       // seconds
 };
@@ -73,11 +74,12 @@ struct Coarse {
 };
 
 // Phase increment of every output sample (reference :211-216, :255-262): 2 pi f0_i / fs with the
-// sample-rate F0 (500 Hz where the interpolated VUV is <= 0.5).  Stored into the output buffer itself
-// (it is cleared again before the overlap-add); the sign carries the VUV: negative = unvoiced.
+// sample-rate F0 (500 Hz where the interpolated VUV is <= 0.5), into a scratch where every utterance is
+// zero-padded to a multiple of 64 samples; the sign carries the VUV: negative = unvoiced.
 __global__ void syn_increment_kernel(TbArgs a, int n_utt, long long total_out, double *__restrict__ inc) {
 	long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 	if (g >= total_out) return;
+	// (the scratch is zero-filled beforehand: every utterance is padded to a multiple of 64 samples)
 	int lo = 0, hi = n_utt - 1;
 	while (lo < hi) {
 		int mid = (lo + hi + 1) >> 1;
@@ -92,7 +94,42 @@ __global__ void syn_increment_kernel(TbArgs a, int n_utt, long long total_out, d
 	f = voiced ? f : 500.0;
 	const double cval = 2.0 * kPi / a.fs;
 	const double d = f * cval;
-	inc[g] = voiced ? d : -d;
+	inc[a.inc_off[lo] + i] = voiced ? d : -d;
+}
+
+// 16 steps of the sequential phase sum: lanes >= K0 + j add |p[j]| at step j.  The increments sit in scalar
+// registers (wave-uniform loads) and the set of participating lanes shrinks by shifting EXEC, so every step
+// is one dependent v_add_f64 -- the reference's summation order at the latency floor of the hardware.
+template <int K0>
+__device__ __forceinline__ void chain16(double &mine, const double *__restrict__ p) {
+	const double v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3], v4 = p[4], v5 = p[5], v6 = p[6], v7 = p[7];
+	const double v8 = p[8], v9 = p[9], v10 = p[10], v11 = p[11], v12 = p[12], v13 = p[13], v14 = p[14], v15 = p[15];
+	unsigned long long save;
+	asm volatile(
+		"s_mov_b64 %[sv], exec\n\t"
+		"s_lshl_b64 exec, %[sv], %[sh]\n\t"
+		"v_add_f64 %[m], %[m], |%[a0]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |%[a1]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |%[a2]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |%[a3]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |%[a4]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |%[a5]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |%[a6]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |%[a7]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |%[a8]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |%[a9]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |%[a10]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |%[a11]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |%[a12]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |%[a13]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |%[a14]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |%[a15]|\n\t"
+		"s_mov_b64 exec, %[sv]\n\t"
+		: [m] "+v"(mine), [sv] "=&s"(save)
+		: [a0] "s"(v0), [a1] "s"(v1), [a2] "s"(v2), [a3] "s"(v3), [a4] "s"(v4), [a5] "s"(v5), [a6] "s"(v6), [a7] "s"(v7),
+		  [a8] "s"(v8), [a9] "s"(v9), [a10] "s"(v10), [a11] "s"(v11), [a12] "s"(v12), [a13] "s"(v13), [a14] "s"(v14),
+		  [a15] "s"(v15), [sh] "n"(K0)
+		: "scc");
 }
 
 // One wavefront per utterance.  The reference accumulates the phase with a sequential running sum
@@ -106,7 +143,7 @@ __global__ __launch_bounds__(64) void syn_timebase_kernel(TbArgs a, const double
 	const UttDesc ud = a.utts[blockIdx.x];
 	const int lane = threadIdx.x;
 	const int n = ud.y_len;
-	const double *__restrict__ inc_g = inc_all + ud.y_off;
+	const double *__restrict__ inc_g = inc_all + a.inc_off[blockIdx.x];
 	const double two_pi = 2.0 * kPi;
 	const long long slot0 = a.cap_off[blockIdx.x];
 	const int cap = a.cap[blockIdx.x];
@@ -114,23 +151,19 @@ __global__ __launch_bounds__(64) void syn_timebase_kernel(TbArgs a, const double
 	double prev_wrap = 0.0;  // wrapped phase / VUV of the previous sample
 	double prev_vu = 0.0;
 	int n_pulses = 0;
-	double nxt = (lane < n) ? inc_g[lane] : 0.0;
 	for (int base = 0; base < n; base += 64) {
 		const int i = base + lane;
-		const double sv = nxt;
-		{  // prefetch the next chunk while the serial chain runs
-			int j = i + 64;
-			nxt = (j < n) ? inc_g[j] : 0.0;
-		}
+		const double sv = inc_g[i];  // padded with zeros past n
 		const double vu = sv > 0.0 ? 1.0 : 0.0;
-		const double inc = fabs(sv);
-		double mine = 0.0;
-#pragma unroll
-		for (int k = 0; k < 64; ++k) {
-			double v = __shfl(inc, k, 64);
-			run = run + v;
-			if (lane == k) mine = run;
-		}
+		// lane L accumulates run + v_0 + ... + v_L in exactly that order: the increments are wave-uniform
+		// (scalar) loads and lanes drop out of the chain one by one
+		double mine = run;
+		const double *__restrict__ pu = inc_g + base;  // wave-uniform address: scalar loads
+		chain16<0>(mine, pu);
+		chain16<16>(mine, pu + 16);
+		chain16<32>(mine, pu + 32);
+		chain16<48>(mine, pu + 48);
+		run = __shfl(mine, 63, 64);
 		const double wrap = fmod(mine, two_pi);
 		double w_prev = __shfl_up(wrap, 1, 64);
 		double v_prev = __shfl_up(vu, 1, 64);
@@ -440,7 +473,7 @@ struct wc_synthesis {
 	int fs, fft_size;
 	double frame_period;  // seconds
 	Device *dev;
-	DevBuf dc_remover, utts, meta, pulses, d_f0, d_sp, d_ap, d_out;
+	DevBuf dc_remover, utts, meta, pulses, incs, d_f0, d_sp, d_ap, d_out;
 	HostBuf h_stage;
 };
 
@@ -472,8 +505,9 @@ static int syn_run_device(wc_synthesis *sy, int n_utt, const double *d_f0, const
 	if (total_out == 0) return WC_OK;
 	int rc;
 	if ((rc = dev->ensure_rng(min_pos, max_end))) return rc;
-	// meta layout (device): cap_off[n] (i64) | pulse_prefix[n+1] (i64) | cap[n] | count[n] | first_index[n] | last_index[n]
-	const size_t meta_bytes = sizeof(long long) * (2 * (size_t)n_utt + 1) + sizeof(int) * 4 * (size_t)n_utt;
+	WC_HIP(hipMemsetAsync(d_out, 0, sizeof(double) * total_out, s));
+	// meta layout (device): cap_off[n] (i64) | pulse_prefix[n+1] (i64) | inc_off[n] (i64) | cap[n] | count[n] | first_index[n] | last_index[n]
+	const size_t meta_bytes = sizeof(long long) * (3 * (size_t)n_utt + 1) + sizeof(int) * 4 * (size_t)n_utt;
 	if ((rc = sy->utts.reserve(sizeof(UttDesc) * n_utt))) return rc;
 	if ((rc = sy->meta.reserve(meta_bytes))) return rc;
 	if ((rc = sy->h_stage.reserve(sizeof(UttDesc) * n_utt + meta_bytes))) return rc;
@@ -481,16 +515,21 @@ static int syn_run_device(wc_synthesis *sy, int n_utt, const double *d_f0, const
 	std::memcpy(hs, utts.data(), sizeof(UttDesc) * n_utt);
 	long long *h_cap_off = reinterpret_cast<long long *>(hs + sizeof(UttDesc) * n_utt);
 	long long *h_prefix = h_cap_off + n_utt;
-	int *h_cap = reinterpret_cast<int *>(h_prefix + n_utt + 1);
+	long long *h_inc_off = h_prefix + n_utt + 1;
+	int *h_cap = reinterpret_cast<int *>(h_inc_off + n_utt);
 	int *h_count = h_cap + n_utt;
 	char *dm = static_cast<char *>(sy->meta.p);
 	long long *d_cap_off = reinterpret_cast<long long *>(dm);
 	long long *d_prefix = d_cap_off + n_utt;
-	int *d_cap = reinterpret_cast<int *>(d_prefix + n_utt + 1);
+	long long *d_inc_off = d_prefix + n_utt + 1;
+	int *d_cap = reinterpret_cast<int *>(d_inc_off + n_utt);
 	int *d_count = d_cap + n_utt;
 	int *d_first = d_count + n_utt;
 	int *d_last = d_first + n_utt;
 
+	long long inc_total = 0;
+	for (int u = 0; u < n_utt; ++u) { h_inc_off[u] = inc_total; inc_total += ((long long)out_length[u] + 63) / 64 * 64 + 64; }
+	if ((rc = sy->incs.reserve(sizeof(double) * inc_total))) return rc;
 	bool full = false;
 	long long total_pulses = 0;
 	for (int attempt = 0; attempt < 2; ++attempt) {
@@ -511,14 +550,17 @@ static int syn_run_device(wc_synthesis *sy, int n_utt, const double *d_f0, const
 		WC_HIP(hipMemcpyAsync(sy->utts.p, hs, sizeof(UttDesc) * n_utt, hipMemcpyHostToDevice, s));
 		WC_HIP(hipMemcpyAsync(d_cap_off, h_cap_off, sizeof(long long) * n_utt, hipMemcpyHostToDevice, s));
 		WC_HIP(hipMemcpyAsync(d_cap, h_cap, sizeof(int) * n_utt, hipMemcpyHostToDevice, s));
+		WC_HIP(hipMemcpyAsync(d_inc_off, h_inc_off, sizeof(long long) * n_utt, hipMemcpyHostToDevice, s));
 		TbArgs ta;
+		ta.inc_off = d_inc_off;
 		ta.utts = sy->utts.as<UttDesc>(); ta.f0 = d_f0; ta.cap_off = d_cap_off; ta.cap = d_cap; ta.p = pb;
 		ta.count = d_count; ta.first_index = d_first; ta.fs = sy->fs; ta.fft_size = sy->fft_size;
 		ta.frame_period = sy->frame_period;
 		if ((rc = dev->time_begin("synthesis_timebase"))) return rc;
+		WC_HIP(hipMemsetAsync(sy->incs.p, 0, sizeof(double) * inc_total, s));
 		hipLaunchKernelGGL(syn_increment_kernel, dim3((unsigned)((total_out + 255) / 256)), dim3(256), 0, s, ta, n_utt,
-						   total_out, d_out);
-		hipLaunchKernelGGL(syn_timebase_kernel, dim3(n_utt), dim3(64), 0, s, ta, (const double *)d_out);
+						   total_out, sy->incs.as<double>());
+		hipLaunchKernelGGL(syn_timebase_kernel, dim3(n_utt), dim3(64), 0, s, ta, (const double *)sy->incs.as<double>());
 		WC_HIP(hipGetLastError());
 		if ((rc = dev->time_end("synthesis_timebase"))) return rc;
 		WC_HIP(hipMemcpyAsync(h_count, d_count, sizeof(int) * n_utt, hipMemcpyDeviceToHost, s));
@@ -532,7 +574,6 @@ static int syn_run_device(wc_synthesis *sy, int n_utt, const double *d_f0, const
 		}
 		h_prefix[n_utt] = total_pulses;
 		if (!overflow) {
-			WC_HIP(hipMemsetAsync(d_out, 0, sizeof(double) * total_out, s));  // it held the phase increments
 			if (total_pulses > 0) {
 				hipLaunchKernelGGL(syn_noise_size_kernel, dim3(8, n_utt), dim3(256), 0, s, d_cap_off, d_count, d_cap, pb, d_first, d_last);
 				WC_HIP(hipMemcpyAsync(d_prefix, h_prefix, sizeof(long long) * (n_utt + 1), hipMemcpyHostToDevice, s));
@@ -607,7 +648,7 @@ wc_synthesis *wc_synthesis_create(int fs, int fft_size, double frame_period_ms) 
 void wc_synthesis_destroy(wc_synthesis *s) {
 	if (!s) return;
 	(void)hipStreamSynchronize(s->dev->stream);
-	s->dc_remover.release(); s->utts.release(); s->meta.release(); s->pulses.release();
+	s->dc_remover.release(); s->utts.release(); s->meta.release(); s->pulses.release(); s->incs.release();
 	s->d_f0.release(); s->d_sp.release(); s->d_ap.release(); s->d_out.release(); s->h_stage.release();
 	delete s;
 }
