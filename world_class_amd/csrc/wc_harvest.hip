@@ -529,31 +529,62 @@ __global__ __launch_bounds__(256) void hv_refine_kernel(RefArgs a) {
 	}
 }
 
-// reference :708-744
-__global__ void hv_unreliable_kernel(const HvUtt *__restrict__ utts, int n_utt, const double *__restrict__ c1,
+// reference :708-744.  One workgroup per frame: the non-zero candidates of the two neighbouring frames are
+// compacted into LDS first (a zero candidate yields the error 1.0, which selectBestF0's allowed range of 1.0
+// already is), then every candidate of this frame scans the two short lists.
+__global__ __launch_bounds__(128) void hv_unreliable_kernel(const HvUtt *__restrict__ utts, int n_utt, const double *__restrict__ c1,
 									 const double *__restrict__ s1, double *__restrict__ c2, double *__restrict__ s2,
-									 long long total_frames, int nc) {
+									 double *__restrict__ base, long long total_frames, int nc) {
+	__shared__ double nxt[7 * MAX_SLOTS], prv[7 * MAX_SLOTS];
+	__shared__ int cnt[2];
+	__shared__ unsigned long long best;  // searchF0Base: (score bits, ~slot) packed so that max = highest score, first slot
 	const long long g = blockIdx.x;
 	if (g >= total_frames) return;
 	const int ui = hv_find(utts, n_utt, g, &HvUtt::l1_off);
 	const HvUtt u = utts[ui];
 	const int i = (int)(g - u.l1_off);
+	const bool interior = i >= 1 && i < u.L1 - 1;
+	if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
+	if (threadIdx.x == 0) best = 0ull;
+	__syncthreads();
+	if (interior) {
+		for (int j = threadIdx.x; j < nc; j += blockDim.x) {
+			const double a = c1[(g + 1) * nc + j], b = c1[(g - 1) * nc + j];
+			if (a != 0) nxt[atomicAdd(&cnt[0], 1)] = a;
+			if (b != 0) prv[atomicAdd(&cnt[1], 1)] = b;
+		}
+	}
+	__syncthreads();
+	const int n1 = cnt[0], n2 = cnt[1];
 	for (int j = threadIdx.x; j < nc; j += blockDim.x) {
 		double ref = c1[g * nc + j], sc = s1[g * nc + j];
-		if (ref != 0 && i >= 1 && i < u.L1 - 1) {
-			double e1 = 1.0, e2 = 1.0;  // selectBestF0(..., allowed_range 1.0, error) keeps the smallest error <= 1
-			const double *__restrict__ nx = c1 + (g + 1) * nc;
-			const double *__restrict__ pv = c1 + (g - 1) * nc;
-			for (int k = 0; k < nc; ++k) {
-				double t1 = fabs(ref - nx[k]) / ref;
-				if (!(t1 > e1)) e1 = t1;
-				double t2 = fabs(ref - pv[k]) / ref;
-				if (!(t2 > e2)) e2 = t2;
-			}
+		if (ref != 0 && interior) {
+			double e1 = 1.0, e2 = 1.0;
+			for (int k = 0; k < n1; ++k) e1 = fmin(e1, fabs(ref - nxt[k]) / ref);
+			for (int k = 0; k < n2; ++k) e2 = fmin(e2, fabs(ref - prv[k]) / ref);
 			if (fmin(e1, e2) > 0.05) { ref = 0; sc = 0; }
 		}
 		c2[g * nc + j] = ref;
 		s2[g * nc + j] = sc;
+		// searchF0Base (reference :254-272): highest score, the first slot on ties; scores are >= 2.5 or 0, and
+		// positive doubles order like their bit patterns, so keep the top 56 bits of the score above the slot
+		if (sc > 0.0) {
+			const unsigned long long key = ((unsigned long long)__double_as_longlong(sc) & ~0xffull) | (unsigned long long)(255 - j);
+			atomicMax(&best, key);
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		double b = 0.0;
+		if (best != 0ull) {
+			// resolve exactly among the slots whose score shares the top 56 bits (practically one)
+			double bs = 0.0;
+			for (int j = 0; j < nc; ++j) {
+				const double sc = s2[g * nc + j];
+				if (sc > bs) { b = c2[g * nc + j]; bs = sc; }
+			}
+		}
+		base[g] = b;
 	}
 }
 
@@ -601,6 +632,19 @@ __device__ __forceinline__ double hv_search_score(double f0, const double *__res
 	return score;
 }
 
+// init + p[0] + p[1] + ... + p[n-1] added strictly in that order (the reference's running sums), with the
+// loads spread over the lanes: 64 values per step, then a 64-step dependent chain on broadcast values.
+__device__ __forceinline__ double hv_ordered_sum(const double *__restrict__ p, int n, double init, int lane) {
+	double run = init;
+	for (int base = 0; base < n; base += 64) {
+		const int i = base + lane;
+		const double v = (i < n) ? p[i] : 0.0;  // + 0.0 is exact
+#pragma unroll
+		for (int k = 0; k < 64; ++k) run = run + __shfl(v, k, 64);
+	}
+	return run;
+}
+
 // boundaries of the voiced sections of f0[0..n) (reference :296-314): returns the number of sections;
 // sec[2k] = first frame, sec[2k+1] = last frame.  Executed by all 64 lanes, ordered by ballot.
 __device__ int hv_sections(const double *__restrict__ f0, int n, int *__restrict__ sec, int max_sec, int lane) {
@@ -637,16 +681,7 @@ __global__ __launch_bounds__(64) void hv_contour_kernel(CtrArgs a) {
 	int *__restrict__ sec = a.sec + (long long)blockIdx.x * 2 * a.max_sec;
 	double *__restrict__ chan = a.chan + (long long)blockIdx.x * a.chan_stride;
 
-	// searchF0Base (reference :254-272)
-	for (int i = lane; i < L; i += 64) {
-		double b = 0.0, bs = 0.0;
-		for (int j = 0; j < nc; ++j) {
-			double sc = score[(long long)i * nc + j];
-			if (sc > bs) { b = cand[(long long)i * nc + j]; bs = sc; }
-		}
-		base[i] = b;
-	}
-	wave_sync();
+	// searchF0Base (reference :254-272) was evaluated by hv_unreliable_kernel
 	// fixStep1 (reference :277-291; entries the reference never writes are 0)
 	for (int i = lane; i < L; i += 64) {
 		double v = 0.0;
@@ -735,7 +770,7 @@ __global__ __launch_bounds__(64) void hv_contour_kernel(CtrArgs a) {
 		for (int k = 0; k < ns; ++k) {
 			const int st = bl[2 * k], ed = bl[2 * k + 1];
 			const int ch = perm[k];
-			for (int j = st; j < ed; ++j) mean_f0 += CH(ch, j);
+			mean_f0 = hv_ordered_sum(cdata + coff[ch] + (st - clo[ch]), ed - st, mean_f0, lane);
 			mean_f0 /= ed - st;
 			if (2200.0 / mean_f0 < ed - st) {
 				wave_sync();
@@ -856,20 +891,42 @@ __global__ __launch_bounds__(64) void hv_smooth_kernel(SmArgs a) {
 		if (k < ns) {
 			const int st = sec[2 * k], ed = sec[2 * k + 1];
 			const double xs = f0[st - lag], xe = f0[ed - lag];
+			// forward pass; outputs before the section start are never read back.  Loads are issued eight steps
+			// ahead of the dependent recursion.
 			double w0 = 0.0, w1 = 0.0;
-			for (int i = 0; i < n; ++i) {
-				const double xv = (i < st) ? xs : (i > ed ? xe : f0[i - lag]);
-				const double wt = xv + a0 * w0 + a1 * w1;
-				tmp[(long long)(n - i - 1) * 64 + lane] = b0 * wt + b1 * w0 + b0 * w1;
-				w1 = w0; w0 = wt;
+			for (int i0 = 0; i0 < n; i0 += 8) {
+				double xin[8];
+#pragma unroll
+				for (int e = 0; e < 8; ++e) xin[e] = f0[clampi(i0 + e - lag, 0, L - 1)];
+#pragma unroll
+				for (int e = 0; e < 8; ++e) {
+					const int i = i0 + e;
+					if (i < n) {
+						const double xv = (i < st) ? xs : (i > ed ? xe : xin[e]);
+						const double wt = xv + a0 * w0 + a1 * w1;
+						if (i >= st) tmp[(long long)(n - i - 1) * 64 + lane] = b0 * wt + b1 * w0 + b0 * w1;
+						w1 = w0; w0 = wt;
+					}
+				}
 			}
+			// backward pass over the reversed signal, up to the section start
 			w0 = w1 = 0.0;
-			for (int i = 0; i < n; ++i) {
-				const double wt = tmp[(long long)i * 64 + lane] + a0 * w0 + a1 * w1;
-				const double yv = b0 * wt + b1 * w0 + b0 * w1;
-				w1 = w0; w0 = wt;
-				const int j = n - i - 1;
-				if (j >= st && j <= ed) out[j - lag] = yv;
+			const int kend = n - 1 - st;
+			for (int i0 = 0; i0 <= kend; i0 += 8) {
+				double tin[8];
+#pragma unroll
+				for (int e = 0; e < 8; ++e) tin[e] = (i0 + e <= kend) ? tmp[(long long)(i0 + e) * 64 + lane] : 0.0;
+#pragma unroll
+				for (int e = 0; e < 8; ++e) {
+					const int i = i0 + e;
+					if (i <= kend) {
+						const double wt = tin[e] + a0 * w0 + a1 * w1;
+						const double yv = b0 * wt + b1 * w0 + b0 * w1;
+						w1 = w0; w0 = wt;
+						const int j = n - i - 1;
+						if (j <= ed) out[j - lag] = yv;
+					}
+				}
 			}
 		}
 		__syncthreads();
@@ -1071,7 +1128,7 @@ static int hv_run_device(wc_harvest *h, int n_utt, const double *d_x, const int 
 	WC_HIP(hipGetLastError());
 	if ((rc = dev->time_end("harvest_refine"))) return rc;
 	hipLaunchKernelGGL(hv_unreliable_kernel, dim3((unsigned)total_l1), dim3(128), 0, s, du, n_utt, h->cand1.as<double>(), h->score1.as<double>(),
-					   h->cand2.as<double>(), h->score2.as<double>(), total_l1, nc);
+					   h->cand2.as<double>(), h->score2.as<double>(), h->base.as<double>(), total_l1, nc);
 	CtrArgs ca;
 	ca.utts = du; ca.cand = h->cand2.as<double>(); ca.score = h->score2.as<double>(); ca.base = h->base.as<double>();
 	ca.s1 = h->s1.as<double>(); ca.s2 = h->s2.as<double>(); ca.s3 = h->s3.as<double>(); ca.fixed = h->fixed.as<double>();
