@@ -47,7 +47,7 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 	constexpr int M = N / 2;
 	constexpr int EPT = (N + T - 1) / T;       // window elements per thread
 	constexpr int BPT = (M + 1 + T - 1) / T;   // bins per thread
-	__shared__ double2 A[M];
+	__shared__ double2 A[fft_lds_size(M)];
 	__shared__ double P[M + 2];
 	__shared__ double red[2 * (T / 64) + 2];
 	double *Ar = reinterpret_cast<double *>(A);

@@ -160,7 +160,7 @@ template <int N, int T>
 __global__ __launch_bounds__(T) void d4c_lovetrain_kernel(D4cArgs a) {
 	constexpr int M = N / 2;
 	constexpr int EPT = N / T;
-	__shared__ double2 A[M];
+	__shared__ double2 A[fft_lds_size(M)];
 	__shared__ double red[2 * (T / 64) + 2];
 	double *Ar = reinterpret_cast<double *>(A);
 	const int tid = threadIdx.x;
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(T, 2) void d4c_frames_kernel(D4cArgs a) {
 	constexpr int EPT = N / T;
 	constexpr int KPT = (M + 1 + T - 1) / T;  // power-spectrum keys per thread
 	// LDS: 32 KB + 2 x 16 KB at N = 4096 -> two workgroups per CU
-	__shared__ double2 A[M];      // FFT workspace / cumulative segment / radix-select histograms
+	__shared__ double2 A[fft_lds_size(M)];  // FFT workspace / cumulative segment / radix-select histograms
 	__shared__ double Br[M + 2];  // smoothed power spectrum, scratch of the last smoothing
 	__shared__ double Cc[M + 2];  // centroid -> static group delay
 	__shared__ double red[2 * (T / 64) + 2];

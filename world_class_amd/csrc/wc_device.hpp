@@ -107,19 +107,22 @@ __device__ __forceinline__ double2 twiddle(const double2 *__restrict__ tw, int i
 }
 
 // ---- in-LDS complex FFT of M points by T threads, sign S (+1: e^{+i}) -------------------------------
-// a: M interleaved complex doubles in LDS (natural order in, natural order out).
-// tw: global twiddle table of kTwiddleN entries.  Ends with a __syncthreads().
+// a: interleaved complex doubles in LDS with room for fft_lds_size(M) = M + M/4 entries; the M points are in
+// natural order in a[0..M) on entry and on exit.  Between the passes the data lives in a padded layout
+// (one spare slot after every 4 entries) so that the stride-4 / stride-16 scatter of the early Stockham
+// passes hits distinct LDS banks (ds_write_b128 is serviced in 8-lane groups, 32 banks x 4 B).
+// tw: global twiddle table of kTwiddleN entries, loaded before the LDS reads of each pass so that the L2
+// latency overlaps them.  Ends with a __syncthreads().
+__host__ __device__ constexpr int fft_lds_size(int M) { return M + M / 4; }
+__device__ __forceinline__ int fft_pad(int e, bool pad) { return pad ? e + (e >> 2) : e; }
+
 template <int M, int T, int S>
 __device__ void fft_lds(double2 *a, const double2 *__restrict__ tw, int tid) {
-#ifdef ABL_NOFFT
-	__syncthreads();
-	return;
-#endif
 	static_assert((M & (M - 1)) == 0 && M >= 16 && M <= kTwiddleN, "M must be a power of two in [16, 4096]");
 	constexpr int LOG2 = __builtin_ctz(M);
 	constexpr bool LEAD2 = (LOG2 & 1) != 0;
 	int Ns = 1;
-	if (LEAD2) {  // radix-2 pass with Ns = 1: no twiddles
+	if (LEAD2) {  // radix-2 pass with Ns = 1: no twiddles; natural in, padded out
 		constexpr int NB = M / 2;
 		constexpr int BPT = (NB + T - 1) / T;
 		double2 v0[BPT], v1[BPT];
@@ -132,7 +135,7 @@ __device__ void fft_lds(double2 *a, const double2 *__restrict__ tw, int tid) {
 #pragma unroll
 		for (int b = 0; b < BPT; ++b) {
 			int j = tid + b * T;
-			if (j < NB) { a[2 * j] = cadd(v0[b], v1[b]); a[2 * j + 1] = csub(v0[b], v1[b]); }
+			if (j < NB) { a[fft_pad(2 * j, true)] = cadd(v0[b], v1[b]); a[fft_pad(2 * j + 1, true)] = csub(v0[b], v1[b]); }
 		}
 		__syncthreads();
 		Ns = 2;
@@ -141,17 +144,32 @@ __device__ void fft_lds(double2 *a, const double2 *__restrict__ tw, int tid) {
 	constexpr int BPT4 = (NB4 + T - 1) / T;
 #pragma unroll 1
 	for (; Ns < M; Ns <<= 2) {
+		const bool in_pad = LEAD2 ? true : (Ns > 1);
+		const bool out_pad = (Ns << 2) < M;
+		const int tstride = (kTwiddleN / 4) / Ns;  // (M / (Ns*4)) * (kTwiddleN / M)
+		double2 w1[BPT4], w2[BPT4], w3[BPT4];
+		if (Ns > 1) {
+#pragma unroll
+			for (int b = 0; b < BPT4; ++b) {
+				int j = tid + b * T;
+				if (j < NB4) {
+					int idx = (j & (Ns - 1)) * tstride;
+					w1[b] = twiddle<S>(tw, idx);
+					w2[b] = twiddle<S>(tw, 2 * idx);
+					w3[b] = twiddle<S>(tw, 3 * idx);
+				}
+			}
+		}
 		double2 v[BPT4][4];
 #pragma unroll
 		for (int b = 0; b < BPT4; ++b) {
 			int j = tid + b * T;
 			if (j < NB4) {
 #pragma unroll
-				for (int r = 0; r < 4; ++r) v[b][r] = a[j + r * NB4];
+				for (int r = 0; r < 4; ++r) v[b][r] = a[fft_pad(j + r * NB4, in_pad)];
 			}
 		}
 		__syncthreads();
-		const int tstride = (kTwiddleN / 4) / Ns;  // (M / (Ns*4)) * (kTwiddleN / M)
 #pragma unroll
 		for (int b = 0; b < BPT4; ++b) {
 			int j = tid + b * T;
@@ -159,18 +177,17 @@ __device__ void fft_lds(double2 *a, const double2 *__restrict__ tw, int tid) {
 				int k = j & (Ns - 1);
 				double2 x0 = v[b][0], x1 = v[b][1], x2 = v[b][2], x3 = v[b][3];
 				if (Ns > 1) {
-					int idx = k * tstride;
-					x1 = cmul(x1, twiddle<S>(tw, idx));
-					x2 = cmul(x2, twiddle<S>(tw, 2 * idx));
-					x3 = cmul(x3, twiddle<S>(tw, 3 * idx));
+					x1 = cmul(x1, w1[b]);
+					x2 = cmul(x2, w2[b]);
+					x3 = cmul(x3, w3[b]);
 				}
 				double2 s02 = cadd(x0, x2), d02 = csub(x0, x2);
 				double2 s13 = cadd(x1, x3), d13 = cmul_i<S>(csub(x1, x3));
 				int j0 = ((j - k) << 2) + k;
-				a[j0] = cadd(s02, s13);
-				a[j0 + Ns] = cadd(d02, d13);
-				a[j0 + 2 * Ns] = csub(s02, s13);
-				a[j0 + 3 * Ns] = csub(d02, d13);
+				a[fft_pad(j0, out_pad)] = cadd(s02, s13);
+				a[fft_pad(j0 + Ns, out_pad)] = cadd(d02, d13);
+				a[fft_pad(j0 + 2 * Ns, out_pad)] = csub(s02, s13);
+				a[fft_pad(j0 + 3 * Ns, out_pad)] = csub(d02, d13);
 			}
 		}
 		__syncthreads();

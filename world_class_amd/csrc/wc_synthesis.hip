@@ -97,39 +97,102 @@ __global__ void syn_increment_kernel(TbArgs a, int n_utt, long long total_out, d
 	inc[a.inc_off[lo] + i] = voiced ? d : -d;
 }
 
-// 16 steps of the sequential phase sum: lanes >= K0 + j add |p[j]| at step j.  The increments sit in scalar
-// registers (wave-uniform loads) and the set of participating lanes shrinks by shifting EXEC, so every step
-// is one dependent v_add_f64 -- the reference's summation order at the latency floor of the hardware.
-template <int K0>
-__device__ __forceinline__ void chain16(double &mine, const double *__restrict__ p) {
-	const double v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3], v4 = p[4], v5 = p[5], v6 = p[6], v7 = p[7];
-	const double v8 = p[8], v9 = p[9], v10 = p[10], v11 = p[11], v12 = p[12], v13 = p[13], v14 = p[14], v15 = p[15];
+// 64 steps of the sequential phase sum, entirely in one asm block: lane L ends with run + |p[0]| + ... + |p[L]|
+// added in exactly that order.  The increments are fetched with scalar loads (8 doubles per s_load_dwordx16)
+// into two register tuples that are refilled while the other one is being consumed (SMEM returns out of
+// order, so the only legal wait is lgkmcnt(0): wait, issue the next load, then run the 8 dependent adds).
+// The set of participating lanes shrinks by shifting EXEC, so each step is one dependent v_add_f64.
+// (the two tuples are the fixed registers s[40:55] and s[56:71], declared as clobbers)
+__device__ __forceinline__ void chain64(double &mine, const double *__restrict__ p) {
 	unsigned long long save;
 	asm volatile(
 		"s_mov_b64 %[sv], exec\n\t"
-		"s_lshl_b64 exec, %[sv], %[sh]\n\t"
-		"v_add_f64 %[m], %[m], |%[a0]|\n\t s_lshl_b64 exec, exec, 1\n\t"
-		"v_add_f64 %[m], %[m], |%[a1]|\n\t s_lshl_b64 exec, exec, 1\n\t"
-		"v_add_f64 %[m], %[m], |%[a2]|\n\t s_lshl_b64 exec, exec, 1\n\t"
-		"v_add_f64 %[m], %[m], |%[a3]|\n\t s_lshl_b64 exec, exec, 1\n\t"
-		"v_add_f64 %[m], %[m], |%[a4]|\n\t s_lshl_b64 exec, exec, 1\n\t"
-		"v_add_f64 %[m], %[m], |%[a5]|\n\t s_lshl_b64 exec, exec, 1\n\t"
-		"v_add_f64 %[m], %[m], |%[a6]|\n\t s_lshl_b64 exec, exec, 1\n\t"
-		"v_add_f64 %[m], %[m], |%[a7]|\n\t s_lshl_b64 exec, exec, 1\n\t"
-		"v_add_f64 %[m], %[m], |%[a8]|\n\t s_lshl_b64 exec, exec, 1\n\t"
-		"v_add_f64 %[m], %[m], |%[a9]|\n\t s_lshl_b64 exec, exec, 1\n\t"
-		"v_add_f64 %[m], %[m], |%[a10]|\n\t s_lshl_b64 exec, exec, 1\n\t"
-		"v_add_f64 %[m], %[m], |%[a11]|\n\t s_lshl_b64 exec, exec, 1\n\t"
-		"v_add_f64 %[m], %[m], |%[a12]|\n\t s_lshl_b64 exec, exec, 1\n\t"
-		"v_add_f64 %[m], %[m], |%[a13]|\n\t s_lshl_b64 exec, exec, 1\n\t"
-		"v_add_f64 %[m], %[m], |%[a14]|\n\t s_lshl_b64 exec, exec, 1\n\t"
-		"v_add_f64 %[m], %[m], |%[a15]|\n\t"
+		"s_load_dwordx16 s[40:55], %[p], 0x0\n\t"
+		"s_waitcnt lgkmcnt(0)\n\t"
+		"s_load_dwordx16 s[56:71], %[p], 0x40\n\t"
+		"v_add_f64 %[m], %[m], |s[40:41]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[42:43]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[44:45]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[46:47]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[48:49]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[50:51]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[52:53]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[54:55]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"s_waitcnt lgkmcnt(0)\n\t"
+		"s_load_dwordx16 s[40:55], %[p], 0x80\n\t"
+		"v_add_f64 %[m], %[m], |s[56:57]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[58:59]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[60:61]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[62:63]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[64:65]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[66:67]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[68:69]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[70:71]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"s_waitcnt lgkmcnt(0)\n\t"
+		"s_load_dwordx16 s[56:71], %[p], 0xc0\n\t"
+		"v_add_f64 %[m], %[m], |s[40:41]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[42:43]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[44:45]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[46:47]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[48:49]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[50:51]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[52:53]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[54:55]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"s_waitcnt lgkmcnt(0)\n\t"
+		"s_load_dwordx16 s[40:55], %[p], 0x100\n\t"
+		"v_add_f64 %[m], %[m], |s[56:57]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[58:59]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[60:61]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[62:63]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[64:65]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[66:67]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[68:69]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[70:71]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"s_waitcnt lgkmcnt(0)\n\t"
+		"s_load_dwordx16 s[56:71], %[p], 0x140\n\t"
+		"v_add_f64 %[m], %[m], |s[40:41]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[42:43]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[44:45]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[46:47]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[48:49]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[50:51]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[52:53]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[54:55]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"s_waitcnt lgkmcnt(0)\n\t"
+		"s_load_dwordx16 s[40:55], %[p], 0x180\n\t"
+		"v_add_f64 %[m], %[m], |s[56:57]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[58:59]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[60:61]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[62:63]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[64:65]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[66:67]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[68:69]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[70:71]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"s_waitcnt lgkmcnt(0)\n\t"
+		"s_load_dwordx16 s[56:71], %[p], 0x1c0\n\t"
+		"v_add_f64 %[m], %[m], |s[40:41]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[42:43]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[44:45]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[46:47]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[48:49]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[50:51]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[52:53]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[54:55]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"s_waitcnt lgkmcnt(0)\n\t"
+		"v_add_f64 %[m], %[m], |s[56:57]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[58:59]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[60:61]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[62:63]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[64:65]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[66:67]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[68:69]|\n\t s_lshl_b64 exec, exec, 1\n\t"
+		"v_add_f64 %[m], %[m], |s[70:71]|\n\t s_lshl_b64 exec, exec, 1\n\t"
 		"s_mov_b64 exec, %[sv]\n\t"
 		: [m] "+v"(mine), [sv] "=&s"(save)
-		: [a0] "s"(v0), [a1] "s"(v1), [a2] "s"(v2), [a3] "s"(v3), [a4] "s"(v4), [a5] "s"(v5), [a6] "s"(v6), [a7] "s"(v7),
-		  [a8] "s"(v8), [a9] "s"(v9), [a10] "s"(v10), [a11] "s"(v11), [a12] "s"(v12), [a13] "s"(v13), [a14] "s"(v14),
-		  [a15] "s"(v15), [sh] "n"(K0)
-		: "scc");
+		: [p] "s"(p)
+		: "scc", "memory", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53",
+		  "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70",
+		  "s71");
 }
 
 // One wavefront per utterance.  The reference accumulates the phase with a sequential running sum
@@ -159,10 +222,7 @@ __global__ __launch_bounds__(64) void syn_timebase_kernel(TbArgs a, const double
 		// (scalar) loads and lanes drop out of the chain one by one
 		double mine = run;
 		const double *__restrict__ pu = inc_g + base;  // wave-uniform address: scalar loads
-		chain16<0>(mine, pu);
-		chain16<16>(mine, pu + 16);
-		chain16<32>(mine, pu + 32);
-		chain16<48>(mine, pu + 48);
+		chain64(mine, pu);
 		run = __shfl(mine, 63, 64);
 		const double wrap = fmod(mine, two_pi);
 		double w_prev = __shfl_up(wrap, 1, 64);
@@ -288,7 +348,7 @@ __global__ __launch_bounds__(T) void syn_pulse_kernel(SynArgs a) {
 	constexpr int M = N / 2;
 	constexpr int BPT = (M + T) / T;  // bins per thread (k <= M)
 	constexpr int EPT = N / T;        // time samples per thread
-	__shared__ double2 A[N];
+	__shared__ double2 A[fft_lds_size(N)];
 	__shared__ double red[2 * (T / 64) + 2];
 	double *Ar = reinterpret_cast<double *>(A);
 	const int tid = threadIdx.x;
