@@ -245,10 +245,11 @@ static void launch_ct(const CtArgs &a, hipStream_t s) {
 	hipLaunchKernelGGL((ct_frames_kernel<N, 256>), dim3((unsigned)blocks), dim3(256), 0, s, a);
 }
 
-static int ct_run_device(wc_cheaptrick *c, int n_utt, const double *d_x, const int *x_length, const double *d_tpos,
-						 const double *d_f0, const int *f0_length, double *d_sp, uint64_t *rng_pos) {
-	Device *dev = c->dev;
-	hipStream_t s = dev->stream;
+// Enqueue-only building blocks (no host synchronisation), shared with the fused pipeline (wc_pipeline.hip):
+//   ct_prepare  descriptors upload, per-frame draw counts, per-utterance scan -> c->off, c->endpos (device)
+//   ct_frames   the per-frame kernel (may run on another stream once ct_prepare's work is done)
+int ct_prepare(wc_cheaptrick *c, hipStream_t s, int n_utt, const int *x_length, const double *d_f0, const int *f0_length,
+			   const uint64_t *rng_pos, long long *total_out, uint64_t *min_pos_out, uint64_t *max_end_out) {
 	const int bins = c->fft_size / 2 + 1;
 	std::vector<UttDesc> utts(n_utt);
 	long long xo = 0, fo = 0;
@@ -267,9 +268,11 @@ static int ct_run_device(wc_cheaptrick *c, int n_utt, const double *d_x, const i
 		if (e > max_end) max_end = e;
 	}
 	const long long total = fo;
+	*total_out = total;
+	*min_pos_out = min_pos;
+	*max_end_out = max_end;
 	if (total == 0) return WC_OK;
 	int rc;
-	if ((rc = dev->ensure_rng(min_pos, max_end))) return rc;
 	if ((rc = c->utts.reserve(sizeof(UttDesc) * n_utt))) return rc;
 	if ((rc = c->cnt.reserve(sizeof(uint32_t) * total))) return rc;
 	if ((rc = c->off.reserve(sizeof(uint64_t) * total))) return rc;
@@ -277,16 +280,26 @@ static int ct_run_device(wc_cheaptrick *c, int n_utt, const double *d_x, const i
 	if ((rc = c->h_stage.reserve(sizeof(UttDesc) * n_utt + sizeof(uint64_t) * n_utt))) return rc;
 	std::memcpy(c->h_stage.p, utts.data(), sizeof(UttDesc) * n_utt);
 	WC_HIP(hipMemcpyAsync(c->utts.p, c->h_stage.p, sizeof(UttDesc) * n_utt, hipMemcpyHostToDevice, s));
+	if ((rc = c->h_stage.mark(s))) return rc;
 	hipLaunchKernelGGL(ct_count_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_f0, total, c->fs,
 					   c->f0_floor, bins, c->cnt.as<uint32_t>());
 	hipLaunchKernelGGL(utt_scan_kernel, dim3(n_utt), dim3(256), 0, s, c->cnt.as<uint32_t>(), c->utts.as<UttDesc>(),
 					   (const unsigned long long *)nullptr, c->off.as<unsigned long long>(), c->endpos.as<unsigned long long>());
+	WC_HIP(hipGetLastError());
+	return WC_OK;
+}
+
+int ct_frames(wc_cheaptrick *c, hipStream_t s, int n_utt, const double *d_x, const double *d_tpos, const double *d_f0,
+			  double *d_sp, long long total) {
+	Device *dev = c->dev;
+	if (total == 0) return WC_OK;
+	int rc;
 	CtArgs a;
 	a.x = d_x; a.utts = c->utts.as<UttDesc>(); a.n_utt = n_utt; a.tpos = d_tpos; a.f0 = d_f0;
 	a.rng_off = c->off.as<unsigned long long>(); a.rng_table = dev->rng_table.as<uint32_t>();
 	a.rng_base = dev->rng_base; a.tw = dev->twiddle; a.sp = d_sp; a.total_frames = total; a.fs = c->fs;
 	a.q1 = c->q1; a.f0_floor = c->f0_floor;
-	if ((rc = dev->time_begin("cheaptrick_frames"))) return rc;
+	if ((rc = dev->time_begin("cheaptrick_frames", s))) return rc;
 	switch (c->fft_size) {
 		case 512: launch_ct<512>(a, s); break;
 		case 1024: launch_ct<1024>(a, s); break;
@@ -295,10 +308,37 @@ static int ct_run_device(wc_cheaptrick *c, int n_utt, const double *d_x, const i
 		default: return fail(WC_ERR_UNSUPPORTED, "cheaptrick: fft_size must be 512, 1024, 2048 or 4096");
 	}
 	WC_HIP(hipGetLastError());
-	if ((rc = dev->time_end("cheaptrick_frames"))) return rc;
+	return dev->time_end("cheaptrick_frames", s);
+}
+
+const unsigned long long *ct_end_positions(const wc_cheaptrick *c) { return c->endpos.as<unsigned long long>(); }
+
+static int ct_run_device(wc_cheaptrick *c, int n_utt, const double *d_x, const int *x_length, const double *d_tpos,
+						 const double *d_f0, const int *f0_length, double *d_sp, uint64_t *rng_pos) {
+	Device *dev = c->dev;
+	hipStream_t s = dev->stream;
+	long long total = 0;
+	uint64_t min_pos = 0, max_end = 0;
+	int rc;
+	// sizes first (the RNG table must exist before anything is enqueued that may outlive a reallocation)
+	{
+		const int bins = c->fft_size / 2 + 1;
+		const uint64_t per_frame_max = (uint64_t)(2 * (c->fft_size / 2) + 1 + bins);
+		uint64_t lo = ~0ull, hi = 0;
+		for (int u = 0; u < n_utt; ++u) {
+			uint64_t p0 = rng_pos ? rng_pos[u] : 0ull;
+			lo = p0 < lo ? p0 : lo;
+			uint64_t e = p0 + per_frame_max * (uint64_t)(f0_length[u] > 0 ? f0_length[u] : 0);
+			hi = e > hi ? e : hi;
+		}
+		if ((rc = dev->ensure_rng(lo, hi))) return rc;
+	}
+	if ((rc = ct_prepare(c, s, n_utt, x_length, d_f0, f0_length, rng_pos, &total, &min_pos, &max_end))) return rc;
+	if (total == 0) return WC_OK;
+	if ((rc = ct_frames(c, s, n_utt, d_x, d_tpos, d_f0, d_sp, total))) return rc;
 	if (rng_pos) {
-		uint64_t *h_end = reinterpret_cast<uint64_t *>(static_cast<char *>(c->h_stage.p) + sizeof(UttDesc) * n_utt);
-		WC_HIP(hipMemcpyAsync(h_end, c->endpos.p, sizeof(uint64_t) * n_utt, hipMemcpyDeviceToHost, s));
+		std::vector<uint64_t> h_end(n_utt);
+		WC_HIP(hipMemcpyAsync(h_end.data(), c->endpos.p, sizeof(uint64_t) * n_utt, hipMemcpyDeviceToHost, s));
 		WC_HIP(hipStreamSynchronize(s));
 		for (int u = 0; u < n_utt; ++u) rng_pos[u] = h_end[u];
 	}

@@ -32,7 +32,13 @@ void DevBuf::release() {
 	p = nullptr;
 	cap = 0;
 }
+int HostBuf::mark(hipStream_t s) {
+	if (!ev) WC_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+	WC_HIP(hipEventRecord(ev, s));
+	return WC_OK;
+}
 int HostBuf::reserve(size_t bytes) {
+	if (ev) WC_HIP(hipEventSynchronize(ev));  // the previous call's copies have read the buffer
 	if (bytes <= cap) return WC_OK;
 	if (p) (void)hipHostFree(p);
 	p = nullptr;
@@ -43,6 +49,7 @@ int HostBuf::reserve(size_t bytes) {
 	return WC_OK;
 }
 void HostBuf::release() {
+	if (ev) { (void)hipEventSynchronize(ev); (void)hipEventDestroy(ev); ev = nullptr; }
 	if (p) (void)hipHostFree(p);
 	p = nullptr;
 	cap = 0;
@@ -166,8 +173,9 @@ int Device::ensure_rng(uint64_t first, uint64_t last) {
 	return WC_OK;
 }
 
-int Device::time_begin(const char *name) {
+int Device::time_begin(const char *name, hipStream_t s) {
 	if (!timing) return WC_OK;
+	if (!s) s = stream;
 	auto it = events.find(name);
 	if (it == events.end()) {
 		hipEvent_t a, b;
@@ -175,14 +183,15 @@ int Device::time_begin(const char *name) {
 		WC_HIP(hipEventCreate(&b));
 		it = events.emplace(name, std::make_pair(a, b)).first;
 	}
-	WC_HIP(hipEventRecord(it->second.first, stream));
+	WC_HIP(hipEventRecord(it->second.first, s));
 	return WC_OK;
 }
-int Device::time_end(const char *name) {
+int Device::time_end(const char *name, hipStream_t s) {
 	if (!timing) return WC_OK;
+	if (!s) s = stream;
 	auto it = events.find(name);
 	if (it == events.end()) return WC_OK;
-	WC_HIP(hipEventRecord(it->second.second, stream));
+	WC_HIP(hipEventRecord(it->second.second, s));
 	return WC_OK;
 }
 

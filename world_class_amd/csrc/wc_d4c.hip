@@ -467,10 +467,13 @@ static void launch_main(const D4cArgs &a, hipStream_t s) {
 	hipLaunchKernelGGL((d4c_frames_kernel<N, 256>), dim3((unsigned)blocks), dim3(256), 0, s, a);
 }
 
-static int d4c_run_device(wc_d4c *d, int n_utt, const double *d_x, const int *x_length, const double *d_tpos,
-						  const double *d_f0, const int *f0_length, int fft_size, double *d_ap, uint64_t *rng_pos) {
+// Enqueue-only (no host synchronisation), shared with the fused pipeline: everything on stream s; the stream
+// positions start at rng_pos[u] (host, may be NULL = 0) or, when d_start is given, at the device array
+// d_start[u] (e.g. CheapTrick's end positions); the end positions are left in d->endpos2 (device).
+int d4c_enqueue(wc_d4c *d, hipStream_t s, int n_utt, const double *d_x, const int *x_length, const double *d_tpos,
+				const double *d_f0, const int *f0_length, int fft_size, double *d_ap, const uint64_t *rng_pos,
+				const unsigned long long *d_start) {
 	Device *dev = d->dev;
-	hipStream_t s = dev->stream;
 	if (fft_size < 2 || (fft_size & 1)) return fail(WC_ERR_INVALID, "d4c: fft_size must be even and positive");
 	std::vector<UttDesc> utts(n_utt);
 	long long xo = 0, fo = 0;
@@ -490,9 +493,9 @@ static int d4c_run_device(wc_d4c *d, int n_utt, const double *d_x, const int *x_
 		if (e > max_end) max_end = e;
 	}
 	const long long total = fo;
+	(void)min_pos; (void)max_end;
 	if (total == 0) return WC_OK;
 	int rc;
-	if ((rc = dev->ensure_rng(min_pos, max_end))) return rc;
 	if ((rc = d->utts.reserve(sizeof(UttDesc) * n_utt))) return rc;
 	if ((rc = d->cnt.reserve(sizeof(uint32_t) * total))) return rc;
 	if ((rc = d->off.reserve(sizeof(uint64_t) * total))) return rc;
@@ -502,17 +505,18 @@ static int d4c_run_device(wc_d4c *d, int n_utt, const double *d_x, const int *x_
 	if ((rc = d->h_stage.reserve(sizeof(UttDesc) * n_utt + sizeof(uint64_t) * n_utt))) return rc;
 	std::memcpy(d->h_stage.p, utts.data(), sizeof(UttDesc) * n_utt);
 	WC_HIP(hipMemcpyAsync(d->utts.p, d->h_stage.p, sizeof(UttDesc) * n_utt, hipMemcpyHostToDevice, s));
+	if ((rc = d->h_stage.mark(s))) return rc;
 	const unsigned grid1 = (unsigned)((total + 255) / 256);
 	hipLaunchKernelGGL(d4c_lt_count_kernel, dim3(grid1), dim3(256), 0, s, d_f0, total, d->fs, d->cnt.as<uint32_t>());
 	hipLaunchKernelGGL(utt_scan_kernel, dim3(n_utt), dim3(256), 0, s, d->cnt.as<uint32_t>(), d->utts.as<UttDesc>(),
-					   (const unsigned long long *)nullptr, d->off.as<unsigned long long>(), d->endpos.as<unsigned long long>());
+					   d_start, d->off.as<unsigned long long>(), d->endpos.as<unsigned long long>());
 	D4cArgs a;
 	a.x = d_x; a.utts = d->utts.as<UttDesc>(); a.n_utt = n_utt; a.tpos = d_tpos; a.f0 = d_f0;
 	a.rng_off = d->off.as<unsigned long long>(); a.rng_table = dev->rng_table.as<uint32_t>(); a.rng_base = dev->rng_base;
 	a.tw = dev->twiddle; a.ap = d_ap; a.ap0 = d->ap0.as<double>(); a.cnt = d->cnt.as<uint32_t>();
 	a.nuttall = d->nuttall.as<double>(); a.total_frames = total; a.fs = d->fs; a.fft_size_out = fft_size;
 	a.n_ap = d->n_ap; a.window_length = d->window_length; a.threshold = d->threshold;
-	if ((rc = dev->time_begin("d4c_lovetrain"))) return rc;
+	if ((rc = dev->time_begin("d4c_lovetrain", s))) return rc;
 	switch (d->fft_size_lt) {
 		case 1024: launch_lt<1024>(a, s); break;
 		case 2048: launch_lt<2048>(a, s); break;
@@ -520,11 +524,11 @@ static int d4c_run_device(wc_d4c *d, int n_utt, const double *d_x, const int *x_
 		default: return fail(WC_ERR_UNSUPPORTED, "d4c: unsupported LoveTrain FFT size (fs must be 8..48 kHz)");
 	}
 	WC_HIP(hipGetLastError());
-	if ((rc = dev->time_end("d4c_lovetrain"))) return rc;
+	if ((rc = dev->time_end("d4c_lovetrain", s))) return rc;
 	// offsets of the main pass start where the LoveTrain draws of the utterance end
 	hipLaunchKernelGGL(utt_scan_kernel, dim3(n_utt), dim3(256), 0, s, d->cnt.as<uint32_t>(), d->utts.as<UttDesc>(),
 					   d->endpos.as<unsigned long long>(), d->off.as<unsigned long long>(), d->endpos2.as<unsigned long long>());
-	if ((rc = dev->time_begin("d4c_frames"))) return rc;
+	if ((rc = dev->time_begin("d4c_frames", s))) return rc;
 	switch (d->fft_size_d4c) {
 		case 1024: launch_main<1024>(a, s); break;
 		case 2048: launch_main<2048>(a, s); break;
@@ -532,10 +536,37 @@ static int d4c_run_device(wc_d4c *d, int n_utt, const double *d_x, const int *x_
 		default: return fail(WC_ERR_UNSUPPORTED, "d4c: unsupported FFT size (fs must be 8..48 kHz)");
 	}
 	WC_HIP(hipGetLastError());
-	if ((rc = dev->time_end("d4c_frames"))) return rc;
-	if (rng_pos) {
-		uint64_t *h_end = reinterpret_cast<uint64_t *>(static_cast<char *>(d->h_stage.p) + sizeof(UttDesc) * n_utt);
-		WC_HIP(hipMemcpyAsync(h_end, d->endpos2.p, sizeof(uint64_t) * n_utt, hipMemcpyDeviceToHost, s));
+	return dev->time_end("d4c_frames", s);
+}
+
+const unsigned long long *d4c_end_positions(const wc_d4c *d) { return d->endpos2.as<unsigned long long>(); }
+
+// upper bound of the stream positions one utterance can consume (LoveTrain + three windows per frame)
+uint64_t d4c_draw_bound(const wc_d4c *d, int f0_length) {
+	const uint64_t lt_max = (uint64_t)(2 * (int)(3.0 * d->fs / 40.0 / 2.0 + 1.0) + 1);
+	const uint64_t main_max = 3ull * (uint64_t)(2 * (int)(4.0 * d->fs / 47.0 / 2.0 + 1.0) + 1);
+	return (lt_max + main_max) * (uint64_t)(f0_length > 0 ? f0_length : 0);
+}
+
+static int d4c_run_device(wc_d4c *d, int n_utt, const double *d_x, const int *x_length, const double *d_tpos,
+						  const double *d_f0, const int *f0_length, int fft_size, double *d_ap, uint64_t *rng_pos) {
+	Device *dev = d->dev;
+	hipStream_t s = dev->stream;
+	int rc;
+	uint64_t lo = ~0ull, hi = 0;
+	long long total = 0;
+	for (int u = 0; u < n_utt; ++u) {
+		uint64_t p0 = rng_pos ? rng_pos[u] : 0ull;
+		lo = p0 < lo ? p0 : lo;
+		uint64_t e = p0 + d4c_draw_bound(d, f0_length[u]);
+		hi = e > hi ? e : hi;
+		total += f0_length[u] > 0 ? f0_length[u] : 0;
+	}
+	if ((rc = dev->ensure_rng(lo, hi))) return rc;
+	if ((rc = d4c_enqueue(d, s, n_utt, d_x, x_length, d_tpos, d_f0, f0_length, fft_size, d_ap, rng_pos, nullptr))) return rc;
+	if (rng_pos && total > 0) {
+		std::vector<uint64_t> h_end(n_utt);
+		WC_HIP(hipMemcpyAsync(h_end.data(), d->endpos2.p, sizeof(uint64_t) * n_utt, hipMemcpyDeviceToHost, s));
 		WC_HIP(hipStreamSynchronize(s));
 		for (int u = 0; u < n_utt; ++u) rng_pos[u] = h_end[u];
 	}

@@ -36,7 +36,9 @@ struct DevBuf {
 struct HostBuf {
 	void *p = nullptr;
 	size_t cap = 0;
-	int reserve(size_t bytes);
+	hipEvent_t ev = nullptr;  // recorded after the async copies that read this buffer
+	int reserve(size_t bytes);  // also waits until earlier async copies out of the buffer are done
+	int mark(hipStream_t s);    // call after enqueueing the copies that read the buffer
 	void release();
 	template <class T> T *as() const { return static_cast<T *>(p); }
 };
@@ -56,8 +58,8 @@ struct Device {
 	// timing
 	bool timing = false;
 	std::map<std::string, std::pair<hipEvent_t, hipEvent_t>> events;
-	int time_begin(const char *name);
-	int time_end(const char *name);
+	int time_begin(const char *name, hipStream_t s = nullptr);  // nullptr = this->stream
+	int time_end(const char *name, hipStream_t s = nullptr);
 };
 
 Device *current_device();  // creates the state on first use; nullptr + error on failure

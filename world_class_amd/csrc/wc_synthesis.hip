@@ -278,7 +278,8 @@ struct SynArgs {
 	const double2 *tw;
 	const double *dc_remover;
 	double *out;
-	long long total_pulses;
+	long long total_pulses;  // launch size (capacity); the real count is pulse_prefix[n_utt]
+	const unsigned long long *rng_start;  // per-utterance stream position (device), NULL = utts[u].rng_pos
 	long long only_pulse;  // debugging aid (env WC_DEBUG_ONLY_PULSE): synthesise only this pulse, -1 = all
 	int fs;
 	double frame_period;
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(T) void syn_pulse_kernel(SynArgs a) {
 	double *Ar = reinterpret_cast<double *>(A);
 	const int tid = threadIdx.x;
 	const long long gp = blockIdx.x;
-	if (gp >= a.total_pulses) return;
+	if (gp >= a.pulse_prefix[a.n_utt]) return;
 	if (a.only_pulse >= 0 && gp != a.only_pulse) return;
 	// utterance of this pulse
 	int lo = 0, hi = a.n_utt - 1;
@@ -452,7 +453,8 @@ __global__ __launch_bounds__(T) void syn_pulse_kernel(SynArgs a) {
 
 	// ---- aperiodic response (reference :479-530) ----
 	{
-		const unsigned long long roff = ud.rng_pos + (unsigned long long)(pidx - a.first_index[u]) - a.rng_base;
+		const unsigned long long rstart = a.rng_start ? a.rng_start[u] : ud.rng_pos;
+		const unsigned long long roff = rstart + (unsigned long long)(pidx - a.first_index[u]) - a.rng_base;
 		double nz[EPT];
 		double s = 0.0;
 #pragma unroll
@@ -535,6 +537,8 @@ struct wc_synthesis {
 	Device *dev;
 	DevBuf dc_remover, utts, meta, pulses, incs, d_f0, d_sp, d_ap, d_out;
 	HostBuf h_stage;
+	long long total_out = 0, cap_total = 0;  // of the most recent syn_prepare
+	int n_utt = 0;
 };
 
 template <int N>
@@ -542,13 +546,35 @@ static void launch_pulses(const SynArgs &a, hipStream_t s) {
 	hipLaunchKernelGGL((syn_pulse_kernel<N, 256>), dim3((unsigned)a.total_pulses), dim3(256), 0, s, a);
 }
 
-static int syn_run_device(wc_synthesis *sy, int n_utt, const double *d_f0, const int *f0_length, const double *d_sp,
-						  const double *d_ap, const int *out_length, double *d_out, uint64_t *rng_pos) {
+// per-utterance pulse prefix, overflow flag and end-of-stage stream positions (one small workgroup)
+__global__ void syn_prefix_kernel(int n_utt, const int *__restrict__ count, const int *__restrict__ cap,
+								  const int *__restrict__ first_index, const int *__restrict__ last_index,
+								  const UttDesc *__restrict__ utts, const unsigned long long *__restrict__ d_start,
+								  long long *__restrict__ prefix, unsigned long long *__restrict__ end_pos, int *__restrict__ overflow) {
+	if (threadIdx.x != 0) return;
+	long long run = 0;
+	int ovf = 0;
+	for (int u = 0; u < n_utt; ++u) {
+		prefix[u] = run;
+		if (count[u] > cap[u]) ovf = 1;
+		run += min(count[u], cap[u]);
+		const unsigned long long st = d_start ? d_start[u] : utts[u].rng_pos;
+		end_pos[u] = st + (unsigned long long)(last_index[u] - first_index[u]);  // reference :106-107, :519-521
+	}
+	prefix[n_utt] = run;
+	*overflow = ovf;
+}
+
+// Enqueue-only building blocks (no host synchronisation), shared with the fused pipeline:
+//   syn_prepare  time base: increments, sequential phase sum, pulse compaction, noise sizes, pulse prefix
+//   syn_pulses   the per-pulse kernel over the pulse *capacity* (workgroups beyond the real count exit)
+// Overflow of the rate-bounded pulse capacity is reported through sy->overflow (device) and handled by the
+// caller by re-running with full == true.
+int syn_prepare(wc_synthesis *sy, hipStream_t s, int n_utt, const double *d_f0, const int *f0_length, const int *out_length,
+				double *d_out, const uint64_t *rng_pos, bool full) {
 	Device *dev = sy->dev;
-	hipStream_t s = dev->stream;
 	std::vector<UttDesc> utts(n_utt);
 	long long fo = 0, yo = 0;
-	uint64_t min_pos = ~0ull, max_end = 0;
 	for (int u = 0; u < n_utt; ++u) {
 		if (f0_length[u] < 2) return fail(WC_ERR_INVALID, "synthesis: f0_length must be at least 2 (reference src/synthesis.cpp:241-242)");
 		if (out_length[u] < 0) return fail(WC_ERR_INVALID, "synthesis: negative out_length");
@@ -557,121 +583,159 @@ static int syn_run_device(wc_synthesis *sy, int n_utt, const double *d_f0, const
 		t.rng_pos = rng_pos ? rng_pos[u] : 0ull;
 		fo += f0_length[u];
 		yo += out_length[u];
-		if (t.rng_pos < min_pos) min_pos = t.rng_pos;
-		uint64_t e = t.rng_pos + (uint64_t)out_length[u];
-		if (e > max_end) max_end = e;
 	}
 	const long long total_out = yo;
+	sy->total_out = total_out;
+	sy->n_utt = n_utt;
+	sy->cap_total = 0;
 	if (total_out == 0) return WC_OK;
 	int rc;
-	if ((rc = dev->ensure_rng(min_pos, max_end))) return rc;
 	WC_HIP(hipMemsetAsync(d_out, 0, sizeof(double) * total_out, s));
-	// meta layout (device): cap_off[n] (i64) | pulse_prefix[n+1] (i64) | inc_off[n] (i64) | cap[n] | count[n] | first_index[n] | last_index[n]
-	const size_t meta_bytes = sizeof(long long) * (3 * (size_t)n_utt + 1) + sizeof(int) * 4 * (size_t)n_utt;
+	// meta layout (device): cap_off[n] (i64) | pulse_prefix[n+1] (i64) | inc_off[n] (i64) | end_pos[n] (u64) |
+	//                       cap[n] | count[n] | first_index[n] | last_index[n] | overflow
+	const size_t meta_bytes = sizeof(long long) * (4 * (size_t)n_utt + 1) + sizeof(int) * (4 * (size_t)n_utt + 1);
 	if ((rc = sy->utts.reserve(sizeof(UttDesc) * n_utt))) return rc;
 	if ((rc = sy->meta.reserve(meta_bytes))) return rc;
 	if ((rc = sy->h_stage.reserve(sizeof(UttDesc) * n_utt + meta_bytes))) return rc;
 	char *hs = static_cast<char *>(sy->h_stage.p);
 	std::memcpy(hs, utts.data(), sizeof(UttDesc) * n_utt);
 	long long *h_cap_off = reinterpret_cast<long long *>(hs + sizeof(UttDesc) * n_utt);
-	long long *h_prefix = h_cap_off + n_utt;
-	long long *h_inc_off = h_prefix + n_utt + 1;
-	int *h_cap = reinterpret_cast<int *>(h_inc_off + n_utt);
-	int *h_count = h_cap + n_utt;
+	long long *h_inc_off = h_cap_off + 2 * n_utt + 1;
+	int *h_cap = reinterpret_cast<int *>(h_cap_off + 4 * n_utt + 1);
 	char *dm = static_cast<char *>(sy->meta.p);
 	long long *d_cap_off = reinterpret_cast<long long *>(dm);
 	long long *d_prefix = d_cap_off + n_utt;
 	long long *d_inc_off = d_prefix + n_utt + 1;
-	int *d_cap = reinterpret_cast<int *>(d_inc_off + n_utt);
+	unsigned long long *d_end = reinterpret_cast<unsigned long long *>(d_inc_off + n_utt);
+	int *d_cap = reinterpret_cast<int *>(d_end + n_utt);
 	int *d_count = d_cap + n_utt;
 	int *d_first = d_count + n_utt;
 	int *d_last = d_first + n_utt;
-
-	long long inc_total = 0;
-	for (int u = 0; u < n_utt; ++u) { h_inc_off[u] = inc_total; inc_total += ((long long)out_length[u] + 63) / 64 * 64 + 64; }
+	int *d_ovf = d_last + n_utt;
+	long long inc_total = 0, co = 0;
+	for (int u = 0; u < n_utt; ++u) {
+		h_inc_off[u] = inc_total;
+		inc_total += ((long long)out_length[u] + 63) / 64 * 64 + 64;
+		// pulses <= samples; the rate bound covers F0 up to 960 Hz and the 500 Hz unvoiced pulses down to 8 kHz
+		const long long soft = (long long)out_length[u] * 960 / sy->fs + 16;
+		const int cap = (full || soft > out_length[u]) ? out_length[u] + 1 : (int)soft;
+		h_cap_off[u] = co;
+		h_cap[u] = cap;
+		co += cap;
+	}
+	sy->cap_total = co;
 	if ((rc = sy->incs.reserve(sizeof(double) * inc_total))) return rc;
-	bool full = false;
-	long long total_pulses = 0;
-	for (int attempt = 0; attempt < 2; ++attempt) {
-		long long co = 0;
-		for (int u = 0; u < n_utt; ++u) {
-			// pulses <= samples; normally f0 < fs / 10, so start with a tenth and retry with the bound
-			int cap = full ? out_length[u] + 1 : out_length[u] / 10 + 16;
-			h_cap_off[u] = co;
-			h_cap[u] = cap;
-			co += cap;
-		}
-		if ((rc = sy->pulses.reserve((size_t)co * (sizeof(int) * 3 + sizeof(double))))) return rc;
-		PulseBuf pb;
-		pb.shift = sy->pulses.as<double>();
-		pb.index = reinterpret_cast<int *>(pb.shift + co);
-		pb.noise_size = pb.index + co;
-		pb.vuv = pb.noise_size + co;
-		WC_HIP(hipMemcpyAsync(sy->utts.p, hs, sizeof(UttDesc) * n_utt, hipMemcpyHostToDevice, s));
-		WC_HIP(hipMemcpyAsync(d_cap_off, h_cap_off, sizeof(long long) * n_utt, hipMemcpyHostToDevice, s));
-		WC_HIP(hipMemcpyAsync(d_cap, h_cap, sizeof(int) * n_utt, hipMemcpyHostToDevice, s));
-		WC_HIP(hipMemcpyAsync(d_inc_off, h_inc_off, sizeof(long long) * n_utt, hipMemcpyHostToDevice, s));
-		TbArgs ta;
-		ta.inc_off = d_inc_off;
-		ta.utts = sy->utts.as<UttDesc>(); ta.f0 = d_f0; ta.cap_off = d_cap_off; ta.cap = d_cap; ta.p = pb;
-		ta.count = d_count; ta.first_index = d_first; ta.fs = sy->fs; ta.fft_size = sy->fft_size;
-		ta.frame_period = sy->frame_period;
-		if ((rc = dev->time_begin("synthesis_timebase"))) return rc;
-		WC_HIP(hipMemsetAsync(sy->incs.p, 0, sizeof(double) * inc_total, s));
-		hipLaunchKernelGGL(syn_increment_kernel, dim3((unsigned)((total_out + 255) / 256)), dim3(256), 0, s, ta, n_utt,
-						   total_out, sy->incs.as<double>());
-		hipLaunchKernelGGL(syn_timebase_kernel, dim3(n_utt), dim3(64), 0, s, ta, (const double *)sy->incs.as<double>());
-		WC_HIP(hipGetLastError());
-		if ((rc = dev->time_end("synthesis_timebase"))) return rc;
-		WC_HIP(hipMemcpyAsync(h_count, d_count, sizeof(int) * n_utt, hipMemcpyDeviceToHost, s));
-		WC_HIP(hipStreamSynchronize(s));
-		bool overflow = false;
-		total_pulses = 0;
-		for (int u = 0; u < n_utt; ++u) {
-			if (h_count[u] > h_cap[u]) overflow = true;
-			h_prefix[u] = total_pulses;
-			total_pulses += h_count[u];
-		}
-		h_prefix[n_utt] = total_pulses;
-		if (!overflow) {
-			if (total_pulses > 0) {
-				hipLaunchKernelGGL(syn_noise_size_kernel, dim3(8, n_utt), dim3(256), 0, s, d_cap_off, d_count, d_cap, pb, d_first, d_last);
-				WC_HIP(hipMemcpyAsync(d_prefix, h_prefix, sizeof(long long) * (n_utt + 1), hipMemcpyHostToDevice, s));
-				SynArgs a;
-				a.utts = sy->utts.as<UttDesc>(); a.n_utt = n_utt; a.pulse_prefix = d_prefix; a.cap_off = d_cap_off;
-				a.first_index = d_first; a.p = pb; a.f0 = d_f0; a.sp = d_sp; a.ap = d_ap;
-				a.rng_table = dev->rng_table.as<uint32_t>(); a.rng_base = dev->rng_base; a.tw = dev->twiddle;
-				a.dc_remover = sy->dc_remover.as<double>(); a.out = d_out; a.total_pulses = total_pulses; a.fs = sy->fs;
-				a.frame_period = sy->frame_period;
-				{
-					const char *dbg = getenv("WC_DEBUG_ONLY_PULSE");
-					a.only_pulse = dbg ? atoll(dbg) : -1;
-				}
-				if ((rc = dev->time_begin("synthesis_pulses"))) return rc;
-				switch (sy->fft_size) {
-					case 512: launch_pulses<512>(a, s); break;
-					case 1024: launch_pulses<1024>(a, s); break;
-					case 2048: launch_pulses<2048>(a, s); break;
-					default: return fail(WC_ERR_UNSUPPORTED, "synthesis: fft_size must be 512, 1024 or 2048");
-				}
-				WC_HIP(hipGetLastError());
-				if ((rc = dev->time_end("synthesis_pulses"))) return rc;
-			}
-			break;
-		}
-		if (full) return fail(WC_ERR_DEVICE, "synthesis: pulse buffer overflow");
-		full = true;
+	if ((rc = sy->pulses.reserve((size_t)co * (sizeof(int) * 3 + sizeof(double))))) return rc;
+	PulseBuf pb;
+	pb.shift = sy->pulses.as<double>();
+	pb.index = reinterpret_cast<int *>(pb.shift + co);
+	pb.noise_size = pb.index + co;
+	pb.vuv = pb.noise_size + co;
+	WC_HIP(hipMemcpyAsync(sy->utts.p, hs, sizeof(UttDesc) * n_utt, hipMemcpyHostToDevice, s));
+	WC_HIP(hipMemcpyAsync(d_cap_off, h_cap_off, sizeof(long long) * n_utt, hipMemcpyHostToDevice, s));
+	WC_HIP(hipMemcpyAsync(d_inc_off, h_inc_off, sizeof(long long) * n_utt, hipMemcpyHostToDevice, s));
+	WC_HIP(hipMemcpyAsync(d_cap, h_cap, sizeof(int) * n_utt, hipMemcpyHostToDevice, s));
+	if ((rc = sy->h_stage.mark(s))) return rc;
+	TbArgs ta;
+	ta.inc_off = d_inc_off;
+	ta.utts = sy->utts.as<UttDesc>(); ta.f0 = d_f0; ta.cap_off = d_cap_off; ta.cap = d_cap; ta.p = pb;
+	ta.count = d_count; ta.first_index = d_first; ta.fs = sy->fs; ta.fft_size = sy->fft_size;
+	ta.frame_period = sy->frame_period;
+	if ((rc = dev->time_begin("synthesis_timebase", s))) return rc;
+	WC_HIP(hipMemsetAsync(sy->incs.p, 0, sizeof(double) * inc_total, s));
+	hipLaunchKernelGGL(syn_increment_kernel, dim3((unsigned)((total_out + 255) / 256)), dim3(256), 0, s, ta, n_utt,
+					   total_out, sy->incs.as<double>());
+	hipLaunchKernelGGL(syn_timebase_kernel, dim3(n_utt), dim3(64), 0, s, ta, (const double *)sy->incs.as<double>());
+	hipLaunchKernelGGL(syn_noise_size_kernel, dim3(8, n_utt), dim3(256), 0, s, d_cap_off, d_count, d_cap, pb, d_first, d_last);
+	WC_HIP(hipGetLastError());
+	return dev->time_end("synthesis_timebase", s);
+}
+
+int syn_pulses(wc_synthesis *sy, hipStream_t s, const double *d_f0, const double *d_sp, const double *d_ap, double *d_out,
+			   const unsigned long long *d_start) {
+	Device *dev = sy->dev;
+	if (sy->total_out == 0 || sy->cap_total == 0) return WC_OK;
+	const int n_utt = sy->n_utt;
+	int rc;
+	char *dm = static_cast<char *>(sy->meta.p);
+	long long *d_cap_off = reinterpret_cast<long long *>(dm);
+	long long *d_prefix = d_cap_off + n_utt;
+	long long *d_inc_off = d_prefix + n_utt + 1;
+	unsigned long long *d_end = reinterpret_cast<unsigned long long *>(d_inc_off + n_utt);
+	int *d_cap = reinterpret_cast<int *>(d_end + n_utt);
+	int *d_count = d_cap + n_utt;
+	int *d_first = d_count + n_utt;
+	int *d_last = d_first + n_utt;
+	int *d_ovf = d_last + n_utt;
+	const long long co = sy->cap_total;
+	PulseBuf pb;
+	pb.shift = sy->pulses.as<double>();
+	pb.index = reinterpret_cast<int *>(pb.shift + co);
+	pb.noise_size = pb.index + co;
+	pb.vuv = pb.noise_size + co;
+	hipLaunchKernelGGL(syn_prefix_kernel, dim3(1), dim3(64), 0, s, n_utt, d_count, d_cap, d_first, d_last, sy->utts.as<UttDesc>(),
+					   d_start, d_prefix, d_end, d_ovf);
+	SynArgs a;
+	a.utts = sy->utts.as<UttDesc>(); a.n_utt = n_utt; a.pulse_prefix = d_prefix; a.cap_off = d_cap_off;
+	a.first_index = d_first; a.p = pb; a.f0 = d_f0; a.sp = d_sp; a.ap = d_ap;
+	a.rng_table = dev->rng_table.as<uint32_t>(); a.rng_base = dev->rng_base; a.tw = dev->twiddle;
+	a.dc_remover = sy->dc_remover.as<double>(); a.out = d_out; a.total_pulses = co; a.fs = sy->fs;
+	a.frame_period = sy->frame_period; a.rng_start = d_start;
+	{
+		const char *dbg = getenv("WC_DEBUG_ONLY_PULSE");
+		a.only_pulse = dbg ? atoll(dbg) : -1;
 	}
-	if (rng_pos) {
-		// total draws = index_last - index_first (reference :106-107, :519-521)
-		std::vector<int> fl(2 * (size_t)n_utt, 0);
-		if (total_pulses > 0) {
-			WC_HIP(hipMemcpyAsync(fl.data(), d_first, sizeof(int) * 2 * n_utt, hipMemcpyDeviceToHost, s));
-			WC_HIP(hipStreamSynchronize(s));
-		}
-		for (int u = 0; u < n_utt; ++u) rng_pos[u] += (uint64_t)(fl[n_utt + u] - fl[u]);
+	if ((rc = dev->time_begin("synthesis_pulses", s))) return rc;
+	switch (sy->fft_size) {
+		case 512: launch_pulses<512>(a, s); break;
+		case 1024: launch_pulses<1024>(a, s); break;
+		case 2048: launch_pulses<2048>(a, s); break;
+		default: return fail(WC_ERR_UNSUPPORTED, "synthesis: fft_size must be 512, 1024 or 2048");
 	}
+	WC_HIP(hipGetLastError());
+	return dev->time_end("synthesis_pulses", s);
+}
+
+// after the stream has been synchronised: overflow flag and (optionally) the end positions
+int syn_finish(wc_synthesis *sy, hipStream_t s, uint64_t *rng_pos_out, bool *overflow) {
+	*overflow = false;
+	if (sy->total_out == 0 || sy->cap_total == 0) return WC_OK;
+	const int n_utt = sy->n_utt;
+	char *dm = static_cast<char *>(sy->meta.p);
+	long long *d_cap_off = reinterpret_cast<long long *>(dm);
+	unsigned long long *d_end = reinterpret_cast<unsigned long long *>(d_cap_off + 3 * n_utt + 1);
+	int *d_ovf = reinterpret_cast<int *>(d_end + n_utt) + 4 * n_utt;
+	int ovf = 0;
+	std::vector<uint64_t> ends(n_utt);
+	WC_HIP(hipMemcpyAsync(&ovf, d_ovf, sizeof(int), hipMemcpyDeviceToHost, s));
+	if (rng_pos_out) WC_HIP(hipMemcpyAsync(ends.data(), d_end, sizeof(uint64_t) * n_utt, hipMemcpyDeviceToHost, s));
+	WC_HIP(hipStreamSynchronize(s));
+	*overflow = ovf != 0;
+	if (rng_pos_out && !ovf) for (int u = 0; u < n_utt; ++u) rng_pos_out[u] = ends[u];
 	return WC_OK;
+}
+
+static int syn_run_device(wc_synthesis *sy, int n_utt, const double *d_f0, const int *f0_length, const double *d_sp,
+						  const double *d_ap, const int *out_length, double *d_out, uint64_t *rng_pos) {
+	Device *dev = sy->dev;
+	hipStream_t s = dev->stream;
+	int rc;
+	uint64_t lo = ~0ull, hi = 0;
+	for (int u = 0; u < n_utt; ++u) {
+		uint64_t p0 = rng_pos ? rng_pos[u] : 0ull;
+		lo = p0 < lo ? p0 : lo;
+		uint64_t e = p0 + (uint64_t)(out_length[u] > 0 ? out_length[u] : 0);
+		hi = e > hi ? e : hi;
+	}
+	if ((rc = dev->ensure_rng(lo, hi))) return rc;
+	for (int attempt = 0; attempt < 2; ++attempt) {
+		if ((rc = syn_prepare(sy, s, n_utt, d_f0, f0_length, out_length, d_out, rng_pos, attempt == 1))) return rc;
+		if ((rc = syn_pulses(sy, s, d_f0, d_sp, d_ap, d_out, nullptr))) return rc;
+		bool overflow = false;
+		if ((rc = syn_finish(sy, s, rng_pos, &overflow))) return rc;
+		if (!overflow) return WC_OK;
+	}
+	return fail(WC_ERR_DEVICE, "synthesis: pulse buffer overflow");
 }
 
 extern "C" {
