@@ -127,11 +127,8 @@ def main():
     f_len = [w.get_samples(FS, n, FRAME_PERIOD) for n in x_len]
     y_len = [w.synthesis_out_length(n, FRAME_PERIOD, FS) for n in f_len]
     frames = sum(f_len)
-    hv = w.Harvest(FS, frame_period=FRAME_PERIOD)
-    ct = w.CheapTrick(FS)
-    d4 = w.D4C(FS)
-    sy = w.Synthesis(FS, ct.fft_size, FRAME_PERIOD)
-    bins = ct.bins
+    pipe = w.Pipeline(FS, frame_period=FRAME_PERIOD)  # Harvest -> CheapTrick -> D4C -> Synthesis, reference defaults
+    bins = pipe.bins
     d_x = torch.from_numpy(np.concatenate(xs)).to(dev)
     d_t = torch.empty(frames, dtype=torch.float64, device=dev)
     d_f = torch.empty(frames, dtype=torch.float64, device=dev)
@@ -141,10 +138,8 @@ def main():
     torch.cuda.synchronize()
 
     def step():
-        hv.compute_device(d_x, x_len, d_t, d_f)
-        pos = ct.compute_device(d_x, x_len, d_t, d_f, f_len, d_sp, rng_pos=[0] * n_utt)
-        pos = d4.compute_device(d_x, x_len, d_t, d_f, f_len, ct.fft_size, d_ap, rng_pos=pos)
-        sy.compute_device(d_f, f_len, d_sp, d_ap, y_len, d_y, rng_pos=pos)
+        # one fused call: all four stages, every utterance starting its noise stream at position 0
+        pipe.run_device(d_x, x_len, d_t, d_f, d_sp, d_ap, d_y)
 
     def barrier():
         L.wc_synchronize()
@@ -208,7 +203,7 @@ def main():
             "config": {"workload": f"{n_utt} synthetic 48 kHz 10 s utterances per GPU ({distinct} distinct, tiled), 5 ms hop, "
                                    "Harvest->CheapTrick->D4C->Synthesis, inputs resident in HBM",
                        "utterances_per_gpu": n_utt, "frames_per_gpu": frames, "fs": FS, "frame_period_ms": FRAME_PERIOD,
-                       "fft_size": ct.fft_size, "parallelism": f"utterance-sharded x{world}, final RCCL all-gather of F0 + checksums"},
+                       "fft_size": pipe.fft_size, "parallelism": f"utterance-sharded x{world}, final RCCL all-gather of F0 + checksums"},
             "roofline": roofline,
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -115,6 +115,19 @@ int wc_synthesis_compute_device(wc_synthesis *s, int n_utt, const double *d_f0, 
                                 const double *d_sp, const double *d_ap, const int *out_length,
                                 double *d_out, uint64_t *rng_pos);
 
+/* ---- fused pipeline (extension): Harvest -> CheapTrick -> D4C -> Synthesis in the demo's order (reference
+ * test/test.cpp:288-384) for a packed batch, everything device resident, the stages overlapped on several HIP
+ * streams and the noise-stream positions chained on the device (CheapTrick -> D4C -> Synthesis).  Frames per
+ * utterance = wc_get_samples(fs, x_length[u], frame_period), output samples = wc_synthesis_out_length(...).
+ * rng_pos: optional in/out host array as for the stage calls. -------------------------------------------- */
+typedef struct wc_pipeline wc_pipeline;
+wc_pipeline *wc_pipeline_create(int fs, double frame_period, double harvest_f0_floor, double harvest_f0_ceil, double q1,
+                                double cheaptrick_f0_floor, int fft_size, double d4c_threshold);
+void wc_pipeline_destroy(wc_pipeline *p);
+int wc_pipeline_get_fft_size(const wc_pipeline *p);
+int wc_pipeline_run_device(wc_pipeline *p, int n_utt, const double *d_x, const int *x_length, double *d_tpos, double *d_f0,
+                           double *d_sp, double *d_ap, double *d_y, uint64_t *rng_pos);
+
 /* ---- device memory plumbing for callers without their own HIP allocator (tests, C++ demo) ------ */
 void *wc_device_malloc(uint64_t bytes);
 void wc_device_free(void *p);

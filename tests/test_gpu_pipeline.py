@@ -80,3 +80,35 @@ def test_full_size_properties(wca):
     assert same.mean() > 0.5 and np.abs(a[same] - b[same]).max() < 0.5
     # resynthesis has the energy of the input (same order of magnitude) and is finite
     assert np.isfinite(y).all() and 0.3 < np.sqrt(np.mean(y ** 2)) / np.sqrt(np.mean(x ** 2)) < 3.0
+
+
+@pytest.mark.parametrize("name", ["c1_16k_2s_floor71", "m48k_1s"])
+def test_fused_pipeline_golden(golden, wca, name):
+    """wc_pipeline_run_device (multi-stream, device-chained noise positions) against the reference goldens."""
+    c = golden.case(name)
+    p = wca.Pipeline(c["fs"], frame_period=c["frame_period"], harvest_f0_floor=c["harvest_floor"])
+    (r,), pos = p.run_batch([c["x"]], rng_pos=[0])
+    s = c["stride"]
+    assert np.array_equal(r["tpos"], c["tpos"])
+    assert np.array_equal(r["f0"] == 0, c["f0"] == 0) and np.abs(r["f0"] - c["f0"]).max() < 1e-6
+    assert (np.abs(r["sp"][::s] - c["sp_rows"]) / c["sp_rows"]).max() < 1e-7
+    assert np.abs(r["ap"][::s] - c["ap_rows"]).max() < 1e-7
+    assert np.abs(r["y"] - c["y"]).max() < 1e-8
+    assert pos[0] > 0
+
+
+def test_fused_pipeline_ragged_batch_equals_stage_calls(wca):
+    fs = 16000
+    xs = [make_utterance(fs, sec, 80 + i) for i, sec in enumerate((0.6, 1.0, 0.25))]
+    p = wca.Pipeline(fs)
+    outs, pos = p.run_batch(xs, rng_pos=[0, 7, 0])
+    for x, r, p0 in zip(xs, outs, [0, 7, 0]):
+        wca.rng_set_position(p0)
+        tpos, f0 = wca.Harvest(fs).compute(x)
+        ct = wca.CheapTrick(fs)
+        sp = ct.compute(x, tpos, f0)
+        ap = wca.D4C(fs).compute(x, tpos, f0, ct.fft_size)
+        y = wca.Synthesis(fs, ct.fft_size, 5.0).compute(f0, sp, ap)
+        assert np.array_equal(r["f0"], f0) and np.array_equal(r["sp"], sp) and np.array_equal(r["ap"], ap)
+        assert np.abs(r["y"] - y).max() < 1e-12
+    assert all(b > a for a, b in zip([0, 7, 0], pos))

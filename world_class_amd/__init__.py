@@ -51,6 +51,10 @@ _SIGNATURES = {
     "wc_synthesis_destroy": (None, [_vp]),
     "wc_synthesis_compute": (C.c_int, [_vp, _dp, C.c_int, C.POINTER(_dp), C.POINTER(_dp), C.c_int, _dp]),
     "wc_synthesis_compute_device": (C.c_int, [_vp, C.c_int, _vp, _ip, _vp, _vp, _ip, _vp, _u64p]),
+    "wc_pipeline_create": (_vp, [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_double]),
+    "wc_pipeline_destroy": (None, [_vp]),
+    "wc_pipeline_get_fft_size": (C.c_int, [_vp]),
+    "wc_pipeline_run_device": (C.c_int, [_vp, C.c_int, _vp, _ip, _vp, _vp, _vp, _vp, _vp, _u64p]),
     "wc_device_malloc": (_vp, [C.c_uint64]),
     "wc_device_free": (None, [_vp]),
     "wc_memcpy_h2d": (C.c_int, [_vp, _vp, C.c_uint64]),
@@ -290,3 +294,4 @@ class D4C:
 
 from ._synthesis import Synthesis  # noqa: E402,F401
 from ._harvest import Harvest  # noqa: E402,F401
+from ._pipeline import Pipeline  # noqa: E402,F401

@@ -1,0 +1,53 @@
+"""Fused device pipeline (extension over the reference's four classes): one call = Harvest -> CheapTrick -> D4C ->
+Synthesis for a packed batch, stages overlapped on HIP streams, noise-stream positions chained on the device."""
+import numpy as np
+
+from . import (DeviceArray, _c, _check, _handle, _ints, _ptr, _rng_arg, get_samples, lib, synthesis_out_length)
+
+
+class Pipeline:
+    def __init__(self, fs, frame_period=5.0, harvest_f0_floor=71.0, harvest_f0_ceil=800.0, q1=-0.15,
+                 cheaptrick_f0_floor=71.0, fft_size=0, d4c_threshold=0.85):
+        self.fs, self.frame_period = fs, frame_period
+        self._h = _handle(lib().wc_pipeline_create(fs, frame_period, harvest_f0_floor, harvest_f0_ceil, q1,
+                                                   cheaptrick_f0_floor, fft_size, d4c_threshold))
+        self.fft_size = lib().wc_pipeline_get_fft_size(self._h)
+        self.bins = self.fft_size // 2 + 1
+
+    def lengths(self, x_lengths):
+        fl = [get_samples(self.fs, n, self.frame_period) for n in x_lengths]
+        yl = [synthesis_out_length(n, self.frame_period, self.fs) for n in fl]
+        return fl, yl
+
+    def run_device(self, d_x, x_lengths, d_tpos, d_f0, d_sp, d_ap, d_y, rng_pos=None):
+        n = len(x_lengths)
+        arr, arg = _rng_arg(rng_pos, n)
+        _check(lib().wc_pipeline_run_device(self._h, n, _ptr(d_x), _ints(x_lengths), _ptr(d_tpos), _ptr(d_f0), _ptr(d_sp),
+                                            _ptr(d_ap), _ptr(d_y), arg))
+        return list(arr) if arr is not None else None
+
+    def run_batch(self, xs, rng_pos=None):
+        """Host lists in, list of dicts (tpos, f0, sp, ap, y) out."""
+        xl = [len(x) for x in xs]
+        fl, yl = self.lengths(xl)
+        d_x = DeviceArray.from_host(np.concatenate([_c(v) for v in xs]))
+        d_t, d_f = DeviceArray(sum(fl)), DeviceArray(sum(fl))
+        d_sp, d_ap = DeviceArray(sum(fl) * self.bins), DeviceArray(sum(fl) * self.bins)
+        d_y = DeviceArray(sum(yl))
+        pos = self.run_device(d_x, xl, d_t, d_f, d_sp, d_ap, d_y, rng_pos)
+        t, f, y = d_t.to_host(), d_f.to_host(), d_y.to_host()
+        sp, ap = d_sp.to_host((sum(fl), self.bins)), d_ap.to_host((sum(fl), self.bins))
+        out, fo, yo = [], 0, 0
+        for nf, ny in zip(fl, yl):
+            out.append(dict(tpos=t[fo:fo + nf], f0=f[fo:fo + nf], sp=sp[fo:fo + nf], ap=ap[fo:fo + nf], y=y[yo:yo + ny]))
+            fo += nf
+            yo += ny
+        return (out, pos) if rng_pos is not None else out
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().wc_pipeline_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass

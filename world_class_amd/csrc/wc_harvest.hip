@@ -326,7 +326,8 @@ __global__ void hv_raw_kernel(RawArgs a) {
 	bool ok = true;
 #pragma unroll
 	for (int ty = 0; ty < 4; ++ty) {
-		n[ty] = cnt[ty] < 2 ? 0 : cnt[ty] - 1;
+		const int ce = min(cnt[ty], cap);  // (an overflowed list is re-done by the caller; stay inside the buffer)
+		n[ty] = ce < 2 ? 0 : ce - 1;
 		ok = ok && n[ty] > 2;
 	}
 	double v = 0.0;
@@ -1003,9 +1004,12 @@ static DecCoef dec_coef(int r) {
 
 static inline int h_mround(double x) { return x > 0 ? static_cast<int>(x + 0.5) : static_cast<int>(x - 0.5); }
 
-static int hv_run_device(wc_harvest *h, int n_utt, const double *d_x, const int *x_length, double *d_tpos, double *d_f0) {
+// Enqueue-only (no host synchronisation), shared with the fused pipeline.  `full` selects the hard bound for the
+// zero-crossing buffers; with the rate bound an overflow is reported through h->overflow (device) and handled by
+// the caller (hv_overflowed) by re-running with full == true.
+int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const int *x_length, double *d_tpos, double *d_f0,
+			   bool full) {
 	Device *dev = h->dev;
-	hipStream_t s = dev->stream;
 	const int r = h->decim;
 	const int lag = (r == 1) ? 0 : static_cast<int>(std::ceil(140.0 / r) * r);
 	std::vector<HvUtt> utts(n_utt);
@@ -1029,8 +1033,7 @@ static int hv_run_device(wc_harvest *h, int n_utt, const double *d_x, const int 
 	const int nb = h->n_bands, S = h->S, nc = 7 * S;
 	const int max_sec = max_L1 / 2 + 8;
 	int rc;
-	// event capacities: per band and type; first try a rate bound, then the hard bound
-	bool full = false;
+	// event capacities per band and type: a rate bound, or the hard bound when `full`
 	std::vector<long long> ev_band_off(nb);
 	std::vector<int> ev_cap(nb);
 	if ((rc = h->overflow.reserve(sizeof(int)))) return rc;
@@ -1054,7 +1057,7 @@ static int hv_run_device(wc_harvest *h, int n_utt, const double *d_x, const int 
 	const long long smooth_stride = (long long)(max_L1 + 600) * 64;
 	if ((rc = h->smooth.reserve(sizeof(double) * smooth_stride * n_utt))) return rc;
 
-	for (int attempt = 0; attempt < 2; ++attempt) {
+	{
 		long long per_utt = 0;
 		for (int b = 0; b < nb; ++b) {
 			int hard = max_ylen / 2 + 4;
@@ -1075,11 +1078,12 @@ static int hv_run_device(wc_harvest *h, int n_utt, const double *d_x, const int 
 		WC_HIP(hipMemcpyAsync(h->utts.p, hs, sizeof(HvUtt) * n_utt, hipMemcpyHostToDevice, s));
 		WC_HIP(hipMemcpyAsync(h->d_ev_band_off.p, hs + sizeof(HvUtt) * n_utt, sizeof(long long) * nb, hipMemcpyHostToDevice, s));
 		WC_HIP(hipMemcpyAsync(h->d_ev_cap.p, hs + sizeof(HvUtt) * n_utt + sizeof(long long) * nb, sizeof(int) * nb, hipMemcpyHostToDevice, s));
+		if ((rc = h->h_stage.mark(s))) return rc;
 		WC_HIP(hipMemsetAsync(h->overflow.p, 0, sizeof(int), s));
 		const HvUtt *du = h->utts.as<HvUtt>();
-		if (attempt == 0) {
+		{
 			WC_HIP(hipMemsetAsync(h->y.p, 0, sizeof(double) * yo, s));
-			if ((rc = dev->time_begin("harvest_decimate"))) return rc;
+			if ((rc = dev->time_begin("harvest_decimate", s))) return rc;
 			if (r == 1) {
 				hipLaunchKernelGGL(hv_copy_kernel, dim3((max_ylen + 255) / 256, n_utt), dim3(256), 0, s, du, d_x, h->y.as<double>());
 			} else {
@@ -1091,42 +1095,36 @@ static int hv_run_device(wc_harvest *h, int n_utt, const double *d_x, const int 
 			}
 			hipLaunchKernelGGL(hv_dc_kernel, dim3(n_utt), dim3(256), 0, s, du, h->y.as<double>());
 			WC_HIP(hipGetLastError());
-			if ((rc = dev->time_end("harvest_decimate"))) return rc;
+			if ((rc = dev->time_end("harvest_decimate", s))) return rc;
 		}
 		BpArgs ba;
 		ba.utts = du; ba.y = h->y.as<double>(); ba.taps = h->d_taps.as<double>(); ba.tap_off = h->d_tap_off.as<int>();
 		ba.half_len = h->d_half_len.as<int>(); ba.ev_band_off = h->d_ev_band_off.as<long long>(); ba.ev_cap = h->d_ev_cap.as<int>();
 		ba.events = h->events.as<double>(); ba.ev_count = h->ev_count.as<int>(); ba.overflow = h->overflow.as<int>(); ba.n_bands = nb;
-		if ((rc = dev->time_begin("harvest_bandpass"))) return rc;
+		if ((rc = dev->time_begin("harvest_bandpass", s))) return rc;
 		hipLaunchKernelGGL(hv_bandpass_kernel, dim3(nb, n_utt), dim3(BP_T), 0, s, ba);
 		WC_HIP(hipGetLastError());
-		if ((rc = dev->time_end("harvest_bandpass"))) return rc;
-		int ovf = 0;
-		WC_HIP(hipMemcpyAsync(&ovf, h->overflow.p, sizeof(int), hipMemcpyDeviceToHost, s));
-		WC_HIP(hipStreamSynchronize(s));
-		if (!ovf) break;
-		if (full) return fail(WC_ERR_DEVICE, "harvest: zero-crossing buffer overflow");
-		full = true;
+		if ((rc = dev->time_end("harvest_bandpass", s))) return rc;
 	}
 	const HvUtt *du = h->utts.as<HvUtt>();
 	RawArgs ra;
 	ra.utts = du; ra.events = h->events.as<double>(); ra.ev_band_off = h->d_ev_band_off.as<long long>(); ra.ev_cap = h->d_ev_cap.as<int>();
 	ra.ev_count = h->ev_count.as<int>(); ra.band_f0 = h->d_band_f0.as<double>(); ra.raw = h->raw.as<double>(); ra.n_bands = nb;
 	ra.fs_d = h->fs_d; ra.f0_floor = h->f0_floor; ra.f0_ceil = h->f0_ceil;
-	if ((rc = dev->time_begin("harvest_raw"))) return rc;
+	if ((rc = dev->time_begin("harvest_raw", s))) return rc;
 	hipLaunchKernelGGL(hv_raw_kernel, dim3((max_L1 + 255) / 256, nb, n_utt), dim3(256), 0, s, ra);
 	hipLaunchKernelGGL(hv_detect_kernel, dim3((max_L1 + 255) / 256, n_utt), dim3(256), 0, s, du, h->raw.as<double>(), h->cand0.as<double>(), nb, S);
 	WC_HIP(hipGetLastError());
-	if ((rc = dev->time_end("harvest_raw"))) return rc;
+	if ((rc = dev->time_end("harvest_raw", s))) return rc;
 	RefArgs fa;
 	fa.utts = du; fa.n_utt = n_utt; fa.y = h->y.as<double>(); fa.cand0 = h->cand0.as<double>(); fa.tw = dev->twiddle; fa.rot = h->d_rot.as<double2>();
 	fa.cand1 = h->cand1.as<double>(); fa.score1 = h->score1.as<double>(); fa.total_frames = total_l1;
 	fa.p.fs = h->fs; fa.p.decim = r; fa.p.n_bands = nb; fa.p.S = S; fa.p.n_cand = nc; fa.p.fs_d = h->fs_d;
 	fa.p.f0_floor = h->f0_floor; fa.p.f0_ceil = h->f0_ceil; fa.p.frame_period = h->frame_period;
-	if ((rc = dev->time_begin("harvest_refine"))) return rc;
+	if ((rc = dev->time_begin("harvest_refine", s))) return rc;
 	hipLaunchKernelGGL(hv_refine_kernel, dim3((unsigned)total_l1), dim3(256), 0, s, fa);
 	WC_HIP(hipGetLastError());
-	if ((rc = dev->time_end("harvest_refine"))) return rc;
+	if ((rc = dev->time_end("harvest_refine", s))) return rc;
 	hipLaunchKernelGGL(hv_unreliable_kernel, dim3((unsigned)total_l1), dim3(128), 0, s, du, n_utt, h->cand1.as<double>(), h->score1.as<double>(),
 					   h->cand2.as<double>(), h->score2.as<double>(), h->base.as<double>(), total_l1, nc);
 	CtrArgs ca;
@@ -1134,7 +1132,7 @@ static int hv_run_device(wc_harvest *h, int n_utt, const double *d_x, const int 
 	ca.s1 = h->s1.as<double>(); ca.s2 = h->s2.as<double>(); ca.s3 = h->s3.as<double>(); ca.fixed = h->fixed.as<double>();
 	ca.sec = h->sec.as<int>(); ca.chan = h->chan.as<double>(); ca.chan_stride = chan_stride; ca.max_sec = max_sec; ca.nc = nc;
 	ca.ibuf = h->ibuf.as<int>();
-	if ((rc = dev->time_begin("harvest_contour"))) return rc;
+	if ((rc = dev->time_begin("harvest_contour", s))) return rc;
 	hipLaunchKernelGGL(hv_contour_kernel, dim3(n_utt), dim3(64), 0, s, ca);
 	SmArgs sa;
 	sa.utts = du; sa.fixed = h->fixed.as<double>(); sa.f0_1ms = h->f0_1ms.as<double>(); sa.sec = h->sec.as<int>();
@@ -1142,9 +1140,30 @@ static int hv_run_device(wc_harvest *h, int n_utt, const double *d_x, const int 
 	hipLaunchKernelGGL(hv_smooth_kernel, dim3(n_utt), dim3(64), 0, s, sa);
 	hipLaunchKernelGGL(hv_output_kernel, dim3((max_L + 255) / 256, n_utt), dim3(256), 0, s, du, h->f0_1ms.as<double>(), d_tpos, d_f0, h->frame_period);
 	WC_HIP(hipGetLastError());
-	if ((rc = dev->time_end("harvest_contour"))) return rc;
+	if ((rc = dev->time_end("harvest_contour", s))) return rc;
 	h->last_utts = utts;
 	return WC_OK;
+}
+
+// after hv_enqueue: synchronises the stream and reports whether the zero-crossing buffers overflowed
+int hv_overflowed(wc_harvest *h, hipStream_t s, bool *overflow) {
+	int ovf = 0;
+	WC_HIP(hipMemcpyAsync(&ovf, h->overflow.p, sizeof(int), hipMemcpyDeviceToHost, s));
+	WC_HIP(hipStreamSynchronize(s));
+	*overflow = ovf != 0;
+	return WC_OK;
+}
+
+static int hv_run_device(wc_harvest *h, int n_utt, const double *d_x, const int *x_length, double *d_tpos, double *d_f0) {
+	hipStream_t s = h->dev->stream;
+	int rc;
+	for (int attempt = 0; attempt < 2; ++attempt) {
+		if ((rc = hv_enqueue(h, s, n_utt, d_x, x_length, d_tpos, d_f0, attempt == 1))) return rc;
+		bool overflow = false;
+		if ((rc = hv_overflowed(h, s, &overflow))) return rc;
+		if (!overflow) return WC_OK;
+	}
+	return fail(WC_ERR_DEVICE, "harvest: zero-crossing buffer overflow");
 }
 
 extern "C" {

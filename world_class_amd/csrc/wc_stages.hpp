@@ -1,0 +1,26 @@
+// Enqueue-only entry points of the four stages (no host synchronisation), used by the fused pipeline
+// (wc_pipeline.hip).  Each is defined next to its stage's kernels.
+#pragma once
+#include "wc_internal.hpp"
+
+int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const int *x_length, double *d_tpos, double *d_f0,
+			   bool full);
+int hv_overflowed(wc_harvest *h, hipStream_t s, bool *overflow);
+
+int ct_prepare(wc_cheaptrick *c, hipStream_t s, int n_utt, const int *x_length, const double *d_f0, const int *f0_length,
+			   const uint64_t *rng_pos, long long *total_out, uint64_t *min_pos_out, uint64_t *max_end_out);
+int ct_frames(wc_cheaptrick *c, hipStream_t s, int n_utt, const double *d_x, const double *d_tpos, const double *d_f0,
+			  double *d_sp, long long total);
+const unsigned long long *ct_end_positions(const wc_cheaptrick *c);
+
+int d4c_enqueue(wc_d4c *d, hipStream_t s, int n_utt, const double *d_x, const int *x_length, const double *d_tpos,
+				const double *d_f0, const int *f0_length, int fft_size, double *d_ap, const uint64_t *rng_pos,
+				const unsigned long long *d_start);
+const unsigned long long *d4c_end_positions(const wc_d4c *d);
+uint64_t d4c_draw_bound(const wc_d4c *d, int f0_length);
+
+int syn_prepare(wc_synthesis *sy, hipStream_t s, int n_utt, const double *d_f0, const int *f0_length, const int *out_length,
+				double *d_out, const uint64_t *rng_pos, bool full);
+int syn_pulses(wc_synthesis *sy, hipStream_t s, const double *d_f0, const double *d_sp, const double *d_ap, double *d_out,
+			   const unsigned long long *d_start);
+int syn_finish(wc_synthesis *sy, hipStream_t s, uint64_t *rng_pos_out, bool *overflow);
