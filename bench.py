@@ -43,51 +43,61 @@ KERNEL_STAGE = {
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def cpu_baseline(xs, budget_s=20.0):
-    """CPU path on a bounded sample (whole utterances of the same workload), rank 0 / N=1 only."""
+def cpu_baseline(xs, budget_s=24.0):
+    """CPU path on a bounded sample (whole utterances of the same workload), rank 0 / N=1 only.
+
+    The reference's OpenMP build is tried at several thread counts on the first utterance (it does not scale to
+    all cores of a large host: its parallel loops allocate and plan FFTs per iteration) and the best count is
+    used for the rest of the sample.  Each run is a fresh process: the reference's noise state is process-global,
+    and its Synthesis overflows its pulse arrays on some inputs, which a subprocess isolates.
+    """
     from oracle import port, ref
     cores = os.cpu_count() or 1
+
+    def ref_once(x, threads):
+        os.environ["OMP_NUM_THREADS"] = str(threads)
+        t0 = time.perf_counter()
+        r = ref.run_fresh("pipeline", x, FS, harvest_floor=71.0, omp=True)
+        dt = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        ref.run_fresh("randn", 1, omp=True)  # process start-up + library load, subtracted
+        return len(r["f0"]), max(dt - (time.perf_counter() - t1), 1e-3)
+
+    if ref.available(omp=True):
+        try:
+            best = None
+            for th in sorted({min(cores, t) for t in (8, 16, 32, 64, cores)}):
+                n, dt = ref_once(xs[0], th)
+                if best is None or dt < best[1]:
+                    best = (th, dt, n)
+            threads, t_used, frames, n_done = best[0], best[1], best[2], 1
+            for x in xs[1:]:
+                if t_used > budget_s * 0.5:
+                    break
+                n, dt = ref_once(x, threads)
+                frames += n
+                t_used += dt
+                n_done += 1
+            return {"value": frames / t_used, "unit": "frames/s", "cores": threads, "kind": "reference",
+                    "sample": f"{n_done} x 48 kHz 10 s utterance(s) of the same synthetic workload, full pipeline, OpenMP build "
+                              f"of the reference (oracle/_ref), best of 8/16/32/64/{cores} threads = {threads} (host has {cores})"}
+        except Exception:
+            pass
     P = port.Port()
+    P.set_threads(cores)
     frames, t_used, n_done = 0, 0.0, 0
-    kind = "port"
-    use_ref = ref.available(omp=True)
     for x in xs:
         if t_used > budget_s * 0.5 and n_done >= 1:
             break
         t0 = time.perf_counter()
-        ok = False
-        if use_ref:
-            # the reference overflows its pulse arrays on some inputs (see oracle/gen_golden.py); a fresh process
-            # isolates that, and only clean runs are counted
-            try:
-                os.environ["OMP_NUM_THREADS"] = str(cores)
-                t0 = time.perf_counter()
-                r = ref.run_fresh("pipeline", x, FS, harvest_floor=71.0, omp=True)
-                dt = time.perf_counter() - t0
-                # subtract the process start-up (library load), measured with a trivial call
-                t1 = time.perf_counter()
-                ref.run_fresh("randn", 1, omp=True)
-                dt -= time.perf_counter() - t1
-                frames += len(r["f0"])
-                t_used += max(dt, 1e-3)
-                ok = True
-                kind = "reference"
-            except Exception:
-                use_ref = False
-        if not ok:
-            P.set_threads(cores)
-            t0 = time.perf_counter()
-            r = P.pipeline(x, FS)
-            t_used += time.perf_counter() - t0
-            frames += len(r["f0"])
-            P.set_threads(0)
-            if kind != "reference":
-                kind = "port"
+        r = P.pipeline(x, FS)
+        t_used += time.perf_counter() - t0
+        frames += len(r["f0"])
         n_done += 1
-    return {"value": frames / t_used, "unit": "frames/s", "cores": cores, "kind": kind,
-            "sample": f"{n_done} x 48 kHz 10 s utterance(s) of the same synthetic workload, full pipeline, "
-                      f"{'OpenMP build of the reference (oracle/_ref)' if kind == 'reference' else 'CPU restatement (oracle/), OpenMP'}"
-                      f", {cores} threads"}
+    P.set_threads(0)
+    return {"value": frames / t_used, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{n_done} x 48 kHz 10 s utterance(s) of the same synthetic workload, full pipeline, CPU restatement "
+                      f"(oracle/), OpenMP, {cores} threads"}
 
 
 def main():
@@ -190,7 +200,7 @@ def main():
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tpath):
                 with open(tpath) as f:
-                    traffic = json.load(f).get(dom)
+                    traffic = json.load(f).get(dom)  # HBM bytes per launch (PMC, see the file's _note)
             roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                         "kernel_ms": kern[dom], "bytes_per_frame": STAGE_BYTES[stage],

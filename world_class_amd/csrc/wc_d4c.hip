@@ -44,6 +44,9 @@ struct D4cArgs {
 
 // F0-adaptive window of reference src/d4c.cpp:246-303 for the calling block; each thread keeps its
 // N/T samples in registers.  type 1 = Hanning, 2 = Blackman.  Returns the window length.
+// The window phase kappa * (i - hw) of a thread's samples i = tid + e T advances by a rotation recurrence
+// from one exact sincos (16 steps at most: a few 1e-16 of drift), and the window is re-generated for the
+// mean-removal pass instead of being kept, which is what keeps the register count down.
 template <int N, int T>
 __device__ __forceinline__ int d4c_windowed(const double *__restrict__ x, int x_len, int fs, double f0, double pos,
 											int type, double ratio, const uint32_t *__restrict__ rng,
@@ -54,33 +57,41 @@ __device__ __forceinline__ int d4c_windowed(const double *__restrict__ x, int x_
 	const int origin = mround(pos * fs + 0.001);
 	const double c1 = 2.0 / ratio / fs;
 	const double c2 = kPi * f0;
-	double w[EPT];
+	double cs0, sn0, csd, snd;
+	sincos(c2 * (c1 * (tid - hw)), &sn0, &cs0);
+	sincos(c2 * (c1 * T), &snd, &csd);
+	auto win = [&](double c) { return type == 1 ? 0.5 * c + 0.5 : 0.42 + 0.5 * c + 0.08 * (2.0 * c * c - 1.0); };
 	double s1 = 0.0, s2 = 0.0;
+	{
+		double c = cs0, sn = sn0;
 #pragma unroll
-	for (int e = 0; e < EPT; ++e) {
-		int i = tid + e * T;
-		w[e] = 0.0;
-		wave[e] = 0.0;
-		if (i < wl) {
-			double position = c1 * (i - hw);
-#ifdef ABL_NOCOS
-			{ double t_ = c2 * position; w[e] = 0.5 + 0.4 * (1.0 - t_ * t_ * 0.1); }
-#else
-			if (type == 1) w[e] = 0.5 * cos(c2 * position) + 0.5;
-			else w[e] = 0.42 + 0.5 * cos(c2 * position) + 0.08 * cos(c2 * position * 2);
-#endif
-			int si = clampi(origin + i - hw, 0, x_len - 1);
-			wave[e] = x[si] * w[e] + randn_at(rng, roff + i) * kSafe;
-			s1 += wave[e];
-			s2 += w[e];
+		for (int e = 0; e < EPT; ++e) {
+			const int i = tid + e * T;
+			wave[e] = 0.0;
+			if (i < wl) {
+				const double w = win(c);
+				const int si = clampi(origin + i - hw, 0, x_len - 1);
+				wave[e] = x[si] * w + randn_at(rng, roff + i) * kSafe;
+				s1 += wave[e];
+				s2 += w;
+			}
+			const double cn = fma(c, csd, -(sn * snd));
+			sn = fma(sn, csd, c * snd);
+			c = cn;
 		}
 	}
 	block_sum2<T>(s1, s2, red, tid);
 	const double wc = s1 / s2;
+	{
+		double c = cs0, sn = sn0;
 #pragma unroll
-	for (int e = 0; e < EPT; ++e) {
-		int i = tid + e * T;
-		if (i < wl) wave[e] -= w[e] * wc;
+		for (int e = 0; e < EPT; ++e) {
+			const int i = tid + e * T;
+			if (i < wl) wave[e] -= win(c) * wc;
+			const double cn = fma(c, csd, -(sn * snd));
+			sn = fma(sn, csd, c * snd);
+			c = cn;
+		}
 	}
 	return wl;
 }

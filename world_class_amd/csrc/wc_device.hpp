@@ -115,6 +115,9 @@ __device__ __forceinline__ double2 twiddle(const double2 *__restrict__ tw, int i
 // latency overlaps them.  Ends with a __syncthreads().
 __host__ __device__ constexpr int fft_lds_size(int M) { return M + M / 4; }
 __device__ __forceinline__ int fft_pad(int e, bool pad) { return pad ? e + (e >> 2) : e; }
+// j < NB, decided at compile time when the butterflies divide evenly among the threads (no predication then)
+template <int NB, int T>
+__device__ __forceinline__ bool fft_in_range(int j) { return (NB % T == 0) ? true : (j < NB); }
 
 template <int M, int T, int S>
 __device__ void fft_lds(double2 *a, const double2 *__restrict__ tw, int tid) {
@@ -129,13 +132,13 @@ __device__ void fft_lds(double2 *a, const double2 *__restrict__ tw, int tid) {
 #pragma unroll
 		for (int b = 0; b < BPT; ++b) {
 			int j = tid + b * T;
-			if (j < NB) { v0[b] = a[j]; v1[b] = a[j + NB]; }
+			if (fft_in_range<NB, T>(j)) { v0[b] = a[j]; v1[b] = a[j + NB]; }
 		}
 		__syncthreads();
 #pragma unroll
 		for (int b = 0; b < BPT; ++b) {
 			int j = tid + b * T;
-			if (j < NB) { a[fft_pad(2 * j, true)] = cadd(v0[b], v1[b]); a[fft_pad(2 * j + 1, true)] = csub(v0[b], v1[b]); }
+			if (fft_in_range<NB, T>(j)) { a[fft_pad(2 * j, true)] = cadd(v0[b], v1[b]); a[fft_pad(2 * j + 1, true)] = csub(v0[b], v1[b]); }
 		}
 		__syncthreads();
 		Ns = 2;
@@ -152,7 +155,7 @@ __device__ void fft_lds(double2 *a, const double2 *__restrict__ tw, int tid) {
 #pragma unroll
 			for (int b = 0; b < BPT4; ++b) {
 				int j = tid + b * T;
-				if (j < NB4) {
+				if (fft_in_range<NB4, T>(j)) {
 					int idx = (j & (Ns - 1)) * tstride;
 					w1[b] = twiddle<S>(tw, idx);
 					w2[b] = twiddle<S>(tw, 2 * idx);
@@ -164,7 +167,7 @@ __device__ void fft_lds(double2 *a, const double2 *__restrict__ tw, int tid) {
 #pragma unroll
 		for (int b = 0; b < BPT4; ++b) {
 			int j = tid + b * T;
-			if (j < NB4) {
+			if (fft_in_range<NB4, T>(j)) {
 #pragma unroll
 				for (int r = 0; r < 4; ++r) v[b][r] = a[fft_pad(j + r * NB4, in_pad)];
 			}
@@ -173,7 +176,7 @@ __device__ void fft_lds(double2 *a, const double2 *__restrict__ tw, int tid) {
 #pragma unroll
 		for (int b = 0; b < BPT4; ++b) {
 			int j = tid + b * T;
-			if (j < NB4) {
+			if (fft_in_range<NB4, T>(j)) {
 				int k = j & (Ns - 1);
 				double2 x0 = v[b][0], x1 = v[b][1], x2 = v[b][2], x3 = v[b][3];
 				if (Ns > 1) {
