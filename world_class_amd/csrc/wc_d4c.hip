@@ -223,7 +223,7 @@ __global__ __launch_bounds__(T) void d4c_lovetrain_kernel(D4cArgs a) {
 }
 
 template <int N, int T>
-__global__ __launch_bounds__(T, 2) void d4c_frames_kernel(D4cArgs a) {
+__global__ __launch_bounds__(T, (2 * T) / 256) void d4c_frames_kernel(D4cArgs a) {
 	constexpr int M = N / 2;
 	constexpr int EPT = N / T;
 	constexpr int KPT = (M + 1 + T - 1) / T;  // power-spectrum keys per thread
@@ -234,6 +234,7 @@ __global__ __launch_bounds__(T, 2) void d4c_frames_kernel(D4cArgs a) {
 	__shared__ double red[2 * (T / 64) + 2];
 	__shared__ unsigned long long sel_prefix[kMaxBands];
 	__shared__ unsigned int sel_k[kMaxBands];
+	__shared__ int sel_done[kMaxBands];
 	__shared__ double coarse[kMaxBands + 2];
 	double *Ar = reinterpret_cast<double *>(A);
 	unsigned int(*hist)[256] = reinterpret_cast<unsigned int(*)[256]>(A);
@@ -364,14 +365,18 @@ __global__ __launch_bounds__(T, 2) void d4c_frames_kernel(D4cArgs a) {
 	}
 	// radix select (8 bits per pass, most significant first) of the K-th smallest power of every band at
 	// once; non-negative doubles order like their bit patterns.
-	if (tid < kMaxBands) { sel_prefix[tid] = 0ull; sel_k[tid] = K; }
+	// A band is resolved as soon as its chosen bucket holds a single element (typically after 2-3 passes);
+	// that element's full bit pattern then replaces the prefix.
+	if (tid < kMaxBands) { sel_prefix[tid] = 0ull; sel_k[tid] = K; sel_done[tid] = (tid < n_ap) ? 0 : 1; }
+	__syncthreads();
 	for (int pass = 0; pass < 8; ++pass) {
+		if (sel_done[0] && sel_done[1] && sel_done[2] && sel_done[3] && sel_done[4]) break;  // block-uniform
 		const int shift = 56 - 8 * pass;
 		for (int i = tid; i < kMaxBands * 256; i += T) (&hist[0][0])[i] = 0u;
 		__syncthreads();
 #pragma unroll
 		for (int bb = 0; bb < kMaxBands; ++bb) {
-			if (bb < n_ap) {
+			if (bb < n_ap && !sel_done[bb]) {
 				const unsigned long long pre = sel_prefix[bb];
 #pragma unroll
 				for (int e = 0; e < KPT; ++e) {
@@ -387,6 +392,7 @@ __global__ __launch_bounds__(T, 2) void d4c_frames_kernel(D4cArgs a) {
 		__syncthreads();
 		// digit search: wave w scans the 256-bin histograms of bands w, w + 4 (4 bins per lane)
 		for (int bb = tid >> 6; bb < n_ap; bb += T / 64) {
+			if (sel_done[bb]) continue;
 			const int lane = tid & 63;
 			const unsigned int need = sel_k[bb];
 			const uint4 h4 = reinterpret_cast<const uint4 *>(&hist[bb][0])[lane];
@@ -408,8 +414,27 @@ __global__ __launch_bounds__(T, 2) void d4c_frames_kernel(D4cArgs a) {
 				else { acc += h4.x + h4.y + h4.z; d += 3; }
 				sel_k[bb] = need - acc;  // rank inside the chosen digit bucket
 				sel_prefix[bb] |= ((unsigned long long)d) << shift;
+				const unsigned int in_bucket = (d & 3) == 0 ? h4.x : (d & 3) == 1 ? h4.y : (d & 3) == 2 ? h4.z : h4.w;
+				sel_done[bb] = (in_bucket == 1u) ? 2 : 0;  // 2 = just resolved: fetch the element's full bits
 			}
 		}
+		__syncthreads();
+#pragma unroll
+		for (int bb = 0; bb < kMaxBands; ++bb) {
+			if (bb < n_ap && sel_done[bb] == 2) {
+				const unsigned long long pre = sel_prefix[bb];
+#pragma unroll
+				for (int e = 0; e < KPT; ++e) {
+					int k = tid + e * T;
+					if (k <= M) {
+						unsigned long long bits = (unsigned long long)__double_as_longlong(key[bb][e]);
+						if ((bits >> shift) == (pre >> shift)) sel_prefix[bb] = bits;  // exactly one element matches
+					}
+				}
+			}
+		}
+		__syncthreads();
+		if (tid < kMaxBands && sel_done[tid] == 2) sel_done[tid] = 1;
 		__syncthreads();
 	}
 	// sum of the K smallest = sum(values < v*) + (remaining rank) * v*, and the total
@@ -475,7 +500,8 @@ static void launch_lt(const D4cArgs &a, hipStream_t s) {
 template <int N>
 static void launch_main(const D4cArgs &a, hipStream_t s) {
 	long long blocks = ((a.total_frames + 7) / 8) * 8;
-	hipLaunchKernelGGL((d4c_frames_kernel<N, 256>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+	constexpr int TF = (N >= 4096) ? 512 : 256;  // 8 waves per frame at N = 4096: half the registers per thread, 2 WG/CU
+	hipLaunchKernelGGL((d4c_frames_kernel<N, TF>), dim3((unsigned)blocks), dim3(TF), 0, s, a);
 }
 
 // Enqueue-only (no host synchronisation), shared with the fused pipeline: everything on stream s; the stream

@@ -107,94 +107,121 @@ __device__ __forceinline__ double2 twiddle(const double2 *__restrict__ tw, int i
 }
 
 // ---- in-LDS complex FFT of M points by T threads, sign S (+1: e^{+i}) -------------------------------
-// a: interleaved complex doubles in LDS with room for fft_lds_size(M) = M + M/4 entries; the M points are in
-// natural order in a[0..M) on entry and on exit.  Between the passes the data lives in a padded layout
-// (one spare slot after every 4 entries) so that the stride-4 / stride-16 scatter of the early Stockham
-// passes hits distinct LDS banks (ds_write_b128 is serviced in 8-lane groups, 32 banks x 4 B).
-// tw: global twiddle table of kTwiddleN entries, loaded before the LDS reads of each pass so that the L2
-// latency overlaps them.  Ends with a __syncthreads().
-__host__ __device__ constexpr int fft_lds_size(int M) { return M + M / 4; }
-__device__ __forceinline__ int fft_pad(int e, bool pad) { return pad ? e + (e >> 2) : e; }
+// a: M interleaved complex doubles in LDS (fft_lds_size(M) entries), natural order in and out.
+// Stockham autosort, radix-4 passes (a leading radix-2 pass when log2 M is odd), two barriers per pass.  tw: global twiddle table of kTwiddleN entries, loaded before the LDS
+// reads of each pass so that the L2 latency overlaps them.  Ends with a __syncthreads().
+#ifndef WC_FFT_PAD
+#define WC_FFT_PAD 0  // measured: the padded layout does not pay for its index arithmetic with the unrolled passes
+#endif
+// intermediate passes keep the data in a padded layout (one spare slot after every 4 entries): the stride-4 /
+// stride-16 scatter of the early passes then hits distinct LDS banks
+__host__ __device__ constexpr int fft_lds_size(int M) { return WC_FFT_PAD ? M + M / 4 : M; }
+__device__ __forceinline__ int fft_pad(int e, bool pad) { return (WC_FFT_PAD && pad) ? e + (e >> 2) : e; }
 // j < NB, decided at compile time when the butterflies divide evenly among the threads (no predication then)
 template <int NB, int T>
 __device__ __forceinline__ bool fft_in_range(int j) { return (NB % T == 0) ? true : (j < NB); }
 
+// R-point DFT in registers, sign S: y[q] = sum_r x[r] e^{S 2 pi i r q / R}
+template <int S>
+__device__ __forceinline__ void dft2(double2 &a, double2 &b) {
+	const double2 t = csub(a, b);
+	a = cadd(a, b);
+	b = t;
+}
+template <int S>
+__device__ __forceinline__ void dft4(double2 (&x)[4]) {
+	const double2 s02 = cadd(x[0], x[2]), d02 = csub(x[0], x[2]);
+	const double2 s13 = cadd(x[1], x[3]), d13 = cmul_i<S>(csub(x[1], x[3]));
+	x[0] = cadd(s02, s13);
+	x[1] = cadd(d02, d13);
+	x[2] = csub(s02, s13);
+	x[3] = csub(d02, d13);
+}
+template <int S>
+__device__ __forceinline__ void dft8(double2 (&x)[8]) {
+	constexpr double h = 0.70710678118654752440;
+	// even / odd halves
+	double2 e[4] = {x[0], x[2], x[4], x[6]};
+	double2 o[4] = {x[1], x[3], x[5], x[7]};
+	dft4<S>(e);
+	dft4<S>(o);
+	// o[q] *= e^{S i pi q / 4}
+	const double2 o1 = S > 0 ? make_double2(h * (o[1].x - o[1].y), h * (o[1].x + o[1].y))
+							 : make_double2(h * (o[1].x + o[1].y), h * (o[1].y - o[1].x));
+	const double2 o2 = cmul_i<S>(o[2]);
+	const double2 o3 = S > 0 ? make_double2(-h * (o[3].x + o[3].y), h * (o[3].x - o[3].y))
+							 : make_double2(h * (o[3].y - o[3].x), -h * (o[3].x + o[3].y));
+	x[0] = cadd(e[0], o[0]); x[4] = csub(e[0], o[0]);
+	x[1] = cadd(e[1], o1);   x[5] = csub(e[1], o1);
+	x[2] = cadd(e[2], o2);   x[6] = csub(e[2], o2);
+	x[3] = cadd(e[3], o3);   x[7] = csub(e[3], o3);
+}
+
+// one Stockham pass of radix R with Ns = product of the earlier radices
+template <int M, int T, int S, int R, int Ns>
+__device__ __forceinline__ void fft_pass(double2 *a, const double2 *__restrict__ tw, int tid) {
+	constexpr int NB = M / R;
+	constexpr int BPT = (NB + T - 1) / T;
+	constexpr int tstride = kTwiddleN / (R * Ns);  // W_{R Ns}^k = tw[k * tstride]
+	double2 w[BPT][R > 1 ? R - 1 : 1];
+	if (Ns > 1) {
+#pragma unroll
+		for (int b = 0; b < BPT; ++b) {
+			const int j = tid + b * T;
+			if (fft_in_range<NB, T>(j)) {
+				const int idx = (j & (Ns - 1)) * tstride;
+#pragma unroll
+				for (int r = 1; r < R; ++r) w[b][r - 1] = twiddle<S>(tw, r * idx);
+			}
+		}
+	}
+	double2 v[BPT][R];
+#pragma unroll
+	for (int b = 0; b < BPT; ++b) {
+		const int j = tid + b * T;
+		if (fft_in_range<NB, T>(j)) {
+#pragma unroll
+			for (int r = 0; r < R; ++r) v[b][r] = a[fft_pad(j + r * NB, Ns > 1)];
+		}
+	}
+	__syncthreads();
+#pragma unroll
+	for (int b = 0; b < BPT; ++b) {
+		const int j = tid + b * T;
+		if (fft_in_range<NB, T>(j)) {
+			if (Ns > 1) {
+#pragma unroll
+				for (int r = 1; r < R; ++r) v[b][r] = cmul(v[b][r], w[b][r - 1]);
+			}
+			if (R == 8) dft8<S>(reinterpret_cast<double2(&)[8]>(v[b]));
+			else if (R == 4) dft4<S>(reinterpret_cast<double2(&)[4]>(v[b]));
+			else dft2<S>(v[b][0], v[b][1]);
+			const int k = j & (Ns - 1);
+			const int j0 = (j - k) * R + k;
+#pragma unroll
+			for (int r = 0; r < R; ++r) a[fft_pad(j0 + r * Ns, Ns * R < M)] = v[b][r];
+		}
+	}
+	__syncthreads();
+}
+
+template <int M, int T, int S, int Ns>
+__device__ __forceinline__ void fft_chain(double2 *a, const double2 *__restrict__ tw, int tid) {
+	if constexpr (Ns < M) {
+		// radix 4 throughout, with a leading twiddle-free radix-2 pass when log2(M) is odd (radix-8 passes were
+		// measured slower here: more registers per butterfly and idle threads at T = 512)
+		constexpr int rem = M / Ns;
+		constexpr bool odd = (__builtin_ctz(M) & 1) != 0;
+		constexpr int R = (Ns == 1 && odd) ? 2 : (rem >= 4 ? 4 : rem);
+		fft_pass<M, T, S, R, Ns>(a, tw, tid);
+		fft_chain<M, T, S, Ns * R>(a, tw, tid);
+	}
+}
+
 template <int M, int T, int S>
 __device__ void fft_lds(double2 *a, const double2 *__restrict__ tw, int tid) {
 	static_assert((M & (M - 1)) == 0 && M >= 16 && M <= kTwiddleN, "M must be a power of two in [16, 4096]");
-	constexpr int LOG2 = __builtin_ctz(M);
-	constexpr bool LEAD2 = (LOG2 & 1) != 0;
-	int Ns = 1;
-	if (LEAD2) {  // radix-2 pass with Ns = 1: no twiddles; natural in, padded out
-		constexpr int NB = M / 2;
-		constexpr int BPT = (NB + T - 1) / T;
-		double2 v0[BPT], v1[BPT];
-#pragma unroll
-		for (int b = 0; b < BPT; ++b) {
-			int j = tid + b * T;
-			if (fft_in_range<NB, T>(j)) { v0[b] = a[j]; v1[b] = a[j + NB]; }
-		}
-		__syncthreads();
-#pragma unroll
-		for (int b = 0; b < BPT; ++b) {
-			int j = tid + b * T;
-			if (fft_in_range<NB, T>(j)) { a[fft_pad(2 * j, true)] = cadd(v0[b], v1[b]); a[fft_pad(2 * j + 1, true)] = csub(v0[b], v1[b]); }
-		}
-		__syncthreads();
-		Ns = 2;
-	}
-	constexpr int NB4 = M / 4;
-	constexpr int BPT4 = (NB4 + T - 1) / T;
-#pragma unroll 1
-	for (; Ns < M; Ns <<= 2) {
-		const bool in_pad = LEAD2 ? true : (Ns > 1);
-		const bool out_pad = (Ns << 2) < M;
-		const int tstride = (kTwiddleN / 4) / Ns;  // (M / (Ns*4)) * (kTwiddleN / M)
-		double2 w1[BPT4], w2[BPT4], w3[BPT4];
-		if (Ns > 1) {
-#pragma unroll
-			for (int b = 0; b < BPT4; ++b) {
-				int j = tid + b * T;
-				if (fft_in_range<NB4, T>(j)) {
-					int idx = (j & (Ns - 1)) * tstride;
-					w1[b] = twiddle<S>(tw, idx);
-					w2[b] = twiddle<S>(tw, 2 * idx);
-					w3[b] = twiddle<S>(tw, 3 * idx);
-				}
-			}
-		}
-		double2 v[BPT4][4];
-#pragma unroll
-		for (int b = 0; b < BPT4; ++b) {
-			int j = tid + b * T;
-			if (fft_in_range<NB4, T>(j)) {
-#pragma unroll
-				for (int r = 0; r < 4; ++r) v[b][r] = a[fft_pad(j + r * NB4, in_pad)];
-			}
-		}
-		__syncthreads();
-#pragma unroll
-		for (int b = 0; b < BPT4; ++b) {
-			int j = tid + b * T;
-			if (fft_in_range<NB4, T>(j)) {
-				int k = j & (Ns - 1);
-				double2 x0 = v[b][0], x1 = v[b][1], x2 = v[b][2], x3 = v[b][3];
-				if (Ns > 1) {
-					x1 = cmul(x1, w1[b]);
-					x2 = cmul(x2, w2[b]);
-					x3 = cmul(x3, w3[b]);
-				}
-				double2 s02 = cadd(x0, x2), d02 = csub(x0, x2);
-				double2 s13 = cadd(x1, x3), d13 = cmul_i<S>(csub(x1, x3));
-				int j0 = ((j - k) << 2) + k;
-				a[fft_pad(j0, out_pad)] = cadd(s02, s13);
-				a[fft_pad(j0 + Ns, out_pad)] = cadd(d02, d13);
-				a[fft_pad(j0 + 2 * Ns, out_pad)] = csub(s02, s13);
-				a[fft_pad(j0 + 3 * Ns, out_pad)] = csub(d02, d13);
-			}
-		}
-		__syncthreads();
-	}
+	fft_chain<M, T, S, 1>(a, tw, tid);
 }
 
 // ---- real FFT of N = 2M points held as M interleaved complex (x[2k], x[2k+1]) -----------------------
