@@ -68,16 +68,26 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 	const int hw = mround(1.5 * fs / f0c);
 	const int wl = 2 * hw + 1;
 	const int origin = mround(pos * fs + 0.001);
+	// The window phase kappa * (i - hw) of this thread's samples i = tid + e T advances by a rotation recurrence
+	// from one exact sincos (EPT steps: a few 1e-16 of drift) instead of EPT libm cosines.
 	double w[EPT];
 	double ssq = 0.0;
+	{
+		const double kappa = kPi * f0c / 1.5 / fs;  // angle per sample: pi * ((i - hw) / 1.5 / fs) * f0c
+		double c, sn, cd, sd;
+		sincos(kappa * (tid - hw), &sn, &c);
+		sincos(kappa * T, &sd, &cd);
 #pragma unroll
-	for (int e = 0; e < EPT; ++e) {
-		int i = tid + e * T;
-		w[e] = 0.0;
-		if (i < wl) {
-			double position = (i - hw) / 1.5 / fs;
-			w[e] = 0.5 * cos(kPi * position * f0c) + 0.5;
-			ssq += w[e] * w[e];
+		for (int e = 0; e < EPT; ++e) {
+			int i = tid + e * T;
+			w[e] = 0.0;
+			if (i < wl) {
+				w[e] = 0.5 * c + 0.5;
+				ssq += w[e] * w[e];
+			}
+			const double cn = fma(c, cd, -(sn * sd));
+			sn = fma(sn, cd, c * sd);
+			c = cn;
 		}
 	}
 	ssq = block_sum<T>(ssq, red, tid);
@@ -200,15 +210,20 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 	r2c_post<M, T>(A, a.tw, tid);
 	{
 		const double q1 = a.q1;
+		// lifters at quefrency k / fs: sinc(f0 q) and 1 - 2 q1 + 2 q1 cos(2 pi q f0); with a = pi f0 k / fs the
+		// cosine is 1 - 2 sin^2 a, and (cos a, sin a) advances over this thread's bins k = tid + e T by rotation
+		const double alpha = kPi * f0c / fs;
+		double c, sn, cd, sd;
+		sincos(alpha * tid, &sn, &c);
+		sincos(alpha * T, &sd, &cd);
 		for (int k = tid; k <= M; k += T) {
 			double sl, cl;
 			if (k == 0) {
 				sl = 1.0;
 				cl = (1.0 - 2.0 * q1) + 2.0 * q1;
 			} else {
-				double q = (double)k / fs;
-				sl = sin(kPi * f0c * q) / (kPi * f0c * q);
-				cl = (1.0 - 2.0 * q1) + 2.0 * q1 * cos(2.0 * kPi * q * f0c);
+				sl = sn / (alpha * k);
+				cl = (1.0 - 2.0 * q1) + 2.0 * q1 * (1.0 - 2.0 * sn * sn);
 			}
 			if (k == M) {
 				P[M] = A[0].y * sl * cl / N;  // parked until every thread has read its own bin
@@ -216,6 +231,9 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 				double re = (k == 0) ? A[0].x : A[k].x;
 				P[k] = re * sl * cl / N;
 			}
+			const double cn = fma(c, cd, -(sn * sd));
+			sn = fma(sn, cd, c * sd);
+			c = cn;
 		}
 		__syncthreads();
 		for (int k = tid; k < M; k += T) A[k] = make_double2(P[k], k == 0 ? P[M] : 0.0);

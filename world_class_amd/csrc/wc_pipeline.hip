@@ -10,6 +10,7 @@
 // positions are chained on the device (CheapTrick end -> D4C start -> Synthesis start), exactly the order a
 // single reference process would consume its global randn() stream.  Capacity overflows of the rate-bounded
 // buffers (Harvest zero crossings, Synthesis pulses) are checked once at the end and re-run with hard bounds.
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -21,7 +22,10 @@ struct wc_pipeline {
 	int fs, fft_size;
 	double frame_period;
 	Device *dev;
-	wc_harvest *hv;
+	wc_harvest *hv[4];  // the batch is split into up to 4 contiguous groups of utterances, one Harvest chain per stream:
+	hipStream_t hs[4];  // the latency-bound Harvest kernels of one group overlap the ALU-bound ones of the others
+	hipEvent_t he[4];
+	int n_split;
 	wc_cheaptrick *ct;
 	wc_d4c *d4;
 	wc_synthesis *sy;
@@ -40,8 +44,22 @@ wc_pipeline *wc_pipeline_create(int fs, double frame_period, double harvest_f0_f
 	p->fs = fs;
 	p->frame_period = frame_period;
 	p->dev = dev;
-	p->hv = wc_harvest_create(fs, harvest_f0_floor, harvest_f0_ceil, frame_period, 8000.0, 40.0, 0);
-	p->ct = p->hv ? wc_cheaptrick_create(fs, q1, cheaptrick_f0_floor, fft_size) : nullptr;
+	{
+		const char *env = getenv("WC_PIPELINE_SPLIT");
+		p->n_split = env ? atoi(env) : 2;  // measured on MI355X: 2 groups beat 1 and 4
+		if (p->n_split < 1) p->n_split = 1;
+		if (p->n_split > 4) p->n_split = 4;
+	}
+	bool hv_ok = true;
+	for (int k = 0; k < p->n_split; ++k) {
+		p->hv[k] = wc_harvest_create(fs, harvest_f0_floor, harvest_f0_ceil, frame_period, 8000.0, 40.0, 0);
+		hv_ok = hv_ok && p->hv[k] != nullptr;
+		if (k > 0 && hv_ok) {
+			hv_ok = hipStreamCreateWithFlags(&p->hs[k], hipStreamNonBlocking) == hipSuccess &&
+					hipEventCreateWithFlags(&p->he[k], hipEventDisableTiming) == hipSuccess;
+		}
+	}
+	p->ct = hv_ok ? wc_cheaptrick_create(fs, q1, cheaptrick_f0_floor, fft_size) : nullptr;
 	p->fft_size = p->ct ? wc_cheaptrick_get_fft_size(p->ct) : 0;
 	p->d4 = p->ct ? wc_d4c_create(fs, d4c_threshold) : nullptr;
 	p->sy = p->d4 ? wc_synthesis_create(fs, p->fft_size, frame_period) : nullptr;
@@ -72,7 +90,11 @@ void wc_pipeline_destroy(wc_pipeline *p) {
 	wc_synthesis_destroy(p->sy);
 	wc_d4c_destroy(p->d4);
 	wc_cheaptrick_destroy(p->ct);
-	wc_harvest_destroy(p->hv);
+	for (int k = 0; k < 4; ++k) {
+		if (p->hs[k]) { (void)hipStreamSynchronize(p->hs[k]); (void)hipStreamDestroy(p->hs[k]); }
+		if (p->he[k]) (void)hipEventDestroy(p->he[k]);
+		wc_harvest_destroy(p->hv[k]);
+	}
 	delete p;
 }
 
@@ -102,16 +124,33 @@ int wc_pipeline_run_device(wc_pipeline *p, int n_utt, const double *d_x, const i
 	int rc;
 	if ((rc = dev->ensure_rng(lo, hi))) return rc;
 	bool hv_full = false, syn_full = false;
+	const int ns = p->n_split < n_utt ? p->n_split : n_utt;
 	for (int attempt = 0; attempt < 3; ++attempt) {
-		if ((rc = hv_enqueue(p->hv, s0, n_utt, d_x, x_length, d_tpos, d_f0, hv_full))) return rc;
+		{
+			// group k = utterances [u0, u1); the packed layout makes every group a contiguous slice
+			long long xo = 0, fo = 0;
+			if (ns > 1) WC_HIP(hipEventRecord(p->e0, s0));  // later groups start after whatever precedes on s0
+			for (int k = 0; k < ns; ++k) {
+				const int u0 = (int)((long long)n_utt * k / ns), u1 = (int)((long long)n_utt * (k + 1) / ns);
+				hipStream_t sk = k == 0 ? s0 : p->hs[k];
+				if (k > 0) WC_HIP(hipStreamWaitEvent(sk, p->e0, 0));
+				if ((rc = hv_enqueue(p->hv[k], sk, u1 - u0, d_x + xo, x_length + u0, d_tpos + fo, d_f0 + fo, hv_full))) return rc;
+				if (k > 0) WC_HIP(hipEventRecord(p->he[k], sk));
+				for (int u = u0; u < u1; ++u) { xo += x_length[u]; fo += f_len[u]; }
+			}
+			for (int k = 1; k < ns; ++k) WC_HIP(hipStreamWaitEvent(s0, p->he[k], 0));
+		}
 		long long total = 0;
 		uint64_t a0 = 0, a1 = 0;
 		if ((rc = ct_prepare(p->ct, s0, n_utt, x_length, d_f0, f_len.data(), rng_pos, &total, &a0, &a1))) return rc;
 		WC_HIP(hipEventRecord(p->e0, s0));
-		WC_HIP(hipStreamWaitEvent(p->s1, p->e0, 0));
+		WC_HIP(hipStreamWaitEvent(ns > 1 ? p->hs[1] : p->s1, p->e0, 0));
 		WC_HIP(hipStreamWaitEvent(p->s2, p->e0, 0));
-		if ((rc = ct_frames(p->ct, p->s1, n_utt, d_x, d_tpos, d_f0, d_sp, total))) return rc;
-		WC_HIP(hipEventRecord(p->e1, p->s1));
+		// CheapTrick's frames go to the second Harvest stream when there is one: HIP multiplexes streams onto a few
+		// hardware queues, and two streams that land on the same queue would serialise CheapTrick and D4C
+		hipStream_t sct = ns > 1 ? p->hs[1] : p->s1;
+		if ((rc = ct_frames(p->ct, sct, n_utt, d_x, d_tpos, d_f0, d_sp, total))) return rc;
+		WC_HIP(hipEventRecord(p->e1, sct));
 		if ((rc = d4c_enqueue(p->d4, p->s2, n_utt, d_x, x_length, d_tpos, d_f0, f_len.data(), p->fft_size, d_ap, nullptr,
 							  ct_end_positions(p->ct))))
 			return rc;
@@ -122,7 +161,11 @@ int wc_pipeline_run_device(wc_pipeline *p, int n_utt, const double *d_x, const i
 		if ((rc = syn_pulses(p->sy, s0, d_f0, d_sp, d_ap, d_y, d4c_end_positions(p->d4)))) return rc;
 		bool o1 = false, o2 = false;
 		if ((rc = syn_finish(p->sy, s0, rng_pos, &o2))) return rc;  // synchronises s0 (and, through E1/E2, s1 and s2)
-		if ((rc = hv_overflowed(p->hv, s0, &o1))) return rc;
+		for (int k = 0; k < ns; ++k) {
+			bool ok = false;
+			if ((rc = hv_overflowed(p->hv[k], s0, &ok))) return rc;  // s0 is already idle; the flag copies are tiny
+			o1 = o1 || ok;
+		}
 		if (!o1 && !o2) return WC_OK;
 		hv_full = hv_full || o1;
 		syn_full = syn_full || o2;
