@@ -160,15 +160,18 @@ struct BpArgs {
 	double *events;           // fine edge positions
 	int *ev_count;            // [utt][band][4]
 	int *overflow;
+	int *tile_run;   // [utt][band][n_tiles + 1][4]: edges found before each tile (lets hv_raw bound its slices)
+	int n_tiles;
 	int n_bands;
 };
 
 __device__ __forceinline__ int padidx(int m) { return m + (m >> 3); }
 
-__global__ __launch_bounds__(BP_T) void hv_bandpass_kernel(BpArgs a) {
+__global__ __launch_bounds__(BP_T, 4) void hv_bandpass_kernel(BpArgs a) {
+	// 36.5 KB of LDS -> four workgroups per CU; the filtered tile reuses the signal tile's storage
 	__shared__ double Ys[(BP_TILE + 2 * HL_MAX + 32) * 9 / 8 + 16];
 	__shared__ double Tp[2 * HL_MAX + 16];
-	__shared__ double Ss[(BP_TILE + 8) * 9 / 8 + 16];
+	double *Ss = Ys;
 	__shared__ unsigned long long scan_s[BP_T / 64];
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const int band = blockIdx.x;
@@ -182,7 +185,9 @@ __global__ __launch_bounds__(BP_T) void hv_bandpass_kernel(BpArgs a) {
 	double *__restrict__ ev = a.events + u.ev_off + a.ev_band_off[band];
 	int run[4] = {0, 0, 0, 0};
 	const int t0 = tid * BP_R;
+	int *__restrict__ trun = a.tile_run + ((long long)blockIdx.y * a.n_bands + band) * (a.n_tiles + 1) * 4;
 	for (int ts = 0; ts < u.y_len; ts += BP_ADV) {
+		if (tid < 4) trun[(ts / BP_ADV) * 4 + tid] = run[tid];
 		// Ys[m] = y[ts + 1 - hl + m], m in [0, TILE + nt8 + 8)
 		__syncthreads();
 		for (int m = tid; m < BP_TILE + nt8 + 8; m += BP_T) {
@@ -208,6 +213,7 @@ __global__ __launch_bounds__(BP_T) void hv_bandpass_kernel(BpArgs a) {
 #pragma unroll
 			for (int c = 0; c < 8; ++c) w[c] = w[8 + c];
 		}
+		__syncthreads();  // every thread is done reading the signal tile
 #pragma unroll
 		for (int j = 0; j < BP_R; ++j) Ss[padidx(t0 + j)] = acc[j];
 		__syncthreads();
@@ -273,6 +279,7 @@ __global__ __launch_bounds__(BP_T) void hv_bandpass_kernel(BpArgs a) {
 		}
 	}
 	if (tid < 4) {
+		for (int q = (u.y_len + BP_ADV - 1) / BP_ADV; q <= a.n_tiles; ++q) trun[q * 4 + tid] = run[tid];
 		int cnt = run[tid];
 		a.ev_count[((long long)blockIdx.y * a.n_bands + band) * 4 + tid] = cnt;
 		if (cnt > cap) atomicExch(a.overflow, 1);
@@ -289,34 +296,47 @@ struct RawArgs {
 	const int *ev_cap;
 	const int *ev_count;
 	const double *band_f0;
+	const int *tile_run;
+	int n_tiles;
 	double *raw;  // [utt: l1_off * n_bands][band][L1]
 	int n_bands;
 	double fs_d, f0_floor, f0_ceil;
 };
 
-// interp1 (reference src/world_matlabfunctions.cpp:157-182) of intervals fs/(e[k+1]-e[k]) located at
-// (e[k]+e[k+1])/2/fs, k < n, evaluated at time t
-__device__ __forceinline__ double hv_interp_events(const double *__restrict__ e, int n, double fs, double t) {
-	// c = #{k < n : loc[k] <= t} by binary search, then clamp to [1, n-1]
-	int lo = 0, hi = n;
+// c = #{k < n : loc[k] <= t} for the interval midpoints loc[k] = (e[k] + e[k+1]) / 2 / fs, searched in [lo, hi)
+template <class E>
+__device__ __forceinline__ int hv_count_le(E e, int lo, int hi, double fs, double t) {
+	// The reference's test is (e[k] + e[k+1]) / 2.0 / fs <= t, two divisions per probe.  Bisect with the
+	// division-free equivalent e[k] + e[k+1] <= 2 fs t (it can differ only when the two sides are within
+	// rounding of each other), then settle the boundary with the exact test.
+	const int lo0 = lo, hi0 = hi;
+	const double tt = 2.0 * fs * t;
 	while (lo < hi) {
-		int mid = (lo + hi) >> 1;
-		double loc = (e[mid] + e[mid + 1]) / 2.0 / fs;
-		if (loc <= t) lo = mid + 1; else hi = mid;
+		const int mid = (lo + hi) >> 1;
+		if (e(mid) + e(mid + 1) <= tt) lo = mid + 1; else hi = mid;
 	}
-	int k = min(max(lo, 1), n - 1);
-	double e0 = e[k - 1], e1 = e[k], e2 = e[k + 1];
-	double x0 = (e0 + e1) / 2.0 / fs, x1 = (e1 + e2) / 2.0 / fs;
-	double y0 = fs / (e1 - e0), y1 = fs / (e2 - e1);
-	double s = (t - x0) / (x1 - x0);
-	return y0 + s * (y1 - y0);
+	auto exact = [&](int k) { return (e(k) + e(k + 1)) / 2.0 / fs <= t; };
+	while (lo < hi0 && exact(lo)) ++lo;
+	while (lo > lo0 && !exact(lo - 1)) --lo;
+	return lo;
 }
 
-__global__ void hv_raw_kernel(RawArgs a) {
+constexpr int RAW_T = 256;      // frames per workgroup
+constexpr int RAW_LDS = 1024;   // staged fine edges per type
+
+// One workgroup per (utterance, band, 256 consecutive 1 ms frames).  The fine edges that can matter for these
+// frames form a short contiguous slice of each of the four event lists; wave `ty` locates and stages the slice
+// of type `ty` in LDS, then every thread interpolates its frame from LDS (falling back to the global lists if
+// a slice does not fit).
+__global__ __launch_bounds__(RAW_T) void hv_raw_kernel(RawArgs a) {
+	__shared__ double E[4][RAW_LDS];
+	__shared__ int s_base[4], s_len[4];
+	const int tid = threadIdx.x, lane = tid & 63, ty_w = tid >> 6;
 	const int band = blockIdx.y;
 	const HvUtt u = a.utts[blockIdx.z];
-	const int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= u.L1) return;
+	const int i0 = blockIdx.x * RAW_T;
+	if (i0 >= u.L1) return;
+	const int i = i0 + tid;
 	const int *cnt = a.ev_count + ((long long)blockIdx.z * a.n_bands + band) * 4;
 	const int cap = a.ev_cap[band];
 	const double *__restrict__ ev = a.events + u.ev_off + a.ev_band_off[band];
@@ -330,19 +350,72 @@ __global__ void hv_raw_kernel(RawArgs a) {
 		n[ty] = ce < 2 ? 0 : ce - 1;
 		ok = ok && n[ty] > 2;
 	}
-	double v = 0.0;
-	if (ok) {
-		const double t = i * 1 / 1000.0;
-		double s = 0.0;
-		// (a + b + c + d) in the reference's order: negative-going, positive-going, peaks, dips
-		s = hv_interp_events(ev, n[0], a.fs_d, t);
-		s = s + hv_interp_events(ev + cap, n[1], a.fs_d, t);
-		s = s + hv_interp_events(ev + 2ll * cap, n[2], a.fs_d, t);
-		s = s + hv_interp_events(ev + 3ll * cap, n[3], a.fs_d, t);
-		v = s / 4.0;
-		const double fb = a.band_f0[band];
-		if (v > fb * 1.1 || v < fb * 0.9 || v > a.f0_ceil || v < a.f0_floor) v = 0.0;
+	if (!ok) {
+		if (i < u.L1) out[i] = 0.0;
+		return;
 	}
+	const double fs = a.fs_d;
+	{
+		// wave ty_w stages the slice of list ty_w that can matter for frames i0 .. i1: the band-pass kernel recorded
+		// how many edges precede every tile, so the slice is bounded without searching
+		const int ty = ty_w;
+		const double *__restrict__ e = ev + (long long)ty * cap;
+		const int *__restrict__ trun = a.tile_run + ((long long)blockIdx.z * a.n_bands + band) * (a.n_tiles + 1) * 4;
+		const int i1 = min(i0 + RAW_T - 1, u.L1 - 1);
+		const int q0 = min(a.n_tiles, max(0, (int)((i0 * 1 / 1000.0) * fs) / BP_ADV));
+		const int q1 = min(a.n_tiles, (int)((i1 * 1 / 1000.0) * fs) / BP_ADV + 1);
+		const int ce = n[ty] + 1;  // edges in the list
+		const int base = max(0, min(trun[q0 * 4 + ty], ce) - 4);
+		const int end = min(ce, min(trun[q1 * 4 + ty], ce) + 4);
+		const int len = end - base;
+		if (lane == 0) { s_base[ty] = (len <= RAW_LDS) ? base : -1; s_len[ty] = len; }
+		if (len <= RAW_LDS)
+			for (int j = lane; j < len; j += 64) E[ty][j] = e[base + j];
+	}
+	__syncthreads();
+	if (i >= u.L1) return;
+	const double t = i * 1 / 1000.0;
+	double s = 0.0;
+#pragma unroll
+	for (int ty = 0; ty < 4; ++ty) {  // (a + b + c + d) in the reference's order: negative-going, positive-going, peaks, dips
+		const double *__restrict__ e = ev + (long long)ty * cap;
+		const int base = s_base[ty];
+		int k;
+		double e0, e1, e2;
+		bool staged = false;
+		if (base >= 0) {
+			// count within the staged slice, valid only if the answer is strictly inside it (otherwise the true
+			// boundary may lie outside: fall back to the whole list)
+			const double *el = E[ty];
+			const int len = s_len[ty];
+			auto es = [&](int q) { return el[q - base]; };
+			const int lo = base, hi = min(n[ty], base + len - 1);  // k with e[k], e[k+1] staged
+			const int c = hv_count_le(es, lo, hi, fs, t);
+			if ((c > lo || lo == 0) && (c < hi || hi == n[ty])) {
+				k = min(max(c, 1), n[ty] - 1);
+				if (k - 1 >= base && k + 1 < base + len) {
+					e0 = es(k - 1); e1 = es(k); e2 = es(k + 1);
+					staged = true;
+				}
+			}
+		}
+		if (!staged) {
+			auto eg = [&](int q) { return e[q]; };
+			const int c = hv_count_le(eg, 0, n[ty], fs, t);
+			k = min(max(c, 1), n[ty] - 1);
+			e0 = e[k - 1]; e1 = e[k]; e2 = e[k + 1];
+		}
+		// interp1 (reference src/world_matlabfunctions.cpp:157-182) of the intervals fs / (e[k+1] - e[k]) located
+		// at the midpoints (reference src/harvest.cpp:1210-1213)
+		const double x0 = (e0 + e1) / 2.0 / fs, x1 = (e1 + e2) / 2.0 / fs;
+		const double y0 = fs / (e1 - e0), y1 = fs / (e2 - e1);
+		const double sl = (t - x0) / (x1 - x0);
+		const double v = y0 + sl * (y1 - y0);
+		s = (ty == 0) ? v : s + v;
+	}
+	double v = s / 4.0;
+	const double fb = a.band_f0[band];
+	if (v > fb * 1.1 || v < fb * 0.9 || v > a.f0_ceil || v < a.f0_floor) v = 0.0;
 	out[i] = v;
 }
 
@@ -963,7 +1036,7 @@ struct wc_harvest {
 	std::vector<double> band_f0;
 	std::vector<int> half_len, tap_off;
 	DevBuf d_taps, d_tap_off, d_half_len, d_band_f0, d_ev_band_off, d_ev_cap, d_rot;
-	DevBuf utts, dec, y, events, ev_count, overflow, raw, cand0, cand1, score1, cand2, score2;
+	DevBuf utts, dec, y, events, ev_count, overflow, tile_run, raw, cand0, cand1, score1, cand2, score2;
 	DevBuf base, s1, s2, s3, fixed, f0_1ms, sec, chan, smooth, ibuf;
 	DevBuf d_x, d_tpos, d_f0;
 	HostBuf h_stage;
@@ -1041,6 +1114,8 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 	if ((rc = h->y.reserve(sizeof(double) * yo))) return rc;
 	if (r != 1 && (rc = h->dec.reserve(sizeof(double) * deco))) return rc;
 	if ((rc = h->ev_count.reserve(sizeof(int) * 4ll * nb * n_utt))) return rc;
+	const int n_tiles = (max_ylen + BP_ADV - 1) / BP_ADV;
+	if ((rc = h->tile_run.reserve(sizeof(int) * 4ll * (n_tiles + 1) * nb * n_utt))) return rc;
 	if ((rc = h->raw.reserve(sizeof(double) * total_l1 * nb))) return rc;
 	if ((rc = h->cand0.reserve(sizeof(double) * total_l1 * S))) return rc;
 	if ((rc = h->cand1.reserve(sizeof(double) * total_l1 * nc))) return rc;
@@ -1101,6 +1176,7 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 		ba.utts = du; ba.y = h->y.as<double>(); ba.taps = h->d_taps.as<double>(); ba.tap_off = h->d_tap_off.as<int>();
 		ba.half_len = h->d_half_len.as<int>(); ba.ev_band_off = h->d_ev_band_off.as<long long>(); ba.ev_cap = h->d_ev_cap.as<int>();
 		ba.events = h->events.as<double>(); ba.ev_count = h->ev_count.as<int>(); ba.overflow = h->overflow.as<int>(); ba.n_bands = nb;
+		ba.tile_run = h->tile_run.as<int>(); ba.n_tiles = n_tiles;
 		if ((rc = dev->time_begin("harvest_bandpass", s))) return rc;
 		hipLaunchKernelGGL(hv_bandpass_kernel, dim3(nb, n_utt), dim3(BP_T), 0, s, ba);
 		WC_HIP(hipGetLastError());
@@ -1110,6 +1186,7 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 	RawArgs ra;
 	ra.utts = du; ra.events = h->events.as<double>(); ra.ev_band_off = h->d_ev_band_off.as<long long>(); ra.ev_cap = h->d_ev_cap.as<int>();
 	ra.ev_count = h->ev_count.as<int>(); ra.band_f0 = h->d_band_f0.as<double>(); ra.raw = h->raw.as<double>(); ra.n_bands = nb;
+	ra.tile_run = h->tile_run.as<int>(); ra.n_tiles = n_tiles;
 	ra.fs_d = h->fs_d; ra.f0_floor = h->f0_floor; ra.f0_ceil = h->f0_ceil;
 	if ((rc = dev->time_begin("harvest_raw", s))) return rc;
 	hipLaunchKernelGGL(hv_raw_kernel, dim3((max_L1 + 255) / 256, nb, n_utt), dim3(256), 0, s, ra);
@@ -1252,7 +1329,7 @@ void wc_harvest_destroy(wc_harvest *h) {
 	if (!h) return;
 	(void)hipStreamSynchronize(h->dev->stream);
 	for (DevBuf *b : {&h->d_rot, &h->d_taps, &h->d_tap_off, &h->d_half_len, &h->d_band_f0, &h->d_ev_band_off, &h->d_ev_cap, &h->utts, &h->dec, &h->y,
-					  &h->events, &h->ev_count, &h->overflow, &h->raw, &h->cand0, &h->cand1, &h->score1, &h->cand2, &h->score2, &h->base,
+					  &h->events, &h->ev_count, &h->overflow, &h->tile_run, &h->raw, &h->cand0, &h->cand1, &h->score1, &h->cand2, &h->score2, &h->base,
 					  &h->s1, &h->s2, &h->s3, &h->fixed, &h->f0_1ms, &h->sec, &h->chan, &h->smooth, &h->ibuf, &h->d_x, &h->d_tpos, &h->d_f0})
 		b->release();
 	h->h_stage.release();
