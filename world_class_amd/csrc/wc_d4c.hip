@@ -495,7 +495,8 @@ struct wc_d4c {
 template <int N>
 static void launch_lt(const D4cArgs &a, hipStream_t s) {
 	long long blocks = ((a.total_frames + 7) / 8) * 8;
-	hipLaunchKernelGGL((d4c_lovetrain_kernel<N, 256>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+	constexpr int TL = (N >= 4096) ? 512 : 256;
+	hipLaunchKernelGGL((d4c_lovetrain_kernel<N, TL>), dim3((unsigned)blocks), dim3(TL), 0, s, a);
 }
 template <int N>
 static void launch_main(const D4cArgs &a, hipStream_t s) {
