@@ -1081,7 +1081,7 @@ static inline int h_mround(double x) { return x > 0 ? static_cast<int>(x + 0.5) 
 // zero-crossing buffers; with the rate bound an overflow is reported through h->overflow (device) and handled by
 // the caller (hv_overflowed) by re-running with full == true.
 int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const int *x_length, double *d_tpos, double *d_f0,
-			   bool full) {
+			   bool full, hipEvent_t mid_event) {
 	Device *dev = h->dev;
 	const int r = h->decim;
 	const int lag = (r == 1) ? 0 : static_cast<int>(std::ceil(140.0 / r) * r);
@@ -1202,6 +1202,9 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 	hipLaunchKernelGGL(hv_refine_kernel, dim3((unsigned)total_l1), dim3(256), 0, s, fa);
 	WC_HIP(hipGetLastError());
 	if ((rc = dev->time_end("harvest_refine", s))) return rc;
+	// the ALU-bound part of this chain is enqueued: a staggered twin chain may start its own now, next to our
+	// latency-bound tail (contour logic, smoothing) and whatever the caller runs after us
+	if (mid_event) WC_HIP(hipEventRecord(mid_event, s));
 	hipLaunchKernelGGL(hv_unreliable_kernel, dim3((unsigned)total_l1), dim3(128), 0, s, du, n_utt, h->cand1.as<double>(), h->score1.as<double>(),
 					   h->cand2.as<double>(), h->score2.as<double>(), h->base.as<double>(), total_l1, nc);
 	CtrArgs ca;
@@ -1235,7 +1238,7 @@ static int hv_run_device(wc_harvest *h, int n_utt, const double *d_x, const int 
 	hipStream_t s = h->dev->stream;
 	int rc;
 	for (int attempt = 0; attempt < 2; ++attempt) {
-		if ((rc = hv_enqueue(h, s, n_utt, d_x, x_length, d_tpos, d_f0, attempt == 1))) return rc;
+		if ((rc = hv_enqueue(h, s, n_utt, d_x, x_length, d_tpos, d_f0, attempt == 1, nullptr))) return rc;
 		bool overflow = false;
 		if ((rc = hv_overflowed(h, s, &overflow))) return rc;
 		if (!overflow) return WC_OK;

@@ -1,24 +1,46 @@
 // Fused analysis + synthesis pipeline (extension; the reference has no such entry point -- its demo calls the
 // four stages one after the other, reference test/test.cpp:288-384).  One call enqueues the whole hot path
-// for a packed batch without any host synchronisation in between:
+// for a packed batch without any host synchronisation in between.  CheapTrick, D4C and the Synthesis time base
+// only depend on the F0 contour; the noise-stream positions are chained on the device (CheapTrick end -> D4C
+// start -> Synthesis start), exactly the order a single reference process would consume its global randn()
+// stream.  Capacity overflows of the rate-bounded buffers (Harvest zero crossings, Synthesis pulses) are
+// checked once at the end and re-run with hard bounds.
 //
-//   main stream   Harvest -> CheapTrick counts/scan --E0--> Synthesis time base ............ --(E1,E2)--> pulses
-//   stream 1                                        E0 -> CheapTrick frames --E1
-//   stream 2                                        E0 -> D4C (LoveTrain, scans, frames) --E2
+// Default schedule ("groups"): the batch is cut into two halves A and B, each with its own stage handles and
+// two streams (main: Harvest, time base, pulses; aux: CheapTrick frames, D4C), and events order the ALU-bound
+// kernels one after the other while every latency-bound stretch runs in the shadow of an ALU-bound one:
 //
-// CheapTrick, D4C and the Synthesis time base only depend on the F0 contour, so they overlap; the noise-stream
-// positions are chained on the device (CheapTrick end -> D4C start -> Synthesis start), exactly the order a
-// single reference process would consume its global randn() stream.  Capacity overflows of the rate-bounded
-// buffers (Harvest zero crossings, Synthesis pulses) are checked once at the end and re-run with hard bounds.
+//   main A  Harvest_A heavy | tail_A ........ | time base_A ....................... | pulses_A
+//   main B                  | Harvest_B heavy | tail_B ............ | time base_B ............... | pulses_B
+//   aux A                                     | CheapTrick_A, D4C_A ............... |
+//   aux B                                                                           | CheapTrick_B, D4C_B |
+//
+// (heavy = band-pass, raw candidates, refinement; tail = unreliable-candidate test, contour logic, smoothing).
+// Measured on MI355X: overlapping two ALU-bound kernels (refinement next to D4C) gains nothing -- they time-share
+// the CUs -- while the tails and time bases (64 wavefronts each) disappear behind the heavy kernels.
+// WC_PIPELINE_MODE=shared selects the older schedule: one set of stages, Harvest split over two streams.
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "wc_stages.hpp"
 
 using namespace wc;
 
+// one independent chain (mode "groups"): its own stage handles and two streams
+struct PipeGroup {
+	wc_harvest *hv = nullptr;
+	wc_cheaptrick *ct = nullptr;
+	wc_d4c *d4 = nullptr;
+	wc_synthesis *sy = nullptr;
+	hipStream_t main = nullptr, aux = nullptr;
+	hipEvent_t e0 = nullptr, e_aux = nullptr, e_mid = nullptr;
+};
+
 struct wc_pipeline {
+	int mode;  // 0: shared stages, Harvest split over streams; 1: independent staggered chains per utterance group
+	PipeGroup grp[2];
 	int fs, fft_size;
 	double frame_period;
 	Device *dev;
@@ -45,6 +67,10 @@ wc_pipeline *wc_pipeline_create(int fs, double frame_period, double harvest_f0_f
 	p->frame_period = frame_period;
 	p->dev = dev;
 	{
+		const char *m = getenv("WC_PIPELINE_MODE");
+		p->mode = (m && std::string(m) == "shared") ? 0 : 1;  // default: two scheduled chains (measured 82 vs 90-96 ms per batch)
+	}
+	{
 		const char *env = getenv("WC_PIPELINE_SPLIT");
 		p->n_split = env ? atoi(env) : 2;  // measured on MI355X: 2 groups beat 1 and 4
 		if (p->n_split < 1) p->n_split = 1;
@@ -69,6 +95,21 @@ wc_pipeline *wc_pipeline_create(int fs, double frame_period, double harvest_f0_f
 	ok = ok && hipEventCreateWithFlags(&p->e0, hipEventDisableTiming) == hipSuccess;
 	ok = ok && hipEventCreateWithFlags(&p->e1, hipEventDisableTiming) == hipSuccess;
 	ok = ok && hipEventCreateWithFlags(&p->e2, hipEventDisableTiming) == hipSuccess;
+	if (ok && p->mode == 1) {
+		for (int g = 0; g < 2 && ok; ++g) {
+			PipeGroup &G = p->grp[g];
+			G.hv = wc_harvest_create(fs, harvest_f0_floor, harvest_f0_ceil, frame_period, 8000.0, 40.0, 0);
+			G.ct = G.hv ? wc_cheaptrick_create(fs, q1, cheaptrick_f0_floor, fft_size) : nullptr;
+			G.d4 = G.ct ? wc_d4c_create(fs, d4c_threshold) : nullptr;
+			G.sy = G.d4 ? wc_synthesis_create(fs, p->fft_size, frame_period) : nullptr;
+			ok = G.sy != nullptr;
+			if (g == 0) { G.main = dev->stream; G.aux = p->s1; }
+			else { G.main = p->n_split > 1 ? p->hs[1] : p->s2; G.aux = p->s2; }
+			ok = ok && hipEventCreateWithFlags(&G.e0, hipEventDisableTiming) == hipSuccess;
+			ok = ok && hipEventCreateWithFlags(&G.e_aux, hipEventDisableTiming) == hipSuccess;
+			ok = ok && hipEventCreateWithFlags(&G.e_mid, hipEventDisableTiming) == hipSuccess;
+		}
+	}
 	if (!ok) {
 		std::string err = wc_last_error();
 		void wc_pipeline_destroy(wc_pipeline *);
@@ -87,6 +128,16 @@ void wc_pipeline_destroy(wc_pipeline *p) {
 	if (p->e0) (void)hipEventDestroy(p->e0);
 	if (p->e1) (void)hipEventDestroy(p->e1);
 	if (p->e2) (void)hipEventDestroy(p->e2);
+	for (int g = 0; g < 2; ++g) {
+		PipeGroup &G = p->grp[g];
+		if (G.e0) (void)hipEventDestroy(G.e0);
+		if (G.e_aux) (void)hipEventDestroy(G.e_aux);
+		if (G.e_mid) (void)hipEventDestroy(G.e_mid);
+		wc_synthesis_destroy(G.sy);
+		wc_d4c_destroy(G.d4);
+		wc_cheaptrick_destroy(G.ct);
+		wc_harvest_destroy(G.hv);
+	}
 	wc_synthesis_destroy(p->sy);
 	wc_d4c_destroy(p->d4);
 	wc_cheaptrick_destroy(p->ct);
@@ -123,6 +174,75 @@ int wc_pipeline_run_device(wc_pipeline *p, int n_utt, const double *d_x, const i
 	}
 	int rc;
 	if ((rc = dev->ensure_rng(lo, hi))) return rc;
+	// the start positions are read from a private copy: rng_pos is also the output and a capacity retry re-reads them
+	std::vector<uint64_t> rng_in;
+	if (rng_pos) rng_in.assign(rng_pos, rng_pos + n_utt);
+	const uint64_t *rng_start = rng_pos ? rng_in.data() : nullptr;
+	if (p->mode == 1 && n_utt >= 2) {
+		// Two chains over the two halves of the batch, scheduled so that ALU-bound kernels never compete with each
+		// other (measured: Harvest refinement and D4C merely time-share a CU) while every latency-bound stretch
+		// runs in the shadow of an ALU-bound one:
+		//   Harvest_A heavy | tail_A next to Harvest_B heavy | tail_B next to CheapTrick/D4C_A | pulses_A | D4C_B | pulses_B
+		// (tail = unreliable-candidate test, contour logic, smoothing; the Synthesis time bases hide the same way)
+		bool full[2][2] = {{false, false}, {false, false}};
+		for (int attempt = 0; attempt < 3; ++attempt) {
+			const int bins_ = p->fft_size / 2 + 1;
+			struct Slice { int u0, nu; long long xo, fo, yo; } sl[2];
+			{
+				long long xo = 0, fo = 0, yo = 0;
+				for (int g = 0; g < 2; ++g) {
+					sl[g].u0 = g == 0 ? 0 : n_utt / 2;
+					sl[g].nu = (g == 0 ? n_utt / 2 : n_utt) - sl[g].u0;
+					sl[g].xo = xo; sl[g].fo = fo; sl[g].yo = yo;
+					for (int u = sl[g].u0; u < sl[g].u0 + sl[g].nu; ++u) { xo += x_length[u]; fo += f_len[u]; yo += y_len[u]; }
+				}
+			}
+			// 1. both Harvest chains; B's starts when A's refinement kernel is done
+			for (int g = 0; g < 2; ++g) {
+				PipeGroup &G = p->grp[g];
+				if (g == 1) WC_HIP(hipStreamWaitEvent(G.main, p->grp[0].e_mid, 0));
+				if ((rc = hv_enqueue(G.hv, G.main, sl[g].nu, d_x + sl[g].xo, x_length + sl[g].u0, d_tpos + sl[g].fo, d_f0 + sl[g].fo,
+									 full[g][0], G.e_mid)))
+					return rc;
+			}
+			// 2. the rest of each chain; A's CheapTrick/D4C wait for B's refinement as well
+			for (int g = 0; g < 2; ++g) {
+				PipeGroup &G = p->grp[g];
+				const int u0 = sl[g].u0, nu = sl[g].nu;
+				const double *gx = d_x + sl[g].xo;
+				double *gt = d_tpos + sl[g].fo, *gf = d_f0 + sl[g].fo, *gsp = d_sp + sl[g].fo * bins_, *gap = d_ap + sl[g].fo * bins_;
+				double *gy = d_y + sl[g].yo;
+				const uint64_t *grp_rng = rng_start ? rng_start + u0 : nullptr;
+				long long total = 0;
+				uint64_t a0 = 0, a1 = 0;
+				if ((rc = ct_prepare(G.ct, G.main, nu, x_length + u0, gf, f_len.data() + u0, grp_rng, &total, &a0, &a1))) return rc;
+				WC_HIP(hipEventRecord(G.e0, G.main));
+				WC_HIP(hipStreamWaitEvent(G.aux, G.e0, 0));
+				if (g == 0) WC_HIP(hipStreamWaitEvent(G.aux, p->grp[1].e_mid, 0));
+				if ((rc = ct_frames(G.ct, G.aux, nu, gx, gt, gf, gsp, total))) return rc;
+				if ((rc = d4c_enqueue(G.d4, G.aux, nu, gx, x_length + u0, gt, gf, f_len.data() + u0, p->fft_size, gap, nullptr,
+									  ct_end_positions(G.ct))))
+					return rc;
+				WC_HIP(hipEventRecord(G.e_aux, G.aux));
+				if ((rc = syn_prepare(G.sy, G.main, nu, gf, f_len.data() + u0, y_len.data() + u0, gy, nullptr, full[g][1]))) return rc;
+				WC_HIP(hipStreamWaitEvent(G.main, G.e_aux, 0));
+				if ((rc = syn_pulses(G.sy, G.main, gf, gsp, gap, gy, d4c_end_positions(G.d4)))) return rc;
+			}
+			bool again = false;
+			for (int g = 0; g < 2; ++g) {
+				PipeGroup &G = p->grp[g];
+				const int u0 = g == 0 ? 0 : n_utt / 2;
+				bool o1 = false, o2 = false;
+				if ((rc = syn_finish(G.sy, G.main, rng_pos ? rng_pos + u0 : nullptr, &o2))) return rc;
+				if ((rc = hv_overflowed(G.hv, G.main, &o1))) return rc;
+				full[g][0] = full[g][0] || o1;
+				full[g][1] = full[g][1] || o2;
+				again = again || o1 || o2;
+			}
+			if (!again) return WC_OK;
+		}
+		return fail(WC_ERR_DEVICE, "pipeline: buffer overflow");
+	}
 	bool hv_full = false, syn_full = false;
 	const int ns = p->n_split < n_utt ? p->n_split : n_utt;
 	for (int attempt = 0; attempt < 3; ++attempt) {
@@ -134,7 +254,7 @@ int wc_pipeline_run_device(wc_pipeline *p, int n_utt, const double *d_x, const i
 				const int u0 = (int)((long long)n_utt * k / ns), u1 = (int)((long long)n_utt * (k + 1) / ns);
 				hipStream_t sk = k == 0 ? s0 : p->hs[k];
 				if (k > 0) WC_HIP(hipStreamWaitEvent(sk, p->e0, 0));
-				if ((rc = hv_enqueue(p->hv[k], sk, u1 - u0, d_x + xo, x_length + u0, d_tpos + fo, d_f0 + fo, hv_full))) return rc;
+				if ((rc = hv_enqueue(p->hv[k], sk, u1 - u0, d_x + xo, x_length + u0, d_tpos + fo, d_f0 + fo, hv_full, nullptr))) return rc;
 				if (k > 0) WC_HIP(hipEventRecord(p->he[k], sk));
 				for (int u = u0; u < u1; ++u) { xo += x_length[u]; fo += f_len[u]; }
 			}
@@ -142,7 +262,7 @@ int wc_pipeline_run_device(wc_pipeline *p, int n_utt, const double *d_x, const i
 		}
 		long long total = 0;
 		uint64_t a0 = 0, a1 = 0;
-		if ((rc = ct_prepare(p->ct, s0, n_utt, x_length, d_f0, f_len.data(), rng_pos, &total, &a0, &a1))) return rc;
+		if ((rc = ct_prepare(p->ct, s0, n_utt, x_length, d_f0, f_len.data(), rng_start, &total, &a0, &a1))) return rc;
 		WC_HIP(hipEventRecord(p->e0, s0));
 		WC_HIP(hipStreamWaitEvent(ns > 1 ? p->hs[1] : p->s1, p->e0, 0));
 		WC_HIP(hipStreamWaitEvent(p->s2, p->e0, 0));
