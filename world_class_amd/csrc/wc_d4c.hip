@@ -61,20 +61,21 @@ __device__ __forceinline__ int d4c_windowed(const double *__restrict__ x, int x_
 	sincos(c2 * (c1 * (tid - hw)), &sn0, &cs0);
 	sincos(c2 * (c1 * T), &snd, &csd);
 	auto win = [&](double c) { return type == 1 ? 0.5 * c + 0.5 : 0.42 + 0.5 * c + 0.08 * (2.0 * c * c - 1.0); };
+	// (select forms instead of conditional updates: predicated register updates inside the unrolled loops cost a
+	// register copy per value and iteration)
 	double s1 = 0.0, s2 = 0.0;
 	{
 		double c = cs0, sn = sn0;
 #pragma unroll
 		for (int e = 0; e < EPT; ++e) {
 			const int i = tid + e * T;
-			wave[e] = 0.0;
-			if (i < wl) {
-				const double w = win(c);
-				const int si = clampi(origin + i - hw, 0, x_len - 1);
-				wave[e] = x[si] * w + randn_at(rng, roff + i) * kSafe;
-				s1 += wave[e];
-				s2 += w;
-			}
+			const bool in = i < wl;
+			const double w = in ? win(c) : 0.0;
+			const int si = clampi(origin + i - hw, 0, x_len - 1);
+			const double noise = randn_at(rng, roff + (in ? i : 0)) * kSafe;
+			wave[e] = in ? x[si] * w + noise : 0.0;
+			s1 += wave[e];
+			s2 += w;
 			const double cn = fma(c, csd, -(sn * snd));
 			sn = fma(sn, csd, c * snd);
 			c = cn;
@@ -87,7 +88,7 @@ __device__ __forceinline__ int d4c_windowed(const double *__restrict__ x, int x_
 #pragma unroll
 		for (int e = 0; e < EPT; ++e) {
 			const int i = tid + e * T;
-			if (i < wl) wave[e] -= win(c) * wc;
+			wave[e] -= (i < wl ? win(c) : 0.0) * wc;
 			const double cn = fma(c, csd, -(sn * snd));
 			sn = fma(sn, csd, c * snd);
 			c = cn;

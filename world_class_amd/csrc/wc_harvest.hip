@@ -495,7 +495,9 @@ __global__ __launch_bounds__(256) void hv_refine_kernel(RefArgs a) {
 			const int hw = min((int)(1.5 * fs / fc + 1.0), RF_MAXHW);
 			const int bt = live ? 2 * hw + 1 : 0;
 			const double wlt = (2.0 * hw + 1.0) / fs;
-			const int fft_index = 2 + (int)(log(hw * 2 + 1.0) / kLog2H);
+			// 2 + int(log(2 hw + 1) / log 2) of reference :962: 2 hw + 1 is odd, so the logarithm is never close to an
+			// integer and the floor is the position of the leading bit
+			const int fft_index = 2 + (31 - __clz(hw * 2 + 1));
 			const int N = 1 << fft_index;
 			const int tsh = kTwiddleN / N;
 			const double bt0 = (-hw) / fs;
@@ -512,6 +514,7 @@ __global__ __launch_bounds__(256) void hv_refine_kernel(RefArgs a) {
 				sincos(tmp2, &ws, &wc);
 			}
 			const double2 r1 = a.rot[2 * hw], r8 = a.rot[2 * hw + 1];  // (cos, sin) of beta and 8 beta, beta = 2 pi / (2 hw + 1)
+			const double k1 = 0.5 * r1.y, k2 = 0.16 * (2.0 * r1.y * r1.x);
 			double2 t[6], st[6];
 #pragma unroll
 			for (int h = 0; h < 6; ++h) {
@@ -523,31 +526,31 @@ __global__ __launch_bounds__(256) void hv_refine_kernel(RefArgs a) {
 			double v[32];
 #pragma unroll
 			for (int k = 0; k < 32; ++k) v[k] = 0.0;
+			// (no per-lane control flow inside the loop: a lane past its window multiplies by a zero sample, which
+			// keeps every accumulator and rotation in place in its registers)
 			for (int n = sub; __ballot(n < bt) != 0ull; n += 8) {
-				if (n < bt) {
-					const double cp = fma(wc, r1.x, ws * r1.y);    // cos(theta - beta)
-					const double cn = fma(wc, r1.x, -(ws * r1.y)); // cos(theta + beta)
-					const double m = 0.42 + 0.5 * wc + 0.08 * (2.0 * wc * wc - 1.0);
-					const double mp = 0.42 + 0.5 * cp + 0.08 * (2.0 * cp * cp - 1.0);
-					const double mn = 0.42 + 0.5 * cn + 0.08 * (2.0 * cn * cn - 1.0);
-					double d;  // differentiated window (reference :794-803)
-					if (n == 0) d = -mn / 2.0;
-					else if (n == bt - 1) d = mp / 2.0;
-					else d = -(mn - mp) / 2.0;
-					const double yv = y[clampi(basic + n - 1, 0, u.y_len - 1)];
-					const double xm = m * yv, xd = d * yv;
+				// Blackman window 0.42 + 0.5 cos + 0.08 cos 2theta = 0.34 + c (0.5 + 0.16 c); its centred difference
+				// -(w[n+1] - w[n-1]) / 2 = sin theta (0.5 sin beta + 0.16 sin 2beta cos theta) in the interior, the
+				// one-sided forms of reference :797-798 at the two ends
+				const double m = fma(wc, fma(0.16, wc, 0.5), 0.34);
+				const bool first = n == 0, last = n == bt - 1;
+				const double cnb = fma(wc, r1.x, first ? -(ws * r1.y) : ws * r1.y);  // cos(theta +- beta)
+				const double mnb = fma(cnb, fma(0.16, cnb, 0.5), 0.34);
+				double d = ws * fma(k2, wc, k1);
+				d = first ? -mnb / 2.0 : (last ? mnb / 2.0 : d);
+				const double yv = (n < bt) ? y[clampi(basic + n - 1, 0, u.y_len - 1)] : 0.0;
+				const double xm = m * yv, xd = d * yv;
 #pragma unroll
-					for (int h = 0; h < 6; ++h) {
-						v[4 * h + 0] = fma(xm, t[h].x, v[4 * h + 0]);
-						v[4 * h + 1] = fma(xm, t[h].y, v[4 * h + 1]);
-						v[4 * h + 2] = fma(xd, t[h].x, v[4 * h + 2]);
-						v[4 * h + 3] = fma(xd, t[h].y, v[4 * h + 3]);
-						t[h] = cmul(t[h], st[h]);
-					}
-					const double nc_ = fma(wc, r8.x, -(ws * r8.y));
-					ws = fma(ws, r8.x, wc * r8.y);
-					wc = nc_;
+				for (int h = 0; h < 6; ++h) {
+					v[4 * h + 0] = fma(xm, t[h].x, v[4 * h + 0]);
+					v[4 * h + 1] = fma(xm, t[h].y, v[4 * h + 1]);
+					v[4 * h + 2] = fma(xd, t[h].x, v[4 * h + 2]);
+					v[4 * h + 3] = fma(xd, t[h].y, v[4 * h + 3]);
+					t[h] = cmul(t[h], st[h]);
 				}
+				const double nc_ = fma(wc, r8.x, -(ws * r8.y));
+				ws = fma(ws, r8.x, wc * r8.y);
+				wc = nc_;
 			}
 			// halving butterfly inside the 8-lane group: afterwards lane `sub` holds v[4 sub .. 4 sub + 3]
 #pragma unroll
