@@ -1,0 +1,118 @@
+"""-m gpu: capacity-retry paths, long and odd-sized inputs, option variations, noise-stream continuity across calls."""
+import os
+
+import numpy as np
+import pytest
+
+from world_class_amd.synth import make_utterance
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def wca():
+    import world_class_amd as w
+    w.lib()
+    return w
+
+
+def check_f0(f0, ref):
+    assert np.array_equal(f0 == 0, ref == 0)
+    assert np.abs(f0 - ref).max() < 1e-6
+
+
+def test_harvest_long_utterance(wca, port):
+    fs = 16000
+    x = np.concatenate([make_utterance(fs, 6.0, 200 + i) for i in range(4)])  # 24 s, many voiced sections
+    t, f = wca.Harvest(fs).compute(x)
+    tr, fr = port.harvest(x, fs)
+    assert np.array_equal(t, tr)
+    check_f0(f, fr)
+
+
+def test_harvest_zero_crossing_buffer_overflow_is_retried(wca, port):
+    fs = 16000
+    x = make_utterance(fs, 1.0, 321)
+    os.environ["WC_DEBUG_SMALL_CAPS"] = "1"
+    try:
+        t, f = wca.Harvest(fs).compute(x)
+        (r,) = wca.Pipeline(fs).run_batch([x])
+    finally:
+        del os.environ["WC_DEBUG_SMALL_CAPS"]
+    tr, fr = port.harvest(x, fs)
+    check_f0(f, fr)
+    check_f0(r["f0"], fr)
+
+
+def test_synthesis_pulse_buffer_overflow_is_retried(wca, port):
+    # F0 above the rate bound of the pulse buffers (960 Hz) forces the hard-bound retry
+    from oracle.gen_golden import synth_params
+    fs, n = 48000, 2048
+    f0, sp, ap = synth_params(fs, n, 41, 777)
+    f0 = np.where(f0 > 0, 1500.0, 0.0)
+    s = wca.Synthesis(fs, n, 5.0)
+    wca.rng_set_position(0)
+    port.rng_reset()
+    y = s.compute(f0, sp, ap)
+    assert np.abs(y - port.synthesis(f0, sp, ap, fs, 5.0)).max() < 1e-8
+    port.rng_reset()
+
+
+@pytest.mark.parametrize("floor,ceil", [(50.0, 600.0), (100.0, 400.0), (71.0, 1000.0)])
+def test_harvest_option_variations(wca, port, floor, ceil):
+    fs = 16000
+    x = make_utterance(fs, 1.0, 55)
+    t, f = wca.Harvest(fs, f0_floor=floor, f0_ceil=ceil).compute(x)
+    tr, fr = port.harvest(x, fs, f0_floor=floor, f0_ceil=ceil)
+    check_f0(f, fr)
+
+
+@pytest.mark.parametrize("n", [801, 1000, 12345, 16001])
+def test_odd_lengths_through_the_pipeline(wca, port, n):
+    fs = 16000
+    x = make_utterance(fs, 1.1, 66)[:n]
+    (r,) = wca.Pipeline(fs).run_batch([x])
+    ref = port.pipeline(x, fs)
+    check_f0(r["f0"], ref["f0"])
+    assert (np.abs(r["sp"] - ref["sp"]) / ref["sp"]).max() < 1e-7
+    assert np.abs(r["ap"] - ref["ap"]).max() < 1e-7
+    assert np.abs(r["y"] - ref["y"]).max() < 1e-8
+
+
+def test_noise_stream_continues_across_calls_like_one_reference_process(wca, port):
+    """Two utterances analysed and synthesised back to back through the host API consume one global stream,
+    exactly as two runs of the demo's stage sequence inside one reference process would."""
+    fs = 16000
+    xs = [make_utterance(fs, 0.5, 91), make_utterance(fs, 0.4, 92)]
+    wca.rng_set_position(0)
+    port.rng_reset()
+    hv, ct, d4 = wca.Harvest(fs), wca.CheapTrick(fs), wca.D4C(fs)
+    sy = wca.Synthesis(fs, ct.fft_size, 5.0)
+    for x in xs:
+        t, f = hv.compute(x)
+        sp = ct.compute(x, t, f)
+        ap = d4.compute(x, t, f, ct.fft_size)
+        y = sy.compute(f, sp, ap)
+        tr, fr = port.harvest(x, fs)
+        spr = port.cheaptrick(x, fs, tr, fr)
+        apr = port.d4c(x, fs, tr, fr, ct.fft_size)
+        yr = port.synthesis(fr, spr, apr, fs)
+        assert wca.rng_get_position() == port.rng_position()
+        assert np.abs(y - yr).max() < 1e-8
+    port.rng_reset()
+
+
+def test_full_size_batch_properties(wca):
+    """The benchmark's own workload shape (48 kHz, 10 s utterances) through the fused pipeline: every copy of
+    the same utterance in a batch yields identical analysis results, and a second run reproduces the first."""
+    fs = 48000
+    xs = [make_utterance(fs, 10.0, 3000), make_utterance(fs, 10.0, 3001)]
+    p = wca.Pipeline(fs)
+    a = p.run_batch([xs[0], xs[1], xs[0], xs[1], xs[0]])
+    b = p.run_batch([xs[1], xs[0]])
+    for i, j in ((0, 2), (0, 4), (1, 3)):
+        for k in ("f0", "sp", "ap"):
+            assert np.array_equal(a[i][k], a[j][k]), (i, j, k)
+        assert np.abs(a[i]["y"] - a[j]["y"]).max() < 1e-12
+    assert np.array_equal(a[0]["f0"], b[1]["f0"]) and np.array_equal(a[1]["sp"], b[0]["sp"])
+    assert all(len(r["f0"]) == 2001 and r["sp"].shape == (2001, 1025) and len(r["y"]) == 480001 for r in a)

@@ -1140,6 +1140,7 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 		for (int b = 0; b < nb; ++b) {
 			int hard = max_ylen / 2 + 4;
 			int soft = static_cast<int>(2.5 * h->band_f0[b] * (max_ylen / h->fs_d)) + 64;
+			if (getenv("WC_DEBUG_SMALL_CAPS")) soft = 24;  // test hook: forces the overflow-and-retry path
 			ev_cap[b] = full ? hard : std::min(hard, soft);
 			ev_band_off[b] = per_utt;
 			per_utt += 4ll * ev_cap[b];
