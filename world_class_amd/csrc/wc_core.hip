@@ -176,12 +176,13 @@ int Device::ensure_rng(uint64_t first, uint64_t last) {
 int Device::time_begin(const char *name, hipStream_t s) {
 	if (!timing) return WC_OK;
 	if (!s) s = stream;
-	auto it = events.find(name);
+	const std::string key = time_tag >= 0 ? std::string(name) + "#" + std::to_string(time_tag) : std::string(name);
+	auto it = events.find(key);
 	if (it == events.end()) {
 		hipEvent_t a, b;
 		WC_HIP(hipEventCreate(&a));
 		WC_HIP(hipEventCreate(&b));
-		it = events.emplace(name, std::make_pair(a, b)).first;
+		it = events.emplace(key, std::make_pair(a, b)).first;
 	}
 	WC_HIP(hipEventRecord(it->second.first, s));
 	return WC_OK;
@@ -189,7 +190,8 @@ int Device::time_begin(const char *name, hipStream_t s) {
 int Device::time_end(const char *name, hipStream_t s) {
 	if (!timing) return WC_OK;
 	if (!s) s = stream;
-	auto it = events.find(name);
+	const std::string key = time_tag >= 0 ? std::string(name) + "#" + std::to_string(time_tag) : std::string(name);
+	auto it = events.find(key);
 	if (it == events.end()) return WC_OK;
 	WC_HIP(hipEventRecord(it->second.second, s));
 	return WC_OK;
@@ -342,18 +344,29 @@ int wc_memcpy_d2h(void *dst, const void *src, uint64_t bytes) {
 int wc_set_kernel_timing(int enable) {
 	Device *d = current_device();
 	if (!d) return WC_ERR_DEVICE;
+	if (enable && !d->timing) {  // a fresh measurement window: forget the events of earlier windows
+		for (auto &kv : d->events) { (void)hipEventDestroy(kv.second.first); (void)hipEventDestroy(kv.second.second); }
+		d->events.clear();
+	}
 	d->timing = enable != 0;
 	return WC_OK;
 }
 float wc_last_kernel_ms(const char *kernel_name) {
+	// sum over the plain event and the per-group events "name#k" of the fused pipeline
 	Device *d = current_device();
 	if (!d) return -1.f;
-	auto it = d->events.find(kernel_name);
-	if (it == d->events.end()) return -1.f;
-	if (hipEventSynchronize(it->second.second) != hipSuccess) return -1.f;
-	float ms = -1.f;
-	if (hipEventElapsedTime(&ms, it->second.first, it->second.second) != hipSuccess) return -1.f;
-	return ms;
+	const std::string base(kernel_name);
+	float total = 0.f;
+	bool any = false;
+	for (auto &kv : d->events) {
+		if (kv.first != base && kv.first.compare(0, base.size() + 1, base + "#") != 0) continue;
+		if (hipEventQuery(kv.second.second) == hipErrorNotReady && hipEventSynchronize(kv.second.second) != hipSuccess) continue;
+		float ms = -1.f;
+		if (hipEventElapsedTime(&ms, kv.second.first, kv.second.second) != hipSuccess) continue;
+		total += ms;
+		any = true;
+	}
+	return any ? total : -1.f;
 }
 
 }  // extern "C"

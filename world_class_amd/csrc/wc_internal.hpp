@@ -57,6 +57,7 @@ struct Device {
 	int ensure_rng(uint64_t first, uint64_t last_exclusive);  // makes [first, last) available
 	// timing
 	bool timing = false;
+	int time_tag = -1;  // >= 0: events are keyed "name#tag" (the pipeline runs each kernel once per utterance group)
 	std::map<std::string, std::pair<hipEvent_t, hipEvent_t>> events;
 	int time_begin(const char *name, hipStream_t s = nullptr);  // nullptr = this->stream
 	int time_end(const char *name, hipStream_t s = nullptr);

@@ -200,6 +200,7 @@ int wc_pipeline_run_device(wc_pipeline *p, int n_utt, const double *d_x, const i
 			// 1. both Harvest chains; B's starts when A's refinement kernel is done
 			for (int g = 0; g < 2; ++g) {
 				PipeGroup &G = p->grp[g];
+				dev->time_tag = g;
 				if (g == 1) WC_HIP(hipStreamWaitEvent(G.main, p->grp[0].e_mid, 0));
 				if ((rc = hv_enqueue(G.hv, G.main, sl[g].nu, d_x + sl[g].xo, x_length + sl[g].u0, d_tpos + sl[g].fo, d_f0 + sl[g].fo,
 									 full[g][0], G.e_mid)))
@@ -208,6 +209,7 @@ int wc_pipeline_run_device(wc_pipeline *p, int n_utt, const double *d_x, const i
 			// 2. the rest of each chain; A's CheapTrick/D4C wait for B's refinement as well
 			for (int g = 0; g < 2; ++g) {
 				PipeGroup &G = p->grp[g];
+				dev->time_tag = g;
 				const int u0 = sl[g].u0, nu = sl[g].nu;
 				const double *gx = d_x + sl[g].xo;
 				double *gt = d_tpos + sl[g].fo, *gf = d_f0 + sl[g].fo, *gsp = d_sp + sl[g].fo * bins_, *gap = d_ap + sl[g].fo * bins_;
@@ -228,6 +230,7 @@ int wc_pipeline_run_device(wc_pipeline *p, int n_utt, const double *d_x, const i
 				WC_HIP(hipStreamWaitEvent(G.main, G.e_aux, 0));
 				if ((rc = syn_pulses(G.sy, G.main, gf, gsp, gap, gy, d4c_end_positions(G.d4)))) return rc;
 			}
+			dev->time_tag = -1;
 			bool again = false;
 			for (int g = 0; g < 2; ++g) {
 				PipeGroup &G = p->grp[g];
