@@ -30,9 +30,13 @@ def _stale(out, deps):
 
 def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "world_class_c.h"))
+    # a shipped library that is newer than every source is used as is (the object directory does not travel to
+    # the GPU box); experimental flags always rebuild
+    if not force and not EXTRA and not _stale(OUT, [os.path.join(CSRC, f) for f in sources()] + headers):
+        return OUT
+    os.makedirs(OBJ, exist_ok=True)
     # objects depend on the flags too: a flags stamp forces a full rebuild when they change
     stamp = os.path.join(OBJ, "flags.txt")
     flags_now = " ".join(FLAGS)
