@@ -1,0 +1,65 @@
+"""Turn two rocprofv3 PMC passes into profiles/pmc_traffic.json (HBM bytes per bench step of each hot kernel).
+
+    cd /tmp && export TMPDIR=/tmp
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_fetch -o p -f csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_write -o p -f csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write --steps 3
+
+Both counters are in KiB.  FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM section: gfx950 reports half of a
+coalesced read stream); WRITE_SIZE is used as is.  With the default pipeline schedule every kernel is launched
+once per half batch, i.e. twice per step: the figure written is the SUM over the launches of one step, which is
+what bench.py's `roofline.achieved` is priced on (whole-batch bytes / summed kernel time).
+"""
+import argparse
+import csv
+import glob
+import json
+import os
+import sys
+
+KERNELS = {  # substring of the kernel symbol -> name bench.py uses
+    "d4c_frames_kernel": "d4c_frames", "ct_frames_kernel": "cheaptrick_frames", "d4c_lovetrain_kernel": "d4c_lovetrain",
+    "hv_refine_kernel": "harvest_refine", "hv_bandpass_kernel": "harvest_bandpass", "hv_raw_kernel": "harvest_raw",
+    "hv_contour_kernel": "harvest_contour", "syn_pulse_kernel": "synthesis_pulses", "syn_timebase_kernel": "synthesis_timebase",
+}
+
+
+def total_kib(d, counter):
+    out = {}
+    for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        with open(path, newline="") as f:
+            for row in csv.DictReader(f):
+                if row["Counter_Name"] != counter:
+                    continue
+                for sub, name in KERNELS.items():
+                    if sub in row["Kernel_Name"]:
+                        out[name] = out.get(name, 0.0) + float(row["Counter_Value"])
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("fetch_dir")
+    ap.add_argument("write_dir")
+    ap.add_argument("--steps", type=int, required=True, help="warmup + timed steps of the profiled bench run")
+    ap.add_argument("-o", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json"))
+    a = ap.parse_args()
+    fetch, write = total_kib(a.fetch_dir, "FETCH_SIZE"), total_kib(a.write_dir, "WRITE_SIZE")
+    if not fetch or not write:
+        sys.exit("no counter rows found")
+    out = {"_note": "HBM bytes per bench STEP (sum over the two half-batch launches of the default schedule) from rocprofv3 PMC, "
+                    "separate passes (--kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE) of `python bench.py --steps 2 --warmup 1 "
+                    "--no-cpu-baseline`; counters are KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (HBM section); WRITE_SIZE as is. "
+                    "Made by tools/pmc_traffic.py.",
+           "_raw_kib_per_step": {}}
+    for name in sorted(set(fetch) & set(write)):
+        f, w_ = fetch[name] / a.steps, write[name] / a.steps
+        out["_raw_kib_per_step"][name] = {"FETCH_SIZE": f, "WRITE_SIZE": w_}
+        out[name] = int((2.0 * f + w_) * 1024)
+    with open(a.o, "w") as fh:
+        json.dump(out, fh, indent=1)
+    print(json.dumps({k: v for k, v in out.items() if not k.startswith("_")}))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,132 @@
+"""BASELINE.json `configs` 2-5 on ONE MI355X (per-GPU share of the multi-GPU ones), synthetic inputs resident in HBM.
+Prints one JSON line per config.  Not the graded bench (that is bench.py, the headline metric); this is the
+evidence table quoted in DESIGN.md section 5.
+
+    python tools/run_configs.py [--configs 2,3,4,5] [--scale 1.0]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import world_class_amd as w  # noqa: E402
+from world_class_amd.synth import make_utterance, true_f0  # noqa: E402
+
+
+def timed(fn, L, iters=3):
+    fn()
+    L.wc_synchronize()
+    best = 1e9
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        fn()
+        L.wc_synchronize()
+        best = min(best, time.perf_counter() - t0)
+    return best
+
+
+def tile(items, n):
+    return [items[i % len(items)] for i in range(n)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", default="2,3,4,5")
+    ap.add_argument("--scale", type=float, default=1.0, help="scale the utterance counts (for quick runs)")
+    a = ap.parse_args()
+    import torch
+    dev = torch.device("cuda", 0)
+    L = w.lib()
+    L.wc_set_device(0)
+    todo = [int(c) for c in a.configs.split(",")]
+
+    if 2 in todo:  # 64 x 16 kHz x 10 s, full pipeline
+        fs, n = 16000, max(2, int(64 * a.scale))
+        xs = tile([make_utterance(fs, 10.0, 2000 + u) for u in range(8)], n)
+        p = w.Pipeline(fs)
+        xl = [len(x) for x in xs]
+        fl, yl = p.lengths(xl)
+        d_x = torch.from_numpy(np.concatenate(xs)).to(dev)
+        d_t = torch.empty(sum(fl), dtype=torch.float64, device=dev)
+        d_f = torch.empty_like(d_t)
+        d_sp = torch.empty(sum(fl) * p.bins, dtype=torch.float64, device=dev)
+        d_ap = torch.empty_like(d_sp)
+        d_y = torch.empty(sum(yl), dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        t = timed(lambda: p.run_device(d_x, xl, d_t, d_f, d_sp, d_ap, d_y), L)
+        print(json.dumps({"config": 2, "what": f"{n} x 16 kHz 10 s, 5 ms hop, full pipeline, 1 GPU", "frames": sum(fl),
+                          "ms": t * 1e3, "frames_per_s": sum(fl) / t}))
+        del d_x, d_t, d_f, d_sp, d_ap, d_y, p
+
+    if 3 in todo:  # 256 x 48 kHz x 10 s, CheapTrick only
+        fs, n = 48000, max(2, int(256 * a.scale))
+        xs = tile([make_utterance(fs, 10.0, 3000 + u) for u in range(8)], n)
+        tf = tile([true_f0(fs, 10.0, 3000 + u) for u in range(8)], n)
+        ct = w.CheapTrick(fs)
+        xl, fl = [len(x) for x in xs], [len(t_) for t_, _ in tf]
+        d_x = torch.from_numpy(np.concatenate(xs)).to(dev)
+        d_t = torch.from_numpy(np.concatenate([t_ for t_, _ in tf])).to(dev)
+        d_f = torch.from_numpy(np.concatenate([f for _, f in tf])).to(dev)
+        d_sp = torch.empty(sum(fl) * ct.bins, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        L.wc_set_kernel_timing(1)
+        t = timed(lambda: ct.compute_device(d_x, xl, d_t, d_f, fl, d_sp), L)
+        k = L.wc_last_kernel_ms(b"cheaptrick_frames") * 1e-3
+        L.wc_set_kernel_timing(0)
+        b_ct = 8 * ct.fft_size + 8 * ct.bins
+        print(json.dumps({"config": 3, "what": f"{n} x 48 kHz 10 s, CheapTrick only (contour given), 1 GPU", "frames": sum(fl),
+                          "ms": t * 1e3, "frames_per_s": sum(fl) / t, "kernel_ms": k * 1e3,
+                          "B_ct_GBps": sum(fl) * b_ct / k / 1e9, "hbm_frac_on_B_ct": sum(fl) * b_ct / k / 8e12}))
+        del d_x, d_t, d_f, d_sp, ct
+
+    if 4 in todo:  # Synthesis only from precomputed {f0, sp, ap}; per-GPU share of 1024 utterances = 128
+        fs, n = 48000, max(2, int(128 * a.scale))
+        base = []
+        p = w.Pipeline(fs)
+        for u in range(4):  # real parameters of 4 utterances, tiled
+            (r,) = p.run_batch([make_utterance(fs, 10.0, 4000 + u)])
+            base.append(r)
+        del p
+        sy = w.Synthesis(fs, 2048, 5.0)
+        fl = [len(base[i % 4]["f0"]) for i in range(n)]
+        yl = [sy.out_length(v) for v in fl]
+        d_f = torch.from_numpy(np.concatenate([base[i % 4]["f0"] for i in range(n)])).to(dev)
+        sp4 = [torch.from_numpy(b["sp"].ravel()).to(dev) for b in base]
+        ap4 = [torch.from_numpy(b["ap"].ravel()).to(dev) for b in base]
+        d_sp = torch.cat([sp4[i % 4] for i in range(n)])
+        d_ap = torch.cat([ap4[i % 4] for i in range(n)])
+        d_y = torch.empty(sum(yl), dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        t = timed(lambda: sy.compute_device(d_f, fl, d_sp, d_ap, yl, d_y), L)
+        print(json.dumps({"config": 4, "what": f"{n} x 48 kHz 10 s (1/8 of 1024), Synthesis only from resident f0/sp/ap "
+                                                f"({(d_sp.numel() + d_ap.numel()) * 8 / 1e9:.1f} GB), 1 GPU",
+                          "frames": sum(fl), "ms": t * 1e3, "frames_per_s": sum(fl) / t}))
+        del d_f, d_sp, d_ap, d_y, sy, sp4, ap4
+
+    if 5 in todo:  # 1 ms hop Harvest + CheapTrick at 24 kHz; per-GPU share of 4096 streams = 512, whole utterances of 2 s
+        fs, n = 24000, max(2, int(512 * a.scale))
+        xs = tile([make_utterance(fs, 2.0, 5000 + u) for u in range(8)], n)
+        hv, ct = w.Harvest(fs, frame_period=1.0), w.CheapTrick(fs)
+        xl = [len(x) for x in xs]
+        fl = [hv.get_samples(v) for v in xl]
+        d_x = torch.from_numpy(np.concatenate(xs)).to(dev)
+        d_t = torch.empty(sum(fl), dtype=torch.float64, device=dev)
+        d_f = torch.empty_like(d_t)
+        d_sp = torch.empty(sum(fl) * ct.bins, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+
+        def run():
+            hv.compute_device(d_x, xl, d_t, d_f)
+            ct.compute_device(d_x, xl, d_t, d_f, fl, d_sp)
+        t = timed(run, L)
+        print(json.dumps({"config": 5, "what": f"{n} x 24 kHz 2 s (1/8 of 4096 streams), 1 ms hop, Harvest + CheapTrick on whole "
+                                                "utterances (Harvest is non-causal: no streaming semantics in the reference), 1 GPU",
+                          "frames": sum(fl), "ms": t * 1e3, "frames_per_s": sum(fl) / t, "batch_latency_ms": t * 1e3}))
+
+
+if __name__ == "__main__":
+    main()

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 	__shared__ double red[2 * (T / 64) + 2];
 	double *Ar = reinterpret_cast<double *>(A);
 
-	const int tid = threadIdx.x;
+	int tid = threadIdx.x;
 	long long g = xcd_frame(blockIdx.x, a.total_frames);
 	if (g >= a.total_frames) return;
 	const int u = find_utt(a.utts, a.n_utt, g);
@@ -91,6 +91,7 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 		}
 	}
 	ssq = block_sum<T>(ssq, red, tid);
+	WC_FRESH(tid);
 	const double norm = sqrt(ssq);
 	double s1 = 0.0, s2 = 0.0;
 	double wv[EPT];
@@ -116,6 +117,7 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 	__syncthreads();
 
 	// ---- power spectrum (reference :198-218) ----
+	WC_FRESH(tid);
 	fft_lds<M, T, +1>(A, a.tw, tid);
 	r2c_post<M, T>(A, a.tw, tid);
 	for (int k = tid; k <= M; k += T) {
@@ -128,6 +130,7 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 	}
 	__syncthreads();
 	// DC correction (reference src/world_common.cpp:61-80)
+	WC_FRESH(tid);
 	{
 		const int upper = 2 + (int)(f0c * N / fs);
 		const double dx = -(double)fs / N;
@@ -152,6 +155,7 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 
 	// ---- linear smoothing, width 2 f0 / 3 (reference src/world_common.cpp:27-52, :82-116) ----
 	double lp[BPT];
+	WC_FRESH(tid);
 	{
 		const double width = f0c * 2.0 / 3.0;
 		int b = (int)(width * N / fs) + 1;
@@ -206,6 +210,7 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 	__syncthreads();
 
 	// ---- smoothing + recovery lifters in the cepstral domain (reference :230-276) ----
+	WC_FRESH(tid);
 	fft_lds<M, T, +1>(A, a.tw, tid);
 	r2c_post<M, T>(A, a.tw, tid);
 	{
@@ -239,8 +244,10 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 		for (int k = tid; k < M; k += T) A[k] = make_double2(P[k], k == 0 ? P[M] : 0.0);
 		__syncthreads();
 	}
+	WC_FRESH(tid);
 	c2r_pre<M, T>(A, a.tw, tid);
 	fft_lds<M, T, -1>(A, a.tw, tid);
+	WC_FRESH(tid);
 	double *__restrict__ out = a.sp + g * (long long)(M + 1);
 	for (int k = tid; k <= M; k += T) out[k] = exp(Ar[k]);
 }

@@ -52,14 +52,18 @@ __device__ __forceinline__ int d4c_windowed(const double *__restrict__ x, int x_
 											int type, double ratio, const uint32_t *__restrict__ rng,
 											unsigned long long roff, double (&wave)[N / T], double *red, int tid) {
 	constexpr int EPT = N / T;
+	// (the three windows of a frame share their cosines; an opaque thread index keeps the compiler from holding
+	// them in registers -- and spilling them -- across the FFTs in between)
+	asm volatile("" : "+v"(tid));
 	const int hw = mround(ratio * fs / f0 / 2.0);
 	const int wl = 2 * hw + 1;
 	const int origin = mround(pos * fs + 0.001);
 	const double c1 = 2.0 / ratio / fs;
-	const double c2 = kPi * f0;
-	double cs0, sn0, csd, snd;
-	sincos(c2 * (c1 * (tid - hw)), &sn0, &cs0);
-	sincos(c2 * (c1 * T), &snd, &csd);
+	double cs0, sn0, csd, snd;  // angles in units of pi: no large-argument reduction code (and its registers)
+	sincospi(f0 * (c1 * (tid - hw)), &sn0, &cs0);
+	sincospi(f0 * (c1 * T), &snd, &csd);
+	snd = uniform_d(snd);
+	csd = uniform_d(csd);
 	auto win = [&](double c) { return type == 1 ? 0.5 * c + 0.5 : 0.42 + 0.5 * c + 0.08 * (2.0 * c * c - 1.0); };
 	// (select forms instead of conditional updates: predicated register updates inside the unrolled loops cost a
 	// register copy per value and iteration)
@@ -82,7 +86,7 @@ __device__ __forceinline__ int d4c_windowed(const double *__restrict__ x, int x_
 		}
 	}
 	block_sum2<T>(s1, s2, red, tid);
-	const double wc = s1 / s2;
+	const double wc = uniform_d(s1 / s2);
 	{
 		double c = cs0, sn = sn0;
 #pragma unroll
@@ -169,13 +173,13 @@ __global__ void d4c_lt_count_kernel(const double *__restrict__ f0, long long tot
 }
 
 template <int N, int T>
-__global__ __launch_bounds__(T) void d4c_lovetrain_kernel(D4cArgs a) {
+__global__ __launch_bounds__(T, T == 512 ? 6 : 1) void d4c_lovetrain_kernel(D4cArgs a) {
 	constexpr int M = N / 2;
 	constexpr int EPT = N / T;
 	__shared__ double2 A[fft_lds_size(M)];
 	__shared__ double red[2 * (T / 64) + 2];
 	double *Ar = reinterpret_cast<double *>(A);
-	const int tid = threadIdx.x;
+	int tid = threadIdx.x;
 	long long g = xcd_frame(blockIdx.x, a.total_frames);
 	if (g >= a.total_frames) return;
 	const int bins_out = a.fft_size_out / 2 + 1;
@@ -196,7 +200,9 @@ __global__ __launch_bounds__(T) void d4c_lovetrain_kernel(D4cArgs a) {
 			Ar[i] = (i < wl) ? wave[e] : 0.0;
 		}
 		__syncthreads();
+		WC_FRESH(tid);
 		fft_lds<M, T, +1>(A, a.tw, tid);
+		WC_FRESH(tid);
 		r2c_post<M, T>(A, a.tw, tid);
 		// cumulative powers above 100 Hz up to 4000 Hz and 7900 Hz (reference :184-186, :226-235)
 		const int b0 = (int)ceil(100.0 * N / fs);
@@ -229,19 +235,16 @@ __global__ __launch_bounds__(T, (2 * T) / 256) void d4c_frames_kernel(D4cArgs a)
 	constexpr int EPT = N / T;
 	constexpr int KPT = (M + 1 + T - 1) / T;  // power-spectrum keys per thread
 	// LDS: 32 KB + 2 x 16 KB at N = 4096 -> two workgroups per CU
-	__shared__ double2 A[fft_lds_size(M)];  // FFT workspace / cumulative segment / radix-select histograms
-	__shared__ double Br[M + 2];  // smoothed power spectrum, scratch of the last smoothing
+	__shared__ double2 A[fft_lds_size(M)];  // FFT workspace / cumulative segment
+	__shared__ double Br[M + 2];  // smoothed power spectrum, scratch of the last smoothing, radix-select histograms
 	__shared__ double Cc[M + 2];  // centroid -> static group delay
 	__shared__ double red[2 * (T / 64) + 2];
-	__shared__ unsigned long long sel_prefix[kMaxBands];
-	__shared__ unsigned int sel_k[kMaxBands];
-	__shared__ int sel_done[kMaxBands];
+	__shared__ double red3[3 * (T / 64)];
 	__shared__ double coarse[kMaxBands + 2];
 	double *Ar = reinterpret_cast<double *>(A);
-	unsigned int(*hist)[256] = reinterpret_cast<unsigned int(*)[256]>(A);
-	static_assert(sizeof(double2) * M >= sizeof(unsigned int) * 256 * kMaxBands, "histograms must fit in A");
 
-	const int tid = threadIdx.x;
+	int tid = threadIdx.x;
+#define WC_FRESH_TID() WC_FRESH(tid)  // see wc_device.hpp
 	long long g = xcd_frame(blockIdx.x, a.total_frames);
 	if (g >= a.total_frames) return;
 	const double f0v = a.f0[g];
@@ -250,13 +253,15 @@ __global__ __launch_bounds__(T, (2 * T) / 256) void d4c_frames_kernel(D4cArgs a)
 	const UttDesc ud = a.utts[u];
 	const double *__restrict__ x = a.x + ud.x_off;
 	const int fs = a.fs;
-	const double f0 = fmax(47.0, f0v);
-	const double pos = a.tpos[g];
+	const double f0 = uniform_d(fmax(47.0, f0v));
+	const double pos = uniform_d(a.tpos[g]);
 	const unsigned long long roff = a.rng_off[g] - a.rng_base;
 
 	// ---- static centroid (reference :339-405) ----
 	int wl = 0;
+#pragma unroll 1
 	for (int c = 0; c < 2; ++c) {
+		WC_FRESH_TID();
 		double wave[EPT];
 		const double p = (c == 0) ? pos - 0.25 / f0 : pos + 0.25 / f0;
 		wl = d4c_windowed<N, T>(x, ud.x_len, fs, f0, p, 2, 4.0, a.rng_table, roff + (unsigned long long)c * wl, wave, red, tid);
@@ -282,6 +287,7 @@ __global__ __launch_bounds__(T, (2 * T) / 256) void d4c_frames_kernel(D4cArgs a)
 			else if (k == M) s1[e] = make_double2(A[0].y, 0.0);
 		}
 		__syncthreads();
+		WC_FRESH_TID();
 #pragma unroll
 		for (int e = 0; e < EPT; ++e) {
 			int i = tid + e * T;
@@ -307,6 +313,7 @@ __global__ __launch_bounds__(T, (2 * T) / 256) void d4c_frames_kernel(D4cArgs a)
 
 	// ---- smoothed power spectrum (reference :411-434) ----
 	{
+		WC_FRESH_TID();
 		double wave[EPT];
 		wl = d4c_windowed<N, T>(x, ud.x_len, fs, f0, pos, 1, 4.0, a.rng_table, roff + 2ull * wl, wave, red, tid);
 #pragma unroll
@@ -326,6 +333,7 @@ __global__ __launch_bounds__(T, (2 * T) / 256) void d4c_frames_kernel(D4cArgs a)
 		linear_smoothing_lds<M, T>(Br, Ar, f0, fs, red, tid, [&](int k, double v) { Br[k] = v; });
 	}
 	// ---- static group delay (reference :440-460) ----
+	WC_FRESH_TID();
 	for (int k = tid; k <= M; k += T) Cc[k] = Cc[k] / Br[k];
 	__syncthreads();
 	linear_smoothing_lds<M, T>(Cc, Ar, f0 / 2.0, fs, red, tid, [&](int k, double v) { Cc[k] = v; });
@@ -340,63 +348,46 @@ __global__ __launch_bounds__(T, (2 * T) / 256) void d4c_frames_kernel(D4cArgs a)
 	const int boundary = mround(N * 8.0 / wln);
 	const int bins = M + 1;
 	const unsigned int K = (unsigned int)(bins - boundary - 1);  // sum of the K smallest powers
-	double key[kMaxBands][KPT];
+	// Per band: FFT of the Nuttall-windowed group delay, the power spectrum straight out of the real-FFT unpacking
+	// into registers (KEYS per thread), then a radix select (8 bits per pass, most significant first;
+	// non-negative doubles order like their bit patterns) of the K-th smallest power.  Every wave scans the
+	// pass's 256-bin histogram itself, so the prefix / rank live in wave-uniform registers and a pass costs a
+	// single barrier; a band stops as soon as its chosen bucket holds one element (typically 2-3 passes).
+	// Histograms: one 1 KB row per pass in Br (no longer needed).
+	constexpr int PAIRS = (M / 2) / T;
+	constexpr int KEYS = 2 * PAIRS + 1;  // last slot: bin M/2, thread 0 only
+	static_assert((M / 2) % T == 0, "pairs per thread");
+	unsigned int(*hist)[256] = reinterpret_cast<unsigned int(*)[256]>(Br);
 	for (int bnd = 0; bnd < n_ap; ++bnd) {
+		WC_FRESH_TID();
+		const int lane = tid & 63;
 		const int center = (int)(3000.0 * (bnd + 1) * N / fs);
 #pragma unroll
 		for (int e = 0; e < EPT; ++e) {
 			int i = tid + e * T;
 			Ar[i] = (i < wln) ? Cc[center - hwl + i] * a.nuttall[i] : 0.0;
 		}
+		for (int i = tid; i < 8 * 256; i += T) (&hist[0][0])[i] = 0u;
 		__syncthreads();
 		fft_lds<M, T, +1>(A, a.tw, tid);
-		r2c_post<M, T>(A, a.tw, tid);
+		double key[KEYS];
+		r2c_power<M, T>(A, a.tw, tid, key);
+		const int nkeys = (tid == 0) ? KEYS : KEYS - 1;
+		unsigned long long pre = 0ull;
+		unsigned int need = K, in_bucket = 0u;
+		int shift = 56;
+		for (int pass = 0; pass < 8; ++pass) {
+			shift = 56 - 8 * pass;
 #pragma unroll
-		for (int e = 0; e < KPT; ++e) {
-			int k = tid + e * T;
-			double p = 0.0;
-			if (k <= M) {
-				double2 v = A[k == M ? 0 : k];
-				p = (k == 0) ? v.x * v.x : (k == M) ? v.y * v.y : v.x * v.x + v.y * v.y;
-			}
-#pragma unroll
-			for (int bb = 0; bb < kMaxBands; ++bb) if (bb == bnd) key[bb][e] = p;
-		}
-		__syncthreads();
-	}
-	// radix select (8 bits per pass, most significant first) of the K-th smallest power of every band at
-	// once; non-negative doubles order like their bit patterns.
-	// A band is resolved as soon as its chosen bucket holds a single element (typically after 2-3 passes);
-	// that element's full bit pattern then replaces the prefix.
-	if (tid < kMaxBands) { sel_prefix[tid] = 0ull; sel_k[tid] = K; sel_done[tid] = (tid < n_ap) ? 0 : 1; }
-	__syncthreads();
-	for (int pass = 0; pass < 8; ++pass) {
-		if (sel_done[0] && sel_done[1] && sel_done[2] && sel_done[3] && sel_done[4]) break;  // block-uniform
-		const int shift = 56 - 8 * pass;
-		for (int i = tid; i < kMaxBands * 256; i += T) (&hist[0][0])[i] = 0u;
-		__syncthreads();
-#pragma unroll
-		for (int bb = 0; bb < kMaxBands; ++bb) {
-			if (bb < n_ap && !sel_done[bb]) {
-				const unsigned long long pre = sel_prefix[bb];
-#pragma unroll
-				for (int e = 0; e < KPT; ++e) {
-					int k = tid + e * T;
-					if (k <= M) {
-						unsigned long long bits = (unsigned long long)__double_as_longlong(key[bb][e]);
-						bool match = (pass == 0) || ((bits >> (shift + 8)) == (pre >> (shift + 8)));
-						if (match) atomicAdd(&hist[bb][(bits >> shift) & 255ull], 1u);
-					}
+			for (int e = 0; e < KEYS; ++e) {
+				if (e < nkeys) {
+					const unsigned long long bits = (unsigned long long)__double_as_longlong(key[e]);
+					const bool match = (pass == 0) || ((bits >> (shift + 8)) == (pre >> (shift + 8)));
+					if (match) atomicAdd(&hist[pass][(bits >> shift) & 255ull], 1u);
 				}
 			}
-		}
-		__syncthreads();
-		// digit search: wave w scans the 256-bin histograms of bands w, w + 4 (4 bins per lane)
-		for (int bb = tid >> 6; bb < n_ap; bb += T / 64) {
-			if (sel_done[bb]) continue;
-			const int lane = tid & 63;
-			const unsigned int need = sel_k[bb];
-			const uint4 h4 = reinterpret_cast<const uint4 *>(&hist[bb][0])[lane];
+			__syncthreads();
+			const uint4 h4 = reinterpret_cast<const uint4 *>(&hist[pass][0])[lane];
 			const unsigned int own = h4.x + h4.y + h4.z + h4.w;
 			unsigned int inc = own;
 #pragma unroll
@@ -406,65 +397,44 @@ __global__ __launch_bounds__(T, (2 * T) / 256) void d4c_frames_kernel(D4cArgs a)
 			}
 			const unsigned long long reach = __ballot(inc >= need);  // never empty: the total count >= need
 			const int first = __ffsll((long long)reach) - 1;
-			if (lane == first) {
-				unsigned int acc = inc - own;
-				int d = 4 * lane;
-				if (acc + h4.x >= need) { d += 0; }
-				else if (acc + h4.x + h4.y >= need) { acc += h4.x; d += 1; }
-				else if (acc + h4.x + h4.y + h4.z >= need) { acc += h4.x + h4.y; d += 2; }
-				else { acc += h4.x + h4.y + h4.z; d += 3; }
-				sel_k[bb] = need - acc;  // rank inside the chosen digit bucket
-				sel_prefix[bb] |= ((unsigned long long)d) << shift;
-				const unsigned int in_bucket = (d & 3) == 0 ? h4.x : (d & 3) == 1 ? h4.y : (d & 3) == 2 ? h4.z : h4.w;
-				sel_done[bb] = (in_bucket == 1u) ? 2 : 0;  // 2 = just resolved: fetch the element's full bits
+			unsigned int acc = inc - own;
+			unsigned int d = 4u * lane, cnt;
+			if (acc + h4.x >= need) { cnt = h4.x; }
+			else if (acc + h4.x + h4.y >= need) { acc += h4.x; d += 1; cnt = h4.y; }
+			else if (acc + h4.x + h4.y + h4.z >= need) { acc += h4.x + h4.y; d += 2; cnt = h4.z; }
+			else { acc += h4.x + h4.y + h4.z; d += 3; cnt = h4.w; }
+			acc = __shfl(acc, first, 64);
+			d = __shfl(d, first, 64);
+			in_bucket = __shfl(cnt, first, 64);
+			need -= acc;  // rank inside the chosen digit bucket
+			pre |= ((unsigned long long)d) << shift;
+			if (in_bucket == 1u) break;  // block-uniform: every wave derives the same values
+		}
+		// sum of the K smallest = sum(values below the bucket) + rank * v*, and the total.  v* is the one element of
+		// the bucket (its value = the sum over the matching elements), or the full bit pattern after 8 passes.
+		double low = 0.0, eq = 0.0, tot = 0.0;
+#pragma unroll
+		for (int e = 0; e < KEYS; ++e) {
+			if (e < nkeys) {
+				const double pw = key[e];
+				const unsigned long long hb = ((unsigned long long)__double_as_longlong(pw)) >> shift;
+				tot += pw;
+				low += (hb < (pre >> shift)) ? pw : 0.0;
+				eq += (hb == (pre >> shift)) ? pw : 0.0;
 			}
 		}
-		__syncthreads();
-#pragma unroll
-		for (int bb = 0; bb < kMaxBands; ++bb) {
-			if (bb < n_ap && sel_done[bb] == 2) {
-				const unsigned long long pre = sel_prefix[bb];
-#pragma unroll
-				for (int e = 0; e < KPT; ++e) {
-					int k = tid + e * T;
-					if (k <= M) {
-						unsigned long long bits = (unsigned long long)__double_as_longlong(key[bb][e]);
-						if ((bits >> shift) == (pre >> shift)) sel_prefix[bb] = bits;  // exactly one element matches
-					}
-				}
-			}
-		}
-		__syncthreads();
-		if (tid < kMaxBands && sel_done[tid] == 2) sel_done[tid] = 1;
-		__syncthreads();
-	}
-	// sum of the K smallest = sum(values < v*) + (remaining rank) * v*, and the total
-	for (int bb = 0; bb < n_ap; ++bb) {
-		const unsigned long long tb = sel_prefix[bb];
-		const double thr = __longlong_as_double((long long)tb);
-		double low = 0.0, tot = 0.0;
-#pragma unroll
-		for (int e = 0; e < KPT; ++e) {
-			int k = tid + e * T;
-			if (k <= M) {
-				double p = 0.0;
-#pragma unroll
-				for (int b2 = 0; b2 < kMaxBands; ++b2) if (b2 == bb) p = key[b2][e];
-				tot += p;
-				if (p < thr) low += p;
-			}
-		}
-		block_sum2<T>(low, tot, red, tid);
+		block_sum3<T>(low, eq, tot, red3, tid);
 		if (tid == 0) {
-			double part = low + (double)sel_k[bb] * thr;
-			double cv = 10 * log10(part / tot);
-			coarse[bb + 1] = fmin(0.0, cv + (f0 - 100) / 50.0);  // reference :326-328
+			const double thr = (in_bucket == 1u) ? eq : __longlong_as_double((long long)pre);
+			const double part = low + (double)need * thr;
+			const double cv = 10 * log10(part / tot);
+			coarse[bnd + 1] = fmin(0.0, cv + (f0 - 100) / 50.0);  // reference :326-328
 		}
-		__syncthreads();
 	}
 	if (tid == 0) { coarse[0] = -60.0; coarse[n_ap + 1] = -kSafe; }
 	__syncthreads();
 	// ---- interp1 onto the output grid + dB -> linear (reference :162-168) ----
+	WC_FRESH_TID();
 	const int bins_out = a.fft_size_out / 2 + 1;
 	double *__restrict__ row = a.ap + g * (long long)bins_out;
 	const int na = n_ap + 2;
@@ -480,6 +450,8 @@ __global__ __launch_bounds__(T, (2 * T) / 256) void d4c_frames_kernel(D4cArgs a)
 		row[k] = pow(10.0, v / 20.0);
 	}
 }
+
+#undef WC_FRESH_TID
 
 }  // namespace wc
 

@@ -74,6 +74,37 @@ __device__ __forceinline__ void block_sum2(double &a, double &b, double *scratch
 	a = sa;
 	b = sb;
 }
+// Thread-index arithmetic (LDS addresses of every FFT pass, index -> double conversions ...) is loop/phase invariant, so
+// the compiler computes all of it up front and keeps -- or spills -- it for the whole kernel.  An opaque copy of the
+// index per phase keeps those values short-lived; they cost a few integer instructions to recompute.
+#define WC_FRESH(v) asm volatile("" : "+v"(v))
+// A wave-uniform double moved to scalar registers: loop-invariant uniform values otherwise sit in (and spill from)
+// vector registers, one copy per lane, because f64 arithmetic is vector-only.
+__device__ __forceinline__ double uniform_d(double v) {
+	const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+	const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+	return __hiloint2double(hi, lo);
+}
+// Three sums at once.  scratch: >= 3 * T/64 doubles.
+template <int T>
+__device__ __forceinline__ void block_sum3(double &a, double &b, double &c, double *scratch, int tid) {
+	a = wave_sum(a);
+	b = wave_sum(b);
+	c = wave_sum(c);
+	__syncthreads();
+	if ((tid & 63) == 0) {
+		scratch[tid >> 6] = a;
+		scratch[T / 64 + (tid >> 6)] = b;
+		scratch[2 * (T / 64) + (tid >> 6)] = c;
+	}
+	__syncthreads();
+	double sa = 0.0, sb = 0.0, sc = 0.0;
+#pragma unroll
+	for (int w = 0; w < T / 64; ++w) { sa += scratch[w]; sb += scratch[T / 64 + w]; sc += scratch[2 * (T / 64) + w]; }
+	a = sa;
+	b = sb;
+	c = sc;
+}
 // Exclusive scan of one value per thread across the block.  scratch: >= T/64 doubles.
 template <int T>
 __device__ __forceinline__ double block_excl_scan(double v, double *scratch, int tid) {
@@ -157,9 +188,29 @@ __device__ __forceinline__ void dft8(double2 (&x)[8]) {
 	x[3] = cadd(e[3], o3);   x[7] = csub(e[3], o3);
 }
 
+// The twiddles a thread needs are the same for every transform of one size, so the compiler would load them once
+// per kernel and pin them in registers (about 60 VGPRs for M = 2048) -- which costs more in spills / occupancy
+// than re-reading them from the (L1/L2 resident) table.  Laundering the table pointer per call prevents that.
+// WC_FFT_TW: 0 = launder per pass (twiddles loaded pass by pass), 1 = per transform (the compiler may prefetch a
+// whole transform's twiddles), 2 = never (pinned for the kernel).
+#ifndef WC_FFT_TW
+#define WC_FFT_TW 1
+#endif
+__device__ __forceinline__ const double2 *tw_fresh(const double2 *tw) {
+#if WC_FFT_TW < 2
+	asm volatile("" : "+s"(tw));
+#endif
+	return tw;
+}
+
 // one Stockham pass of radix R with Ns = product of the earlier radices
 template <int M, int T, int S, int R, int Ns>
-__device__ __forceinline__ void fft_pass(double2 *a, const double2 *__restrict__ tw, int tid) {
+__device__ __forceinline__ void fft_pass(double2 *a, const double2 *__restrict__ tw_, int tid) {
+#if WC_FFT_TW == 0
+	const double2 *__restrict__ tw = tw_fresh(tw_);
+#else
+	const double2 *__restrict__ tw = tw_;
+#endif
 	constexpr int NB = M / R;
 	constexpr int BPT = (NB + T - 1) / T;
 	constexpr int tstride = kTwiddleN / (R * Ns);  // W_{R Ns}^k = tw[k * tstride]
@@ -219,8 +270,9 @@ __device__ __forceinline__ void fft_chain(double2 *a, const double2 *__restrict_
 }
 
 template <int M, int T, int S>
-__device__ void fft_lds(double2 *a, const double2 *__restrict__ tw, int tid) {
+__device__ void fft_lds(double2 *a, const double2 *__restrict__ tw_, int tid) {
 	static_assert((M & (M - 1)) == 0 && M >= 16 && M <= kTwiddleN, "M must be a power of two in [16, 4096]");
+	const double2 *__restrict__ tw = tw_fresh(tw_);
 	fft_chain<M, T, S, 1>(a, tw, tid);
 }
 
@@ -228,8 +280,9 @@ __device__ void fft_lds(double2 *a, const double2 *__restrict__ tw, int tid) {
 // After fft_lds<M,T,+1> on that array, unpack to the spectrum X[0..M] (reference r2c convention).
 // Packed in place: a[0] = (X[0].re, X[M].re); a[k] = X[k] for 0 < k < M.  Ends with a __syncthreads().
 template <int M, int T>
-__device__ void r2c_post(double2 *a, const double2 *__restrict__ tw, int tid) {
+__device__ void r2c_post(double2 *a, const double2 *__restrict__ tw_, int tid) {
 	constexpr int TS = kTwiddleN / (2 * M);  // W_N^k = tw[k * TS]
+	const double2 *__restrict__ tw = tw_fresh(tw_);
 	// pairs (k, M-k), k = 1 .. M/2-1 ; k = 0 and k = M/2 handled apart
 	for (int k = tid; k <= M / 2; k += T) {
 		if (k == 0) {
@@ -250,11 +303,36 @@ __device__ void r2c_post(double2 *a, const double2 *__restrict__ tw, int tid) {
 	}
 	__syncthreads();
 }
+// Power spectrum |X[k]|^2, k = 0..M, straight from the half-size FFT output into registers, with the arithmetic of
+// r2c_post followed by re^2 + im^2.  Thread t gets the bin pairs (k, M-k) for k = t + e T (k = 0: bins 0 and M) in
+// key[2e], key[2e+1]; thread 0 also gets bin M/2 in the last slot (unused on the other threads).  Read-only on a.
+template <int M, int T>
+__device__ __forceinline__ void r2c_power(const double2 *a, const double2 *__restrict__ tw_, int tid,
+										  double (&key)[2 * ((M / 2) / T) + 1]) {
+	constexpr int TS = kTwiddleN / (2 * M);
+	const double2 *__restrict__ tw = tw_fresh(tw_);
+	constexpr int PAIRS = (M / 2) / T;
+#pragma unroll
+	for (int e = 0; e < PAIRS; ++e) {
+		const int k = tid + e * T;
+		const double2 zk = a[k], zm = a[(M - k) & (M - 1)];
+		const double2 ev = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
+		const double2 od = make_double2(0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x));
+		const double2 wo = cmul(tw[k * TS], od);
+		const double2 xk = cadd(ev, wo), xm = csub(ev, wo);
+		const double r0 = zk.x + zk.y, rm = zk.x - zk.y;  // k = 0: X[0], X[M] (both real)
+		key[2 * e] = (k == 0) ? r0 * r0 : xk.x * xk.x + xk.y * xk.y;
+		key[2 * e + 1] = (k == 0) ? rm * rm : xm.x * xm.x + xm.y * xm.y;
+	}
+	const double2 zh = a[M / 2];
+	key[2 * PAIRS] = zh.x * zh.x + zh.y * zh.y;
+}
 // Inverse of the above: a holds the packed spectrum Y (a[0] = (Y[0].re, Y[M].re)); produce Z so that
 // fft_lds<M,T,-1> yields the real signal y[n] interleaved (reference c2r convention, unnormalised).
 template <int M, int T>
-__device__ void c2r_pre(double2 *a, const double2 *__restrict__ tw, int tid) {
+__device__ void c2r_pre(double2 *a, const double2 *__restrict__ tw_, int tid) {
 	constexpr int TS = kTwiddleN / (2 * M);
+	const double2 *__restrict__ tw = tw_fresh(tw_);
 	for (int k = tid; k <= M / 2; k += T) {
 		if (k == 0) {
 			double2 y = a[0];

@@ -294,6 +294,7 @@ __device__ __forceinline__ void minimum_phase_lds(double2 *A, const double (&ls)
 	constexpr int M = N / 2;
 	constexpr int BPT = (M + T) / T;
 	double *Ar = reinterpret_cast<double *>(A);
+	WC_FRESH(tid);
 #pragma unroll
 	for (int e = 0; e < BPT; ++e) {
 		int k = tid + e * T;
@@ -305,6 +306,7 @@ __device__ __forceinline__ void minimum_phase_lds(double2 *A, const double (&ls)
 	__syncthreads();
 	fft_lds<M, T, +1>(A, tw, tid);
 	r2c_post<M, T>(A, tw, tid);
+	WC_FRESH(tid);
 	// cepstrum folding (reference :207-217): bins 1..M-1 doubled and conjugated, upper half zeroed
 	double2 c[BPT];
 #pragma unroll
@@ -324,6 +326,7 @@ __device__ __forceinline__ void minimum_phase_lds(double2 *A, const double (&ls)
 	}
 	__syncthreads();
 	fft_lds<N, T, +1>(A, tw, tid);
+	WC_FRESH(tid);
 #pragma unroll
 	for (int e = 0; e < BPT; ++e) {
 		int k = tid + e * T;
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(T) void syn_pulse_kernel(SynArgs a) {
 	__shared__ double2 A[fft_lds_size(N)];
 	__shared__ double red[2 * (T / 64) + 2];
 	double *Ar = reinterpret_cast<double *>(A);
-	const int tid = threadIdx.x;
+	int tid = threadIdx.x;
 	const long long gp = blockIdx.x;
 	if (gp >= a.pulse_prefix[a.n_utt]) return;
 	if (a.only_pulse >= 0 && gp != a.only_pulse) return;
@@ -406,6 +409,7 @@ __global__ __launch_bounds__(T) void syn_pulse_kernel(SynArgs a) {
 	__syncthreads();
 
 	// ---- periodic response (reference :403-474) ----
+	WC_FRESH(tid);
 	double periodic[EPT];
 #pragma unroll
 	for (int e = 0; e < EPT; ++e) periodic[e] = 0.0;
@@ -414,6 +418,7 @@ __global__ __launch_bounds__(T) void syn_pulse_kernel(SynArgs a) {
 		for (int e = 0; e < BPT; ++e) ls[e] = log(env[e] * (1.0 - ar[e]) + kSafe) / 2.0;
 		minimum_phase_lds<N, T>(A, ls, a.tw, tid);
 		// fractional time shift (reference :443-457), then pack for c2r
+		WC_FRESH(tid);
 		const double coef = 2.0 * kPi * shift * fs / N;
 		double2 sp_[BPT];
 #pragma unroll
@@ -438,6 +443,7 @@ __global__ __launch_bounds__(T) void syn_pulse_kernel(SynArgs a) {
 		__syncthreads();
 		c2r_pre<M, T>(A, a.tw, tid);
 		fft_lds<M, T, -1>(A, a.tw, tid);
+		WC_FRESH(tid);
 		// fftshift + DC removal (reference :459-474): dc = sum of the shifted second half = sum wave[0..M)
 		double part = 0.0;
 		for (int i = tid; i < M; i += T) part += Ar[i];
@@ -453,6 +459,7 @@ __global__ __launch_bounds__(T) void syn_pulse_kernel(SynArgs a) {
 
 	// ---- aperiodic response (reference :479-530) ----
 	{
+		WC_FRESH(tid);
 		const unsigned long long rstart = a.rng_start ? a.rng_start[u] : ud.rng_pos;
 		const unsigned long long roff = rstart + (unsigned long long)(pidx - a.first_index[u]) - a.rng_base;
 		double nz[EPT];
@@ -473,6 +480,7 @@ __global__ __launch_bounds__(T) void syn_pulse_kernel(SynArgs a) {
 		__syncthreads();
 		fft_lds<M, T, +1>(A, a.tw, tid);
 		r2c_post<M, T>(A, a.tw, tid);
+		WC_FRESH(tid);
 		double2 ns[BPT];
 #pragma unroll
 		for (int e = 0; e < BPT; ++e) {
@@ -491,6 +499,7 @@ __global__ __launch_bounds__(T) void syn_pulse_kernel(SynArgs a) {
 			for (int e = 0; e < BPT; ++e) ls[e] = log(env[e]) / 2.0;
 		}
 		minimum_phase_lds<N, T>(A, ls, a.tw, tid);
+		WC_FRESH(tid);
 		double2 pr[BPT];
 #pragma unroll
 		for (int e = 0; e < BPT; ++e) {
@@ -514,6 +523,7 @@ __global__ __launch_bounds__(T) void syn_pulse_kernel(SynArgs a) {
 		fft_lds<M, T, -1>(A, a.tw, tid);
 	}
 	// ---- mix + overlap-add (reference :339-343, :118-139) ----
+	WC_FRESH(tid);
 	const double sq = sqrt((double)noise_size);
 	double *__restrict__ out = a.out + ud.y_off;
 	const int index = pidx - M;
