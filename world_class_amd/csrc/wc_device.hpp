@@ -204,7 +204,7 @@ __device__ __forceinline__ const double2 *tw_fresh(const double2 *tw) {
 }
 
 // one Stockham pass of radix R with Ns = product of the earlier radices
-template <int M, int T, int S, int R, int Ns>
+template <int M, int T, int S, int R, int Ns, bool SY = true>
 __device__ __forceinline__ void fft_pass(double2 *a, const double2 *__restrict__ tw_, int tid) {
 #if WC_FFT_TW == 0
 	const double2 *__restrict__ tw = tw_fresh(tw_);
@@ -235,7 +235,7 @@ __device__ __forceinline__ void fft_pass(double2 *a, const double2 *__restrict__
 			for (int r = 0; r < R; ++r) v[b][r] = a[fft_pad(j + r * NB, Ns > 1)];
 		}
 	}
-	__syncthreads();
+	if (SY) __syncthreads();
 #pragma unroll
 	for (int b = 0; b < BPT; ++b) {
 		const int j = tid + b * T;
@@ -253,10 +253,10 @@ __device__ __forceinline__ void fft_pass(double2 *a, const double2 *__restrict__
 			for (int r = 0; r < R; ++r) a[fft_pad(j0 + r * Ns, Ns * R < M)] = v[b][r];
 		}
 	}
-	__syncthreads();
+	if (SY) __syncthreads();
 }
 
-template <int M, int T, int S, int Ns>
+template <int M, int T, int S, int Ns, bool SY = true>
 __device__ __forceinline__ void fft_chain(double2 *a, const double2 *__restrict__ tw, int tid) {
 	if constexpr (Ns < M) {
 		// radix 4 throughout, with a leading twiddle-free radix-2 pass when log2(M) is odd (radix-8 passes were
@@ -264,16 +264,16 @@ __device__ __forceinline__ void fft_chain(double2 *a, const double2 *__restrict_
 		constexpr int rem = M / Ns;
 		constexpr bool odd = (__builtin_ctz(M) & 1) != 0;
 		constexpr int R = (Ns == 1 && odd) ? 2 : (rem >= 4 ? 4 : rem);
-		fft_pass<M, T, S, R, Ns>(a, tw, tid);
-		fft_chain<M, T, S, Ns * R>(a, tw, tid);
+		fft_pass<M, T, S, R, Ns, SY>(a, tw, tid);
+		fft_chain<M, T, S, Ns * R, SY>(a, tw, tid);
 	}
 }
 
-template <int M, int T, int S>
+template <int M, int T, int S, bool SY = true>
 __device__ void fft_lds(double2 *a, const double2 *__restrict__ tw_, int tid) {
 	static_assert((M & (M - 1)) == 0 && M >= 16 && M <= kTwiddleN, "M must be a power of two in [16, 4096]");
 	const double2 *__restrict__ tw = tw_fresh(tw_);
-	fft_chain<M, T, S, 1>(a, tw, tid);
+	fft_chain<M, T, S, 1, SY>(a, tw, tid);
 }
 
 // ---- real FFT of N = 2M points held as M interleaved complex (x[2k], x[2k+1]) -----------------------

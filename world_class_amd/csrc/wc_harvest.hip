@@ -322,14 +322,15 @@ __device__ __forceinline__ int hv_count_le(E e, int lo, int hi, double fs, doubl
 }
 
 constexpr int RAW_T = 256;      // frames per workgroup
-constexpr int RAW_LDS = 1024;   // staged fine edges per type
+constexpr int RAW_LDS = 512;    // staged intervals per type
 
 // One workgroup per (utterance, band, 256 consecutive 1 ms frames).  The fine edges that can matter for these
-// frames form a short contiguous slice of each of the four event lists; wave `ty` locates and stages the slice
-// of type `ty` in LDS, then every thread interpolates its frame from LDS (falling back to the global lists if
-// a slice does not fit).
+// frames form a short contiguous slice of each of the four event lists; wave `ty` locates the slice of type `ty`
+// and stages its intervals in LDS as (midpoint time, interval frequency) pairs -- the divisions of reference
+// :1210-1213 done once per interval instead of once per frame and probe -- then every thread interpolates its
+// frame from LDS (falling back to the global lists if a slice does not fit).
 __global__ __launch_bounds__(RAW_T) void hv_raw_kernel(RawArgs a) {
-	__shared__ double E[4][RAW_LDS];
+	__shared__ double X[4][RAW_LDS], Y[4][RAW_LDS];
 	__shared__ int s_base[4], s_len[4];
 	const int tid = threadIdx.x, lane = tid & 63, ty_w = tid >> 6;
 	const int band = blockIdx.y;
@@ -356,8 +357,7 @@ __global__ __launch_bounds__(RAW_T) void hv_raw_kernel(RawArgs a) {
 	}
 	const double fs = a.fs_d;
 	{
-		// wave ty_w stages the slice of list ty_w that can matter for frames i0 .. i1: the band-pass kernel recorded
-		// how many edges precede every tile, so the slice is bounded without searching
+		// the band-pass kernel recorded how many edges precede every tile, so the slice is bounded without searching
 		const int ty = ty_w;
 		const double *__restrict__ e = ev + (long long)ty * cap;
 		const int *__restrict__ trun = a.tile_run + ((long long)blockIdx.z * a.n_bands + band) * (a.n_tiles + 1) * 4;
@@ -367,10 +367,14 @@ __global__ __launch_bounds__(RAW_T) void hv_raw_kernel(RawArgs a) {
 		const int ce = n[ty] + 1;  // edges in the list
 		const int base = max(0, min(trun[q0 * 4 + ty], ce) - 4);
 		const int end = min(ce, min(trun[q1 * 4 + ty], ce) + 4);
-		const int len = end - base;
+		const int len = end - base - 1;  // staged intervals base .. base + len - 1
 		if (lane == 0) { s_base[ty] = (len <= RAW_LDS) ? base : -1; s_len[ty] = len; }
 		if (len <= RAW_LDS)
-			for (int j = lane; j < len; j += 64) E[ty][j] = e[base + j];
+			for (int j = lane; j < len; j += 64) {
+				const double ea = e[base + j], eb = e[base + j + 1];
+				X[ty][j] = (ea + eb) / 2.0 / fs;
+				Y[ty][j] = fs / (eb - ea);
+			}
 	}
 	__syncthreads();
 	if (i >= u.L1) return;
@@ -380,21 +384,24 @@ __global__ __launch_bounds__(RAW_T) void hv_raw_kernel(RawArgs a) {
 	for (int ty = 0; ty < 4; ++ty) {  // (a + b + c + d) in the reference's order: negative-going, positive-going, peaks, dips
 		const double *__restrict__ e = ev + (long long)ty * cap;
 		const int base = s_base[ty];
-		int k;
-		double e0, e1, e2;
+		double x0, x1, y0, y1;
 		bool staged = false;
 		if (base >= 0) {
-			// count within the staged slice, valid only if the answer is strictly inside it (otherwise the true
-			// boundary may lie outside: fall back to the whole list)
-			const double *el = E[ty];
+			// c = #{k < n : X[k] <= t} within the staged intervals, valid only if the answer is strictly inside them
+			// (otherwise the true boundary may lie outside: fall back to the whole list)
+			const double *xs = X[ty];
 			const int len = s_len[ty];
-			auto es = [&](int q) { return el[q - base]; };
-			const int lo = base, hi = min(n[ty], base + len - 1);  // k with e[k], e[k+1] staged
-			const int c = hv_count_le(es, lo, hi, fs, t);
-			if ((c > lo || lo == 0) && (c < hi || hi == n[ty])) {
-				k = min(max(c, 1), n[ty] - 1);
-				if (k - 1 >= base && k + 1 < base + len) {
-					e0 = es(k - 1); e1 = es(k); e2 = es(k + 1);
+			int lo = 0, hi = len;
+			while (lo < hi) {
+				const int mid = (lo + hi) >> 1;
+				if (xs[mid] <= t) lo = mid + 1; else hi = mid;
+			}
+			const int c = base + lo;
+			if ((lo > 0 || base == 0) && (lo < len || base + len == n[ty])) {
+				const int k = min(max(c, 1), n[ty] - 1) - base;  // interp1 between intervals k - 1 and k
+				if (k >= 1 && k < len) {
+					x0 = xs[k - 1]; x1 = xs[k];
+					y0 = Y[ty][k - 1]; y1 = Y[ty][k];
 					staged = true;
 				}
 			}
@@ -402,13 +409,13 @@ __global__ __launch_bounds__(RAW_T) void hv_raw_kernel(RawArgs a) {
 		if (!staged) {
 			auto eg = [&](int q) { return e[q]; };
 			const int c = hv_count_le(eg, 0, n[ty], fs, t);
-			k = min(max(c, 1), n[ty] - 1);
-			e0 = e[k - 1]; e1 = e[k]; e2 = e[k + 1];
+			const int k = min(max(c, 1), n[ty] - 1);
+			const double e0 = e[k - 1], e1 = e[k], e2 = e[k + 1];
+			x0 = (e0 + e1) / 2.0 / fs; x1 = (e1 + e2) / 2.0 / fs;
+			y0 = fs / (e1 - e0); y1 = fs / (e2 - e1);
 		}
 		// interp1 (reference src/world_matlabfunctions.cpp:157-182) of the intervals fs / (e[k+1] - e[k]) located
 		// at the midpoints (reference src/harvest.cpp:1210-1213)
-		const double x0 = (e0 + e1) / 2.0 / fs, x1 = (e1 + e2) / 2.0 / fs;
-		const double y0 = fs / (e1 - e0), y1 = fs / (e2 - e1);
 		const double sl = (t - x0) / (x1 - x0);
 		const double v = y0 + sl * (y1 - y0);
 		s = (ty == 0) ? v : s + v;
@@ -515,20 +522,19 @@ __global__ __launch_bounds__(256) void hv_refine_kernel(RefArgs a) {
 			}
 			const double2 r1 = a.rot[2 * hw], r8 = a.rot[2 * hw + 1];  // (cos, sin) of beta and 8 beta, beta = 2 pi / (2 hw + 1)
 			const double k1 = 0.5 * r1.y, k2 = 0.16 * (2.0 * r1.y * r1.x);
-			double2 t[6], st[6];
+			// DFT bins of the lane's sub-sequence n = sub + 8 q by Goertzel's recurrence s_q = x_q + 2 cos(w) s_{q-1} - s_{q-2}
+			// (w = 8 phi_h): two instructions per sample, harmonic and window instead of the four plus a twiddle rotation
+			// of a direct accumulation.  sum_q x_q e^{-i w q} = e^{-i w (Q-1)} (s_{Q-1} - e^{-i w} s_{Q-2}); with the lane's
+			// own phase e^{-i phi sub} both factors are exact table twiddles.  The loop is unrolled by two so the
+			// (s_{q-1}, s_{q-2}) pair alternates between two register sets; trailing zero samples are harmless.
+			double c2[6];
 #pragma unroll
-			for (int h = 0; h < 6; ++h) {
-				const double2 t0 = a.tw[((idx[h] * sub) & (N - 1)) * tsh];
-				const double2 s0 = a.tw[((idx[h] * 8) & (N - 1)) * tsh];
-				t[h] = make_double2(t0.x, -t0.y);   // e^{-i theta}
-				st[h] = make_double2(s0.x, -s0.y);
-			}
-			double v[32];
+			for (int h = 0; h < 6; ++h) c2[h] = 2.0 * a.tw[((idx[h] * 8) & (N - 1)) * tsh].x;
+			double sa[12], sb[12];  // [2 h] main window, [2 h + 1] difference window; sa = newest after a full trip
 #pragma unroll
-			for (int k = 0; k < 32; ++k) v[k] = 0.0;
-			// (no per-lane control flow inside the loop: a lane past its window multiplies by a zero sample, which
-			// keeps every accumulator and rotation in place in its registers)
-			for (int n = sub; __ballot(n < bt) != 0ull; n += 8) {
+			for (int k = 0; k < 12; ++k) { sa[k] = 0.0; sb[k] = 0.0; }
+			// (no per-lane control flow inside the loop: a lane past its window feeds zero samples)
+			auto sample = [&](int n, double &xm, double &xd) {
 				// Blackman window 0.42 + 0.5 cos + 0.08 cos 2theta = 0.34 + c (0.5 + 0.16 c); its centred difference
 				// -(w[n+1] - w[n-1]) / 2 = sin theta (0.5 sin beta + 0.16 sin 2beta cos theta) in the interior, the
 				// one-sided forms of reference :797-798 at the two ends
@@ -539,18 +545,40 @@ __global__ __launch_bounds__(256) void hv_refine_kernel(RefArgs a) {
 				double d = ws * fma(k2, wc, k1);
 				d = first ? -mnb / 2.0 : (last ? mnb / 2.0 : d);
 				const double yv = (n < bt) ? y[clampi(basic + n - 1, 0, u.y_len - 1)] : 0.0;
-				const double xm = m * yv, xd = d * yv;
-#pragma unroll
-				for (int h = 0; h < 6; ++h) {
-					v[4 * h + 0] = fma(xm, t[h].x, v[4 * h + 0]);
-					v[4 * h + 1] = fma(xm, t[h].y, v[4 * h + 1]);
-					v[4 * h + 2] = fma(xd, t[h].x, v[4 * h + 2]);
-					v[4 * h + 3] = fma(xd, t[h].y, v[4 * h + 3]);
-					t[h] = cmul(t[h], st[h]);
-				}
+				xm = m * yv;
+				xd = d * yv;
 				const double nc_ = fma(wc, r8.x, -(ws * r8.y));
 				ws = fma(ws, r8.x, wc * r8.y);
 				wc = nc_;
+			};
+			int Q = 0;
+			for (int n = sub; __ballot(n < bt) != 0ull; n += 16) {
+				double xm, xd;
+				sample(n, xm, xd);
+#pragma unroll
+				for (int h = 0; h < 6; ++h) {
+					sb[2 * h] = fma(c2[h], sa[2 * h], xm) - sb[2 * h];
+					sb[2 * h + 1] = fma(c2[h], sa[2 * h + 1], xd) - sb[2 * h + 1];
+				}
+				sample(n + 8, xm, xd);
+#pragma unroll
+				for (int h = 0; h < 6; ++h) {
+					sa[2 * h] = fma(c2[h], sb[2 * h], xm) - sa[2 * h];
+					sa[2 * h + 1] = fma(c2[h], sb[2 * h + 1], xd) - sa[2 * h + 1];
+				}
+				Q += 2;
+			}
+			double v[32];
+#pragma unroll
+			for (int k = 24; k < 32; ++k) v[k] = 0.0;
+#pragma unroll
+			for (int h = 0; h < 6; ++h) {
+				const double2 e1 = a.tw[((idx[h] * (sub + 8 * (Q - 1))) & (N - 1)) * tsh];  // conj = e^{-i phi (sub + 8 (Q-1))}
+				const double2 e2 = a.tw[((idx[h] * (sub + 8 * Q)) & (N - 1)) * tsh];
+				v[4 * h + 0] = sa[2 * h] * e1.x - sb[2 * h] * e2.x;
+				v[4 * h + 1] = sb[2 * h] * e2.y - sa[2 * h] * e1.y;
+				v[4 * h + 2] = sa[2 * h + 1] * e1.x - sb[2 * h + 1] * e2.x;
+				v[4 * h + 3] = sb[2 * h + 1] * e2.y - sa[2 * h + 1] * e1.y;
 			}
 			// halving butterfly inside the 8-lane group: afterwards lane `sub` holds v[4 sub .. 4 sub + 3]
 #pragma unroll

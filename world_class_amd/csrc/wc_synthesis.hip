@@ -332,8 +332,9 @@ __device__ __forceinline__ void minimum_phase_lds(double2 *A, const double (&ls)
 		int k = tid + e * T;
 		if (k <= M) {
 			double2 m = A[k];
-			double t = exp(m.x / N);
-			c[e] = make_double2(t * cos(m.y / N), t * sin(m.y / N));
+			double t = exp(m.x / N), sn, cs;
+			sincos(m.y / N, &sn, &cs);
+			c[e] = make_double2(t * cs, t * sn);
 		}
 	}
 	__syncthreads();
