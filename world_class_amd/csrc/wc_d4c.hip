@@ -230,7 +230,7 @@ __global__ __launch_bounds__(T, T == 512 ? 6 : 1) void d4c_lovetrain_kernel(D4cA
 }
 
 #ifndef WC_D4C_FFTSYNC
-#define WC_D4C_FFTSYNC true  // (false: timing ablation only, wrong results)
+#define WC_D4C_FFTSYNC 1  // FFT flags; 0 (no barriers) and 3 (no twiddle loads) are timing ablations with wrong results
 #endif
 template <int N, int T>
 __global__ __launch_bounds__(T, (2 * T) / 256) void d4c_frames_kernel(D4cArgs a) {
@@ -313,6 +313,10 @@ __global__ __launch_bounds__(T, (2 * T) / 256) void d4c_frames_kernel(D4cArgs a)
 		__syncthreads();
 	}
 	dc_correction_lds<M, T>(Cc, f0, fs, tid);
+#if defined(WC_D4C_STOP) && WC_D4C_STOP == 1
+	if (tid == 0) a.ap[g * (long long)(a.fft_size_out / 2 + 1)] = Cc[1] + Br[1];
+	return;
+#endif
 
 	// ---- smoothed power spectrum (reference :411-434) ----
 	{
@@ -335,6 +339,10 @@ __global__ __launch_bounds__(T, (2 * T) / 256) void d4c_frames_kernel(D4cArgs a)
 		dc_correction_lds<M, T>(Br, f0, fs, tid);
 		linear_smoothing_lds<M, T>(Br, Ar, f0, fs, red, tid, [&](int k, double v) { Br[k] = v; });
 	}
+#if defined(WC_D4C_STOP) && WC_D4C_STOP == 2
+	if (tid == 0) a.ap[g * (long long)(a.fft_size_out / 2 + 1)] = Cc[1] + Br[1];
+	return;
+#endif
 	// ---- static group delay (reference :440-460) ----
 	WC_FRESH_TID();
 	for (int k = tid; k <= M; k += T) Cc[k] = Cc[k] / Br[k];
@@ -344,6 +352,10 @@ __global__ __launch_bounds__(T, (2 * T) / 256) void d4c_frames_kernel(D4cArgs a)
 	for (int k = tid; k <= M; k += T) Cc[k] -= Br[k];
 	__syncthreads();
 
+#if defined(WC_D4C_STOP) && WC_D4C_STOP == 3
+	if (tid == 0) a.ap[g * (long long)(a.fft_size_out / 2 + 1)] = Cc[1] + Br[1];
+	return;
+#endif
 	// ---- coarse aperiodicity (reference :466-503) ----
 	const int n_ap = a.n_ap;
 	const int wln = a.window_length;
@@ -372,22 +384,40 @@ __global__ __launch_bounds__(T, (2 * T) / 256) void d4c_frames_kernel(D4cArgs a)
 		}
 		for (int i = tid; i < 8 * 256; i += T) (&hist[0][0])[i] = 0u;
 		__syncthreads();
+#ifndef WC_D4C_NOBANDFFT
 		fft_lds<M, T, +1, WC_D4C_FFTSYNC>(A, a.tw, tid);
+#endif
 		double key[KEYS];
 		r2c_power<M, T>(A, a.tw, tid, key);
 		const int nkeys = (tid == 0) ? KEYS : KEYS - 1;
 		unsigned long long pre = 0ull;
 		unsigned int need = K, in_bucket = 0u;
 		int shift = 56;
-		for (int pass = 0; pass < 8; ++pass) {
+#ifndef WC_D4C_NPASS
+#define WC_D4C_NPASS 8
+#endif
+		for (int pass = 0; pass < WC_D4C_NPASS; ++pass) {
 			shift = 56 - 8 * pass;
 #pragma unroll
 			for (int e = 0; e < KEYS; ++e) {
-				if (e < nkeys) {
-					const unsigned long long bits = (unsigned long long)__double_as_longlong(key[e]);
-					const bool match = (pass == 0) || ((bits >> (shift + 8)) == (pre >> (shift + 8)));
-					if (match) atomicAdd(&hist[pass][(bits >> shift) & 255ull], 1u);
+				const unsigned long long bits = (unsigned long long)__double_as_longlong(key[e]);
+				bool match = (e < nkeys) && ((pass == 0) || ((bits >> (shift + 8)) == (pre >> (shift + 8))));
+				const unsigned int bucket = (unsigned int)((bits >> shift) & 255ull);
+				// The leading digits are shared by nearly all keys (same exponent range): 64 lanes adding to one LDS
+				// word serialise.  The two most common buckets of the wave are counted by ballot, one add each.
+				unsigned long long act = __ballot(match);
+#pragma unroll
+				for (int it = 0; it < 2; ++it) {
+					if (act != 0ull) {  // wave-uniform
+						const int leader = __ffsll((long long)act) - 1;
+						const unsigned int bl = __shfl(bucket, leader, 64);
+						const unsigned long long same = __ballot(match && bucket == bl);
+						if (lane == leader) atomicAdd(&hist[pass][bl], (unsigned int)__popcll(same));
+						act &= ~same;
+						match = match && bucket != bl;
+					}
 				}
+				if (match) atomicAdd(&hist[pass][bucket], 1u);
 			}
 			__syncthreads();
 			const uint4 h4 = reinterpret_cast<const uint4 *>(&hist[pass][0])[lane];
@@ -436,6 +466,10 @@ __global__ __launch_bounds__(T, (2 * T) / 256) void d4c_frames_kernel(D4cArgs a)
 	}
 	if (tid == 0) { coarse[0] = -60.0; coarse[n_ap + 1] = -kSafe; }
 	__syncthreads();
+#if defined(WC_D4C_STOP) && WC_D4C_STOP == 4
+	if (tid == 0) a.ap[g * (long long)(a.fft_size_out / 2 + 1)] = Cc[1] + Br[1];
+	return;
+#endif
 	// ---- interp1 onto the output grid + dB -> linear (reference :162-168) ----
 	WC_FRESH_TID();
 	const int bins_out = a.fft_size_out / 2 + 1;

@@ -131,9 +131,18 @@ template <int S>
 __device__ __forceinline__ double2 cmul_i(double2 a) {
 	return S > 0 ? make_double2(-a.y, a.x) : make_double2(a.y, -a.x);
 }
+// Load from the (global) twiddle table through an explicit global-address-space pointer: a pointer that went
+// through tw_fresh() is opaque to the compiler, which would otherwise emit FLAT loads -- those count against
+// lgkmcnt as well, so every LDS wait would also wait for the outstanding twiddle loads.
+__device__ __forceinline__ double2 tw_load(const double2 *tw, int idx) {
+	typedef double v2d __attribute__((ext_vector_type(2)));
+	typedef const v2d __attribute__((address_space(1))) *gptr;
+	const v2d v = ((gptr)tw)[idx];
+	return make_double2(v.x, v.y);
+}
 template <int S>
 __device__ __forceinline__ double2 twiddle(const double2 *__restrict__ tw, int idx) {
-	double2 w = tw[idx];
+	double2 w = tw_load(tw, idx);
 	return S > 0 ? w : cconj(w);
 }
 
@@ -193,6 +202,9 @@ __device__ __forceinline__ void dft8(double2 (&x)[8]) {
 // than re-reading them from the (L1/L2 resident) table.  Laundering the table pointer per call prevents that.
 // WC_FFT_TW: 0 = launder per pass (twiddles loaded pass by pass), 1 = per transform (the compiler may prefetch a
 // whole transform's twiddles), 2 = never (pinned for the kernel).
+#ifndef WC_FFT_RADIX8
+#define WC_FFT_RADIX8 0
+#endif
 #ifndef WC_FFT_TW
 #define WC_FFT_TW 1
 #endif
@@ -203,29 +215,56 @@ __device__ __forceinline__ const double2 *tw_fresh(const double2 *tw) {
 	return tw;
 }
 
-// one Stockham pass of radix R with Ns = product of the earlier radices
-template <int M, int T, int S, int R, int Ns, bool SY = true>
-__device__ __forceinline__ void fft_pass(double2 *a, const double2 *__restrict__ tw_, int tid) {
-#if WC_FFT_TW == 0
-	const double2 *__restrict__ tw = tw_fresh(tw_);
+// radix of the pass that starts at Ns (product of the earlier radices); 1 when the transform is complete
+template <int M, int Ns>
+__host__ __device__ constexpr int fft_radix() {
+	if (Ns >= M) return 1;
+	constexpr int rem = M / (Ns < M ? Ns : M);
+#if WC_FFT_RADIX8
+	// radix 8 with a leading radix-2 / radix-4 pass when log2(M) is not a multiple of 3
+	constexpr int lead = 1 << (__builtin_ctz(M) % 3);
+	return (Ns == 1 && lead > 1) ? lead : (rem >= 8 ? 8 : rem);
 #else
-	const double2 *__restrict__ tw = tw_;
+	// radix 4 throughout, with a leading twiddle-free radix-2 pass when log2(M) is odd
+	constexpr bool odd = (__builtin_ctz(M) & 1) != 0;
+	return (Ns == 1 && odd) ? 2 : (rem >= 4 ? 4 : rem);
 #endif
-	constexpr int NB = M / R;
-	constexpr int BPT = (NB + T - 1) / T;
-	constexpr int tstride = kTwiddleN / (R * Ns);  // W_{R Ns}^k = tw[k * tstride]
+}
+
+// the twiddles W_{R Ns}^{r k}, r = 1 .. R-1, of a thread's butterflies in the pass (R, Ns)
+template <int M, int T, int R, int Ns>
+struct FftTw {
+	static constexpr int NB = M / (R > 0 ? R : 1);
+	static constexpr int BPT = (NB + T - 1) / T;
 	double2 w[BPT][R > 1 ? R - 1 : 1];
-	if (Ns > 1) {
+};
+template <int M, int T, int S, int R, int Ns, int FL>
+__device__ __forceinline__ void fft_load_tw(FftTw<M, T, R, Ns> &tw_regs, const double2 *__restrict__ tw, int tid) {
+	if constexpr (R > 1 && Ns > 1 && Ns < M) {
+		constexpr int NB = M / R;
+		constexpr int BPT = (NB + T - 1) / T;
+		constexpr int tstride = kTwiddleN / (R * Ns);  // W_{R Ns}^k = tw[k * tstride]
 #pragma unroll
 		for (int b = 0; b < BPT; ++b) {
 			const int j = tid + b * T;
 			if (fft_in_range<NB, T>(j)) {
 				const int idx = (j & (Ns - 1)) * tstride;
 #pragma unroll
-				for (int r = 1; r < R; ++r) w[b][r - 1] = twiddle<S>(tw, r * idx);
+				for (int r = 1; r < R; ++r)
+					tw_regs.w[b][r - 1] = (FL & 2) ? make_double2(1.0 - r * idx * 1e-9, r * idx * 1e-9) /* timing ablation */ : twiddle<S>(tw, r * idx);
 			}
 		}
 	}
+}
+
+// One Stockham pass of radix R with Ns = product of the earlier radices.  The pass's own twiddles arrive in
+// registers; the NEXT pass's twiddles are requested from the global table right after the LDS reads, so their
+// latency hides behind this pass's barrier and butterflies instead of standing at the head of the next pass.
+template <int M, int T, int S, int R, int Ns, int FL = 1>
+__device__ __forceinline__ void fft_pass(double2 *a, const double2 *__restrict__ tw, int tid, const FftTw<M, T, R, Ns> &cur,
+										 FftTw<M, T, fft_radix<M, Ns * R>(), Ns * R> &next) {
+	constexpr int NB = M / R;
+	constexpr int BPT = (NB + T - 1) / T;
 	double2 v[BPT][R];
 #pragma unroll
 	for (int b = 0; b < BPT; ++b) {
@@ -235,14 +274,18 @@ __device__ __forceinline__ void fft_pass(double2 *a, const double2 *__restrict__
 			for (int r = 0; r < R; ++r) v[b][r] = a[fft_pad(j + r * NB, Ns > 1)];
 		}
 	}
-	if (SY) __syncthreads();
+	// (with several butterflies per thread the extra registers cost occupancy: request late, overlapping only the
+	// closing barrier)
+	constexpr bool early = BPT == 1;
+	if (early) fft_load_tw<M, T, S, fft_radix<M, Ns * R>(), Ns * R, FL>(next, tw, tid);
+	if (FL & 1) __syncthreads();
 #pragma unroll
 	for (int b = 0; b < BPT; ++b) {
 		const int j = tid + b * T;
 		if (fft_in_range<NB, T>(j)) {
 			if (Ns > 1) {
 #pragma unroll
-				for (int r = 1; r < R; ++r) v[b][r] = cmul(v[b][r], w[b][r - 1]);
+				for (int r = 1; r < R; ++r) v[b][r] = cmul(v[b][r], cur.w[b][r - 1]);
 			}
 			if (R == 8) dft8<S>(reinterpret_cast<double2(&)[8]>(v[b]));
 			else if (R == 4) dft4<S>(reinterpret_cast<double2(&)[4]>(v[b]));
@@ -253,27 +296,27 @@ __device__ __forceinline__ void fft_pass(double2 *a, const double2 *__restrict__
 			for (int r = 0; r < R; ++r) a[fft_pad(j0 + r * Ns, Ns * R < M)] = v[b][r];
 		}
 	}
-	if (SY) __syncthreads();
+	if (!early) fft_load_tw<M, T, S, fft_radix<M, Ns * R>(), Ns * R, FL>(next, tw, tid);
+	if (FL & 1) __syncthreads();
 }
 
-template <int M, int T, int S, int Ns, bool SY = true>
-__device__ __forceinline__ void fft_chain(double2 *a, const double2 *__restrict__ tw, int tid) {
+template <int M, int T, int S, int Ns, int FL = 1>
+__device__ __forceinline__ void fft_chain(double2 *a, const double2 *__restrict__ tw, int tid,
+										  const FftTw<M, T, fft_radix<M, Ns>(), Ns> &cur) {
 	if constexpr (Ns < M) {
-		// radix 4 throughout, with a leading twiddle-free radix-2 pass when log2(M) is odd (radix-8 passes were
-		// measured slower here: more registers per butterfly and idle threads at T = 512)
-		constexpr int rem = M / Ns;
-		constexpr bool odd = (__builtin_ctz(M) & 1) != 0;
-		constexpr int R = (Ns == 1 && odd) ? 2 : (rem >= 4 ? 4 : rem);
-		fft_pass<M, T, S, R, Ns, SY>(a, tw, tid);
-		fft_chain<M, T, S, Ns * R, SY>(a, tw, tid);
+		constexpr int R = fft_radix<M, Ns>();
+		FftTw<M, T, fft_radix<M, Ns * R>(), Ns * R> next;
+		fft_pass<M, T, S, R, Ns, FL>(a, tw, tid, cur, next);
+		fft_chain<M, T, S, Ns * R, FL>(a, tw, tid, next);
 	}
 }
 
-template <int M, int T, int S, bool SY = true>
+template <int M, int T, int S, int FL = 1>
 __device__ void fft_lds(double2 *a, const double2 *__restrict__ tw_, int tid) {
 	static_assert((M & (M - 1)) == 0 && M >= 16 && M <= kTwiddleN, "M must be a power of two in [16, 4096]");
 	const double2 *__restrict__ tw = tw_fresh(tw_);
-	fft_chain<M, T, S, 1, SY>(a, tw, tid);
+	FftTw<M, T, fft_radix<M, 1>(), 1> first;  // the first pass has no twiddles (Ns = 1)
+	fft_chain<M, T, S, 1, FL>(a, tw, tid, first);
 }
 
 // ---- real FFT of N = 2M points held as M interleaved complex (x[2k], x[2k+1]) -----------------------
@@ -294,7 +337,7 @@ __device__ void r2c_post(double2 *a, const double2 *__restrict__ tw_, int tid) {
 			double2 zk = a[k], zm = a[M - k];
 			double2 e = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));   // (Zk + conj Zm)/2
 			double2 o = make_double2(0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x));  // (Zk - conj Zm)/(2i)
-			double2 w = tw[k * TS];
+			double2 w = tw_load(tw, k * TS);
 			double2 wo = cmul(w, o);
 			a[k] = cadd(e, wo);
 			// X[M-k] = conj(E) + W^{M-k} conj(O),  W^{M-k} = -conj(W^k)  =>  X[M-k] = conj(E - W O)
@@ -318,7 +361,7 @@ __device__ __forceinline__ void r2c_power(const double2 *a, const double2 *__res
 		const double2 zk = a[k], zm = a[(M - k) & (M - 1)];
 		const double2 ev = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
 		const double2 od = make_double2(0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x));
-		const double2 wo = cmul(tw[k * TS], od);
+		const double2 wo = cmul(tw_load(tw, k * TS), od);
 		const double2 xk = cadd(ev, wo), xm = csub(ev, wo);
 		const double r0 = zk.x + zk.y, rm = zk.x - zk.y;  // k = 0: X[0], X[M] (both real)
 		key[2 * e] = (k == 0) ? r0 * r0 : xk.x * xk.x + xk.y * xk.y;
@@ -346,7 +389,7 @@ __device__ void c2r_pre(double2 *a, const double2 *__restrict__ tw_, int tid) {
 			double2 yk = a[k], ym = a[M - k];
 			double2 e = make_double2(yk.x + ym.x, yk.y - ym.y);  // Yk + conj Ym
 			double2 d = make_double2(yk.x - ym.x, yk.y + ym.y);  // Yk - conj Ym
-			double2 w = cconj(tw[k * TS]);
+			double2 w = cconj(tw_load(tw, k * TS));
 			double2 o = cmul(d, w);
 			a[k] = make_double2(e.x - o.y, e.y + o.x);  // E + i O
 			// index M-k: E' = conj(E), D' = -conj(D), conj(W^{M-k}) = -W^k ... O' = conj(D) W^k = conj(D conj W) = conj(O)
