@@ -53,6 +53,28 @@ def test_harvest_intermediates_vs_oracle(wca, port):
         check_f0(h.debug_fetch(name), d[key])
 
 
+def test_harvest_bandpass_formulations_agree(wca, port):
+    """The sliding-DFT band-pass (default) and the direct FIR evaluation of the same filter (WC_HARVEST_BANDPASS=fir)
+    give the same raw candidates and contour; both match the oracle."""
+    import os
+    fs = 48000
+    x = make_utterance(fs, 2.0, 77)
+    hs = wca.Harvest(fs)
+    ts, f_s = hs.compute(x)
+    raw_s = hs.debug_fetch("raw")
+    os.environ["WC_HARVEST_BANDPASS"] = "fir"
+    try:
+        hf = wca.Harvest(fs)
+    finally:
+        del os.environ["WC_HARVEST_BANDPASS"]
+    tf, f_f = hf.compute(x)
+    raw_f = hf.debug_fetch("raw")
+    assert np.array_equal(raw_s == 0, raw_f == 0)
+    assert np.abs(raw_s - raw_f).max() < 1e-8
+    check_f0(f_s, f_f)
+    check_f0(f_s, port.harvest(x, fs)[1])
+
+
 def test_harvest_ragged_batch(wca, port):
     fs = 16000
     xs = [make_utterance(fs, sec, 300 + i) for i, sec in enumerate((0.5, 1.3, 0.05, 0.9))]

@@ -40,7 +40,11 @@ constexpr int HL_MAX = 512;       // longest supported half filter length (f0_fl
 constexpr int BP_T = 256;         // threads of the band-pass workgroup
 constexpr int BP_R = 8;           // consecutive outputs per thread
 constexpr int BP_TILE = BP_T * BP_R;
-constexpr int BP_ADV = BP_TILE - 2;  // the detectors look two samples ahead
+constexpr int BP_ADV = BP_TILE;      // tile unit of the per-tile edge counts (tile_run) that hv_raw reads
+constexpr int SD_CH = BP_ADV;       // output samples per lane of the sliding band-pass
+constexpr int FIR_ADV = BP_TILE - 2; // tile advance of the FIR band-pass: its detectors look two samples ahead
+// zero margins around every utterance's decimated signal, so the sliding band-pass reads without bounds checks
+constexpr int Y_PADL = 2 * HL_MAX + 16, Y_PADR = SD_CH + 2 * HL_MAX + 16;
 constexpr int MAX_SLOTS = 32;     // candidates per frame before overlap (reference: round(bands/10))
 
 struct HvUtt {
@@ -186,8 +190,8 @@ __global__ __launch_bounds__(BP_T, 4) void hv_bandpass_kernel(BpArgs a) {
 	int run[4] = {0, 0, 0, 0};
 	const int t0 = tid * BP_R;
 	int *__restrict__ trun = a.tile_run + ((long long)blockIdx.y * a.n_bands + band) * (a.n_tiles + 1) * 4;
-	for (int ts = 0; ts < u.y_len; ts += BP_ADV) {
-		if (tid < 4) trun[(ts / BP_ADV) * 4 + tid] = run[tid];
+	for (int ts = 0; ts < u.y_len; ts += FIR_ADV) {
+		if (tid < 4) trun[(ts / FIR_ADV) * 4 + tid] = run[tid];
 		// Ys[m] = y[ts + 1 - hl + m], m in [0, TILE + nt8 + 8)
 		__syncthreads();
 		for (int m = tid; m < BP_TILE + nt8 + 8; m += BP_T) {
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(BP_T, 4) void hv_bandpass_kernel(BpArgs a) {
 #pragma unroll
 		for (int j = 0; j < BP_R; ++j) {
 			const int t = t0 + j, i = ts + t;
-			if (t < BP_ADV) {
+			if (t < FIR_ADV) {
 				const double s0 = s[j], s1 = s[j + 1], s2 = s[j + 2];
 				if (i + 1 < u.y_len) {  // zeroCrossingEngine over y_length samples
 					if (0.0 < s0 && s1 <= 0.0) mask[0] |= 1u << j;    // positive -> negative
@@ -279,10 +283,209 @@ __global__ __launch_bounds__(BP_T, 4) void hv_bandpass_kernel(BpArgs a) {
 		}
 	}
 	if (tid < 4) {
-		for (int q = (u.y_len + BP_ADV - 1) / BP_ADV; q <= a.n_tiles; ++q) trun[q * 4 + tid] = run[tid];
+		for (int q = (u.y_len + FIR_ADV - 1) / FIR_ADV; q <= a.n_tiles; ++q) trun[q * 4 + tid] = run[tid];
 		int cnt = run[tid];
 		a.ev_count[((long long)blockIdx.y * a.n_bands + band) * 4 + tid] = cnt;
 		if (cnt > cap) atomicExch(a.overflow, 1);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same band-pass as a sliding DFT.  The filter is a Nuttall window (a sum of four cosines of k Omega,
+// Omega = pi / hl) times cos(w (k - hl)), so its output is a weighted sum of the real parts of seven sliding
+// sums  D_v(m) = P0 sum_{k=0}^{2hl} y[m-k] e^{i v k},  v = w, w +- Omega, w +- 2 Omega, w +- 3 Omega,
+// P0 = e^{-i w hl}, with weights a0, -a1/2, -a1/2, a2/2, a2/2, -a3/2, -a3/2.  Each obeys
+//      D_v(m+1) = R_v (D_v(m) - y[m-2hl] conj(P0)) + y[m+1] P0,      R_v = e^{i v},
+// (e^{i v 2hl} is the same for all seven v), i.e. 6 instructions per sample and frequency instead of 2 hl + 1
+// multiply-adds per sample.  A lane owns one (band, chunk of SD_CH output samples): it builds its sums from
+// zero over the first window (the same recurrence without the leaving sample), then slides, running the four
+// zero-crossing detectors of reference :1179-1255 on its outputs as they appear (rounding errors of the
+// rotations random-walk over one chunk only: ~1e-14 relative).  Edges go to per-(band, chunk, type) slots;
+// hv_compact_kernel packs them in time order into the event lists and fills tile_run.
+// ------------------------------------------------------------------------------------------------
+struct SdArgs {
+	const HvUtt *utts;
+	const double *y;
+	const double2 *rot;        // [band][7]  R_v
+	const double2 *p0;         // [band]     P0
+	const int *half_len;       // hl per band
+	const long long *slot_off; // per band: first slot relative to the utterance's slot base
+	const int *slot_cap;       // per band: capacity of one (chunk, type) slot
+	long long slots_per_utt;
+	double *slots;
+	int *slot_count;           // [utt][band][chunk][4]
+	int n_bands, n_chunks;
+};
+
+__global__ __launch_bounds__(64) void hv_bandpass_sdft_kernel(SdArgs a) {
+	const int lane = threadIdx.x;
+	const HvUtt u = a.utts[blockIdx.y];
+	const int item = blockIdx.x * 64 + lane;  // (chunk, band), band fastest: a wave holds neighbouring bands
+	const bool valid = item < a.n_bands * a.n_chunks;
+	const int chunk = valid ? item / a.n_bands : 0;
+	const int band = valid ? item - chunk * a.n_bands : 0;
+	const int i0 = chunk * SD_CH;
+	const bool live = valid && i0 < u.y_len;
+	if (__ballot(live) == 0ull) {
+		if (valid) {
+			int *c = a.slot_count + (((long long)blockIdx.y * a.n_bands + band) * a.n_chunks + chunk) * 4;
+			c[0] = c[1] = c[2] = c[3] = 0;
+		}
+		return;
+	}
+	const int hl = live ? a.half_len[band] : 0;
+	const double *__restrict__ y = a.y + u.y_off;  // zero margins of Y_PADL / Y_PADR samples: no bounds checks below
+	const int ylen = u.y_len;
+	double2 R[7], D[7];
+#pragma unroll
+	for (int v = 0; v < 7; ++v) { R[v] = a.rot[band * 7 + v]; D[v] = make_double2(0.0, 0.0); }
+	const double2 P = a.p0[band];
+	// ---- first window: samples i0 + 1 - hl .. i0 + 1 + hl (m = i + 1 + hl is the newest sample of output i) ----
+	int hlmax = hl;
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) hlmax = max(hlmax, __shfl_xor(hlmax, o, 64));
+	const int qb = live ? i0 + 1 + hl - 2 * hlmax : 0;  // (>= -Y_PADL; idle lanes read their own margin)
+	for (int sidx = 0; sidx <= 2 * hlmax; ++sidx) {
+		const int q = qb + sidx;   // this lane's window starts at sidx = 2 (hlmax - hl)
+		const double yv = (live && sidx >= 2 * (hlmax - hl)) ? y[q] : 0.0;
+		const double ux = yv * P.x, uy = yv * P.y;
+#pragma unroll
+		for (int v = 0; v < 7; ++v) {
+			const double nx = fma(R[v].x, D[v].x, fma(-R[v].y, D[v].y, ux));
+			const double ny = fma(R[v].x, D[v].y, fma(R[v].y, D[v].x, uy));
+			D[v] = make_double2(nx, ny);
+		}
+	}
+	auto out = [&]() -> double {
+		// Nuttall coefficients of reference src/world_common.cpp:118-126, halved for the +- pairs
+		double f = 0.355768 * D[0].x;
+		f = fma(-0.243698, D[1].x + D[2].x, f);
+		f = fma(0.072116, D[3].x + D[4].x, f);
+		f = fma(-0.006302, D[5].x + D[6].x, f);
+		return f;
+	};
+	auto quot = [](double n, double d) -> double {  // n / d for |n| <= |d|, d a normal number
+		double r = __builtin_amdgcn_rcp(d);
+		r = fma(fma(-d, r, 1.0), r, r);
+		r = fma(fma(-d, r, 1.0), r, r);
+		const double q = n * r;
+		return fma(fma(-d, q, n), r, q);
+	};
+	auto slide = [&](double yn, double yo) {  // from output i to output i + 1: yn = y[i + 2 + hl] enters, yo = y[i + 1 - hl] leaves
+		const double ux = yn * P.x, uy = yn * P.y;
+		const double vx = yo * P.x, vy = -(yo * P.y);
+#pragma unroll
+		for (int v = 0; v < 7; ++v) {
+			const double tx = D[v].x - vx, ty = D[v].y - vy;
+			const double nx = fma(R[v].x, tx, fma(-R[v].y, ty, ux));
+			const double ny = fma(R[v].x, ty, fma(R[v].y, tx, uy));
+			D[v] = make_double2(nx, ny);
+		}
+	};
+	const double *__restrict__ pn = y + (live ? i0 + 2 + hl : 0), *__restrict__ po = y + (live ? i0 + 1 - hl : 0);
+	double s0 = out();
+	slide(pn[0], po[0]);
+	double s1 = out();
+	const int cap = a.slot_cap[band];
+	double *__restrict__ slot = a.slots + blockIdx.y * a.slots_per_utt + a.slot_off[band] + (long long)chunk * 4 * cap;
+	int cnt[4] = {0, 0, 0, 0};
+	const int i_end = live ? min(i0 + SD_CH, ylen) : i0;
+	int steps = i_end - i0;  // (lanes of one wave may sit in two different chunks)
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) steps = max(steps, __shfl_xor(steps, o, 64));
+	// four outputs per trip; the samples of a trip are requested one trip ahead of their use
+	constexpr int U = 4;
+	double yn[U], yo[U];
+#pragma unroll
+	for (int k = 0; k < U; ++k) { yn[k] = pn[1 + k]; yo[k] = po[1 + k]; }
+	for (int st = 0; st < steps; st += U) {
+		double cn[U], co[U];
+#pragma unroll
+		for (int k = 0; k < U; ++k) { cn[k] = yn[k]; co[k] = yo[k]; }
+#pragma unroll
+		for (int k = 0; k < U; ++k) { yn[k] = pn[st + U + 1 + k]; yo[k] = po[st + U + 1 + k]; }
+#pragma unroll
+		for (int k = 0; k < U; ++k) {
+			const int i = i0 + st + k;
+			slide(cn[k], co[k]);
+			const double s2 = out();
+			// zeroCrossingEngine (reference :1179-1219) over the y_length samples (types 0, 1) and over the
+			// y_length - 1 first differences (types 2, 3); fine edge = edges[e] - sig[e-1] / (sig[e] - sig[e-1]) with
+			// edges = i + 1, the same for a signal and its negation
+			const double d0 = s1 - s0, d1 = s2 - s1;
+			const bool in1 = i < i_end && i + 1 < ylen, in2 = i < i_end && i + 2 < ylen;
+			const bool neg = in1 && 0.0 < s0 && s1 <= 0.0, pos = in1 && 0.0 < -s0 && -s1 <= 0.0;
+			const bool pk = in2 && 0.0 < d0 && d1 <= 0.0, dp = in2 && 0.0 < -d0 && -d1 <= 0.0;
+			// (some lane of the wave has an edge at almost every step, so these blocks run all the time: selects between
+			// two counters instead of an indexed array, and a short reciprocal-based quotient -- the ratio lies in [-1, 0]
+			// and is good to an ulp, far below the band-pass's own rounding)
+			if (neg || pos) {
+				const double fine = (i + 1) - quot(s0, d0);
+				const int c = neg ? cnt[0] : cnt[1];
+				if (c < cap) slot[(neg ? 0 : cap) + c] = fine;
+				cnt[0] += neg ? 1 : 0;
+				cnt[1] += pos ? 1 : 0;
+			}
+			if (pk || dp) {
+				const double fine = (i + 1) - quot(d0, d1 - d0);
+				const int c = pk ? cnt[2] : cnt[3];
+				if (c < cap) slot[(pk ? 2 * cap : 3 * cap) + c] = fine;
+				cnt[2] += pk ? 1 : 0;
+				cnt[3] += dp ? 1 : 0;
+			}
+			s0 = s1;
+			s1 = s2;
+		}
+	}
+	if (valid) {
+		int *c = a.slot_count + (((long long)blockIdx.y * a.n_bands + band) * a.n_chunks + chunk) * 4;
+#pragma unroll
+		for (int ty = 0; ty < 4; ++ty) c[ty] = cnt[ty];
+	}
+}
+
+struct CpArgs {
+	const HvUtt *utts;
+	const long long *slot_off;
+	const int *slot_cap;
+	long long slots_per_utt;
+	const double *slots;
+	const int *slot_count;
+	const long long *ev_band_off;
+	const int *ev_cap;
+	double *events;
+	int *ev_count;
+	int *overflow;
+	int *tile_run;  // [utt][band][n_chunks + 1][4]
+	int n_bands, n_chunks;
+};
+
+// One workgroup per (band, utterance), wave ty packs the slots of type ty chunk after chunk.
+__global__ __launch_bounds__(256) void hv_compact_kernel(CpArgs a) {
+	const int lane = threadIdx.x & 63, ty = threadIdx.x >> 6;
+	const int band = blockIdx.x;
+	const HvUtt u = a.utts[blockIdx.y];
+	const int scap = a.slot_cap[band], cap = a.ev_cap[band];
+	const double *__restrict__ slot = a.slots + blockIdx.y * a.slots_per_utt + a.slot_off[band];
+	const int *__restrict__ sc = a.slot_count + ((long long)blockIdx.y * a.n_bands + band) * a.n_chunks * 4;
+	double *__restrict__ ev = a.events + u.ev_off + a.ev_band_off[band] + (long long)ty * cap;
+	int *__restrict__ trun = a.tile_run + ((long long)blockIdx.y * a.n_bands + band) * (a.n_chunks + 1) * 4;
+	int run = 0;
+	bool ovf = false;
+	for (int c = 0; c < a.n_chunks; ++c) {
+		if (lane == 0) trun[c * 4 + ty] = run;
+		const int n = sc[c * 4 + ty];
+		ovf = ovf || n > scap;
+		const int m = min(n, scap);
+		const double *__restrict__ src = slot + ((long long)c * 4 + ty) * scap;
+		for (int j = lane; j < m; j += 64)
+			if (run + j < cap) ev[run + j] = src[j];
+		run += n;
+	}
+	if (lane == 0) {
+		trun[a.n_chunks * 4 + ty] = run;
+		a.ev_count[((long long)blockIdx.y * a.n_bands + band) * 4 + ty] = run;
+		if (ovf || run > cap) atomicExch(a.overflow, 1);
 	}
 }
 
@@ -297,7 +500,7 @@ struct RawArgs {
 	const int *ev_count;
 	const double *band_f0;
 	const int *tile_run;
-	int n_tiles;
+	int n_tiles, tile_adv;  // tile_run[q] = edges before sample q * tile_adv
 	double *raw;  // [utt: l1_off * n_bands][band][L1]
 	int n_bands;
 	double fs_d, f0_floor, f0_ceil;
@@ -362,8 +565,8 @@ __global__ __launch_bounds__(RAW_T) void hv_raw_kernel(RawArgs a) {
 		const double *__restrict__ e = ev + (long long)ty * cap;
 		const int *__restrict__ trun = a.tile_run + ((long long)blockIdx.z * a.n_bands + band) * (a.n_tiles + 1) * 4;
 		const int i1 = min(i0 + RAW_T - 1, u.L1 - 1);
-		const int q0 = min(a.n_tiles, max(0, (int)((i0 * 1 / 1000.0) * fs) / BP_ADV));
-		const int q1 = min(a.n_tiles, (int)((i1 * 1 / 1000.0) * fs) / BP_ADV + 1);
+		const int q0 = min(a.n_tiles, max(0, (int)((i0 * 1 / 1000.0) * fs) / a.tile_adv));
+		const int q1 = min(a.n_tiles, (int)((i1 * 1 / 1000.0) * fs) / a.tile_adv + 1);
 		const int ce = n[ty] + 1;  // edges in the list
 		const int base = max(0, min(trun[q0 * 4 + ty], ce) - 4);
 		const int end = min(ce, min(trun[q1 * 4 + ty], ce) + 4);
@@ -1067,6 +1270,8 @@ struct wc_harvest {
 	std::vector<double> band_f0;
 	std::vector<int> half_len, tap_off;
 	DevBuf d_taps, d_tap_off, d_half_len, d_band_f0, d_ev_band_off, d_ev_cap, d_rot;
+	DevBuf d_sd_rot, d_sd_p0, d_slot_off, d_slot_cap, slots, slot_count;
+	bool use_fir;  // WC_HARVEST_BANDPASS=fir: the direct FIR band-pass instead of the sliding DFT (A/B and tests)
 	DevBuf utts, dec, y, events, ev_count, overflow, tile_run, raw, cand0, cand1, score1, cand2, score2;
 	DevBuf base, s1, s2, s3, fixed, f0_1ms, sec, chan, smooth, ibuf;
 	DevBuf d_x, d_tpos, d_f0;
@@ -1122,14 +1327,14 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 	for (int u = 0; u < n_utt; ++u) {
 		if (x_length[u] <= 0) return fail(WC_ERR_INVALID, "harvest: non-positive x_length");
 		HvUtt &t = utts[u];
-		t.x_off = xo; t.dec_off = deco; t.y_off = yo; t.l1_off = l1o; t.out_off = oo; t.ev_off = 0;
+		t.x_off = xo; t.dec_off = deco; t.y_off = yo + Y_PADL; t.l1_off = l1o; t.out_off = oo; t.ev_off = 0;
 		t.x_len = x_length[u];
 		t.y_len = 1 + x_length[u] / r;                              // reference :1400
 		t.L1 = wc_get_samples(h->fs, x_length[u], 1);                // reference :1411
 		t.L = (h->frame_period == 1.0) ? t.L1 : wc_get_samples(h->fs, x_length[u], h->frame_period);
 		if (t.L1 < 3) return fail(WC_ERR_INVALID, "harvest: signal shorter than 3 ms");
 		const int len = t.x_len + 2 * lag + 18;
-		xo += t.x_len; deco += len; yo += t.y_len; l1o += t.L1; oo += t.L;
+		xo += t.x_len; deco += len; yo += t.y_len + Y_PADL + Y_PADR; l1o += t.L1; oo += t.L;
 		max_len = std::max(max_len, len); max_ylen = std::max(max_ylen, t.y_len);
 		max_L1 = std::max(max_L1, t.L1); max_L = std::max(max_L, t.L);
 	}
@@ -1145,7 +1350,8 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 	if ((rc = h->y.reserve(sizeof(double) * yo))) return rc;
 	if (r != 1 && (rc = h->dec.reserve(sizeof(double) * deco))) return rc;
 	if ((rc = h->ev_count.reserve(sizeof(int) * 4ll * nb * n_utt))) return rc;
-	const int n_tiles = (max_ylen + BP_ADV - 1) / BP_ADV;
+	const int tile_adv = h->use_fir ? FIR_ADV : BP_ADV;
+	const int n_tiles = (max_ylen + tile_adv - 1) / tile_adv;
 	if ((rc = h->tile_run.reserve(sizeof(int) * 4ll * (n_tiles + 1) * nb * n_utt))) return rc;
 	if ((rc = h->raw.reserve(sizeof(double) * total_l1 * nb))) return rc;
 	if ((rc = h->cand0.reserve(sizeof(double) * total_l1 * S))) return rc;
@@ -1177,14 +1383,40 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 		if ((rc = h->events.reserve(sizeof(double) * per_utt * n_utt))) return rc;
 		if ((rc = h->d_ev_band_off.reserve(sizeof(long long) * nb))) return rc;
 		if ((rc = h->d_ev_cap.reserve(sizeof(int) * nb))) return rc;
-		if ((rc = h->h_stage.reserve(sizeof(HvUtt) * n_utt + sizeof(long long) * nb + sizeof(int) * nb + 64))) return rc;
+		// sliding band-pass: one slot per (band, chunk, type); same rate bound / hard bound policy per chunk
+		std::vector<long long> slot_off(nb);
+		std::vector<int> slot_cap(nb);
+		long long slots_per_utt = 0;
+		for (int b = 0; b < nb; ++b) {
+			const int hard = SD_CH / 2 + 2;
+			int soft = static_cast<int>(2.5 * h->band_f0[b] * (SD_CH / h->fs_d)) + 16;
+			if (getenv("WC_DEBUG_SMALL_CAPS")) soft = 3;
+			slot_cap[b] = full ? hard : std::min(hard, soft);
+			slot_off[b] = slots_per_utt;
+			slots_per_utt += 4ll * n_tiles * slot_cap[b];
+		}
+		if (!h->use_fir) {
+			if ((rc = h->slots.reserve(sizeof(double) * slots_per_utt * n_utt))) return rc;
+			if ((rc = h->slot_count.reserve(sizeof(int) * 4ll * n_tiles * nb * n_utt))) return rc;
+			if ((rc = h->d_slot_off.reserve(sizeof(long long) * nb))) return rc;
+			if ((rc = h->d_slot_cap.reserve(sizeof(int) * nb))) return rc;
+		}
+		const size_t o1 = sizeof(HvUtt) * n_utt, o2 = o1 + sizeof(long long) * nb, o3 = o2 + sizeof(int) * nb + 8;
+		const size_t o3a = o3 & ~size_t(7), o4 = o3a + sizeof(long long) * nb;
+		if ((rc = h->h_stage.reserve(o4 + sizeof(int) * nb + 64))) return rc;
 		char *hs = static_cast<char *>(h->h_stage.p);
 		std::memcpy(hs, utts.data(), sizeof(HvUtt) * n_utt);
-		std::memcpy(hs + sizeof(HvUtt) * n_utt, ev_band_off.data(), sizeof(long long) * nb);
-		std::memcpy(hs + sizeof(HvUtt) * n_utt + sizeof(long long) * nb, ev_cap.data(), sizeof(int) * nb);
+		std::memcpy(hs + o1, ev_band_off.data(), sizeof(long long) * nb);
+		std::memcpy(hs + o2, ev_cap.data(), sizeof(int) * nb);
+		std::memcpy(hs + o3a, slot_off.data(), sizeof(long long) * nb);
+		std::memcpy(hs + o4, slot_cap.data(), sizeof(int) * nb);
 		WC_HIP(hipMemcpyAsync(h->utts.p, hs, sizeof(HvUtt) * n_utt, hipMemcpyHostToDevice, s));
-		WC_HIP(hipMemcpyAsync(h->d_ev_band_off.p, hs + sizeof(HvUtt) * n_utt, sizeof(long long) * nb, hipMemcpyHostToDevice, s));
-		WC_HIP(hipMemcpyAsync(h->d_ev_cap.p, hs + sizeof(HvUtt) * n_utt + sizeof(long long) * nb, sizeof(int) * nb, hipMemcpyHostToDevice, s));
+		WC_HIP(hipMemcpyAsync(h->d_ev_band_off.p, hs + o1, sizeof(long long) * nb, hipMemcpyHostToDevice, s));
+		WC_HIP(hipMemcpyAsync(h->d_ev_cap.p, hs + o2, sizeof(int) * nb, hipMemcpyHostToDevice, s));
+		if (!h->use_fir) {
+			WC_HIP(hipMemcpyAsync(h->d_slot_off.p, hs + o3a, sizeof(long long) * nb, hipMemcpyHostToDevice, s));
+			WC_HIP(hipMemcpyAsync(h->d_slot_cap.p, hs + o4, sizeof(int) * nb, hipMemcpyHostToDevice, s));
+		}
 		if ((rc = h->h_stage.mark(s))) return rc;
 		WC_HIP(hipMemsetAsync(h->overflow.p, 0, sizeof(int), s));
 		const HvUtt *du = h->utts.as<HvUtt>();
@@ -1210,7 +1442,21 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 		ba.events = h->events.as<double>(); ba.ev_count = h->ev_count.as<int>(); ba.overflow = h->overflow.as<int>(); ba.n_bands = nb;
 		ba.tile_run = h->tile_run.as<int>(); ba.n_tiles = n_tiles;
 		if ((rc = dev->time_begin("harvest_bandpass", s))) return rc;
-		hipLaunchKernelGGL(hv_bandpass_kernel, dim3(nb, n_utt), dim3(BP_T), 0, s, ba);
+		if (h->use_fir) {
+			hipLaunchKernelGGL(hv_bandpass_kernel, dim3(nb, n_utt), dim3(BP_T), 0, s, ba);
+		} else {
+			SdArgs sa;
+			sa.utts = du; sa.y = h->y.as<double>(); sa.rot = h->d_sd_rot.as<double2>(); sa.p0 = h->d_sd_p0.as<double2>();
+			sa.half_len = h->d_half_len.as<int>(); sa.slot_off = h->d_slot_off.as<long long>(); sa.slot_cap = h->d_slot_cap.as<int>();
+			sa.slots_per_utt = slots_per_utt; sa.slots = h->slots.as<double>(); sa.slot_count = h->slot_count.as<int>();
+			sa.n_bands = nb; sa.n_chunks = n_tiles;
+			hipLaunchKernelGGL(hv_bandpass_sdft_kernel, dim3((nb * n_tiles + 63) / 64, n_utt), dim3(64), 0, s, sa);
+			CpArgs ca;
+			ca.utts = du; ca.slot_off = sa.slot_off; ca.slot_cap = sa.slot_cap; ca.slots_per_utt = slots_per_utt; ca.slots = sa.slots;
+			ca.slot_count = sa.slot_count; ca.ev_band_off = ba.ev_band_off; ca.ev_cap = ba.ev_cap; ca.events = ba.events;
+			ca.ev_count = ba.ev_count; ca.overflow = ba.overflow; ca.tile_run = ba.tile_run; ca.n_bands = nb; ca.n_chunks = n_tiles;
+			hipLaunchKernelGGL(hv_compact_kernel, dim3(nb, n_utt), dim3(256), 0, s, ca);
+		}
 		WC_HIP(hipGetLastError());
 		if ((rc = dev->time_end("harvest_bandpass", s))) return rc;
 	}
@@ -1218,7 +1464,7 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 	RawArgs ra;
 	ra.utts = du; ra.events = h->events.as<double>(); ra.ev_band_off = h->d_ev_band_off.as<long long>(); ra.ev_cap = h->d_ev_cap.as<int>();
 	ra.ev_count = h->ev_count.as<int>(); ra.band_f0 = h->d_band_f0.as<double>(); ra.raw = h->raw.as<double>(); ra.n_bands = nb;
-	ra.tile_run = h->tile_run.as<int>(); ra.n_tiles = n_tiles;
+	ra.tile_run = h->tile_run.as<int>(); ra.n_tiles = n_tiles; ra.tile_adv = tile_adv;
 	ra.fs_d = h->fs_d; ra.f0_floor = h->f0_floor; ra.f0_ceil = h->f0_ceil;
 	if ((rc = dev->time_begin("harvest_raw", s))) return rc;
 	hipLaunchKernelGGL(hv_raw_kernel, dim3((max_L1 + 255) / 256, nb, n_utt), dim3(256), 0, s, ra);
@@ -1343,6 +1589,27 @@ wc_harvest *wc_harvest_create(int fs, double f0_floor, double f0_ceil, double fr
 	ok = ok && hipMemcpy(h->d_half_len.p, h->half_len.data(), sizeof(int) * h->n_bands, hipMemcpyHostToDevice) == hipSuccess;
 	ok = ok && hipMemcpy(h->d_band_f0.p, h->band_f0.data(), sizeof(double) * h->n_bands, hipMemcpyHostToDevice) == hipSuccess;
 	{
+		// sliding band-pass: rotations e^{i v} for v = w, w +- Omega, w +- 2 Omega, w +- 3 Omega and P0 = e^{-i w hl}
+		std::vector<double2> sd_rot(7 * h->n_bands), sd_p0(h->n_bands);
+		const long double lpi = 3.14159265358979323846264338327950288L;
+		for (int b = 0; b < h->n_bands; ++b) {
+			const long double w = 2.0L * lpi * (long double)h->band_f0[b] / (long double)h->fs_d;
+			const long double om = lpi / (long double)h->half_len[b];
+			const int mult[7] = {0, 1, -1, 2, -2, 3, -3};
+			for (int v = 0; v < 7; ++v) {
+				const long double nu = w + mult[v] * om;
+				sd_rot[7 * b + v] = make_double2((double)cosl(nu), (double)sinl(nu));
+			}
+			const long double ph = w * (long double)h->half_len[b];
+			sd_p0[b] = make_double2((double)cosl(ph), (double)-sinl(ph));
+		}
+		ok = ok && h->d_sd_rot.reserve(sizeof(double2) * sd_rot.size()) == 0 && h->d_sd_p0.reserve(sizeof(double2) * sd_p0.size()) == 0 &&
+			 hipMemcpy(h->d_sd_rot.p, sd_rot.data(), sizeof(double2) * sd_rot.size(), hipMemcpyHostToDevice) == hipSuccess &&
+			 hipMemcpy(h->d_sd_p0.p, sd_p0.data(), sizeof(double2) * sd_p0.size(), hipMemcpyHostToDevice) == hipSuccess;
+		const char *bp = getenv("WC_HARVEST_BANDPASS");
+		h->use_fir = bp && std::strcmp(bp, "fir") == 0;
+	}
+	{
 		std::vector<double2> rot(2 * (RF_MAXHW + 1));
 		for (int hw = 0; hw <= RF_MAXHW; ++hw) {
 			const double beta = 2.0 * pi / (2 * hw + 1);
@@ -1363,7 +1630,7 @@ wc_harvest *wc_harvest_create(int fs, double f0_floor, double f0_ceil, double fr
 void wc_harvest_destroy(wc_harvest *h) {
 	if (!h) return;
 	(void)hipStreamSynchronize(h->dev->stream);
-	for (DevBuf *b : {&h->d_rot, &h->d_taps, &h->d_tap_off, &h->d_half_len, &h->d_band_f0, &h->d_ev_band_off, &h->d_ev_cap, &h->utts, &h->dec, &h->y,
+	for (DevBuf *b : {&h->d_sd_rot, &h->d_sd_p0, &h->d_slot_off, &h->d_slot_cap, &h->slots, &h->slot_count, &h->d_rot, &h->d_taps, &h->d_tap_off, &h->d_half_len, &h->d_band_f0, &h->d_ev_band_off, &h->d_ev_cap, &h->utts, &h->dec, &h->y,
 					  &h->events, &h->ev_count, &h->overflow, &h->tile_run, &h->raw, &h->cand0, &h->cand1, &h->score1, &h->cand2, &h->score2, &h->base,
 					  &h->s1, &h->s2, &h->s3, &h->fixed, &h->f0_1ms, &h->sec, &h->chan, &h->smooth, &h->ibuf, &h->d_x, &h->d_tpos, &h->d_f0})
 		b->release();
