@@ -680,7 +680,7 @@ constexpr int RF_MAXW = 2 * RF_MAXHW + 1;
 // advance by rotation recurrences from exact starting values (one sincos and 6 table twiddles per lane);
 // the 24 partial sums are reduced inside the 8-lane group by a halving butterfly that leaves harmonic h
 // in lane h.
-__global__ __launch_bounds__(256) void hv_refine_kernel(RefArgs a) {
+__global__ __launch_bounds__(256, 3) void hv_refine_kernel(RefArgs a) {  // 3 waves per SIMD (<= 168 VGPRs): measured best
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	const int blk = lane >> 3, sub = lane & 7;
 	const long long g = blockIdx.x;
