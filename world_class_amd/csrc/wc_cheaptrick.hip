@@ -73,10 +73,10 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 	double w[EPT];
 	double ssq = 0.0;
 	{
-		const double kappa = kPi * f0c / 1.5 / fs;  // angle per sample: pi * ((i - hw) / 1.5 / fs) * f0c
+		const double kappa = f0c / 1.5 / fs;  // angle per sample in units of pi: pi * ((i - hw) / 1.5 / fs) * f0c
 		double c, sn, cd, sd;
-		sincos(kappa * (tid - hw), &sn, &c);
-		sincos(kappa * T, &sd, &cd);
+		sincospi(kappa * (tid - hw), &sn, &c);
+		sincospi(kappa * T, &sd, &cd);
 #pragma unroll
 		for (int e = 0; e < EPT; ++e) {
 			int i = tid + e * T;
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 	}
 	ssq = block_sum<T>(ssq, red, tid);
 	WC_FRESH(tid);
-	const double norm = sqrt(ssq);
+	const double rnorm = 1.0 / sqrt(ssq);  // (the reference divides each window sample by the norm: an ulp apart)
 	double s1 = 0.0, s2 = 0.0;
 	double wv[EPT];
 #pragma unroll
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 		int i = tid + e * T;
 		wv[e] = 0.0;
 		if (i < wl) {
-			w[e] = w[e] / norm;
+			w[e] = w[e] * rnorm;
 			int si = clampi(origin + i - hw, 0, ud.x_len - 1);
 			wv[e] = x[si] * w[e] + randn_at(a.rng_table, roff + i) * 0.000000000000001;
 			s1 += wv[e];
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 	WC_FRESH(tid);
 	{
 		const int upper = 2 + (int)(f0c * N / fs);
-		const double dx = -(double)fs / N;
+		const double dx = -(double)fs / N, rdx = 1.0 / dx;
 		double rep[2];
 #pragma unroll
 		for (int e = 0; e < 2; ++e) {
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 			rep[e] = 0.0;
 			if (i < upper - 1 && i <= M) {
 				double axis = (double)i * fs / N;
-				rep[e] = interp1q(f0c, dx, [&](int b) { return P[min(max(b, 0), M)]; }, upper + 1, axis);
+				rep[e] = interp1q_rcp(f0c, dx, rdx, [&](int b) { return P[min(max(b, 0), M)]; }, upper + 1, axis);
 			}
 		}
 		__syncthreads();
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 		}
 		__syncthreads();
 		const double origin_axis = -(b - 0.5) * fs / N;
-		const double step = (double)fs / N;
+		const double step = (double)fs / N, rstep = 1.0 / step;
 		auto seg = [&](int i) -> double { return Ar[min(max(i, 0), len - 1)]; };
 #pragma unroll
 		for (int e = 0; e < BPT; ++e) {
@@ -189,8 +189,8 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 			if (k <= M) {
 				double lo_axis = (double)k / N * fs - width / 2.0;
 				double hi_axis = lo_axis + width;
-				double lo_v = interp1q(origin_axis, step, seg, len, lo_axis);
-				double hi_v = interp1q(origin_axis, step, seg, len, hi_axis);
+				double lo_v = interp1q_rcp(origin_axis, step, rstep, seg, len, lo_axis);
+				double hi_v = interp1q_rcp(origin_axis, step, rstep, seg, len, hi_axis);
 				double sm = (hi_v - lo_v) / width;
 				// infinitesimal noise (reference :220-228) then log (reference :251-252)
 				sm += fabs(randn_at(a.rng_table, roff + wl + k)) * 0.00000000000000022204460492503131;
@@ -219,8 +219,8 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 		// cosine is 1 - 2 sin^2 a, and (cos a, sin a) advances over this thread's bins k = tid + e T by rotation
 		const double alpha = kPi * f0c / fs;
 		double c, sn, cd, sd;
-		sincos(alpha * tid, &sn, &c);
-		sincos(alpha * T, &sd, &cd);
+		sincospi(f0c / fs * tid, &sn, &c);
+		sincospi(f0c / fs * T, &sd, &cd);
 		for (int k = tid; k <= M; k += T) {
 			double sl, cl;
 			if (k == 0) {

@@ -106,7 +106,7 @@ template <int M, int T>
 __device__ __forceinline__ void dc_correction_lds(double *P, double f0, int fs, int tid) {
 	constexpr int N = 2 * M;
 	const int upper = 2 + (int)(f0 * N / fs);
-	const double dx = -(double)fs / N;
+	const double dx = -(double)fs / N, rdx = 1.0 / dx;
 	double rep[2];
 #pragma unroll
 	for (int e = 0; e < 2; ++e) {
@@ -114,7 +114,7 @@ __device__ __forceinline__ void dc_correction_lds(double *P, double f0, int fs, 
 		rep[e] = 0.0;
 		if (i < upper - 1 && i <= M) {
 			double axis = (double)i * fs / N;
-			rep[e] = interp1q(f0, dx, [&](int b) { return P[min(max(b, 0), M)]; }, upper + 1, axis);
+			rep[e] = interp1q_rcp(f0, dx, rdx, [&](int b) { return P[min(max(b, 0), M)]; }, upper + 1, axis);
 		}
 	}
 	__syncthreads();
@@ -152,13 +152,13 @@ __device__ __forceinline__ void linear_smoothing_lds(const double *P, double *S,
 	}
 	__syncthreads();
 	const double origin_axis = -(b - 0.5) * fs / N;
-	const double step = (double)fs / N;
+	const double step = (double)fs / N, rstep = 1.0 / step;
 	auto seg = [&](int i) -> double { return S[min(max(i, 0), len - 1)]; };
 	for (int k = tid; k <= M; k += T) {
 		double lo_axis = (double)k / N * fs - width / 2.0;
 		double hi_axis = lo_axis + width;
-		double lo_v = interp1q(origin_axis, step, seg, len, lo_axis);
-		double hi_v = interp1q(origin_axis, step, seg, len, hi_axis);
+		double lo_v = interp1q_rcp(origin_axis, step, rstep, seg, len, lo_axis);
+		double hi_v = interp1q_rcp(origin_axis, step, rstep, seg, len, hi_axis);
 		out(k, (hi_v - lo_v) / width);
 	}
 	__syncthreads();
@@ -271,11 +271,11 @@ __global__ __launch_bounds__(T, (2 * T) / 256) void d4c_frames_kernel(D4cArgs a)
 		double pw = 0.0;
 #pragma unroll
 		for (int e = 0; e < EPT; ++e) pw += wave[e] * wave[e];
-		pw = sqrt(block_sum<T>(pw, red, tid));
+		pw = 1.0 / sqrt(block_sum<T>(pw, red, tid));  // (the reference divides every sample: an ulp apart)
 #pragma unroll
 		for (int e = 0; e < EPT; ++e) {
 			int i = tid + e * T;
-			wave[e] = (i < wl) ? wave[e] / pw : 0.0;
+			wave[e] = (i < wl) ? wave[e] * pw : 0.0;
 			Ar[i] = wave[e];
 		}
 		__syncthreads();
