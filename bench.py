@@ -40,7 +40,9 @@ KERNEL_STAGE = {
     "cheaptrick_frames": "cheaptrick", "d4c_lovetrain": "d4c", "d4c_frames": "d4c",
     "synthesis_timebase": "synthesis", "synthesis_pulses": "synthesis",
 }
+SEQUENTIAL_SCANS = ("synthesis_timebase", "harvest_contour")
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+VALU_PEAK_GINSTR = 614.4  # wave-level f64 vector instructions per second: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles
 
 
 def cpu_baseline(xs, budget_s=24.0):
@@ -197,20 +199,29 @@ def main():
         total_frames = frames * world
         ms_per_step = elapsed / a.steps * 1e3
         value = total_frames * a.steps / elapsed
-        dom = max(kern, key=kern.get) if kern else None
+        # dominant = longest of the full-grid kernels.  The two one-wavefront-per-utterance sequential scans (Synthesis time
+        # base, Harvest contour logic) keep 32 of the chip's 8192 wave slots busy and run underneath the others in the
+        # schedule: their wall time is listed in all_kernels_ms but they are not what bounds the step.
+        full_grid = {k: v for k, v in kern.items() if k not in SEQUENTIAL_SCANS}
+        dom = max(full_grid, key=full_grid.get) if full_grid else None
         roofline = None
         if dom:
             stage = KERNEL_STAGE[dom]
             achieved = frames * STAGE_BYTES[stage] / (kern[dom] * 1e-3) / 1e9
-            traffic = None
+            traffic, valu = None, None
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tpath):
                 with open(tpath) as f:
-                    traffic = json.load(f).get(dom)  # HBM bytes per launch (PMC, see the file's _note)
+                    pmc = json.load(f)
+                traffic = pmc.get(dom)  # HBM bytes per step (PMC, see the file's _note)
+                insts = pmc.get("_valu_insts_per_step", {}).get(dom)
+                if insts:  # the ceiling that actually binds: FP64 vector issue
+                    valu = {"insts_per_step": insts, "peak_ginstr_per_s": VALU_PEAK_GINSTR,
+                            "issue_frac": insts / (kern[dom] * 1e-3) / (VALU_PEAK_GINSTR * 1e9)}
             roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                         "kernel_ms": kern[dom], "bytes_per_frame": STAGE_BYTES[stage],
-                        "all_kernels_ms": kern}
+                        "fp64_vector_issue": valu, "all_kernels_ms": kern}
         out = {
             "metric": "analysis+synthesis frames/sec (whole node), 48 kHz 5 ms hop",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

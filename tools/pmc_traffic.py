@@ -3,7 +3,8 @@
     cd /tmp && export TMPDIR=/tmp
     rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_fetch -o p -f csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline
     rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_write -o p -f csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline
-    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write --steps 3
+    rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS -d gpurun_out/pmc_valu -o p -f csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write --valu-dir gpurun_out/pmc_valu --steps 3
 
 Both counters are in KiB.  FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM section: gfx950 reports half of a
 coalesced read stream); WRITE_SIZE is used as is.  With the default pipeline schedule every kernel is launched
@@ -19,7 +20,8 @@ import sys
 
 KERNELS = {  # substring of the kernel symbol -> name bench.py uses
     "d4c_frames_kernel": "d4c_frames", "ct_frames_kernel": "cheaptrick_frames", "d4c_lovetrain_kernel": "d4c_lovetrain",
-    "hv_refine_kernel": "harvest_refine", "hv_bandpass_kernel": "harvest_bandpass", "hv_raw_kernel": "harvest_raw",
+    "hv_refine_kernel": "harvest_refine", "hv_bandpass_kernel": "harvest_bandpass", "hv_bandpass_sdft_kernel": "harvest_bandpass",
+    "hv_compact_kernel": "harvest_bandpass", "hv_raw_kernel": "harvest_raw",
     "hv_contour_kernel": "harvest_contour", "syn_pulse_kernel": "synthesis_pulses", "syn_timebase_kernel": "synthesis_timebase",
 }
 
@@ -41,6 +43,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("fetch_dir")
     ap.add_argument("write_dir")
+    ap.add_argument("--valu-dir", default=None, help="pass with SQ_INSTS_VALU (vector instructions issued, per wave)")
     ap.add_argument("--steps", type=int, required=True, help="warmup + timed steps of the profiled bench run")
     ap.add_argument("-o", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json"))
     a = ap.parse_args()
@@ -56,6 +59,12 @@ def main():
         f, w_ = fetch[name] / a.steps, write[name] / a.steps
         out["_raw_kib_per_step"][name] = {"FETCH_SIZE": f, "WRITE_SIZE": w_}
         out[name] = int((2.0 * f + w_) * 1024)
+    if a.valu_dir:
+        valu = total_kib(a.valu_dir, "SQ_INSTS_VALU")
+        out["_valu_note"] = ("SQ_INSTS_VALU per bench step (wave-level vector instructions).  An f64 instruction occupies a SIMD for 4 "
+                             "cycles, so the chip issues at most 1024 SIMDs x 2.4 GHz / 4 = 614.4 G of them per second; bench.py divides "
+                             "by the live kernel time to report the vector-issue utilisation next to the HBM fraction.")
+        out["_valu_insts_per_step"] = {k: v / a.steps for k, v in sorted(valu.items())}
     with open(a.o, "w") as fh:
         json.dump(out, fh, indent=1)
     print(json.dumps({k: v for k, v in out.items() if not k.startswith("_")}))
