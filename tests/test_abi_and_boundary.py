@@ -16,6 +16,12 @@ def header_symbols():
     return sorted(set(re.findall(r"\b(wc_[a-z0-9_]+)\s*\(", src)))
 
 
+def io_header_symbols():
+    src = open(os.path.join(ROOT, "include", "world_class_io.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", src)))
+
+
 @pytest.fixture(scope="module")
 def built_lib():
     from world_class_amd import build
@@ -29,11 +35,18 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert len(declared) >= 30
     missing = [s for s in declared if s not in exported]
     assert not missing, missing
+    # the data-format header: the reference's own function names plus the wc_ extensions
+    exported_all = set(re.findall(r" T ([A-Za-z_][A-Za-z0-9_]*)", out))
+    io_declared = io_header_symbols()
+    assert {"wavread", "wavwrite", "GetAudioLength", "ReadF0", "WriteSpectralEnvelope", "wc_modify_parameters_device"} <= set(io_declared)
+    assert not [s for s in io_declared if s not in exported_all]
 
 
 def test_python_mirror_binds_the_header(built_lib):
     import world_class_amd as w
     assert sorted(w.EXPORTED_SYMBOLS) == header_symbols()
+    from world_class_amd import io as wio
+    assert sorted(wio.IO_SIGNATURES) == io_header_symbols()
     lib = w.lib()  # loads and sets every prototype
     assert lib.wc_version().startswith(b"world_class_amd")
     # pure host helpers work without a device and match the reference's formulas (goldens in test_oracle_golden)

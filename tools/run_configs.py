@@ -35,7 +35,7 @@ def tile(items, n):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--configs", default="2,3,4,5")
+    ap.add_argument("--configs", default="2,3,4,5,6")
     ap.add_argument("--scale", type=float, default=1.0, help="scale the utterance counts (for quick runs)")
     a = ap.parse_args()
     import torch
@@ -126,6 +126,22 @@ def main():
         print(json.dumps({"config": 5, "what": f"{n} x 24 kHz 2 s (1/8 of 4096 streams), 1 ms hop, Harvest + CheapTrick on whole "
                                                 "utterances (Harvest is non-causal: no streaming semantics in the reference), 1 GPU",
                           "frames": sum(fl), "ms": t * 1e3, "frames_per_s": sum(fl) / t, "batch_latency_ms": t * 1e3}))
+
+    if 6 in todo:  # section 8(f) kernels: int16 PCM expansion and the demo's parameter modification, HBM-bound
+        from world_class_amd import io as wio
+        n = 64 * 480000
+        d_pcm = torch.randint(-32768, 32767, (n,), dtype=torch.int16, device=dev)
+        d_x = torch.empty(n, dtype=torch.float64, device=dev)
+        t = timed(lambda: wio.pcm16_to_double_device(d_pcm, n, d_x), L)
+        print(json.dumps({"config": "pcm16->f64", "what": "64 x 48 kHz x 10 s of int16 PCM expanded on the device", "ms": t * 1e3,
+                          "GBps": n * 10 / t / 1e9, "hbm_frac": n * 10 / t / 8e12}))
+        frames, fft = 128064, 2048
+        d_f0 = torch.full((frames,), 200.0, dtype=torch.float64, device=dev)
+        d_sp = torch.rand(frames * (fft // 2 + 1), dtype=torch.float64, device=dev) + 1e-6
+        t = timed(lambda: wio.modify_parameters_device(48000, fft, frames, d_f0, d_sp, 1.0, 1.1), L)
+        b = frames * (fft // 2 + 1) * 16
+        print(json.dumps({"config": "modify", "what": "spectral stretching of 128064 rows of 1025 bins in place (log, interp1, exp)",
+                          "ms": t * 1e3, "GBps": b / t / 1e9, "hbm_frac": b / t / 8e12}))
 
 
 if __name__ == "__main__":

@@ -35,7 +35,6 @@
 namespace wc {
 
 constexpr double kSafeH = 0.000000000001;
-constexpr double kLog2H = 0.69314718055994529;
 constexpr int HL_MAX = 512;       // longest supported half filter length (f0_floor >= ~35 Hz at 8 kHz)
 constexpr int BP_T = 256;         // threads of the band-pass workgroup
 constexpr int BP_R = 8;           // consecutive outputs per thread

@@ -623,7 +623,6 @@ int syn_prepare(wc_synthesis *sy, hipStream_t s, int n_utt, const double *d_f0, 
 	int *d_count = d_cap + n_utt;
 	int *d_first = d_count + n_utt;
 	int *d_last = d_first + n_utt;
-	int *d_ovf = d_last + n_utt;
 	long long inc_total = 0, co = 0;
 	for (int u = 0; u < n_utt; ++u) {
 		h_inc_off[u] = inc_total;
