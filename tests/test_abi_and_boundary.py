@@ -16,8 +16,8 @@ def header_symbols():
     return sorted(set(re.findall(r"\b(wc_[a-z0-9_]+)\s*\(", src)))
 
 
-def io_header_symbols():
-    src = open(os.path.join(ROOT, "include", "world_class_io.h")).read()
+def io_header_symbols(name="world_class_io.h"):
+    src = open(os.path.join(ROOT, "include", name)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", src)))
 
@@ -40,6 +40,9 @@ def test_library_exports_every_declared_symbol(built_lib):
     io_declared = io_header_symbols()
     assert {"wavread", "wavwrite", "GetAudioLength", "ReadF0", "WriteSpectralEnvelope", "wc_modify_parameters_device"} <= set(io_declared)
     assert not [s for s in io_declared if s not in exported_all]
+    codec_declared = io_header_symbols("world_class_codec.h")
+    assert {"CodeSpectralEnvelope", "DecodeAperiodicity", "GetNumberOfAperiodicities"} <= set(codec_declared)
+    assert not [s for s in codec_declared if s not in exported_all]
 
 
 def test_python_mirror_binds_the_header(built_lib):
@@ -47,6 +50,8 @@ def test_python_mirror_binds_the_header(built_lib):
     assert sorted(w.EXPORTED_SYMBOLS) == header_symbols()
     from world_class_amd import io as wio
     assert sorted(wio.IO_SIGNATURES) == io_header_symbols()
+    from world_class_amd import codec
+    assert sorted(codec.CODEC_SIGNATURES) == io_header_symbols("world_class_codec.h")
     lib = w.lib()  # loads and sets every prototype
     assert lib.wc_version().startswith(b"world_class_amd")
     # pure host helpers work without a device and match the reference's formulas (goldens in test_oracle_golden)
