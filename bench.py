@@ -37,7 +37,7 @@ STAGE_BYTES = {
 KERNEL_STAGE = {
     "harvest_decimate": "harvest", "harvest_bandpass": "harvest", "harvest_raw": "harvest",
     "harvest_refine": "harvest", "harvest_contour": "harvest",
-    "cheaptrick_frames": "cheaptrick", "d4c_lovetrain": "d4c", "d4c_frames": "d4c",
+    "cheaptrick_frames": "cheaptrick", "d4c_lovetrain": "d4c", "d4c_frames": "d4c", "d4c_bands": "d4c",
     "synthesis_timebase": "synthesis", "synthesis_pulses": "synthesis",
 }
 SEQUENTIAL_SCANS = ("synthesis_timebase", "harvest_contour")

@@ -12,7 +12,7 @@ import world_class_amd as w  # noqa: E402
 from world_class_amd.synth import make_utterance, true_f0  # noqa: E402
 
 KERNELS = ["harvest_decimate", "harvest_bandpass", "harvest_raw", "harvest_refine", "harvest_contour",
-           "cheaptrick_frames", "d4c_lovetrain", "d4c_frames", "synthesis_timebase", "synthesis_pulses"]
+           "cheaptrick_frames", "d4c_lovetrain", "d4c_frames", "d4c_bands", "synthesis_timebase", "synthesis_pulses"]
 
 
 def main():

@@ -35,6 +35,8 @@ struct D4cArgs {
 	const double2 *tw;
 	double *ap;        // [total_frames][bins_out]
 	double *ap0;       // [total_frames] LoveTrain result
+	double *sgd;       // [total_frames][N/2+1] static group delay of gated frames (split schedule)
+	double *coarse;    // [total_frames][kMaxBands] coarse aperiodicity (split schedule)
 	uint32_t *cnt;     // [total_frames] draws of the main pass (written by LoveTrain)
 	const double *nuttall;  // window_length_ entries
 	long long total_frames;
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(T, T == 512 ? 6 : 1) void d4c_lovetrain_kernel(D4cA
 #ifndef WC_D4C_FFTSYNC
 #define WC_D4C_FFTSYNC 1  // FFT flags; 0 (no barriers) and 3 (no twiddle loads) are timing ablations with wrong results
 #endif
-template <int N, int T>
+template <int N, int T, bool SPLIT>
 __global__ __launch_bounds__(T, (2 * T) / 256) void d4c_frames_kernel(D4cArgs a) {
 	constexpr int M = N / 2;
 	constexpr int EPT = N / T;
@@ -356,6 +358,11 @@ __global__ __launch_bounds__(T, (2 * T) / 256) void d4c_frames_kernel(D4cArgs a)
 	if (tid == 0) a.ap[g * (long long)(a.fft_size_out / 2 + 1)] = Cc[1] + Br[1];
 	return;
 #endif
+	if (SPLIT) {  // the band loop runs as its own kernel (one band per workgroup, leaner and with more waves in flight)
+		double *__restrict__ dst = a.sgd + g * (long long)(M + 1);
+		for (int k = tid; k <= M; k += T) dst[k] = Cc[k];
+		return;
+	}
 	// ---- coarse aperiodicity (reference :466-503) ----
 	const int n_ap = a.n_ap;
 	const int wln = a.window_length;
@@ -490,6 +497,183 @@ __global__ __launch_bounds__(T, (2 * T) / 256) void d4c_frames_kernel(D4cArgs a)
 
 #undef WC_FRESH_TID
 
+#ifndef WC_D4C_PRUNE
+#define WC_D4C_PRUNE 1
+#endif
+// Split schedule, second kernel: one workgroup per (gated frame, band).  Same arithmetic as the band loop of
+// d4c_frames_kernel (reference :466-503), with the group delay read back from global memory: 36 KB of LDS and 54
+// registers instead of 64 KB / 128 VGPRs, i.e. four instead of two workgroups per CU.
+template <int N, int T>
+__global__ __launch_bounds__(T, (4 * T) / 256) void d4c_band_kernel(D4cArgs a) {
+	constexpr int M = N / 2;
+	constexpr int EPT = N / T;
+	constexpr int PAIRS = (M / 2) / T;
+	constexpr int KEYS = 2 * PAIRS + 1;
+	__shared__ double2 A[fft_lds_size(M)];
+	__shared__ unsigned int hist[4][256];  // ring of pass histograms: pass p uses row p & 3 (36 KB of LDS: four workgroups per CU)
+	__shared__ double red3[3 * (T / 64)];
+	double *Ar = reinterpret_cast<double *>(A);
+	int tid = threadIdx.x;
+	const int n_ap = a.n_ap;
+	const long long blk = blockIdx.x;
+	const long long g = xcd_frame(blk / n_ap, a.total_frames);
+	const int bnd = (int)(blk % n_ap);
+	if (g >= a.total_frames) return;
+	const double f0v = a.f0[g];
+	if (f0v == 0.0 || a.ap0[g] <= a.threshold) return;
+	const double f0 = fmax(47.0, f0v);
+	const int fs = a.fs;
+	const int wln = a.window_length, hwl = wln / 2;
+	const int boundary = mround(N * 8.0 / wln);
+	const int bins = M + 1;
+	const unsigned int K = (unsigned int)(bins - boundary - 1);
+	const double *__restrict__ sgd = a.sgd + g * (long long)(M + 1);
+	const int center = (int)(3000.0 * (bnd + 1) * N / fs);
+	for (int i = tid; i < 4 * 256; i += T) (&hist[0][0])[i] = 0u;
+	if constexpr (M == 2048 && WC_D4C_PRUNE) {
+		// The windowed group delay has 513 (<= 2 * 257) real samples of 4096: as interleaved complex z[0..256] it is zero
+		// beyond entry 256, so the radix-2 pass and the first radix-4 pass of the transform only replicate -- the array
+		// after them is A[p] = z[p >> 3], plus the terms of z[256] in the two butterflies that see it (p < 8).  Written
+		// directly (bit-identical to running the passes), then the remaining four passes.
+		if (wln <= 513) {
+			auto xs = [&](int i) { return sgd[center - hwl + i] * a.nuttall[i]; };
+#pragma unroll
+			for (int e = 0; e < M / T; ++e) {
+				const int p = tid + e * T;
+				const int i0 = 2 * (p >> 3);
+				double2 v = make_double2(xs(i0), xs(i0 + 1));
+				if (p < 8 && wln == 513) {
+					double2 x1 = make_double2(xs(512), 0.0);                      // z[256]
+					if (p & 1) x1 = cmul(x1, tw_load(a.tw, kTwiddleN / 8));         // W_8^1 of the first radix-4 pass
+					const int q = p >> 1;                                           // dft4 output q with x2 = x3 = 0
+					const double2 t = (q & 1) ? make_double2(-x1.y, x1.x) : x1;     // i x1 for q = 1, 3
+					v = (q & 2) ? csub(v, t) : cadd(v, t);
+				}
+				A[p] = v;
+			}
+			__syncthreads();
+			WC_FRESH(tid);
+			fft_lds_tail<M, T, +1, 8>(A, a.tw, tid);
+		} else {
+#pragma unroll
+			for (int e = 0; e < EPT; ++e) {
+				int i = tid + e * T;
+				Ar[i] = (i < wln) ? sgd[center - hwl + i] * a.nuttall[i] : 0.0;
+			}
+			__syncthreads();
+			WC_FRESH(tid);
+			fft_lds<M, T, +1>(A, a.tw, tid);
+		}
+	} else {
+#pragma unroll
+		for (int e = 0; e < EPT; ++e) {
+			int i = tid + e * T;
+			Ar[i] = (i < wln) ? sgd[center - hwl + i] * a.nuttall[i] : 0.0;
+		}
+		__syncthreads();
+		WC_FRESH(tid);
+		fft_lds<M, T, +1>(A, a.tw, tid);
+	}
+	double key[KEYS];
+	r2c_power<M, T>(A, a.tw, tid, key);
+	WC_FRESH(tid);
+	const int lane = tid & 63;
+	const int nkeys = (tid == 0) ? KEYS : KEYS - 1;
+	unsigned long long pre = 0ull;
+	unsigned int need = K, in_bucket = 0u;
+	int shift = 56;
+	for (int pass = 0; pass < 8; ++pass) {
+		shift = 56 - 8 * pass;
+		unsigned int *__restrict__ hrow = hist[pass & 3];
+		// row (pass - 2) & 3 was last read before the previous barrier; clear it for pass + 2
+		if (pass >= 2) for (int i = tid; i < 256; i += T) hist[(pass - 2) & 3][i] = 0u;
+#pragma unroll
+		for (int e = 0; e < KEYS; ++e) {
+			const unsigned long long bits = (unsigned long long)__double_as_longlong(key[e]);
+			bool match = (e < nkeys) && ((pass == 0) || ((bits >> (shift + 8)) == (pre >> (shift + 8))));
+			const unsigned int bucket = (unsigned int)((bits >> shift) & 255ull);
+			unsigned long long act = __ballot(match);
+#pragma unroll
+			for (int it = 0; it < 2; ++it) {
+				if (act != 0ull) {
+					const int leader = __ffsll((long long)act) - 1;
+					const unsigned int bl = __shfl(bucket, leader, 64);
+					const unsigned long long same = __ballot(match && bucket == bl);
+					if (lane == leader) atomicAdd(&hrow[bl], (unsigned int)__popcll(same));
+					act &= ~same;
+					match = match && bucket != bl;
+				}
+			}
+			if (match) atomicAdd(&hrow[bucket], 1u);
+		}
+		__syncthreads();
+		const uint4 h4 = reinterpret_cast<const uint4 *>(hrow)[lane];
+		const unsigned int own = h4.x + h4.y + h4.z + h4.w;
+		unsigned int inc = own;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			unsigned int t = __shfl_up(inc, o, 64);
+			if (lane >= o) inc += t;
+		}
+		const unsigned long long reach = __ballot(inc >= need);
+		const int first = __ffsll((long long)reach) - 1;
+		unsigned int acc = inc - own;
+		unsigned int d = 4u * lane, cnt;
+		if (acc + h4.x >= need) { cnt = h4.x; }
+		else if (acc + h4.x + h4.y >= need) { acc += h4.x; d += 1; cnt = h4.y; }
+		else if (acc + h4.x + h4.y + h4.z >= need) { acc += h4.x + h4.y; d += 2; cnt = h4.z; }
+		else { acc += h4.x + h4.y + h4.z; d += 3; cnt = h4.w; }
+		acc = __shfl(acc, first, 64);
+		d = __shfl(d, first, 64);
+		in_bucket = __shfl(cnt, first, 64);
+		need -= acc;
+		pre |= ((unsigned long long)d) << shift;
+		if (in_bucket == 1u) break;
+	}
+	double low = 0.0, eq = 0.0, tot = 0.0;
+#pragma unroll
+	for (int e = 0; e < KEYS; ++e) {
+		if (e < nkeys) {
+			const double pw = key[e];
+			const unsigned long long hb = ((unsigned long long)__double_as_longlong(pw)) >> shift;
+			tot += pw;
+			low += (hb < (pre >> shift)) ? pw : 0.0;
+			eq += (hb == (pre >> shift)) ? pw : 0.0;
+		}
+	}
+	block_sum3<T>(low, eq, tot, red3, tid);
+	if (tid == 0) {
+		const double thr = (in_bucket == 1u) ? eq : __longlong_as_double((long long)pre);
+		const double part = low + (double)need * thr;
+		const double cv = 10 * log10(part / tot);
+		a.coarse[g * kMaxBands + bnd] = fmin(0.0, cv + (f0 - 100) / 50.0);
+	}
+}
+
+// Split schedule, third kernel: interp1 of the coarse aperiodicity onto the output grid + dB -> linear (reference :162-168)
+__global__ __launch_bounds__(256) void d4c_rows_kernel(D4cArgs a) {
+	const long long g = blockIdx.x;
+	const double f0v = a.f0[g];
+	if (f0v == 0.0 || a.ap0[g] <= a.threshold) return;
+	const int n_ap = a.n_ap, fs = a.fs;
+	const int bins_out = a.fft_size_out / 2 + 1;
+	const double *__restrict__ co = a.coarse + g * kMaxBands;
+	double *__restrict__ row = a.ap + g * (long long)bins_out;
+	const int na = n_ap + 2;
+	auto val = [&](int q) { return q == 0 ? -60.0 : (q == na - 1 ? -kSafe : co[q - 1]); };
+	for (int k = threadIdx.x; k < bins_out; k += 256) {
+		double f = (double)k * fs / a.fft_size_out;
+		int c = 1;
+		while (c < na && f >= ((c == na - 1) ? fs / 2.0 : c * 3000.0)) ++c;
+		c = min(c, na - 1);
+		double x0 = (c - 1) * 3000.0;
+		double x1 = (c == na - 1) ? fs / 2.0 : c * 3000.0;
+		double s = (f - x0) / (x1 - x0);
+		double v = val(c - 1) + s * (val(c) - val(c - 1));
+		row[k] = exp(v * 0.11512925464970228);
+	}
+}
+
 }  // namespace wc
 
 using namespace wc;
@@ -497,8 +681,9 @@ using namespace wc;
 struct wc_d4c {
 	int fs, fft_size_d4c, fft_size_lt, n_ap, window_length;
 	double threshold;
+	bool split;  // band loop and row output as separate kernels (default; WC_D4C_SPLIT=0: one fused kernel)
 	Device *dev;
-	DevBuf nuttall, utts, cnt, off, endpos, endpos2, ap0, d_x, d_tpos, d_f0, d_ap;
+	DevBuf nuttall, utts, cnt, off, endpos, endpos2, ap0, sgd, coarse, d_x, d_tpos, d_f0, d_ap;
 	HostBuf h_stage;
 };
 
@@ -508,11 +693,18 @@ static void launch_lt(const D4cArgs &a, hipStream_t s) {
 	constexpr int TL = (N >= 4096) ? 512 : 256;
 	hipLaunchKernelGGL((d4c_lovetrain_kernel<N, TL>), dim3((unsigned)blocks), dim3(TL), 0, s, a);
 }
+// part 0: frames kernel (fused, or up to the group delay when split); part 1: bands + rows of the split schedule
 template <int N>
-static void launch_main(const D4cArgs &a, hipStream_t s) {
+static void launch_main(const D4cArgs &a, hipStream_t s, bool split, int part) {
 	long long blocks = ((a.total_frames + 7) / 8) * 8;
 	constexpr int TF = (N >= 4096) ? 512 : 256;  // 8 waves per frame at N = 4096: half the registers per thread, 2 WG/CU
-	hipLaunchKernelGGL((d4c_frames_kernel<N, TF>), dim3((unsigned)blocks), dim3(TF), 0, s, a);
+	if (part == 0) {
+		if (!split) hipLaunchKernelGGL((d4c_frames_kernel<N, TF, false>), dim3((unsigned)blocks), dim3(TF), 0, s, a);
+		else hipLaunchKernelGGL((d4c_frames_kernel<N, TF, true>), dim3((unsigned)blocks), dim3(TF), 0, s, a);
+		return;
+	}
+	if (a.n_ap > 0) hipLaunchKernelGGL((d4c_band_kernel<N, TF>), dim3((unsigned)(blocks * a.n_ap)), dim3(TF), 0, s, a);
+	hipLaunchKernelGGL(d4c_rows_kernel, dim3((unsigned)a.total_frames), dim3(256), 0, s, a);
 }
 
 // Enqueue-only (no host synchronisation), shared with the fused pipeline: everything on stream s; the stream
@@ -548,6 +740,11 @@ int d4c_enqueue(wc_d4c *d, hipStream_t s, int n_utt, const double *d_x, const in
 	if ((rc = d->cnt.reserve(sizeof(uint32_t) * total))) return rc;
 	if ((rc = d->off.reserve(sizeof(uint64_t) * total))) return rc;
 	if ((rc = d->ap0.reserve(sizeof(double) * total))) return rc;
+	const bool split = d->split;
+	if (split) {
+		if ((rc = d->sgd.reserve(sizeof(double) * (size_t)total * (d->fft_size_d4c / 2 + 1)))) return rc;
+		if ((rc = d->coarse.reserve(sizeof(double) * (size_t)total * kMaxBands))) return rc;
+	}
 	if ((rc = d->endpos.reserve(sizeof(uint64_t) * n_utt))) return rc;
 	if ((rc = d->endpos2.reserve(sizeof(uint64_t) * n_utt))) return rc;
 	if ((rc = d->h_stage.reserve(sizeof(UttDesc) * n_utt + sizeof(uint64_t) * n_utt))) return rc;
@@ -562,6 +759,7 @@ int d4c_enqueue(wc_d4c *d, hipStream_t s, int n_utt, const double *d_x, const in
 	a.x = d_x; a.utts = d->utts.as<UttDesc>(); a.n_utt = n_utt; a.tpos = d_tpos; a.f0 = d_f0;
 	a.rng_off = d->off.as<unsigned long long>(); a.rng_table = dev->rng_table.as<uint32_t>(); a.rng_base = dev->rng_base;
 	a.tw = dev->twiddle; a.ap = d_ap; a.ap0 = d->ap0.as<double>(); a.cnt = d->cnt.as<uint32_t>();
+	a.sgd = d->sgd.as<double>(); a.coarse = d->coarse.as<double>();
 	a.nuttall = d->nuttall.as<double>(); a.total_frames = total; a.fs = d->fs; a.fft_size_out = fft_size;
 	a.n_ap = d->n_ap; a.window_length = d->window_length; a.threshold = d->threshold;
 	if ((rc = dev->time_begin("d4c_lovetrain", s))) return rc;
@@ -576,15 +774,19 @@ int d4c_enqueue(wc_d4c *d, hipStream_t s, int n_utt, const double *d_x, const in
 	// offsets of the main pass start where the LoveTrain draws of the utterance end
 	hipLaunchKernelGGL(utt_scan_kernel, dim3(n_utt), dim3(256), 0, s, d->cnt.as<uint32_t>(), d->utts.as<UttDesc>(),
 					   d->endpos.as<unsigned long long>(), d->off.as<unsigned long long>(), d->endpos2.as<unsigned long long>());
-	if ((rc = dev->time_begin("d4c_frames", s))) return rc;
-	switch (d->fft_size_d4c) {
-		case 1024: launch_main<1024>(a, s); break;
-		case 2048: launch_main<2048>(a, s); break;
-		case 4096: launch_main<4096>(a, s); break;
-		default: return fail(WC_ERR_UNSUPPORTED, "d4c: unsupported FFT size (fs must be 8..48 kHz)");
+	for (int part = 0; part < (split ? 2 : 1); ++part) {
+		const char *name = part == 0 ? "d4c_frames" : "d4c_bands";
+		if ((rc = dev->time_begin(name, s))) return rc;
+		switch (d->fft_size_d4c) {
+			case 1024: launch_main<1024>(a, s, split, part); break;
+			case 2048: launch_main<2048>(a, s, split, part); break;
+			case 4096: launch_main<4096>(a, s, split, part); break;
+			default: return fail(WC_ERR_UNSUPPORTED, "d4c: unsupported FFT size (fs must be 8..48 kHz)");
+		}
+		WC_HIP(hipGetLastError());
+		if ((rc = dev->time_end(name, s))) return rc;
 	}
-	WC_HIP(hipGetLastError());
-	return dev->time_end("d4c_frames", s);
+	return WC_OK;
 }
 
 const unsigned long long *d4c_end_positions(const wc_d4c *d) { return d->endpos2.as<unsigned long long>(); }
@@ -631,6 +833,10 @@ wc_d4c *wc_d4c_create(int fs, double threshold) {
 	d->fs = fs;
 	d->threshold = threshold;
 	d->dev = dev;
+	{
+		const char *sp = getenv("WC_D4C_SPLIT");  // default: split schedule; WC_D4C_SPLIT=0 runs the single fused kernel
+		d->split = !(sp && sp[0] == '0');
+	}
 	// reference src/d4c.cpp:60-111
 	d->fft_size_d4c = static_cast<int>(std::pow(2.0, 1.0 + static_cast<int>(std::log(4.0 * fs / 47.0 + 1) / 0.69314718055994529)));
 	d->n_ap = static_cast<int>(std::fmin(15000.0, fs / 2.0 - 3000.0) / 3000.0);
@@ -661,7 +867,7 @@ void wc_d4c_destroy(wc_d4c *d) {
 	if (!d) return;
 	(void)hipStreamSynchronize(d->dev->stream);
 	d->nuttall.release(); d->utts.release(); d->cnt.release(); d->off.release(); d->endpos.release(); d->endpos2.release();
-	d->ap0.release(); d->d_x.release(); d->d_tpos.release(); d->d_f0.release(); d->d_ap.release(); d->h_stage.release();
+	d->ap0.release(); d->sgd.release(); d->coarse.release(); d->d_x.release(); d->d_tpos.release(); d->d_f0.release(); d->d_ap.release(); d->h_stage.release();
 	delete d;
 }
 

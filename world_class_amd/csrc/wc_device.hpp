@@ -334,6 +334,16 @@ __device__ void fft_lds(double2 *a, const double2 *__restrict__ tw_, int tid) {
 	fft_chain<M, T, S, 1, FL>(a, tw, tid, first);
 }
 
+// The passes from Ns = NS0 on, for callers that can write the state after the first passes directly (an input that is
+// zero beyond its first M / NS0 entries makes those passes pure replication).
+template <int M, int T, int S, int NS0>
+__device__ void fft_lds_tail(double2 *a, const double2 *__restrict__ tw_, int tid) {
+	const double2 *__restrict__ tw = tw_fresh(tw_);
+	FftTw<M, T, fft_radix<M, NS0>(), NS0> first;
+	fft_load_tw<M, T, S, fft_radix<M, NS0>(), NS0, 1>(first, tw, tid);
+	fft_chain<M, T, S, NS0, 1>(a, tw, tid, first);
+}
+
 // ---- real FFT of N = 2M points held as M interleaved complex (x[2k], x[2k+1]) -----------------------
 // After fft_lds<M,T,+1> on that array, unpack to the spectrum X[0..M] (reference r2c convention).
 // Packed in place: a[0] = (X[0].re, X[M].re); a[k] = X[k] for 0 < k < M.  Ends with a __syncthreads().
