@@ -1316,7 +1316,7 @@ static inline int h_mround(double x) { return x > 0 ? static_cast<int>(x + 0.5) 
 // zero-crossing buffers; with the rate bound an overflow is reported through h->overflow (device) and handled by
 // the caller (hv_overflowed) by re-running with full == true.
 int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const int *x_length, double *d_tpos, double *d_f0,
-			   bool full, hipEvent_t mid_event) {
+			   bool full, hipEvent_t mid_event, hipEvent_t start_after) {
 	Device *dev = h->dev;
 	const int r = h->decim;
 	const int lag = (r == 1) ? 0 : static_cast<int>(std::ceil(140.0 / r) * r);
@@ -1435,6 +1435,9 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 			WC_HIP(hipGetLastError());
 			if ((rc = dev->time_end("harvest_decimate", s))) return rc;
 		}
+		// a staggered twin chain holds its ALU-bound kernels back until the other chain's are through; the latency-bound
+		// decimation above may run underneath them
+		if (start_after) WC_HIP(hipStreamWaitEvent(s, start_after, 0));
 		BpArgs ba;
 		ba.utts = du; ba.y = h->y.as<double>(); ba.taps = h->d_taps.as<double>(); ba.tap_off = h->d_tap_off.as<int>();
 		ba.half_len = h->d_half_len.as<int>(); ba.ev_band_off = h->d_ev_band_off.as<long long>(); ba.ev_cap = h->d_ev_cap.as<int>();
@@ -1515,7 +1518,7 @@ static int hv_run_device(wc_harvest *h, int n_utt, const double *d_x, const int 
 	hipStream_t s = h->dev->stream;
 	int rc;
 	for (int attempt = 0; attempt < 2; ++attempt) {
-		if ((rc = hv_enqueue(h, s, n_utt, d_x, x_length, d_tpos, d_f0, attempt == 1, nullptr))) return rc;
+		if ((rc = hv_enqueue(h, s, n_utt, d_x, x_length, d_tpos, d_f0, attempt == 1, nullptr, nullptr))) return rc;
 		bool overflow = false;
 		if ((rc = hv_overflowed(h, s, &overflow))) return rc;
 		if (!overflow) return WC_OK;

@@ -201,9 +201,8 @@ int wc_pipeline_run_device(wc_pipeline *p, int n_utt, const double *d_x, const i
 			for (int g = 0; g < 2; ++g) {
 				PipeGroup &G = p->grp[g];
 				dev->time_tag = g;
-				if (g == 1) WC_HIP(hipStreamWaitEvent(G.main, p->grp[0].e_mid, 0));
 				if ((rc = hv_enqueue(G.hv, G.main, sl[g].nu, d_x + sl[g].xo, x_length + sl[g].u0, d_tpos + sl[g].fo, d_f0 + sl[g].fo,
-									 full[g][0], G.e_mid)))
+									 full[g][0], G.e_mid, g == 1 ? p->grp[0].e_mid : nullptr)))
 					return rc;
 			}
 			// 2. the rest of each chain; A's CheapTrick/D4C wait for B's refinement as well
@@ -257,7 +256,7 @@ int wc_pipeline_run_device(wc_pipeline *p, int n_utt, const double *d_x, const i
 				const int u0 = (int)((long long)n_utt * k / ns), u1 = (int)((long long)n_utt * (k + 1) / ns);
 				hipStream_t sk = k == 0 ? s0 : p->hs[k];
 				if (k > 0) WC_HIP(hipStreamWaitEvent(sk, p->e0, 0));
-				if ((rc = hv_enqueue(p->hv[k], sk, u1 - u0, d_x + xo, x_length + u0, d_tpos + fo, d_f0 + fo, hv_full, nullptr))) return rc;
+				if ((rc = hv_enqueue(p->hv[k], sk, u1 - u0, d_x + xo, x_length + u0, d_tpos + fo, d_f0 + fo, hv_full, nullptr, nullptr))) return rc;
 				if (k > 0) WC_HIP(hipEventRecord(p->he[k], sk));
 				for (int u = u0; u < u1; ++u) { xo += x_length[u]; fo += f_len[u]; }
 			}

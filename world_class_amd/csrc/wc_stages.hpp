@@ -4,7 +4,7 @@
 #include "wc_internal.hpp"
 
 int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const int *x_length, double *d_tpos, double *d_f0,
-			   bool full, hipEvent_t mid_event);
+			   bool full, hipEvent_t mid_event, hipEvent_t start_after);
 int hv_overflowed(wc_harvest *h, hipStream_t s, bool *overflow);
 
 int ct_prepare(wc_cheaptrick *c, hipStream_t s, int n_utt, const int *x_length, const double *d_f0, const int *f0_length,
