@@ -844,7 +844,8 @@ __global__ __launch_bounds__(128) void hv_unreliable_kernel(const HvUtt *__restr
 									 double *__restrict__ base, long long total_frames, int nc) {
 	__shared__ double nxt[7 * MAX_SLOTS], prv[7 * MAX_SLOTS];
 	__shared__ int cnt[2];
-	__shared__ unsigned long long best;  // searchF0Base: (score bits, ~slot) packed so that max = highest score, first slot
+	__shared__ unsigned long long best;  // searchF0Base: bit pattern of the highest score (positive doubles order like their bits)
+	__shared__ int best_slot;
 	const long long g = blockIdx.x;
 	if (g >= total_frames) return;
 	const int ui = hv_find(utts, n_utt, g, &HvUtt::l1_off);
@@ -852,7 +853,7 @@ __global__ __launch_bounds__(128) void hv_unreliable_kernel(const HvUtt *__restr
 	const int i = (int)(g - u.l1_off);
 	const bool interior = i >= 1 && i < u.L1 - 1;
 	if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
-	if (threadIdx.x == 0) best = 0ull;
+	if (threadIdx.x == 0) { best = 0ull; best_slot = 0x7fffffff; }
 	__syncthreads();
 	if (interior) {
 		for (int j = threadIdx.x; j < nc; j += blockDim.x) {
@@ -863,35 +864,39 @@ __global__ __launch_bounds__(128) void hv_unreliable_kernel(const HvUtt *__restr
 	}
 	__syncthreads();
 	const int n1 = cnt[0], n2 = cnt[1];
-	for (int j = threadIdx.x; j < nc; j += blockDim.x) {
-		double ref = c1[g * nc + j], sc = s1[g * nc + j];
-		if (ref != 0 && interior) {
-			double e1 = 1.0, e2 = 1.0;
-			for (int k = 0; k < n1; ++k) e1 = fmin(e1, fabs(ref - nxt[k]) / ref);
-			for (int k = 0; k < n2; ++k) e2 = fmin(e2, fabs(ref - prv[k]) / ref);
-			if (fmin(e1, e2) > 0.05) { ref = 0; sc = 0; }
-		}
-		c2[g * nc + j] = ref;
-		s2[g * nc + j] = sc;
-		// searchF0Base (reference :254-272): highest score, the first slot on ties; scores are >= 2.5 or 0, and
-		// positive doubles order like their bit patterns, so keep the top 56 bits of the score above the slot
-		if (sc > 0.0) {
-			const unsigned long long key = ((unsigned long long)__double_as_longlong(sc) & ~0xffull) | (unsigned long long)(255 - j);
-			atomicMax(&best, key);
+	// (one slot per thread: nc <= 7 * MAX_SLOTS = 224 <= 2 * blockDim.x, so at most two slots each)
+	double my_ref[2] = {0.0, 0.0}, my_sc[2] = {0.0, 0.0};
+#pragma unroll
+	for (int q = 0; q < 2; ++q) {
+		const int j = threadIdx.x + q * 128;
+		if (j < nc) {
+			double ref = c1[g * nc + j], sc = s1[g * nc + j];
+			if (ref != 0 && interior) {
+				double e1 = 1.0, e2 = 1.0;
+				for (int k = 0; k < n1; ++k) e1 = fmin(e1, fabs(ref - nxt[k]) / ref);
+				for (int k = 0; k < n2; ++k) e2 = fmin(e2, fabs(ref - prv[k]) / ref);
+				if (fmin(e1, e2) > 0.05) { ref = 0; sc = 0; }
+			}
+			c2[g * nc + j] = ref;
+			s2[g * nc + j] = sc;
+			my_ref[q] = ref;
+			my_sc[q] = sc;
+			if (sc > 0.0) atomicMax(&best, (unsigned long long)__double_as_longlong(sc));
 		}
 	}
 	__syncthreads();
-	if (threadIdx.x == 0) {
-		double b = 0.0;
-		if (best != 0ull) {
-			// resolve exactly among the slots whose score shares the top 56 bits (practically one)
-			double bs = 0.0;
-			for (int j = 0; j < nc; ++j) {
-				const double sc = s2[g * nc + j];
-				if (sc > bs) { b = c2[g * nc + j]; bs = sc; }
-			}
-		}
-		base[g] = b;
+	// searchF0Base (reference :254-272): highest score, the first slot on ties
+	const unsigned long long top = best;
+#pragma unroll
+	for (int q = 0; q < 2; ++q)
+		if (my_sc[q] > 0.0 && (unsigned long long)__double_as_longlong(my_sc[q]) == top) atomicMin(&best_slot, (int)(threadIdx.x + q * 128));
+	__syncthreads();
+	if (top == 0ull) {
+		if (threadIdx.x == 0) base[g] = 0.0;
+	} else {
+#pragma unroll
+		for (int q = 0; q < 2; ++q)
+			if ((int)(threadIdx.x + q * 128) == best_slot) base[g] = my_ref[q];
 	}
 }
 
