@@ -43,6 +43,7 @@ KERNEL_STAGE = {
 SEQUENTIAL_SCANS = ("synthesis_timebase", "harvest_contour")
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 VALU_PEAK_GINSTR = 614.4  # wave-level f64 vector instructions per second: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles
+VALU_SUSTAINED_GINSTR = 420.0  # what a pure FP64 FMA stream sustains on this part (tools/fp64_issue_rate.hip, profiles/r01_fp64_issue_rate.txt)
 
 
 def cpu_baseline(xs, budget_s=24.0):
@@ -216,8 +217,10 @@ def main():
                 traffic = pmc.get(dom)  # HBM bytes per step (PMC, see the file's _note)
                 insts = pmc.get("_valu_insts_per_step", {}).get(dom)
                 if insts:  # the ceiling that actually binds: FP64 vector issue
-                    valu = {"insts_per_step": insts, "peak_ginstr_per_s": VALU_PEAK_GINSTR,
-                            "issue_frac": insts / (kern[dom] * 1e-3) / (VALU_PEAK_GINSTR * 1e9)}
+                    rate = insts / (kern[dom] * 1e-3) / 1e9
+                    valu = {"insts_per_step": insts, "ginstr_per_s": rate, "peak_ginstr_per_s": VALU_PEAK_GINSTR,
+                            "issue_frac": rate / VALU_PEAK_GINSTR, "sustained_fma_ginstr_per_s": VALU_SUSTAINED_GINSTR,
+                            "frac_of_sustained": rate / VALU_SUSTAINED_GINSTR}
             roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                         "kernel_ms": kern[dom], "bytes_per_frame": STAGE_BYTES[stage],
