@@ -90,3 +90,27 @@ def test_d4c_edges(wca, port):
     assert np.abs(d.compute(x, tpos, f0, 1024) - port.d4c(x, fs, tpos, f0, 1024)).max() < AP_ABS
     assert d.compute(x, [], [], 1024).shape == (0, 513)
     port.rng_reset()
+
+
+@pytest.mark.parametrize("fs", [16000, 48000])
+def test_d4c_fused_and_split_schedules_agree(wca, port, fs):
+    """default: frames / band / rows kernels; WC_D4C_SPLIT=0: one fused kernel.  Same arithmetic, so identical rows
+    (the pruned band FFT of the split kernel at 48 kHz is bit-identical to running all passes)."""
+    import os
+    x = make_utterance(fs, 0.6, 4321)
+    tpos, f0 = port.harvest(x, fs)
+    fft = wca.cheaptrick_fft_size(fs)
+    wca.rng_set_position(0)
+    a = wca.D4C(fs).compute(x, tpos, f0, fft)
+    os.environ["WC_D4C_SPLIT"] = "0"
+    try:
+        d = wca.D4C(fs)
+    finally:
+        del os.environ["WC_D4C_SPLIT"]
+    wca.rng_set_position(0)
+    b = d.compute(x, tpos, f0, fft)
+    wca.rng_set_position(0)
+    assert np.array_equal(a, b)
+    port.rng_reset()
+    assert np.abs(a - port.d4c(x, fs, tpos, f0, fft)).max() < AP_ABS
+    port.rng_reset()
