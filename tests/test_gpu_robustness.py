@@ -116,3 +116,23 @@ def test_full_size_batch_properties(wca):
         assert np.abs(a[i]["y"] - a[j]["y"]).max() < 1e-12
     assert np.array_equal(a[0]["f0"], b[1]["f0"]) and np.array_equal(a[1]["sp"], b[0]["sp"])
     assert all(len(r["f0"]) == 2001 and r["sp"].shape == (2001, 1025) and len(r["y"]) == 480001 for r in a)
+
+
+def test_digital_silence(wca, port):
+    """exact-zero runs: the reference's fixStep1 reads uninitialised memory there; the oracle
+    and the device define it as upstream WORLD does (zeros), so both must agree, and nothing may turn non-finite"""
+    fs = 16000
+    x = make_utterance(fs, 1.2, 555)
+    x[6000:11000] = 0.0
+    (r,) = wca.Pipeline(fs).run_batch([x])
+    o = port.pipeline(x, fs)
+    check_f0(r["f0"], o["f0"])
+    assert np.isfinite(r["sp"]).all() and np.isfinite(r["ap"]).all() and np.isfinite(r["y"]).all()
+    assert (np.abs(r["sp"] - o["sp"]) / o["sp"]).max() < 1e-7
+    assert np.abs(r["ap"] - o["ap"]).max() < 1e-7
+    assert np.abs(r["y"] - o["y"]).max() < 1e-8
+    z = np.zeros(8000)
+    (rz,) = wca.Pipeline(fs).run_batch([z])
+    assert not rz["f0"].any() and np.isfinite(rz["sp"]).all() and np.isfinite(rz["y"]).all()
+    oz = port.pipeline(z, fs)
+    assert np.abs(rz["y"] - oz["y"]).max() < 1e-8
