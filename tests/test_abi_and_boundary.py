@@ -19,6 +19,7 @@ def header_symbols():
 def io_header_symbols(name="world_class_io.h"):
     src = open(os.path.join(ROOT, "include", name)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
     return sorted(set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", src)))
 
 
@@ -40,6 +41,9 @@ def test_library_exports_every_declared_symbol(built_lib):
     io_declared = io_header_symbols()
     assert {"wavread", "wavwrite", "GetAudioLength", "ReadF0", "WriteSpectralEnvelope", "wc_modify_parameters_device"} <= set(io_declared)
     assert not [s for s in io_declared if s not in exported_all]
+    helper_declared = [n for n in io_header_symbols("world_matlabfunctions.hpp") if not n.startswith(("My", "GetSafe"))]
+    assert {"interp1", "decimate", "randn", "DCCorrection"} <= set(helper_declared)
+    assert not [s for s in helper_declared if s not in exported_all]
     codec_declared = io_header_symbols("world_class_codec.h")
     assert {"CodeSpectralEnvelope", "DecodeAperiodicity", "GetNumberOfAperiodicities"} <= set(codec_declared)
     assert not [s for s in codec_declared if s not in exported_all]

@@ -300,6 +300,21 @@ int wc_synchronize(void) {
 uint64_t wc_rng_get_position(void) { return g_rng_position; }
 void wc_rng_set_position(uint64_t position) { g_rng_position = position; }
 
+// reference src/world_matlabfunctions.cpp:243-264 as a host function on the same process-wide stream the stages
+// use: draws at the current position and advances it by one (declared in include/world_matlabfunctions.hpp)
+double randn(void) {
+	static uint64_t cached_pos = ~0ull;
+	static XorShift cached;
+	if (cached_pos != g_rng_position) {  // someone moved the stream (a stage ran, or wc_rng_set_position): jump there
+		uint32_t st[4];
+		rng_state_at(g_rng_position, st);
+		cached = XorShift{st[0], st[1], st[2], st[3]};
+	}
+	const uint32_t raw = cached.draw();
+	cached_pos = ++g_rng_position;
+	return raw / 268435456.0 - 6.0;
+}
+
 // reference src/harvest.cpp:173-181
 int wc_get_samples(int fs, int x_length, double frame_period) {
 	return static_cast<int>(1000.0 * x_length / fs / frame_period) + 1;

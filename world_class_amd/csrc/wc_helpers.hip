@@ -1,0 +1,168 @@
+// Host implementations of the reference's free helper functions (include/world_matlabfunctions.hpp): restates
+// reference src/world_matlabfunctions.cpp:27-241, :303-313 and src/world_common.cpp:27-126.  They exist so that callers
+// of those helpers link against this library unchanged; the kernels do not use them.
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "../../include/world_matlabfunctions.hpp"
+
+namespace {
+
+// FilterForDecimate, reference src/world_matlabfunctions.cpp:27-125: order-3 IIR, coefficient sets for r = 2..12
+void iir3(const double *x, int n, int r, double *y) {
+	static const double A[13][3] = {
+		{0, 0, 0}, {0, 0, 0},
+		{0.041156734567757189, -0.42599112459189636, 0.041037215479961225},
+		{0.95039378983237421, -0.67429146741526791, 0.15412211621346475},
+		{1.4499664446880227, -0.98943497080950582, 0.24578252340690215},
+		{1.7610939654280557, -1.2554914843859768, 0.3237186507788215},
+		{1.9715352749512141, -1.4686795689225347, 0.3893908434965701},
+		{2.1225239019534703, -1.6395144861046302, 0.44469707800587366},
+		{2.2357462340187593, -1.7780899984041358, 0.49152555365968692},
+		{2.3236003491759578, -1.8921545617463598, 0.53148928133729068},
+		{2.3936475118069387, -1.9873904075111861, 0.5658879979027055},
+		{2.450743295230728, -2.06794904601978, 0.59574774438332101},
+		{2.4981398605924205, -2.1368928194784025, 0.62187513816221485}};
+	static const double B[13][2] = {
+		{0, 0}, {0, 0},
+		{0.16797464681802227, 0.50392394045406674},
+		{0.071221945171178636, 0.21366583551353591},
+		{0.036710750339322612, 0.11013225101796784},
+		{0.021334858522387423, 0.06400457556716227},
+		{0.013469181309343825, 0.040407543928031475},
+		{0.0090366882681608418, 0.027110064804482525},
+		{0.0063522763407111993, 0.019056829022133598},
+		{0.0046331164041389372, 0.013899349212416812},
+		{0.0034818622251927556, 0.010445586675578267},
+		{0.0026822508007163792, 0.0080467524021491377},
+		{0.0021097275904709001, 0.0063291827714127002}};
+	const int idx = (r >= 2 && r <= 12) ? r : 0;  // (the reference leaves the coefficients at zero for other ratios)
+	const double *a = A[idx], *b = B[idx];
+	double w0 = 0, w1 = 0, w2 = 0;
+	for (int i = 0; i < n; ++i) {
+		const double wt = x[i] + a[0] * w0 + a[1] * w1 + a[2] * w2;
+		y[i] = b[0] * wt + b[1] * w0 + b[1] * w1 + b[0] * w2;
+		w2 = w1;
+		w1 = w0;
+		w0 = wt;
+	}
+}
+
+inline double interp1q_at(double x0, double dx, const double *y, int n, double xi) {
+	const int base = static_cast<int>((xi - x0) / dx);
+	const double frac = (xi - x0) / dx - base;
+	const double dy = (base == n - 1) ? 0.0 : y[base + 1] - y[base];
+	return y[base] + dy * frac;
+}
+
+}  // namespace
+
+extern "C" {
+
+void fftshift(const double *x, int x_length, double *y) {
+	const int h = x_length / 2;
+	for (int i = 0; i < h; ++i) {
+		y[i] = x[i + h];
+		y[i + h] = x[i];
+	}
+}
+
+void histc(const double *x, int x_length, const double *edges, int edges_length, int *index) {
+	int count = 1, i = 0;
+	for (; i < edges_length; ++i) {
+		index[i] = 1;
+		if (edges[i] >= x[0]) break;
+	}
+	for (; i < edges_length; ++i) {
+		if (edges[i] < x[count]) index[i] = count;
+		else index[i--] = count++;
+		if (count == x_length) break;
+	}
+	count--;
+	for (i++; i < edges_length; ++i) index[i] = count;
+}
+
+void interp1(const double *x, const double *y, int x_length, const double *xi, int xi_length, double *yi) {
+	std::vector<int> k(xi_length > 0 ? xi_length : 0, 0);
+	histc(x, x_length, xi, xi_length, k.data());
+	for (int i = 0; i < xi_length; ++i) {
+		const int j = k[i];
+		const double s = (xi[i] - x[j - 1]) / (x[j] - x[j - 1]);
+		yi[i] = y[j - 1] + s * (y[j] - y[j - 1]);
+	}
+}
+
+void decimate(const double *x, int x_length, int r, double *y) {
+	const int kNFact = 9;
+	const int len = x_length + 2 * kNFact;
+	std::vector<double> t1(len), t2(len);
+	for (int i = 0; i < kNFact; ++i) t1[i] = 2 * x[0] - x[kNFact - i];
+	for (int i = 0; i < x_length; ++i) t1[kNFact + i] = x[i];
+	for (int i = 0; i < kNFact; ++i) t1[kNFact + x_length + i] = 2 * x[x_length - 1] - x[x_length - 2 - i];
+	iir3(t1.data(), len, r, t2.data());
+	std::reverse_copy(t2.begin(), t2.end(), t1.begin());
+	iir3(t1.data(), len, r, t2.data());
+	std::reverse_copy(t2.begin(), t2.end(), t1.begin());
+	const int nout = x_length / r + 1;
+	const int nbeg = r - r * nout + x_length;
+	int count = 0;
+	for (int i = nbeg; i < x_length + kNFact; i += r) y[count++] = t1[i + kNFact - 1];
+}
+
+int matlab_round(double x) { return x > 0 ? static_cast<int>(x + 0.5) : static_cast<int>(x - 0.5); }
+
+void diff(const double *x, int x_length, double *y) {
+	for (int i = 0; i < x_length - 1; ++i) y[i] = x[i + 1] - x[i];
+}
+
+void interp1Q(double x, double shift, const double *y, int x_length, const double *xi, int xi_length, double *yi) {
+	for (int i = 0; i < xi_length; ++i) yi[i] = interp1q_at(x, shift, y, x_length, xi[i]);
+}
+
+double matlab_std(const double *x, int x_length) {
+	double average = 0.0;
+	for (int i = 0; i < x_length; ++i) average += x[i];
+	average /= x_length;
+	double s = 0.0;
+	for (int i = 0; i < x_length; ++i) s += std::pow(x[i] - average, 2.0);
+	return std::sqrt(s / (x_length - 1));
+}
+
+int GetSuitableFFTSize(int sample) {
+	return static_cast<int>(std::pow(2.0, static_cast<int>(std::log(static_cast<double>(sample)) / 0.69314718055994529) + 1.0));
+}
+
+void DCCorrection(const double *input, double current_f0, int fs, int fft_size, double *output) {
+	const int upper = 2 + static_cast<int>(current_f0 * fft_size / fs);
+	std::vector<double> rep(upper > 1 ? upper - 1 : 0);
+	for (int i = 0; i < upper - 1; ++i)
+		rep[i] = interp1q_at(current_f0, -static_cast<double>(fs) / fft_size, input, upper + 1, static_cast<double>(i) * fs / fft_size);
+	for (int i = 0; i < upper - 1; ++i) output[i] = input[i] + rep[i];
+}
+
+void LinearSmoothing(const double *input, double width, int fs, int fft_size, double *output) {
+	const int b = static_cast<int>(width * fft_size / fs) + 1;
+	const int half = fft_size / 2, len = half + 2 * b + 1;
+	std::vector<double> seg(len);
+	auto mirrored = [&](int i) { return i < b ? input[b - i] : (i < half + b ? input[i - b] : input[half - (i - (half + b))]); };
+	seg[0] = mirrored(0) * fs / fft_size;
+	for (int i = 1; i < len; ++i) seg[i] = mirrored(i) * fs / fft_size + seg[i - 1];
+	const double origin = -(b - 0.5) * fs / fft_size, step = static_cast<double>(fs) / fft_size;
+	std::vector<double> res(half + 1);
+	for (int i = 0; i <= half; ++i) {
+		const double lo = static_cast<double>(i) / fft_size * fs - width / 2.0;
+		res[i] = (interp1q_at(origin, step, seg.data(), len, lo + width) - interp1q_at(origin, step, seg.data(), len, lo)) / width;
+	}
+	std::copy(res.begin(), res.end(), output);
+}
+
+void NuttallWindow(int y_length, double *y) {
+	const double pi = 3.1415926535897932384;
+	for (int i = 0; i < y_length; ++i) {
+		const double t = i / (y_length - 1.0);
+		y[i] = 0.355768 - 0.487396 * std::cos(2.0 * pi * t) + 0.144232 * std::cos(4.0 * pi * t) - 0.012604 * std::cos(6.0 * pi * t);
+	}
+}
+
+}  // extern "C"
