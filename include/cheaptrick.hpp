@@ -21,6 +21,7 @@ public:
 	~CheapTrick() { wc_cheaptrick_destroy(c_); }
 	CheapTrick(const CheapTrick &) = delete;
 	CheapTrick &operator=(const CheapTrick &) = delete;
+	CheapTrick(CheapTrick &&o) noexcept : c_(o.c_) { o.c_ = nullptr; }  // movable: `CheapTrick x = CheapTrick(...)` of the reference's demo
 
 	// reference src/cheaptrick.cpp:48-95; spectrogram[i] points at fft_size / 2 + 1 doubles (rows need not be contiguous).
 	// Noise draws use and advance the process-wide stream position like the reference's global randn().

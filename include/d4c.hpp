@@ -18,6 +18,7 @@ public:
 	~D4C() { wc_d4c_destroy(d_); }
 	D4C(const D4C &) = delete;
 	D4C &operator=(const D4C &) = delete;
+	D4C(D4C &&o) noexcept : d_(o.d_) { o.d_ = nullptr; }  // movable: `D4C x = D4C(...)` of the reference's demo
 
 	// reference src/d4c.cpp:113-173; aperiodicity[i] points at fft_size / 2 + 1 doubles
 	void compute(const double *x, int x_length, const double *temporal_positions, const double *f0, int f0_length, int fft_size,

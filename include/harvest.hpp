@@ -30,8 +30,11 @@ public:
 											   option.channels_in_octave, option.use_cos_table ? 1 : 0),
 							 "Harvest")) {}
 	~Harvest() { wc_harvest_destroy(h_); }
+	// not copyable (the object owns device workspaces); movable, so that the reference's own idiom
+	// `Harvest harvest = Harvest(fs, option);` (test/test.cpp:97) compiles under C++11
 	Harvest(const Harvest &) = delete;
 	Harvest &operator=(const Harvest &) = delete;
+	Harvest(Harvest &&o) noexcept : option_(o.option_), fs_(o.fs_), h_(o.h_) { o.h_ = nullptr; }
 
 	// reference src/harvest.cpp:183-208
 	void compute(const double *x, int x_length, double *temporal_positions, double *f0) {

@@ -14,6 +14,7 @@ public:
 	~Synthesis() { wc_synthesis_destroy(s_); }
 	Synthesis(const Synthesis &) = delete;
 	Synthesis &operator=(const Synthesis &) = delete;
+	Synthesis(Synthesis &&o) noexcept : s_(o.s_) { o.s_ = nullptr; }  // movable: `Synthesis x = Synthesis(...)` of the reference's demo
 
 	// reference src/synthesis.cpp:77-177.  Defined (unlike the reference) for an all-unvoiced contour: noise only.
 	// f0_length must be at least 2 (the reference reads f0[f0_length - 2]).

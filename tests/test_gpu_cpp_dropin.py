@@ -61,3 +61,31 @@ def test_cpp_file_level_demo(golden, port, tmp_path):
     y, fs_y, nbit = wio.wavread(tmp_path / "out.wav")
     assert (fs_y, nbit) == (fs, 16)
     assert np.abs(y * 32768 - port_io.pcm16_of(r["y"])).max() <= 1  # a sample within 1e-8 of a quantisation step may flip
+
+
+def test_reference_demo_unchanged_on_the_product(golden, port, tmp_path):
+    """oracle/_ref/ref_demo_on_product is the reference's own test/test.cpp, compiled unchanged against this repository's
+    include/ and linked to libworldclass_hip.so (oracle/Makefile; built where the reference sources exist).  Run with the
+    demo's F0 and spectral factors and compared with the oracle: CPU analysis (Harvest floor 40 like the demo), numpy
+    modification, CPU synthesis, wavwrite quantisation."""
+    from oracle import port_io
+    from world_class_amd import io as wio
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_demo_on_product")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_demo_on_product not built (needs the reference sources at build time)")
+    c = golden.case("c1_16k_2s_floor40")
+    fs = int(c["fs"])
+    wio.wavwrite(c["x"][:fs], fs, tmp_path / "in.wav")
+    subprocess.run([exe, str(tmp_path / "in.wav"), str(tmp_path / "out"), "1.2", "0.9"], check=True, cwd=tmp_path,
+                   stdout=subprocess.DEVNULL)
+    x = port_io.pcm16_of(c["x"][:fs]) / 32768.0
+    port.rng_reset()
+    tpos, f0 = port.harvest(x, fs, f0_floor=40.0)
+    sp = port.cheaptrick(x, fs, tpos, f0)
+    ap = port.d4c(x, fs, tpos, f0, 1024)
+    f0m, spm = port_io.parameter_modification(fs, 1024, f0, sp, 1.2, 0.9)
+    y_ref = port.synthesis(f0m, spm, ap, fs, 5.0)
+    port.rng_reset()
+    y, fs_y, nbit = wio.wavread(tmp_path / "out_1.wav")
+    assert (fs_y, nbit, len(y)) == (fs, 16, len(y_ref))
+    assert np.abs(y * 32768 - port_io.pcm16_of(y_ref)).max() <= 1  # a sample within 1e-8 of a quantisation step may flip
