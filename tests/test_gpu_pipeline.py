@@ -112,3 +112,24 @@ def test_fused_pipeline_ragged_batch_equals_stage_calls(wca):
         assert np.array_equal(r["f0"], f0) and np.array_equal(r["sp"], sp) and np.array_equal(r["ap"], ap)
         assert np.abs(r["y"] - y).max() < 1e-12
     assert all(b > a for a, b in zip([0, 7, 0], pos))
+
+
+def test_host_batch_front_end_pcm16_and_double(wca):
+    """wc_pipeline_run_batch_host: ragged batch from host pointers through pinned staging; int16 PCM in (expanded on the
+    device like wavread) and out (quantised like wavwrite) gives exactly what the device-resident path gives"""
+    from oracle import port_io
+    fs = 16000
+    xs = [make_utterance(fs, sec, seed) for sec, seed in ((0.5, 31), (0.9, 32), (0.35, 33))]
+    pcm = [port_io.pcm16_of(x * 32768.0 / 32767.0) for x in xs]   # any int16 samples will do
+    xq = [p.astype(np.float64) / 32768.0 for p in pcm]
+    p = wca.Pipeline(fs)
+    ref = p.run_batch(xq)
+    got = p.run_batch_host(pcm, y_pcm16=True)
+    for r, g in zip(ref, got):
+        assert np.array_equal(g["tpos"], r["tpos"]) and np.array_equal(g["f0"], r["f0"])
+        assert np.array_equal(g["sp"], r["sp"]) and np.array_equal(g["ap"], r["ap"])
+        assert g["y"].dtype == np.int16 and np.abs(g["y"].astype(np.int64) - port_io.pcm16_of(r["y"])).max() <= 1
+    got = p.run_batch_host(xq, want=("f0", "y"))
+    for r, g in zip(ref, got):
+        assert set(g) == {"f0", "y"} and np.array_equal(g["f0"], r["f0"])
+        assert np.abs(g["y"] - r["y"]).max() < 1e-10   # overlap-add order differs between runs at the 1e-16 level

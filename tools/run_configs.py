@@ -35,7 +35,7 @@ def tile(items, n):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--configs", default="2,3,4,5,6")
+    ap.add_argument("--configs", default="2,3,4,5,6,7")
     ap.add_argument("--scale", type=float, default=1.0, help="scale the utterance counts (for quick runs)")
     a = ap.parse_args()
     import torch
@@ -126,6 +126,21 @@ def main():
         print(json.dumps({"config": 5, "what": f"{n} x 24 kHz 2 s (1/8 of 4096 streams), 1 ms hop, Harvest + CheapTrick on whole "
                                                 "utterances (Harvest is non-causal: no streaming semantics in the reference), 1 GPU",
                           "frames": sum(fl), "ms": t * 1e3, "frames_per_s": sum(fl) / t, "batch_latency_ms": t * 1e3}))
+
+    if 7 in todo:  # PCIe-inclusive: host batch front-end, int16 PCM in, f0 + int16 waveform out (and everything out)
+        fs, n = 48000, max(2, int(64 * a.scale))
+        xs = tile([make_utterance(fs, 10.0, 3000 + u) for u in range(8)], n)
+        pcm = [np.clip(np.round(x * 32768), -32768, 32767).astype(np.int16) for x in xs]
+        p = w.Pipeline(fs)
+        frames = sum(p.lengths([len(v) for v in pcm])[0])
+        p.run_batch_host(pcm, want=("f0", "y"), y_pcm16=True)
+        for want, label in ((("f0", "y"), "f0 + int16 waveform back"), (("tpos", "f0", "sp", "ap", "y"), "all five outputs back (2.1 GB of sp + ap)")):
+            t0 = time.perf_counter()
+            p.run_batch_host(pcm, want=want, y_pcm16=True)
+            t = time.perf_counter() - t0
+            print(json.dumps({"config": "host", "what": f"{n} x 48 kHz 10 s from host int16 PCM through pinned staging, full pipeline, {label}",
+                              "frames": frames, "ms": t * 1e3, "frames_per_s": frames / t}))
+        del p
 
     if 6 in todo:  # section 8(f) kernels: int16 PCM expansion and the demo's parameter modification, HBM-bound
         from world_class_amd import io as wio

@@ -44,6 +44,35 @@ class Pipeline:
             yo += ny
         return (out, pos) if rng_pos is not None else out
 
+    def run_batch_host(self, xs, want=("tpos", "f0", "sp", "ap", "y"), y_pcm16=False, rng_pos=None):
+        """Host front-end of the C-ABI (wc_pipeline_run_batch_host): xs = list of float64 or int16 (WAV PCM) arrays;
+        pinned staging, one copy each way, int16 expanded / quantised on the device.  Returns a list of dicts."""
+        import ctypes as C
+        pcm = xs[0].dtype == np.int16
+        xs = [np.ascontiguousarray(v, dtype=np.int16 if pcm else np.float64) for v in xs]
+        n = len(xs)
+        xl = [len(v) for v in xs]
+        fl, yl = self.lengths(xl)
+        VP = C.c_void_p * n
+        outs = {k: None for k in ("tpos", "f0", "sp", "ap", "y")}
+        tabs = {}
+        for k in outs:
+            if k not in want:
+                tabs[k] = None
+                continue
+            if k in ("tpos", "f0"):
+                outs[k] = [np.empty(f) for f in fl]
+            elif k in ("sp", "ap"):
+                outs[k] = [np.empty((f, self.bins)) for f in fl]
+            else:
+                outs[k] = [np.empty(m, dtype=np.int16 if y_pcm16 else np.float64) for m in yl]
+            tabs[k] = VP(*[a.ctypes.data for a in outs[k]])
+        arr, arg = _rng_arg(rng_pos, n)
+        _check(lib().wc_pipeline_run_batch_host(self._h, n, VP(*[v.ctypes.data for v in xs]), 1 if pcm else 0, _ints(xl), tabs["tpos"],
+                                                tabs["f0"], tabs["sp"], tabs["ap"], tabs["y"], 1 if y_pcm16 else 0, arg))
+        res = [{k: outs[k][u] for k in outs if outs[k] is not None} for u in range(n)]
+        return (res, list(arr)) if rng_pos is not None else res
+
     def __del__(self):
         try:
             if getattr(self, "_h", None):

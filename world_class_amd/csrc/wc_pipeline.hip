@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "wc_stages.hpp"
+#include "../../include/world_class_io.h"
 
 using namespace wc;
 
@@ -53,6 +54,9 @@ struct wc_pipeline {
 	wc_synthesis *sy;
 	hipStream_t s1, s2;
 	hipEvent_t e0, e1, e2;
+	// host batch front-end (wc_pipeline_run_batch_host): device-resident batch + pinned staging, grow-only
+	DevBuf b_x, b_pcm, b_t, b_f, b_sp, b_ap, b_y, b_ypcm;
+	HostBuf st_in, st_out;
 };
 
 extern "C" {
@@ -123,6 +127,9 @@ wc_pipeline *wc_pipeline_create(int fs, double frame_period, double harvest_f0_f
 void wc_pipeline_destroy(wc_pipeline *p) {
 	if (!p) return;
 	if (p->dev) (void)hipStreamSynchronize(p->dev->stream);
+	for (DevBuf *b : {&p->b_x, &p->b_pcm, &p->b_t, &p->b_f, &p->b_sp, &p->b_ap, &p->b_y, &p->b_ypcm}) b->release();
+	p->st_in.release();
+	p->st_out.release();
 	if (p->s1) { (void)hipStreamSynchronize(p->s1); (void)hipStreamDestroy(p->s1); }
 	if (p->s2) { (void)hipStreamSynchronize(p->s2); (void)hipStreamDestroy(p->s2); }
 	if (p->e0) (void)hipEventDestroy(p->e0);
@@ -293,6 +300,86 @@ int wc_pipeline_run_device(wc_pipeline *p, int n_utt, const double *d_x, const i
 		syn_full = syn_full || o2;
 	}
 	return fail(WC_ERR_DEVICE, "pipeline: buffer overflow");
+}
+
+// Host batch front-end: ragged utterances as 16-bit PCM (as stored in a WAV file) or as doubles,
+// gathered into pinned memory, one H2D copy, expanded on the device, fused pipeline, outputs packed into pinned memory with
+// one D2H copy per requested array, scattered to the caller's per-utterance buffers.  Any output table may be NULL.
+int wc_pipeline_run_batch_host(wc_pipeline *p, int n_utt, const void *const *x, int x_is_pcm16, const int *x_length, double *const *tpos,
+							   double *const *f0, double *const *sp, double *const *ap, void *const *y, int y_is_pcm16,
+							   uint64_t *rng_pos) {
+	if (!p || n_utt <= 0 || !x || !x_length) return fail(WC_ERR_INVALID, "pipeline batch: null argument");
+	WC_HIP(hipSetDevice(p->dev->id));
+	hipStream_t s = p->dev->stream;
+	const int bins = p->fft_size / 2 + 1;
+	std::vector<int> f_len(n_utt), y_len(n_utt);
+	long long nx = 0, nf = 0, ny = 0;
+	for (int u = 0; u < n_utt; ++u) {
+		if (x_length[u] <= 0 || !x[u]) return fail(WC_ERR_INVALID, "pipeline batch: empty utterance");
+		f_len[u] = wc_get_samples(p->fs, x_length[u], p->frame_period);
+		y_len[u] = wc_synthesis_out_length(f_len[u], p->frame_period, p->fs);
+		nx += x_length[u]; nf += f_len[u]; ny += y_len[u];
+	}
+	int rc;
+	const size_t in_elem = x_is_pcm16 ? sizeof(int16_t) : sizeof(double);
+	if ((rc = p->st_in.reserve(in_elem * nx))) return rc;
+	if ((rc = p->b_x.reserve(sizeof(double) * nx))) return rc;
+	if (x_is_pcm16 && (rc = p->b_pcm.reserve(sizeof(int16_t) * nx))) return rc;
+	if ((rc = p->b_t.reserve(sizeof(double) * nf))) return rc;
+	if ((rc = p->b_f.reserve(sizeof(double) * nf))) return rc;
+	if ((rc = p->b_sp.reserve(sizeof(double) * nf * bins))) return rc;
+	if ((rc = p->b_ap.reserve(sizeof(double) * nf * bins))) return rc;
+	if ((rc = p->b_y.reserve(sizeof(double) * ny))) return rc;
+	{
+		char *dst = static_cast<char *>(p->st_in.p);
+		for (int u = 0; u < n_utt; ++u) {
+			std::memcpy(dst, x[u], in_elem * x_length[u]);
+			dst += in_elem * x_length[u];
+		}
+	}
+	if (x_is_pcm16) {
+		WC_HIP(hipMemcpyAsync(p->b_pcm.p, p->st_in.p, sizeof(int16_t) * nx, hipMemcpyHostToDevice, s));
+		if ((rc = wc_pcm16_to_double_device(p->b_pcm.as<int16_t>(), nx, p->b_x.as<double>()))) return rc;
+	} else {
+		WC_HIP(hipMemcpyAsync(p->b_x.p, p->st_in.p, sizeof(double) * nx, hipMemcpyHostToDevice, s));
+	}
+	if ((rc = p->st_in.mark(s))) return rc;
+	if ((rc = wc_pipeline_run_device(p, n_utt, p->b_x.as<double>(), x_length, p->b_t.as<double>(), p->b_f.as<double>(),
+									 p->b_sp.as<double>(), p->b_ap.as<double>(), p->b_y.as<double>(), rng_pos)))
+		return rc;
+	// outputs: one packed region of pinned memory, [tpos | f0 | sp | ap | y]
+	const size_t y_elem = y_is_pcm16 ? sizeof(int16_t) : sizeof(double);
+	size_t off_t = 0, off_f = off_t + (tpos ? sizeof(double) * nf : 0), off_sp = off_f + (f0 ? sizeof(double) * nf : 0);
+	size_t off_ap = off_sp + (sp ? sizeof(double) * nf * bins : 0), off_y = off_ap + (ap ? sizeof(double) * nf * bins : 0);
+	const size_t total = off_y + (y ? y_elem * ny : 0);
+	if (total == 0) return WC_OK;
+	if ((rc = p->st_out.reserve(total))) return rc;
+	char *out = static_cast<char *>(p->st_out.p);
+	if (tpos) WC_HIP(hipMemcpyAsync(out + off_t, p->b_t.p, sizeof(double) * nf, hipMemcpyDeviceToHost, s));
+	if (f0) WC_HIP(hipMemcpyAsync(out + off_f, p->b_f.p, sizeof(double) * nf, hipMemcpyDeviceToHost, s));
+	if (sp) WC_HIP(hipMemcpyAsync(out + off_sp, p->b_sp.p, sizeof(double) * nf * bins, hipMemcpyDeviceToHost, s));
+	if (ap) WC_HIP(hipMemcpyAsync(out + off_ap, p->b_ap.p, sizeof(double) * nf * bins, hipMemcpyDeviceToHost, s));
+	if (y) {
+		if (y_is_pcm16) {
+			if ((rc = p->b_ypcm.reserve(sizeof(int16_t) * ny))) return rc;
+			if ((rc = wc_double_to_pcm16_device(p->b_y.as<double>(), ny, p->b_ypcm.as<int16_t>()))) return rc;
+			WC_HIP(hipMemcpyAsync(out + off_y, p->b_ypcm.p, sizeof(int16_t) * ny, hipMemcpyDeviceToHost, s));
+		} else {
+			WC_HIP(hipMemcpyAsync(out + off_y, p->b_y.p, sizeof(double) * ny, hipMemcpyDeviceToHost, s));
+		}
+	}
+	WC_HIP(hipStreamSynchronize(s));
+	long long fo = 0, yo = 0;
+	for (int u = 0; u < n_utt; ++u) {
+		if (tpos && tpos[u]) std::memcpy(tpos[u], out + off_t + sizeof(double) * fo, sizeof(double) * f_len[u]);
+		if (f0 && f0[u]) std::memcpy(f0[u], out + off_f + sizeof(double) * fo, sizeof(double) * f_len[u]);
+		if (sp && sp[u]) std::memcpy(sp[u], out + off_sp + sizeof(double) * fo * bins, sizeof(double) * f_len[u] * bins);
+		if (ap && ap[u]) std::memcpy(ap[u], out + off_ap + sizeof(double) * fo * bins, sizeof(double) * f_len[u] * bins);
+		if (y && y[u]) std::memcpy(y[u], out + off_y + y_elem * yo, y_elem * y_len[u]);
+		fo += f_len[u];
+		yo += y_len[u];
+	}
+	return WC_OK;
 }
 
 }  // extern "C"
