@@ -248,6 +248,199 @@ __global__ __launch_bounds__(64) void syn_timebase_kernel(TbArgs a, const double
 	if (lane == 0) a.count[blockIdx.x] = n_pulses;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same running sum, exactly, in parallel.  While the sum stays inside one binade [2^e, 2^(e+1)) every partial sum is
+// an integer multiple m u of u = 2^(e-52), and  fl(S + v) = S + (floor(v / u) + [fraction of v / u > 1/2]) u  unless the
+// fraction is exactly 1/2 (round-to-even then depends on the parity of the running integer) or the sum leaves the
+// binade (the rounding unit doubles).  So a window of samples is an integer prefix sum -- exact and associative -- up to
+// the first such exceptional sample; that one sample is added in floating point (which *is* the reference's
+// operation) and the scan restarts behind it.  Exceptions are the ~20 binade crossings of an utterance plus rare ties;
+// a run of consecutive exceptions (the first few dozen samples, where the sum doubles every few steps, or a constant
+// increment that happens to tie throughout a binade) is walked serially.  One workgroup per utterance.
+// ------------------------------------------------------------------------------------------------
+constexpr int TB_T = 256, TB_K = 16, TB_W = TB_T * TB_K;  // threads, samples per thread, samples per window
+constexpr int TB_SERIAL = 64;                             // serial stretch at the start and after back-to-back exceptions
+
+__global__ __launch_bounds__(TB_T) void syn_phase_kernel(TbArgs a, const double *__restrict__ inc_all, double *__restrict__ phase_all) {
+	__shared__ unsigned long long wsum[TB_T / 64];
+	__shared__ int wmin[TB_T / 64];
+	__shared__ double s_state;  // exact sum up to sample p - 1
+	__shared__ int s_p, s_serial;
+	const UttDesc ud = a.utts[blockIdx.x];
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int n = ud.y_len;
+	const double *__restrict__ inc = inc_all + a.inc_off[blockIdx.x];
+	double *__restrict__ phase = phase_all + a.inc_off[blockIdx.x];
+	if (tid == 0) { s_state = 0.0; s_p = 0; s_serial = 1; }
+	__syncthreads();
+	while (true) {
+		int p = s_p;
+		if (p >= n) break;
+		if (s_serial) {  // serial stretch by one thread: plain floating-point adds, the reference's own operation
+			if (tid == 0) {
+				double S = s_state;
+				const int end = min(n, p + TB_SERIAL);
+				for (int i = p; i < end; ++i) {
+					S = S + fabs(inc[i]);
+					phase[i] = S;
+				}
+				s_state = S;
+				s_p = end;
+				s_serial = 0;
+			}
+			__syncthreads();
+			continue;
+		}
+		const double S = s_state;
+		const long long sb = __double_as_longlong(S);
+		const int e = (int)((sb >> 52) & 0x7ff);               // biased exponent of the running sum (S > 0, normal)
+		const unsigned long long m0 = (unsigned long long)((sb & 0xfffffffffffffll) | (1ll << 52));  // S = m0 * 2^(e - 1075)
+		// this thread's samples of the window
+		const int j0 = p + tid * TB_K;
+		unsigned long long d[TB_K];  // (unsigned: partial sums past the first crossing may wrap, harmlessly)
+		int exc = TB_W;  // first exceptional sample of the window (relative index), TB_W = none
+		unsigned long long loc = 0;
+#pragma unroll
+		for (int k = 0; k < TB_K; ++k) {
+			const int j = j0 + k;
+			unsigned long long dk = 0;
+			if (j < n) {
+				const long long vb = __double_as_longlong(fabs(inc[j]));
+				const int ev = (int)((vb >> 52) & 0x7ff);
+				const long long mant = (vb & 0xfffffffffffffll) | (1ll << 52);
+				const int sh = e - ev;  // v = mant * 2^(ev - 1075) = (mant >> sh) u + remainder
+				if (ev == 0 || sh < 0) {  // zero / subnormal increment or one larger than the sum: leave it to the exact add
+					exc = min(exc, tid * TB_K + k);
+				} else if (sh == 0) {
+					dk = (unsigned long long)mant;
+				} else if (sh <= 53) {
+					const long long rem = mant & ((1ll << sh) - 1ll), half = 1ll << (sh - 1);
+					dk = (unsigned long long)(mant >> sh);
+					if (rem > half) dk += 1;
+					else if (rem == half) exc = min(exc, tid * TB_K + k);  // tie: parity decides
+				}  // sh > 53: less than half a unit, the sum does not move
+			}
+			d[k] = dk;
+			loc += dk;
+		}
+		// block exclusive scan of the per-thread sums
+		unsigned long long incl = loc;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			const unsigned long long t = __shfl_up(incl, o, 64);
+			if (lane >= o) incl += t;
+		}
+		if (lane == 63) wsum[wv] = incl;
+		__syncthreads();
+		unsigned long long base = m0;
+#pragma unroll
+		for (int w = 0; w < TB_T / 64; ++w) if (w < wv) base += wsum[w];
+		unsigned long long run = base + incl - loc;
+		// partial sums of this thread's samples; the first one that reaches 2^53 has left the binade
+		unsigned long long mk[TB_K];
+#pragma unroll
+		for (int k = 0; k < TB_K; ++k) {
+			run += d[k];
+			mk[k] = run;
+			if (run >= (1ull << 53) && j0 + k < n) exc = min(exc, tid * TB_K + k);
+		}
+		// first exception of the window over the block
+		int mn = exc;
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) mn = min(mn, __shfl_xor(mn, o, 64));
+		if (lane == 0) wmin[wv] = mn;
+		__syncthreads();
+		int x = TB_W;
+#pragma unroll
+		for (int w = 0; w < TB_T / 64; ++w) x = min(x, wmin[w]);
+		const int valid = min(x, n - p);  // samples p .. p + valid - 1 are exact integer sums
+		const double unit = __longlong_as_double((long long)(e - 52) << 52);  // 2^(e - 1023 - 52), e >= 53 here
+#pragma unroll
+		for (int k = 0; k < TB_K; ++k) {
+			const int r = tid * TB_K + k;
+			if (r < valid) phase[p + r] = (double)mk[k] * unit;
+			if (r == valid - 1) s_state = (double)mk[k] * unit;  // (valid == 0 leaves the state alone)
+		}
+		__syncthreads();
+		if (tid == 0) {
+			int np = p + valid;
+			int serial = 0;
+			if (x < TB_W && np < n) {  // the exceptional sample: one exact floating-point add
+				const double Sx = s_state + fabs(inc[np]);
+				phase[np] = Sx;
+				s_state = Sx;
+				++np;
+				serial = (valid == 0);  // two exceptions in a row: walk a stretch serially
+			}
+			s_p = np;
+			s_serial = serial;
+		}
+		__syncthreads();
+	}
+}
+
+// Wrap, pulse detection (reference :262-288) and ordered compaction from the exact phases; one workgroup per utterance.
+__global__ __launch_bounds__(TB_T) void syn_pulses_from_phase_kernel(TbArgs a, const double *__restrict__ inc_all,
+																	 const double *__restrict__ phase_all) {
+	__shared__ int wcnt[TB_T / 64];
+	const UttDesc ud = a.utts[blockIdx.x];
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int n = ud.y_len;
+	const double *__restrict__ inc = inc_all + a.inc_off[blockIdx.x];
+	const double *__restrict__ phase = phase_all + a.inc_off[blockIdx.x];
+	const double two_pi = 2.0 * kPi;
+	const long long slot0 = a.cap_off[blockIdx.x];
+	const int cap = a.cap[blockIdx.x];
+	constexpr int K = 8;
+	int n_pulses = 0;
+	for (int base = 0; base < n; base += TB_T * K) {
+		const int i0 = base + tid * K;
+		double w[K + 1];
+		w[0] = (i0 >= 1 && i0 - 1 < n) ? fmod(phase[i0 - 1], two_pi) : 0.0;
+		unsigned int flags = 0;
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			const int i = i0 + k;
+			w[k + 1] = (i < n) ? fmod(phase[i], two_pi) : 0.0;
+			// pulse between samples i-1 and i  <=>  |wrap[i] - wrap[i-1]| > pi ; the pulse sits at i-1
+			if (i < n && i >= 1 && fabs(w[k + 1] - w[k]) > kPi) flags |= 1u << k;
+		}
+		const int mine = __popc(flags);
+		int incl = mine;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			const int t = __shfl_up(incl, o, 64);
+			if (lane >= o) incl += t;
+		}
+		__syncthreads();  // (wcnt of the previous tile has been read by everyone)
+		if (lane == 63) wcnt[wv] = incl;
+		__syncthreads();
+		int before = 0, total = 0;
+#pragma unroll
+		for (int q = 0; q < TB_T / 64; ++q) {
+			if (q < wv) before += wcnt[q];
+			total += wcnt[q];
+		}
+		int slot = n_pulses + before + incl - mine;
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			if (flags & (1u << k)) {
+				const int i = i0 + k;
+				if (slot < cap) {
+					const double y1 = w[k] - two_pi, y2 = w[k + 1];
+					const double xx = -y1 / (y2 - y1);
+					a.p.index[slot0 + slot] = i - 1;
+					a.p.shift[slot0 + slot] = xx / a.fs;
+					a.p.vuv[slot0 + slot] = inc[i - 1] > 0.0 ? 1 : 0;
+				}
+				++slot;
+			}
+		}
+		n_pulses += total;
+	}
+	if (tid == 0) a.count[blockIdx.x] = n_pulses;
+}
+
 // noise_size of every pulse and the first pulse index of the utterance
 __global__ void syn_noise_size_kernel(const long long *__restrict__ cap_off, const int *__restrict__ count,
 									  const int *__restrict__ cap, PulseBuf p, int *__restrict__ first_index,
@@ -546,7 +739,8 @@ struct wc_synthesis {
 	int fs, fft_size;
 	double frame_period;  // seconds
 	Device *dev;
-	DevBuf dc_remover, utts, meta, pulses, incs, d_f0, d_sp, d_ap, d_out;
+	DevBuf dc_remover, utts, meta, pulses, incs, phase, d_f0, d_sp, d_ap, d_out;
+	bool serial_timebase;  // WC_SYN_TIMEBASE=serial: the one-wavefront sequential accumulation instead of the exact parallel one
 	HostBuf h_stage;
 	long long total_out = 0, cap_total = 0;  // of the most recent syn_prepare
 	int n_utt = 0;
@@ -636,6 +830,7 @@ int syn_prepare(wc_synthesis *sy, hipStream_t s, int n_utt, const double *d_f0, 
 	}
 	sy->cap_total = co;
 	if ((rc = sy->incs.reserve(sizeof(double) * inc_total))) return rc;
+	if (!sy->serial_timebase && (rc = sy->phase.reserve(sizeof(double) * inc_total))) return rc;
 	if ((rc = sy->pulses.reserve((size_t)co * (sizeof(int) * 3 + sizeof(double))))) return rc;
 	PulseBuf pb;
 	pb.shift = sy->pulses.as<double>();
@@ -656,7 +851,13 @@ int syn_prepare(wc_synthesis *sy, hipStream_t s, int n_utt, const double *d_f0, 
 	WC_HIP(hipMemsetAsync(sy->incs.p, 0, sizeof(double) * inc_total, s));
 	hipLaunchKernelGGL(syn_increment_kernel, dim3((unsigned)((total_out + 255) / 256)), dim3(256), 0, s, ta, n_utt,
 					   total_out, sy->incs.as<double>());
-	hipLaunchKernelGGL(syn_timebase_kernel, dim3(n_utt), dim3(64), 0, s, ta, (const double *)sy->incs.as<double>());
+	if (sy->serial_timebase) {
+		hipLaunchKernelGGL(syn_timebase_kernel, dim3(n_utt), dim3(64), 0, s, ta, (const double *)sy->incs.as<double>());
+	} else {
+		hipLaunchKernelGGL(syn_phase_kernel, dim3(n_utt), dim3(TB_T), 0, s, ta, (const double *)sy->incs.as<double>(), sy->phase.as<double>());
+		hipLaunchKernelGGL(syn_pulses_from_phase_kernel, dim3(n_utt), dim3(TB_T), 0, s, ta, (const double *)sy->incs.as<double>(),
+						   (const double *)sy->phase.as<double>());
+	}
 	hipLaunchKernelGGL(syn_noise_size_kernel, dim3(8, n_utt), dim3(256), 0, s, d_cap_off, d_count, d_cap, pb, d_first, d_last);
 	WC_HIP(hipGetLastError());
 	return dev->time_end("synthesis_timebase", s);
@@ -763,6 +964,10 @@ wc_synthesis *wc_synthesis_create(int fs, int fft_size, double frame_period_ms) 
 	s->fs = fs;
 	s->fft_size = fft_size;
 	s->frame_period = frame_period_ms / 1000.;  // reference :31
+	{
+		const char *tb = getenv("WC_SYN_TIMEBASE");
+		s->serial_timebase = tb && std::string(tb) == "serial";
+	}
 	s->dev = dev;
 	// getDCRemover, reference :290-303
 	std::vector<double> d(fft_size);
@@ -783,7 +988,7 @@ wc_synthesis *wc_synthesis_create(int fs, int fft_size, double frame_period_ms) 
 void wc_synthesis_destroy(wc_synthesis *s) {
 	if (!s) return;
 	(void)hipStreamSynchronize(s->dev->stream);
-	s->dc_remover.release(); s->utts.release(); s->meta.release(); s->pulses.release(); s->incs.release();
+	s->dc_remover.release(); s->utts.release(); s->meta.release(); s->pulses.release(); s->incs.release(); s->phase.release();
 	s->d_f0.release(); s->d_sp.release(); s->d_ap.release(); s->d_out.release(); s->h_stage.release();
 	delete s;
 }
