@@ -82,8 +82,8 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 			int i = tid + e * T;
 			w[e] = 0.0;
 			if (i < wl) {
-				w[e] = 0.5 * c + 0.5;
-				ssq += w[e] * w[e];
+				w[e] = fma(0.5, c, 0.5);
+				ssq = fma(w[e], w[e], ssq);
 			}
 			const double cn = fma(c, cd, -(sn * sd));
 			sn = fma(sn, cd, c * sd);
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 		if (i < wl) {
 			w[e] = w[e] * rnorm;
 			int si = clampi(origin + i - hw, 0, ud.x_len - 1);
-			wv[e] = x[si] * w[e] + randn_at(a.rng_table, roff + i) * 0.000000000000001;
+			wv[e] = fma(x[si], w[e], randn_at(a.rng_table, roff + i) * 0.000000000000001);
 			s1 += wv[e];
 			s2 += w[e];
 		}
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 #pragma unroll
 	for (int e = 0; e < EPT; ++e) {
 		int i = tid + e * T;
-		if (i < N) Ar[i] = (i < wl) ? wv[e] - w[e] * wc : 0.0;
+		if (i < N) Ar[i] = (i < wl) ? fma(-w[e], wc, wv[e]) : 0.0;
 	}
 	__syncthreads();
 
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 		double p;
 		if (k == 0) p = v.x * v.x;
 		else if (k == M) p = v.y * v.y;
-		else p = v.x * v.x + v.y * v.y;
+		else p = fma(v.x, v.x, v.y * v.y);
 		P[k] = p;
 	}
 	__syncthreads();
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 				double hi_v = interp1q_rcp(origin_axis, step, rstep, seg, len, hi_axis);
 				double sm = (hi_v - lo_v) / width;
 				// infinitesimal noise (reference :220-228) then log (reference :251-252)
-				sm += fabs(randn_at(a.rng_table, roff + wl + k)) * 0.00000000000000022204460492503131;
+				sm = fma(fabs(randn_at(a.rng_table, roff + wl + k)), 0.00000000000000022204460492503131, sm);
 				lp[e] = log(sm);
 			}
 		}
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 				cl = (1.0 - 2.0 * q1) + 2.0 * q1;
 			} else {
 				sl = sn / (alpha * k);
-				cl = (1.0 - 2.0 * q1) + 2.0 * q1 * (1.0 - 2.0 * sn * sn);
+				cl = fma(2.0 * q1, fma(-2.0 * sn, sn, 1.0), 1.0 - 2.0 * q1);
 			}
 			if (k == M) {
 				P[M] = A[0].y * sl * cl / N;  // parked until every thread has read its own bin

@@ -66,7 +66,8 @@ __device__ __forceinline__ int d4c_windowed(const double *__restrict__ x, int x_
 	sincospi(f0 * (c1 * T), &snd, &csd);
 	snd = uniform_d(snd);
 	csd = uniform_d(csd);
-	auto win = [&](double c) { return type == 1 ? 0.5 * c + 0.5 : 0.42 + 0.5 * c + 0.08 * (2.0 * c * c - 1.0); };
+	// Hanning 0.5 c + 0.5; Blackman 0.42 + 0.5 c + 0.08 cos 2theta = 0.34 + c (0.5 + 0.16 c): two fused multiply-adds
+	auto win = [&](double c) { return type == 1 ? fma(0.5, c, 0.5) : fma(c, fma(0.16, c, 0.5), 0.34); };
 	// (select forms instead of conditional updates: predicated register updates inside the unrolled loops cost a
 	// register copy per value and iteration)
 	double s1 = 0.0, s2 = 0.0;
@@ -79,7 +80,7 @@ __device__ __forceinline__ int d4c_windowed(const double *__restrict__ x, int x_
 			const double w = in ? win(c) : 0.0;
 			const int si = clampi(origin + i - hw, 0, x_len - 1);
 			const double noise = randn_at(rng, roff + (in ? i : 0)) * kSafe;
-			wave[e] = in ? x[si] * w + noise : 0.0;
+			wave[e] = in ? fma(x[si], w, noise) : 0.0;
 			s1 += wave[e];
 			s2 += w;
 			const double cn = fma(c, csd, -(sn * snd));
@@ -94,7 +95,7 @@ __device__ __forceinline__ int d4c_windowed(const double *__restrict__ x, int x_
 #pragma unroll
 		for (int e = 0; e < EPT; ++e) {
 			const int i = tid + e * T;
-			wave[e] -= (i < wl ? win(c) : 0.0) * wc;
+			wave[e] = fma(-(i < wl ? win(c) : 0.0), wc, wave[e]);
 			const double cn = fma(c, csd, -(sn * snd));
 			sn = fma(sn, csd, c * snd);
 			c = cn;
@@ -134,6 +135,7 @@ __device__ __forceinline__ void dc_correction_lds(double *P, double f0, int fs, 
 template <int M, int T, class Out>
 __device__ __forceinline__ void linear_smoothing_lds(const double *P, double *S, double width, int fs, double *red,
 													 int tid, Out out) {
+#pragma clang fp contract(fast)  // values only (the segment indices come from interp1q_rcp's own arithmetic)
 	constexpr int N = 2 * M;
 	int b = (int)(width * N / fs) + 1;
 	if (M + 2 * b + 1 > N) b = (N - M - 1) / 2;
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(T, T == 512 ? 6 : 1) void d4c_lovetrain_kernel(D4cA
 		double p1 = 0.0, p2 = 0.0;
 		for (int k = b0 + 1 + tid; k <= min(b2, M); k += T) {
 			double2 v = A[k == M ? 0 : k];
-			double p = (k == M) ? v.y * v.y : v.x * v.x + v.y * v.y;
+			double p = (k == M) ? v.y * v.y : fma(v.x, v.x, v.y * v.y);
 			p2 += p;
 			if (k <= b1) p1 += p;
 		}
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(T, (2 * T) / 256) void d4c_frames_kernel(D4cArgs a)
 		wl = d4c_windowed<N, T>(x, ud.x_len, fs, f0, p, 2, 4.0, a.rng_table, roff + (unsigned long long)c * wl, wave, red, tid);
 		double pw = 0.0;
 #pragma unroll
-		for (int e = 0; e < EPT; ++e) pw += wave[e] * wave[e];
+		for (int e = 0; e < EPT; ++e) pw = fma(wave[e], wave[e], pw);
 		pw = 1.0 / sqrt(block_sum<T>(pw, red, tid));  // (the reference divides every sample: an ulp apart)
 #pragma unroll
 		for (int e = 0; e < EPT; ++e) {
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(T, (2 * T) / 256) void d4c_frames_kernel(D4cArgs a)
 				double v;
 				if (k == 0) v = A[0].x * s1[e].x;
 				else if (k == M) v = A[0].y * s1[e].x;
-				else v = A[k].x * s1[e].x + s1[e].y * A[k].y;
+				else v = fma(A[k].x, s1[e].x, s1[e].y * A[k].y);
 				Cc[k] = (c == 0) ? v : Cc[k] + v;
 			}
 		}
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(T, (2 * T) / 256) void d4c_frames_kernel(D4cArgs a)
 		r2c_post<M, T>(A, a.tw, tid);
 		for (int k = tid; k <= M; k += T) {
 			double2 v = A[k == M ? 0 : k];
-			Br[k] = (k == 0) ? v.x * v.x : (k == M) ? v.y * v.y : v.x * v.x + v.y * v.y;
+			Br[k] = (k == 0) ? v.x * v.x : (k == M) ? v.y * v.y : fma(v.x, v.x, v.y * v.y);
 		}
 		__syncthreads();
 		dc_correction_lds<M, T>(Br, f0, fs, tid);

@@ -46,7 +46,7 @@ __device__ __forceinline__ double interp1q_rcp(double x0, double dx, double rdx,
 	double frac = q - b;
 	double y0 = y(b);
 	double dy = (b == n - 1) ? 0.0 : y(b + 1) - y0;
-	return y0 + dy * frac;
+	return fma(dy, frac, y0);
 }
 
 // ---- wave / block collectives ------------------------------------------------------------------
@@ -389,11 +389,11 @@ __device__ __forceinline__ void r2c_power(const double2 *a, const double2 *__res
 		const double2 wo = cmul(tw_load(tw, k * TS), od);
 		const double2 xk = cadd(ev, wo), xm = csub(ev, wo);
 		const double r0 = zk.x + zk.y, rm = zk.x - zk.y;  // k = 0: X[0], X[M] (both real)
-		key[2 * e] = (k == 0) ? r0 * r0 : xk.x * xk.x + xk.y * xk.y;
-		key[2 * e + 1] = (k == 0) ? rm * rm : xm.x * xm.x + xm.y * xm.y;
+		key[2 * e] = (k == 0) ? r0 * r0 : fma(xk.x, xk.x, xk.y * xk.y);
+		key[2 * e + 1] = (k == 0) ? rm * rm : fma(xm.x, xm.x, xm.y * xm.y);
 	}
 	const double2 zh = a[M / 2];
-	key[2 * PAIRS] = zh.x * zh.x + zh.y * zh.y;
+	key[2 * PAIRS] = fma(zh.x, zh.x, zh.y * zh.y);
 }
 // Inverse of the above: a holds the packed spectrum Y (a[0] = (Y[0].re, Y[M].re)); produce Z so that
 // fft_lds<M,T,-1> yields the real signal y[n] interleaved (reference c2r convention, unnormalised).
