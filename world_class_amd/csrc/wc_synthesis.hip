@@ -590,8 +590,8 @@ __global__ __launch_bounds__(T) void syn_pulse_kernel(SynArgs a) {
 				double s = safe_ap(af[k]);
 				ar[e] = s * s;
 			} else {
-				env[e] = (1.0 - ipol) * fabs(sf[k]) + ipol * fabs(sc[k]);
-				double s = (1.0 - ipol) * safe_ap(af[k]) + ipol * safe_ap(ac[k]);
+				env[e] = fma(1.0 - ipol, fabs(sf[k]), ipol * fabs(sc[k]));
+				double s = fma(1.0 - ipol, safe_ap(af[k]), ipol * safe_ap(ac[k]));
 				ar[e] = s * s;
 			}
 		}
@@ -623,7 +623,7 @@ __global__ __launch_bounds__(T) void syn_pulse_kernel(SynArgs a) {
 				double2 m = A[k];
 				double re2 = cos(coef * k);
 				double im2 = sqrt(1.0 - re2 * re2);
-				sp_[e] = make_double2(m.x * re2 - m.y * im2, m.x * im2 + m.y * re2);
+				sp_[e] = make_double2(fma(m.x, re2, -(m.y * im2)), fma(m.x, im2, m.y * re2));
 			}
 		}
 		__syncthreads();
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(T) void syn_pulse_kernel(SynArgs a) {
 		for (int e = 0; e < EPT; ++e) {
 			int j = tid + e * T;  // index in the shifted response
 			if (j < M) periodic[e] = -dc * a.dc_remover[j];
-			else periodic[e] = Ar[j - M] + (-dc * a.dc_remover[j - M]);
+			else periodic[e] = fma(-dc, a.dc_remover[j - M], Ar[j - M]);
 		}
 		__syncthreads();
 	}
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(T) void syn_pulse_kernel(SynArgs a) {
 			pr[e] = make_double2(0.0, 0.0);
 			if (k <= M) {
 				double2 m = A[k];
-				pr[e] = make_double2(m.x * ns[e].x - m.y * ns[e].y, m.x * ns[e].y + m.y * ns[e].x);
+				pr[e] = make_double2(fma(m.x, ns[e].x, -(m.y * ns[e].y)), fma(m.x, ns[e].y, m.y * ns[e].x));
 			}
 		}
 		__syncthreads();
@@ -725,7 +725,7 @@ __global__ __launch_bounds__(T) void syn_pulse_kernel(SynArgs a) {
 	for (int e = 0; e < EPT; ++e) {
 		int j = tid + e * T;
 		double aper = (j < M) ? Ar[j + M] : Ar[j - M];  // fftshift
-		double r = (periodic[e] * sq + aper) / N;
+		double r = fma(periodic[e], sq, aper) / N;
 		int o = index + 1 + j;
 		if (o >= 0 && o < ud.y_len) atomicAdd(&out[o], r);
 	}
