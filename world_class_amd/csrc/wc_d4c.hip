@@ -1,14 +1,16 @@
 // D4C band-aperiodicity estimation on gfx950.
 //
-// Restates reference src/d4c.cpp:113-503.  Two per-frame kernels, one workgroup per frame:
-//   d4c_lovetrain_kernel  the "Love Train" voiced/unvoiced gate (reference :181-240): Blackman 3 T0
-//                         window, one real FFT, ratio of cumulative powers; also writes the
-//                         1 - 1e-12 rows of frames that fail the gate (reference :127-132)
-//   d4c_frames_kernel     for gated frames (reference :308-503): two energy centroids (2 real FFTs
-//                         each), smoothed power spectrum, static group delay (three prefix-sum
-//                         smoothings), per 3 kHz band a Nuttall-windowed FFT whose power spectrum is
-//                         ranked by an in-LDS radix select instead of std::sort (the reference only
-//                         needs the sum of the bins-boundary-1 smallest values), dB -> linear.
+// Restates reference src/d4c.cpp:113-503:
+//   d4c_lovetrain_kernel  the "Love Train" voiced/unvoiced gate (reference :181-240), one workgroup per frame: Blackman
+//                         3 T0 window, one real FFT, ratio of cumulative powers; also writes the 1 - 1e-12 rows of
+//                         frames that fail the gate (reference :127-132)
+//   d4c_frames_kernel     gated frames (reference :308-460), one workgroup per frame: two energy centroids (2 real
+//                         FFTs each), smoothed power spectrum, static group delay (three prefix-sum smoothings)
+//   d4c_band_kernel       (reference :466-503) one workgroup per (gated frame, 3 kHz band): Nuttall-windowed FFT whose
+//                         power spectrum is ranked by an in-LDS radix select instead of std::sort (the reference only
+//                         needs the sum of the bins-boundary-1 smallest values)
+//   d4c_rows_kernel       coarse dB values -> interp1 -> linear rows (reference :162-168)
+//   (WC_D4C_SPLIT=0 runs the last three in one fused d4c_frames_kernel.)
 // The noise draws come from the exact stream positions of the reference's serial order: all
 // LoveTrain frames first, then the gated frames (RNG draw-count contract).
 #include <cmath>

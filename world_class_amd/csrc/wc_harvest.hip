@@ -7,15 +7,17 @@
 //                        split into independent chunks that warm up on the preceding samples (the
 //                        filter's impulse response is below 1e-20 after 768 samples), two passes.
 //   hv_dc_kernel         the reference's int-typed "DC removal" (:239) -- a no-op unless abs(y) >= 1
-//   hv_bandpass_kernel   one workgroup per (utterance, band): the band-pass of reference :1261-1305
-//                        evaluated as the equivalent linear FIR (<= 2*512+1 Nuttall*cos taps, register
-//                        tiled, signal tile + taps in LDS) fused with the four zero-crossing detectors
-//                        of :1179-1255; fine edge positions are stream-compacted in time order
+//   hv_bandpass_sdft_kernel, hv_compact_kernel
+//                        the band-pass of reference :1261-1305 -- a Nuttall * cosine FIR of <= 2*512+1 taps -- as a
+//                        sliding DFT (a lane per (band, 2048-sample chunk), seven rotating sums) fused with the four
+//                        zero-crossing detectors of :1179-1255; edges land in per-chunk slots that the second kernel
+//                        packs in time order.  hv_bandpass_kernel is the direct FIR evaluation (one workgroup per
+//                        (utterance, band), register tiled from LDS), kept behind WC_HARVEST_BANDPASS=fir
 //   hv_raw_kernel        interp1 of the four interval series onto the 1 ms grid (:1098-1143)
 //   hv_detect_kernel     per-frame candidate detection over bands (:1005-1083)
 //   hv_refine_kernel     one wavefront per (frame, candidate): overlap (:987-1000) folded into the
 //                        gather, Blackman / differentiated windows, and -- instead of the reference's two
-//                        full FFTs -- direct DFTs of the <= 6 harmonic bins fixF0 reads (:809-927)
+//                        full FFTs -- Goertzel recurrences for the <= 6 harmonic bins fixF0 reads (:809-927)
 //   hv_unreliable_kernel (:708-744)
 //   hv_contour_kernel    one wavefront per utterance walks the sequential contour logic
 //                        (:254-634: base contour, fixStep1..4, extend, merge) with the candidate

@@ -2,16 +2,17 @@
 //
 // Restates reference src/synthesis.cpp:77-530 and MinimumPhaseAnalysis of
 // src/world_common.cpp:196-233.
-//   syn_timebase_kernel  one workgroup per utterance walks the output samples in chunks: sample-rate
-//                        F0 / VUV interpolation (reference :180-243), phase accumulation as a
-//                        chunked block prefix sum (the reference's running sum, :245-288), wrap
-//                        detection and an ordered stream compaction of the pulses
+//   syn_increment_kernel sample-rate F0 / VUV interpolation (reference :180-243) -> phase increments
+//   syn_phase_kernel     the reference's running phase sum (:245-262) reproduced bit for bit by integer prefix sums
+//                        per binade, exceptional samples (ties, binade crossings) added in floating point
+//   syn_pulses_from_phase_kernel   wrap detection (:262-288) and ordered compaction of the pulses
+//   syn_timebase_kernel  the same sum as a sequential one-wavefront chain (WC_SYN_TIMEBASE=serial; cross-check)
 //   syn_pulse_kernel     one workgroup per pulse (reference :308-530): sp/ap row blend, two
 //                        minimum-phase analyses (r2c + c2c in LDS), fractional delay, DC removal,
 //                        noise excitation from the exact stream position, overlap-add with FP64
 //                        atomics (reference :118-139)
-// The sum order of the phase accumulation and of the overlap-add differs from the reference's
-// sequential loops (documented in DESIGN.md); everything else is the same arithmetic.
+// The sum order of the overlap-add (FP64 atomics) differs from the reference's sequential loop;
+// the phase accumulation is exact.
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
