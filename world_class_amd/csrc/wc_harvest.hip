@@ -923,20 +923,50 @@ __device__ __forceinline__ void wave_sync() {
 
 // argmin_k |ref - c[k]| / ref over the lanes with the reference's tie rule (the last smallest error that
 // does not exceed `allowed` wins), reference :347-365
-__device__ __forceinline__ double hv_select_best(double ref, const double *__restrict__ c, int nc, double allowed, int lane) {
-	double best_err = allowed;
+// (the candidates of a row arrive in registers -- lane l holds c[l] and c[l + 64] -- so that callers can request the
+// next row while this one is being searched, and the winner's value travels with the reduction instead of being
+// re-read from memory)
+__device__ __forceinline__ double hv_select_best_regs(double ref, double c0, double c1, int nc, double allowed, int lane) {
+	double best_err = allowed, best_v = 0.0;
 	int best_k = -1;
-	for (int k = lane; k < nc; k += 64) {
-		double t = fabs(ref - c[k]) / ref;
-		if (!(t > best_err)) { best_err = t; best_k = k; }
+	if (lane < nc) {
+		double t = fabs(ref - c0) / ref;
+		if (!(t > best_err)) { best_err = t; best_k = lane; best_v = c0; }
+	}
+	if (lane + 64 < nc) {
+		double t = fabs(ref - c1) / ref;
+		if (!(t > best_err)) { best_err = t; best_k = lane + 64; best_v = c1; }
 	}
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) {
 		double oe = __shfl_xor(best_err, o, 64);
+		double ov = __shfl_xor(best_v, o, 64);
 		int ok = __shfl_xor(best_k, o, 64);
-		if (ok >= 0 && (best_k < 0 || oe < best_err || (oe == best_err && ok > best_k))) { best_err = oe; best_k = ok; }
+		if (ok >= 0 && (best_k < 0 || oe < best_err || (oe == best_err && ok > best_k))) { best_err = oe; best_k = ok; best_v = ov; }
 	}
-	return best_k >= 0 ? c[best_k] : 0.0;
+	return best_k >= 0 ? best_v : 0.0;
+}
+__device__ __forceinline__ double hv_select_best(double ref, const double *__restrict__ c, int nc, double allowed, int lane) {
+	// nc <= 7 * MAX_SLOTS = 224 in general; two registers per lane cover nc <= 128, longer rows take the loop
+	if (nc <= 128) {
+		const double c0 = lane < nc ? c[lane] : 0.0, c1 = lane + 64 < nc ? c[lane + 64] : 0.0;
+		return hv_select_best_regs(ref, c0, c1, nc, allowed, lane);
+	}
+	double best_err = allowed, best_v = 0.0;
+	int best_k = -1;
+	for (int k = lane; k < nc; k += 64) {
+		const double cv = c[k];
+		double t = fabs(ref - cv) / ref;
+		if (!(t > best_err)) { best_err = t; best_k = k; best_v = cv; }
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		double oe = __shfl_xor(best_err, o, 64);
+		double ov = __shfl_xor(best_v, o, 64);
+		int ok = __shfl_xor(best_k, o, 64);
+		if (ok >= 0 && (best_k < 0 || oe < best_err || (oe == best_err && ok > best_k))) { best_err = oe; best_k = ok; best_v = ov; }
+	}
+	return best_k >= 0 ? best_v : 0.0;
 }
 // reference :463-470
 __device__ __forceinline__ double hv_search_score(double f0, const double *__restrict__ c, const double *__restrict__ s, int nc) {
@@ -1058,9 +1088,20 @@ __global__ __launch_bounds__(64) void hv_contour_kernel(CtrArgs a) {
 			int shifted_origin = origin;
 			const int distance = abs(last_point - origin);
 			int miss = 0;
+			// the rows the walk will visit are known in advance: request the next one while this one is searched
+			auto row = [&](int t, double &c0, double &c1) {
+				const double *__restrict__ r = cand + (long long)(origin + shift * t + shift) * nc;
+				c0 = (t <= distance && lane < nc) ? r[lane] : 0.0;
+				c1 = (t <= distance && lane + 64 < nc) ? r[lane + 64] : 0.0;
+			};
+			double n0, n1;
+			row(0, n0, n1);
 			for (int t = 0; t <= distance; ++t) {
 				const int idx = origin + shift * t + shift;
-				const double sel = hv_select_best(tmp_f0, cand + (long long)idx * nc, nc, 0.18, lane);
+				const double c0 = n0, c1 = n1;
+				row(t + 1, n0, n1);
+				const double sel = nc <= 128 ? hv_select_best_regs(tmp_f0, c0, c1, nc, 0.18, lane)
+										 : hv_select_best(tmp_f0, cand + (long long)idx * nc, nc, 0.18, lane);
 				if (lane == 0) CH(k, idx) = sel;
 				if (sel == 0.0) {
 					miss++;
