@@ -3,7 +3,7 @@
 // classes (the demo's ParameterModification calls interp1, test/test.cpp:231).  Host functions of libworldclass_hip.so with the
 // reference's names, argument meaning and arithmetic; randn() draws from the same process-wide noise stream the stages
 // consume (wc_rng_get_position / wc_rng_set_position), as in the reference.
-// Not provided: fast_fftfilt and the fft_plan_* / ForwardRealFFT-style buffer structs (the kernels have their own FFT).
+// fast_fftfilt and the FFT buffer structs are in world_common.hpp, the plan API in world_fft.hpp.
 #ifndef WORLD_MATLABFUNCTIONS_HPP
 #define WORLD_MATLABFUNCTIONS_HPP
 

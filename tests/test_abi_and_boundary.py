@@ -44,6 +44,9 @@ def test_library_exports_every_declared_symbol(built_lib):
     helper_declared = [n for n in io_header_symbols("world_matlabfunctions.hpp") if not n.startswith(("My", "GetSafe"))]
     assert {"interp1", "decimate", "randn", "DCCorrection"} <= set(helper_declared)
     assert not [s for s in helper_declared if s not in exported_all]
+    fft_declared = io_header_symbols("world_fft.hpp")
+    assert {"fft_plan_dft_r2c_1d", "fft_execute", "fft_destroy_plan"} <= set(fft_declared)
+    assert not [s for s in fft_declared if s not in exported_all]
     codec_declared = io_header_symbols("world_class_codec.h")
     assert {"CodeSpectralEnvelope", "DecodeAperiodicity", "GetNumberOfAperiodicities"} <= set(codec_declared)
     assert not [s for s in codec_declared if s not in exported_all]

@@ -35,6 +35,7 @@ def build(force=False, verbose=False):
     headers.append(os.path.join(os.path.dirname(HERE), "include", "world_class_io.h"))
     headers.append(os.path.join(os.path.dirname(HERE), "include", "world_class_codec.h"))
     headers.append(os.path.join(os.path.dirname(HERE), "include", "world_matlabfunctions.hpp"))
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "world_fft.hpp"))
     # a shipped library that is newer than every source is used as is (the object directory does not travel to
     # the GPU box); experimental flags always rebuild
     if not force and not EXTRA and not _stale(OUT, [os.path.join(CSRC, f) for f in sources()] + headers):

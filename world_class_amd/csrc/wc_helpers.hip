@@ -1,10 +1,12 @@
-// Host implementations of the reference's free helper functions (include/world_matlabfunctions.hpp): restates
-// reference src/world_matlabfunctions.cpp:27-241, :303-313 and src/world_common.cpp:27-126.  They exist so that callers
+// Host implementations of the reference's free helper functions (include/world_matlabfunctions.hpp) and of its FFT plan API
+// (include/world_fft.hpp): restates reference src/world_matlabfunctions.cpp:27-241, :303-313, src/world_common.cpp:27-126 and the
+// conventions of src/world_fft.cpp:31-167 (with a plain radix-2 transform instead of the bundled split-radix one).  They exist so that callers
 // of those helpers link against this library unchanged; the kernels do not use them.
 #include <algorithm>
 #include <cmath>
 #include <vector>
 
+#include "../../include/world_fft.hpp"
 #include "../../include/world_matlabfunctions.hpp"
 
 namespace {
@@ -56,9 +58,106 @@ inline double interp1q_at(double x0, double dx, const double *y, int n, double x
 	return y[base] + dy * frac;
 }
 
+// In-place radix-2 transform of n complex numbers (n a power of two) with e^{sign * 2 pi i k m / n}; tw holds
+// cos / sin of 2 pi j / n for j < n / 2.
+void cfft_pow2(double *a, int n, int sign, const double *tw) {
+	for (int i = 1, j = 0; i < n; ++i) {  // bit reversal
+		int bit = n >> 1;
+		for (; j & bit; bit >>= 1) j ^= bit;
+		j ^= bit;
+		if (i < j) {
+			std::swap(a[2 * i], a[2 * j]);
+			std::swap(a[2 * i + 1], a[2 * j + 1]);
+		}
+	}
+	for (int len = 2; len <= n; len <<= 1) {
+		const int half = len >> 1, step = n / len;
+		for (int s0 = 0; s0 < n; s0 += len) {
+			for (int k = 0; k < half; ++k) {
+				const double wr = tw[2 * (k * step)], wi = sign * tw[2 * (k * step) + 1];
+				double *u = a + 2 * (s0 + k), *v = a + 2 * (s0 + k + half);
+				const double tr = v[0] * wr - v[1] * wi, ti = v[0] * wi + v[1] * wr;
+				v[0] = u[0] - tr;
+				v[1] = u[1] - ti;
+				u[0] += tr;
+				u[1] += ti;
+			}
+		}
+	}
+}
+
+fft_plan make_plan(int n, int sign, unsigned int flags) {
+	fft_plan p;
+	p.n = n;
+	p.sign = sign;
+	p.flags = flags;
+	p.c_in = nullptr; p.in = nullptr; p.c_out = nullptr; p.out = nullptr;
+	p.input = new double[2 * static_cast<size_t>(n > 0 ? n : 1)];
+	p.ip = new int[1];
+	p.ip[0] = 0;
+	p.w = new double[static_cast<size_t>(n > 1 ? n : 2)];
+	const double pi = 3.1415926535897932384;
+	for (int j = 0; j < n / 2; ++j) {
+		p.w[2 * j] = std::cos(2.0 * pi * j / n);
+		p.w[2 * j + 1] = std::sin(2.0 * pi * j / n);
+	}
+	return p;
+}
+
 }  // namespace
 
 extern "C" {
+
+fft_plan fft_plan_dft_1d(int n, fft_complex *in, fft_complex *out, int sign, unsigned int flags) {
+	fft_plan p = make_plan(n, sign, flags);
+	p.c_in = in;
+	p.c_out = out;
+	return p;
+}
+fft_plan fft_plan_dft_c2r_1d(int n, fft_complex *in, double *out, unsigned int flags) {
+	fft_plan p = make_plan(n, FFT_BACKWARD, flags);
+	p.c_in = in;
+	p.out = out;
+	return p;
+}
+fft_plan fft_plan_dft_r2c_1d(int n, double *in, fft_complex *out, unsigned int flags) {
+	fft_plan p = make_plan(n, FFT_FORWARD, flags);
+	p.in = in;
+	p.c_out = out;
+	return p;
+}
+
+// reference src/world_fft.cpp:31-77, :151-157
+void fft_execute(fft_plan p) {
+	const int n = p.n;
+	double *a = p.input;
+	if (p.sign == FFT_FORWARD && p.c_in == nullptr) {  // r2c
+		for (int i = 0; i < n; ++i) { a[2 * i] = p.in[i]; a[2 * i + 1] = 0.0; }
+		cfft_pow2(a, n, +1, p.w);
+		for (int i = 0; i <= n / 2; ++i) { p.c_out[i][0] = a[2 * i]; p.c_out[i][1] = a[2 * i + 1]; }
+		p.c_out[0][1] = 0.0;
+		p.c_out[n / 2][1] = 0.0;
+	} else if (p.sign != FFT_FORWARD && p.c_out == nullptr) {  // c2r: Hermitian extension, bins 0 and n/2 real
+		a[0] = p.c_in[0][0]; a[1] = 0.0;
+		a[2 * (n / 2)] = p.c_in[n / 2][0]; a[2 * (n / 2) + 1] = 0.0;
+		for (int i = 1; i < n / 2; ++i) {
+			a[2 * i] = p.c_in[i][0]; a[2 * i + 1] = p.c_in[i][1];
+			a[2 * (n - i)] = p.c_in[i][0]; a[2 * (n - i) + 1] = -p.c_in[i][1];
+		}
+		cfft_pow2(a, n, -1, p.w);
+		for (int i = 0; i < n; ++i) p.out[i] = a[2 * i];
+	} else {  // c2c
+		for (int i = 0; i < n; ++i) { a[2 * i] = p.c_in[i][0]; a[2 * i + 1] = p.c_in[i][1]; }
+		cfft_pow2(a, n, p.sign == FFT_FORWARD ? +1 : -1, p.w);
+		for (int i = 0; i < n; ++i) { p.c_out[i][0] = a[2 * i]; p.c_out[i][1] = a[2 * i + 1]; }
+	}
+}
+
+void fft_destroy_plan(fft_plan p) {
+	delete[] p.input;
+	delete[] p.ip;
+	delete[] p.w;
+}
 
 void fftshift(const double *x, int x_length, double *y) {
 	const int h = x_length / 2;
