@@ -43,4 +43,19 @@ def port():
     return _port.Port()
 
 
+HARVEST_LONG_CASES = ["tie_48k_10s_9033", "plain_48k_10s_9001", "plain_16k_10s_12003_floor40"]
+
+
+def harvest_long_case(name):
+    """(x, fs, f0_floor, expected F0 of the real reference) from tests/golden/harvest_long.npz (oracle/gen_golden_harvest.py);
+    the samples are regenerated from the seed and checked against the stored digest"""
+    import hashlib
+    from world_class_amd.synth import make_utterance
+    z = np.load(os.path.join(ROOT, "tests", "golden", "harvest_long.npz"))
+    fs, sec, seed, floor = z[name + "/meta"]
+    x = make_utterance(int(fs), float(sec), int(seed))
+    assert hashlib.sha256(x.tobytes()).digest() == z[name + "/x_sha256"].tobytes(), "synthetic generator drifted"
+    return x, int(fs), float(floor), z[name + "/f0"]
+
+
 PIPELINE_CASES = ["c1_16k_2s_floor71", "c1_16k_2s_floor40", "m48k_1s", "m24k_1s_1ms"]

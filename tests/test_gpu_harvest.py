@@ -3,7 +3,7 @@ reference and against the CPU oracle (final contour and intermediates)."""
 import numpy as np
 import pytest
 
-from conftest import PIPELINE_CASES
+from conftest import HARVEST_LONG_CASES, PIPELINE_CASES, harvest_long_case
 from world_class_amd.synth import make_utterance
 
 pytestmark = pytest.mark.gpu
@@ -32,6 +32,15 @@ def test_harvest_golden(golden, wca, name):
     tpos, f0 = h.compute(c["x"])
     assert np.array_equal(tpos, c["tpos"])
     check_f0(f0, c["f0"])
+
+
+@pytest.mark.parametrize("name", HARVEST_LONG_CASES)
+def test_harvest_long_utterances_golden(wca, name):
+    """10 s utterances against the real reference's contour, one of them decided by how std::sort orders voiced sections
+    starting on the same frame (reference src/harvest.cpp:508-517; wc_argsort.hpp)"""
+    x, fs, floor, f0 = harvest_long_case(name)
+    _, got = wca.Harvest(fs, f0_floor=floor).compute(x)
+    check_f0(got, f0)
 
 
 def test_harvest_intermediates_vs_oracle(wca, port):

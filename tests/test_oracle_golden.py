@@ -4,7 +4,7 @@ These pin the oracle that the -m gpu parity tests then use as the checker."""
 import numpy as np
 import pytest
 
-from conftest import PIPELINE_CASES
+from conftest import HARVEST_LONG_CASES, PIPELINE_CASES, harvest_long_case
 from world_class_amd.synth import make_utterance
 
 # tolerances of the restatement vs the reference (FP64; only the FFT rounding differs)
@@ -127,3 +127,29 @@ def test_port_against_live_reference(golden, port):
     assert (np.abs(r["sp"] - p["sp"]) / r["sp"]).max() < SP_REL
     assert np.abs(r["ap"] - p["ap"]).max() < AP_ABS
     assert np.abs(r["y"] - p["y"]).max() < Y_ABS
+
+
+@pytest.mark.parametrize("name", HARVEST_LONG_CASES)
+def test_harvest_long_utterances_against_golden(port, name):
+    """whole 10 s utterances; "tie_*" is the one whose contour hangs on std::sort's order of voiced sections that
+    start on the same frame (reference src/harvest.cpp:508-517)"""
+    x, fs, floor, f0 = harvest_long_case(name)
+    port.set_threads(4)
+    try:
+        _, got = port.harvest(x, fs, f0_floor=floor)
+    finally:
+        port.set_threads(0)
+    assert np.array_equal(got == 0, f0 == 0)
+    assert np.abs(got - f0).max() < F0_ABS
+
+
+def test_device_argsort_reproduces_std_sort(tmp_path):
+    """world_class_amd/csrc/wc_argsort.hpp (what hv_contour_kernel runs) against std::sort of the library the reference is
+    built with, on tie-heavy keys and on a sequence that drives introsort into its heap sort"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "argsort_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(root, "tests", "cpp", "argsort_check.cpp")], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr

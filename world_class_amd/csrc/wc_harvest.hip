@@ -30,6 +30,7 @@
 #include <string>
 #include <vector>
 
+#include "wc_argsort.hpp"
 #include "wc_device.hpp"
 #include "wc_internal.hpp"
 #include "wc_frames.hpp"
@@ -1144,14 +1145,11 @@ __global__ __launch_bounds__(64) void hv_contour_kernel(CtrArgs a) {
 		// merged = the row at position 0, whatever its rank in time
 		const int ch0 = perm[0];
 		for (int i = lane; i < L; i += 64) s3[i] = chv(ch0, i);
-		// order[] = positions 0..count-1 sorted by start frame
+		// order[] = positions 0..count-1 sorted by start frame the way the reference's std::sort leaves them: sections
+		// that start on the same frame (several can extend back to frame 0) keep libstdc++'s order, see wc_argsort.hpp
 		if (lane == 0) {
 			for (int k = 0; k < count; ++k) order[k] = k;
-			for (int k = 1; k < count; ++k) {
-				int v = order[k], key = bl[2 * v], m = k - 1;
-				while (m >= 0 && bl[2 * order[m]] > key) { order[m + 1] = order[m]; --m; }
-				order[m + 1] = v;
-			}
+			wc_argsort::sort_like_libstdcxx(order, count, wc_argsort::ByKey{bl, 2});
 		}
 		wave_sync();
 		for (int q = 1; q < count; ++q) {
