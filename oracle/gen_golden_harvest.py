@@ -5,8 +5,14 @@ than 16 sections, so libstdc++'s introsort decides).  Run in the build container
 
     make -C oracle ref && python oracle/gen_golden_harvest.py
 
-Only data travels: the inputs are regenerated from their seeds by world_class_amd.synth.make_utterance (a checksum of
-the samples is stored), the expected F0 comes from the reference.
+The last case pins a second place where the reference reads memory it never wrote: removeUnreliableCandidates compares
+frames 1 and L-2 with rows 0 and L-1 of a copy that only holds rows 1 .. L-2 (src/harvest.cpp:714-715).  The oracle's build
+of the reference zero-fills new[] (ref_shim.cpp), so those rows are zero; for that case the candidates of frames 1 and L-2
+after the removal (from the stage taps, ref_harvest_taps.cpp) are stored next to the contour.
+
+Only data travels: utterances are regenerated from their seeds by world_class_amd.synth.make_utterance (a checksum of
+the samples is stored); the float test signal is stored as the int16 samples it was quantised to.  Expected values come
+from the reference.
 """
 import hashlib
 import os
@@ -17,7 +23,7 @@ import numpy as np
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, _ROOT)
 from oracle import ref  # noqa: E402
-from world_class_amd.synth import make_utterance  # noqa: E402
+from world_class_amd.synth import make_signal, make_utterance  # noqa: E402
 
 # name, fs, seconds, seed, f0_floor
 CASES = [
@@ -36,6 +42,34 @@ def main():
         out[name + "/x_sha256"] = np.frombuffer(hashlib.sha256(x.tobytes()).digest(), dtype=np.uint8)
         out[name + "/f0"] = f0
         print(name, "frames", len(f0), "voiced", int((f0 > 0).sum()))
+    # two voices a fifth apart; the lower one is only matched by the last frame at frame L-2
+    name, fs, sec, seed, floor = "edge_rows_16k_3s_duet", 16000, 3.0, 40004, 71.0
+    xi = np.clip(np.round(make_signal(fs, sec, seed) * 32768.0), -32768, 32767).astype(np.int16)
+    x = xi.astype(np.float64) / 32768.0
+    tpos, f0 = ref.run_fresh("harvest", x, fs, f0_floor=floor)
+    taps = ref.harvest_taps(x, fs, f0_floor=floor)
+    L1 = len(taps["f0_1ms"])
+    out[name + "/meta"] = np.array([fs, sec, seed, floor], dtype=np.float64)
+    out[name + "/x_i16"] = xi
+    out[name + "/f0"] = f0
+    out[name + "/cand_rows"] = np.array([1, L1 - 2])
+    out[name + "/cand"] = taps["cand"][[1, L1 - 2]]
+    out[name + "/cand_refined"] = taps["cand_refined"][[0, 1, 2, L1 - 3, L1 - 2, L1 - 1]]
+    print(name, "frames", len(f0), "voiced", int((f0 > 0).sum()), "candidates kept at L-2:", int((taps["cand"][L1 - 2] != 0).sum()),
+          "of", int((taps["cand_refined"][L1 - 2] != 0).sum()))
+    # a loud noisy voice (|x| up to 4): many candidates of a frame share window length and bins, the reference returns
+    # bitwise equal refined F0s for them with different scores, and mergeF0's searchScore (src/harvest.cpp:463-470) takes
+    # the best score among EQUAL values -- an implementation whose refined values differ in the last bit merges differently
+    name, fs, sec, seed, floor = "equal_refined_16k_3s_loud", 16000, 3.0, 40017, 71.0
+    xf = make_signal(fs, sec, seed).astype(np.float32)
+    x = xf.astype(np.float64)
+    tpos, f0 = ref.run_fresh("harvest", x, fs, f0_floor=floor)
+    taps = ref.harvest_taps(x, fs, f0_floor=floor)
+    dup = sum(len(r[r != 0]) - len(np.unique(r[r != 0])) for r in taps["cand"])
+    out[name + "/meta"] = np.array([fs, sec, seed, floor], dtype=np.float64)
+    out[name + "/x_f32"] = xf
+    out[name + "/f0"] = f0
+    print(name, "frames", len(f0), "voiced", int((f0 > 0).sum()), "bitwise-equal candidate pairs", dup)
     path = os.path.join(_ROOT, "tests", "golden", "harvest_long.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")

@@ -199,6 +199,30 @@ class Ref:
         return dict(tpos=tpos, f0=f0, sp=sp, ap=ap, y=y)
 
 
+def taps_available():
+    return os.path.exists(os.path.join(_HERE, "_ref", "libworld_ref_taps.so"))
+
+
+def harvest_taps(x, fs, f0_floor=71.0, f0_ceil=800.0):
+    """Intermediates of the real reference's Harvest (oracle/ref_harvest_taps.cpp): y, raw [band][frame], candidates and
+    scores after refinement and after removeUnreliableCandidates [frame][max_candidates], base / fixed / smoothed 1 ms
+    contours.  Harvest draws no random numbers, so no fresh process is needed."""
+    lib = C.CDLL(os.path.join(_HERE, "_ref", "libworld_ref_taps.so"))
+    lib.ref_harvest_taps.restype = C.c_int
+    lib.ref_harvest_taps.argtypes = [_dp, C.c_int, C.c_int, C.c_double, C.c_double, _ip] + [_dp] * 9
+    x = _c(x)
+    dims = np.zeros(4, dtype=np.int32)
+    nul = [None] * 9
+    L1 = lib.ref_harvest_taps(_p(x), len(x), fs, f0_floor, f0_ceil, dims.ctypes.data_as(_ip), *nul)
+    yl, nb, mc, nc = [int(v) for v in dims]
+    out = dict(y=np.zeros(yl), raw=np.zeros((nb, L1)), cand_refined=np.zeros((L1, mc)), score_refined=np.zeros((L1, mc)),
+               cand=np.zeros((L1, mc)), score=np.zeros((L1, mc)), f0_base=np.zeros(L1), f0_fixed=np.zeros(L1), f0_1ms=np.zeros(L1))
+    lib.ref_harvest_taps(_p(x), len(x), fs, f0_floor, f0_ceil, dims.ctypes.data_as(_ip), *[_p(out[k]) for k in
+                         ("y", "raw", "cand_refined", "score_refined", "cand", "score", "f0_base", "f0_fixed", "f0_1ms")])
+    out["n_cand"] = nc
+    return out
+
+
 def run_fresh(method, *args, omp=False, **kwargs):
     """Run Ref().<method>(*args, **kwargs) in a brand-new process (RNG at its seed state)."""
     payload = pickle.dumps((method, args, kwargs, omp))

@@ -959,7 +959,13 @@ static double select_best_f0(double ref, const double *c, int n, double allowed,
 }
 // :708-744
 static void hv_remove_unreliable(Harvest &H) {
+	// the reference copies frames 1 .. L-2 only (:714-715); rows 0 and L-1 of its copy are never written
+	// (uninitialised read; zero with the zero-filling operator new[] of ref_shim.cpp, restated as zero)
 	std::vector<vd> tmp(H.cand);
+	if (H.L > 0) {
+		std::fill(tmp[0].begin(), tmp[0].end(), 0.0);
+		std::fill(tmp[H.L - 1].begin(), tmp[H.L - 1].end(), 0.0);
+	}
 	for (int i = 1; i < H.L - 1; ++i)
 		for (int j = 0; j < H.n_cand; ++j) {
 			double ref = H.cand[i][j];

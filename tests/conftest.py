@@ -43,7 +43,8 @@ def port():
     return _port.Port()
 
 
-HARVEST_LONG_CASES = ["tie_48k_10s_9033", "plain_48k_10s_9001", "plain_16k_10s_12003_floor40"]
+HARVEST_LONG_CASES = ["tie_48k_10s_9033", "plain_48k_10s_9001", "plain_16k_10s_12003_floor40", "edge_rows_16k_3s_duet",
+                      "equal_refined_16k_3s_loud"]
 
 
 def harvest_long_case(name):
@@ -53,9 +54,26 @@ def harvest_long_case(name):
     from world_class_amd.synth import make_utterance
     z = np.load(os.path.join(ROOT, "tests", "golden", "harvest_long.npz"))
     fs, sec, seed, floor = z[name + "/meta"]
-    x = make_utterance(int(fs), float(sec), int(seed))
-    assert hashlib.sha256(x.tobytes()).digest() == z[name + "/x_sha256"].tobytes(), "synthetic generator drifted"
+    if name + "/x_i16" in z:
+        x = z[name + "/x_i16"].astype(np.float64) / 32768.0
+    elif name + "/x_f32" in z:
+        x = z[name + "/x_f32"].astype(np.float64)
+    else:
+        x = make_utterance(int(fs), float(sec), int(seed))
+        assert hashlib.sha256(x.tobytes()).digest() == z[name + "/x_sha256"].tobytes(), "synthetic generator drifted"
     return x, int(fs), float(floor), z[name + "/f0"]
+
+
+def harvest_edge_rows():
+    """candidates of frames 1 and L-2 after removeUnreliableCandidates of the real reference for "edge_rows_16k_3s_duet":
+    (frame indices, [2][max_candidates])"""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "harvest_long.npz"))
+    return z["edge_rows_16k_3s_duet/cand_rows"], z["edge_rows_16k_3s_duet/cand"]
+
+
+def same_candidates(a, b, tol=1e-8):
+    a, b = np.sort(a[a != 0]), np.sort(b[b != 0])
+    return len(a) == len(b) and (len(a) == 0 or np.abs(a - b).max() < tol)
 
 
 PIPELINE_CASES = ["c1_16k_2s_floor71", "c1_16k_2s_floor40", "m48k_1s", "m24k_1s_1ms"]

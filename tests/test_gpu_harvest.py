@@ -3,7 +3,7 @@ reference and against the CPU oracle (final contour and intermediates)."""
 import numpy as np
 import pytest
 
-from conftest import HARVEST_LONG_CASES, PIPELINE_CASES, harvest_long_case
+from conftest import HARVEST_LONG_CASES, PIPELINE_CASES, harvest_edge_rows, harvest_long_case, same_candidates
 from world_class_amd.synth import make_utterance
 
 pytestmark = pytest.mark.gpu
@@ -41,6 +41,36 @@ def test_harvest_long_utterances_golden(wca, name):
     x, fs, floor, f0 = harvest_long_case(name)
     _, got = wca.Harvest(fs, f0_floor=floor).compute(x)
     check_f0(got, f0)
+
+
+def test_unreliable_candidates_edge_rows(wca):
+    """frames 1 and L-2 are compared with rows the reference never wrote (reference src/harvest.cpp:714-715, zero in the
+    oracle's build of it): candidates only matched by frame 0 / L-1 are removed"""
+    x, fs, floor, _ = harvest_long_case("edge_rows_16k_3s_duet")
+    rows, cand = harvest_edge_rows()
+    h = wca.Harvest(fs, f0_floor=floor)
+    h.compute(x)
+    got = h.debug_fetch("cand").reshape(int(rows[1]) + 2, -1)  # [1 ms frames][slots]
+    for r, c in zip(rows, cand):
+        assert same_candidates(got[r], c)
+
+
+def test_refined_candidates_are_equal_where_the_reference_makes_them_equal(wca, port):
+    """Candidates of a frame that share window length and bins refine to bitwise equal F0s in the reference (the window
+    is quantised, src/harvest.cpp:950-958) and mergeF0's searchScore compares with == (:463-470): the number of distinct
+    values per frame has to match, whatever else shares the wavefront"""
+    x, fs, floor, f0 = harvest_long_case("equal_refined_16k_3s_loud")
+    d = port.harvest_debug(x, fs, f0_floor=floor)
+    h = wca.Harvest(fs, f0_floor=floor)
+    check_f0(h.compute(x)[1], f0)
+    L1 = len(d["f0_1ms"])
+    got = h.debug_fetch("cand").reshape(L1, -1)
+    equal_pairs = 0
+    for i in range(L1):
+        a, b = got[i][got[i] != 0], d["cand"][i][d["cand"][i] != 0]
+        assert len(a) == len(b) and len(np.unique(a)) == len(np.unique(b)), "frame %d" % i
+        equal_pairs += len(b) - len(np.unique(b))
+    assert equal_pairs > 1000  # the case is only worth its name while the reference does produce such candidates
 
 
 def test_harvest_intermediates_vs_oracle(wca, port):

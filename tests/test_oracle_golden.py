@@ -4,7 +4,7 @@ These pin the oracle that the -m gpu parity tests then use as the checker."""
 import numpy as np
 import pytest
 
-from conftest import HARVEST_LONG_CASES, PIPELINE_CASES, harvest_long_case
+from conftest import HARVEST_LONG_CASES, PIPELINE_CASES, harvest_edge_rows, harvest_long_case, same_candidates
 from world_class_amd.synth import make_utterance
 
 # tolerances of the restatement vs the reference (FP64; only the FFT rounding differs)
@@ -141,6 +141,36 @@ def test_harvest_long_utterances_against_golden(port, name):
         port.set_threads(0)
     assert np.array_equal(got == 0, f0 == 0)
     assert np.abs(got - f0).max() < F0_ABS
+
+
+def test_unreliable_candidates_edge_rows(port):
+    """removeUnreliableCandidates compares frames 1 and L-2 with rows the reference never wrote (reference
+    src/harvest.cpp:714-715; zero in the oracle's build of it): the lower voice at frame L-2 is matched by frame L-1 only
+    and has to go"""
+    x, fs, floor, _ = harvest_long_case("edge_rows_16k_3s_duet")
+    rows, cand = harvest_edge_rows()
+    d = port.harvest_debug(x, fs, f0_floor=floor)
+    for r, c in zip(rows, cand):
+        assert same_candidates(d["cand"][r], c)
+    assert (d["cand"][rows[1]] != 0).sum() == 7
+
+
+def test_harvest_stages_against_live_reference(port):
+    """stage by stage against the real reference's own member functions (oracle/ref_harvest_taps.cpp), when it is built"""
+    from oracle import ref
+    if not ref.taps_available():
+        pytest.skip("oracle/_ref/libworld_ref_taps.so not built (no reference sources here)")
+    fs = 16000
+    x = make_utterance(fs, 1.5, 4242)
+    for floor in (71.0, 40.0):
+        a, b = port.harvest_debug(x, fs, f0_floor=floor), ref.harvest_taps(x, fs, f0_floor=floor)
+        assert a["n_cand"] == b["n_cand"] and a["cand"].shape == b["cand"].shape
+        assert np.array_equal(a["y"], b["y"])
+        assert np.array_equal(a["raw"] == 0, b["raw"] == 0) and np.abs(a["raw"] - b["raw"]).max() < 1e-7
+        assert np.array_equal(a["cand"] == 0, b["cand"] == 0) and np.abs(a["cand"] - b["cand"]).max() < 1e-9
+        assert (np.abs(a["score"] - b["score"]) / np.maximum(b["score"], 1.0)).max() < 1e-6
+        for k in ("f0_base", "f0_fixed", "f0_1ms"):
+            assert np.array_equal(a[k] == 0, b[k] == 0) and np.abs(a[k] - b[k]).max() < 1e-9
 
 
 def test_device_argsort_reproduces_std_sort(tmp_path):

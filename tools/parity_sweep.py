@@ -1,6 +1,6 @@
 """Parity sweep beyond the committed goldens (development aid, run on a GPU box): N seeded 48 kHz utterances through the fused
 pipeline against the CPU oracle; prints the worst deviations and any voiced/unvoiced disagreement.
-    python tools/parity_sweep.py [--n 32] [--seconds 10] [--fs 48000] [--first-seed 9000] [--floor 71] [--frame-period 5] [--ragged]"""
+    python tools/parity_sweep.py [--n 32] [--seconds 10] [--fs 48000] [--first-seed 9000] [--floor 71] [--frame-period 5] [--ragged] [--zoo]"""
 import argparse
 import os
 import sys
@@ -10,7 +10,20 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import world_class_amd as w  # noqa: E402
 from oracle import port  # noqa: E402  (tools/ may use the oracle as the checker, like tests/)
-from world_class_amd.synth import make_utterance  # noqa: E402
+from world_class_amd.synth import SIGNAL_KINDS as ZOO, make_signal as zoo_signal, make_utterance  # noqa: E402
+
+
+def dev(a, b, rel=False):
+    """largest deviation; NaN / inf have to sit in the same places with the same sign"""
+    fa, fb = np.isfinite(a), np.isfinite(b)
+    if not np.array_equal(fa, fb) or not np.array_equal(np.nan_to_num(a[~fa], nan=7.0), np.nan_to_num(b[~fb], nan=7.0)):
+        return float("inf")
+    if not fa.any():
+        return 0.0
+    d = np.abs(a[fa] - b[fa])
+    if rel:
+        d = d / np.maximum(np.abs(b[fa]), 1e-300)
+    return float(d.max()) if d.size else 0.0
 
 
 def main():
@@ -20,11 +33,13 @@ def main():
     ap.add_argument("--fs", type=int, default=48000)
     ap.add_argument("--first-seed", type=int, default=9000)
     ap.add_argument("--floor", type=float, default=71.0)
+    ap.add_argument("--zoo", action="store_true", help="signals of other kinds (noise, chirps, impulse trains, ...) instead of utterances")
     ap.add_argument("--frame-period", type=float, default=5.0)
     ap.add_argument("--ragged", action="store_true", help="utterance i lasts seconds * (0.2 + 0.8 * ((i * 7) % 10) / 9)")
     a = ap.parse_args()
     dur = [a.seconds * (0.2 + 0.8 * ((i * 7) % 10) / 9) if a.ragged else a.seconds for i in range(a.n)]
-    xs = [make_utterance(a.fs, dur[i], a.first_seed + i) for i in range(a.n)]
+    gen = zoo_signal if a.zoo else make_utterance
+    xs = [gen(a.fs, dur[i], a.first_seed + i) for i in range(a.n)]
     res = w.Pipeline(a.fs, frame_period=a.frame_period, harvest_f0_floor=a.floor).run_batch(xs)
     P = port.Port()
     P.set_threads(os.cpu_count() or 1)
@@ -35,12 +50,12 @@ def main():
         fl = int(np.sum((r["f0"] == 0) != (o["f0"] == 0)))
         flips += fl
         same = (r["f0"] == 0) == (o["f0"] == 0)
-        e = dict(f0=np.abs(r["f0"] - o["f0"])[same].max(), sp=(np.abs(r["sp"] - o["sp"]) / o["sp"]).max(),
-                 ap=np.abs(r["ap"] - o["ap"]).max(), y=np.abs(r["y"] - o["y"]).max())
+        e = dict(f0=dev(r["f0"][same], o["f0"][same]), sp=dev(r["sp"], o["sp"], rel=True), ap=dev(r["ap"], o["ap"]),
+                 y=dev(r["y"], o["y"]) / max(1.0, float(np.abs(x).max())))
         for k in worst:
             worst[k] = max(worst[k], float(e[k]))
         if fl or e["f0"] > 1e-6 or e["sp"] > 1e-7 or e["ap"] > 1e-7 or e["y"] > 1e-8:
-            print("seed", a.first_seed + i, "V/UV flips", fl, {k: "%.2e" % v for k, v in e.items()})
+            print("seed", a.first_seed + i, ZOO[(a.first_seed + i) % len(ZOO)] if a.zoo else "", "V/UV flips", fl, {k: "%.2e" % v for k, v in e.items()})
     print("fs", a.fs, "floor", a.floor, "hop", a.frame_period, "utterances", a.n, "V/UV flips", flips, "worst", {k: "%.2e" % v for k, v in worst.items()})
 
 

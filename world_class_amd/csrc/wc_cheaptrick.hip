@@ -178,6 +178,10 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 			run = mir(i) * fs / N + run;
 			Ar[i] = run;
 		}
+		// non-decreasing like the reference's sequential sum (the smoothed value below is a difference of two
+		// neighbourhoods of it and goes into a logarithm): clamp every segment to the largest value before it
+		const double floor_v = block_excl_max_scan<T>(run, red, tid);
+		for (int i = lo; i < hi; ++i) Ar[i] = fmax(Ar[i], floor_v);
 		__syncthreads();
 		const double origin_axis = -(b - 0.5) * fs / N;
 		const double step = (double)fs / N, rstep = 1.0 / step;

@@ -134,7 +134,7 @@ __device__ __forceinline__ void dc_correction_lds(double *P, double f0, int fs, 
 // LinearSmoothing of reference src/world_common.cpp:27-52, :82-116.  P[0..M] in LDS is the input,
 // S (>= N doubles of LDS) receives the mirrored cumulative segment, out(k, value) is called for
 // every bin once the segment is complete (it may overwrite P[k]).  Ends with a __syncthreads().
-template <int M, int T, class Out>
+template <int M, int T, bool NONNEG, class Out>
 __device__ __forceinline__ void linear_smoothing_lds(const double *P, double *S, double width, int fs, double *red,
 													 int tid, Out out) {
 #pragma clang fp contract(fast)  // values only (the segment indices come from interp1q_rcp's own arithmetic)
@@ -155,6 +155,12 @@ __device__ __forceinline__ void linear_smoothing_lds(const double *P, double *S,
 	for (int i = lo; i < hi; ++i) {
 		run = mir(i) * fs / N + run;
 		S[i] = run;
+	}
+	if (NONNEG) {
+		// a power spectrum: keep the cumulative sum non-decreasing like the reference's sequential one (the smoothed
+		// spectrum becomes a divisor); every segment is clamped to the largest value before it
+		const double floor_v = block_excl_max_scan<T>(run, red, tid);
+		for (int i = lo; i < hi; ++i) S[i] = fmax(S[i], floor_v);
 	}
 	__syncthreads();
 	const double origin_axis = -(b - 0.5) * fs / N;
@@ -343,7 +349,7 @@ __global__ __launch_bounds__(T, (2 * T) / 256) void d4c_frames_kernel(D4cArgs a)
 		}
 		__syncthreads();
 		dc_correction_lds<M, T>(Br, f0, fs, tid);
-		linear_smoothing_lds<M, T>(Br, Ar, f0, fs, red, tid, [&](int k, double v) { Br[k] = v; });
+		linear_smoothing_lds<M, T, true>(Br, Ar, f0, fs, red, tid, [&](int k, double v) { Br[k] = v; });
 	}
 #if defined(WC_D4C_STOP) && WC_D4C_STOP == 2
 	if (tid == 0) a.ap[g * (long long)(a.fft_size_out / 2 + 1)] = Cc[1] + Br[1];
@@ -353,8 +359,8 @@ __global__ __launch_bounds__(T, (2 * T) / 256) void d4c_frames_kernel(D4cArgs a)
 	WC_FRESH_TID();
 	for (int k = tid; k <= M; k += T) Cc[k] = Cc[k] / Br[k];
 	__syncthreads();
-	linear_smoothing_lds<M, T>(Cc, Ar, f0 / 2.0, fs, red, tid, [&](int k, double v) { Cc[k] = v; });
-	linear_smoothing_lds<M, T>(Cc, Ar, f0, fs, red, tid, [&](int k, double v) { Br[k] = v; });
+	linear_smoothing_lds<M, T, false>(Cc, Ar, f0 / 2.0, fs, red, tid, [&](int k, double v) { Cc[k] = v; });
+	linear_smoothing_lds<M, T, false>(Cc, Ar, f0, fs, red, tid, [&](int k, double v) { Br[k] = v; });
 	for (int k = tid; k <= M; k += T) Cc[k] -= Br[k];
 	__syncthreads();
 

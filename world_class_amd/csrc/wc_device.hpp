@@ -133,6 +133,29 @@ __device__ __forceinline__ double block_excl_scan(double v, double *scratch, int
 	for (int k = 0; k < T / 64; ++k) if (k < w) base += scratch[k];
 	return base + inc - v;
 }
+// Exclusive running maximum of one value per thread across the block (values >= 0).  Used to take the ulp-sized
+// inversions out of tree-scanned prefix sums of non-negative terms: a tree scan gives every position its own association
+// order, so such sums can DEcrease by an ulp from one thread's segment to the next, which the reference's sequential
+// cumulative sum (src/world_common.cpp:95-101) never does -- and LinearSmoothing's differences of them feed a logarithm
+// (CheapTrick) and a divisor (D4C).  max is exact in any order, so the clamped sequence is non-decreasing.
+// scratch: >= T/64 doubles.
+template <int T>
+__device__ __forceinline__ double block_excl_max_scan(double v, double *scratch, int tid) {
+	const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		double t = __shfl_up(v, o, 64);
+		if (lane >= o) v = fmax(v, t);
+	}
+	__syncthreads();
+	if (lane == 63) scratch[w] = v;
+	__syncthreads();
+	double m = __shfl_up(v, 1, 64);
+	if (lane == 0) m = 0.0;
+#pragma unroll
+	for (int k = 0; k < T / 64; ++k) if (k < w) m = fmax(m, scratch[k]);
+	return m;
+}
 
 // ---- complex helpers ----------------------------------------------------------------------------
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) {

@@ -738,7 +738,6 @@ __global__ __launch_bounds__(256, 3) void hv_refine_kernel(RefArgs a) {  // 3 wa
 			double sa[12], sb[12];  // [2 h] main window, [2 h + 1] difference window; sa = newest after a full trip
 #pragma unroll
 			for (int k = 0; k < 12; ++k) { sa[k] = 0.0; sb[k] = 0.0; }
-			// (no per-lane control flow inside the loop: a lane past its window feeds zero samples)
 			auto sample = [&](int n, double &xm, double &xd) {
 				// Blackman window 0.42 + 0.5 cos + 0.08 cos 2theta = 0.34 + c (0.5 + 0.16 c); its centred difference
 				// -(w[n+1] - w[n-1]) / 2 = sin theta (0.5 sin beta + 0.16 sin 2beta cos theta) in the interior, the
@@ -756,22 +755,29 @@ __global__ __launch_bounds__(256, 3) void hv_refine_kernel(RefArgs a) {  // 3 wa
 				ws = fma(ws, r8.x, wc * r8.y);
 				wc = nc_;
 			};
+			// A lane stops after its own last sample (at most one trailing zero): the refined F0 must be a function of
+			// the candidate's window and bins alone.  The reference returns bitwise EQUAL values for candidates of a frame
+			// that share them (the window length is quantised, :950-958) and mergeF0's searchScore compares with ==
+			// (:463-470); running every lane to the longest window in the wavefront made the result depend on the
+			// neighbours through the number of trailing rotations.
 			int Q = 0;
 			for (int n = sub; __ballot(n < bt) != 0ull; n += 16) {
-				double xm, xd;
-				sample(n, xm, xd);
+				if (n < bt) {
+					double xm, xd;
+					sample(n, xm, xd);
 #pragma unroll
-				for (int h = 0; h < 6; ++h) {
-					sb[2 * h] = fma(c2[h], sa[2 * h], xm) - sb[2 * h];
-					sb[2 * h + 1] = fma(c2[h], sa[2 * h + 1], xd) - sb[2 * h + 1];
-				}
-				sample(n + 8, xm, xd);
+					for (int h = 0; h < 6; ++h) {
+						sb[2 * h] = fma(c2[h], sa[2 * h], xm) - sb[2 * h];
+						sb[2 * h + 1] = fma(c2[h], sa[2 * h + 1], xd) - sb[2 * h + 1];
+					}
+					sample(n + 8, xm, xd);
 #pragma unroll
-				for (int h = 0; h < 6; ++h) {
-					sa[2 * h] = fma(c2[h], sb[2 * h], xm) - sa[2 * h];
-					sa[2 * h + 1] = fma(c2[h], sb[2 * h + 1], xd) - sa[2 * h + 1];
+					for (int h = 0; h < 6; ++h) {
+						sa[2 * h] = fma(c2[h], sb[2 * h], xm) - sa[2 * h];
+						sa[2 * h + 1] = fma(c2[h], sb[2 * h + 1], xd) - sa[2 * h + 1];
+					}
+					Q += 2;
 				}
-				Q += 2;
 			}
 			double v[32];
 #pragma unroll
@@ -860,7 +866,9 @@ __global__ __launch_bounds__(128) void hv_unreliable_kernel(const HvUtt *__restr
 	__syncthreads();
 	if (interior) {
 		for (int j = threadIdx.x; j < nc; j += blockDim.x) {
-			const double a = c1[(g + 1) * nc + j], b = c1[(g - 1) * nc + j];
+			// the reference's comparison copy holds frames 1 .. L-2 only (:714-715); its rows 0 and L-1 are never written
+			// (uninitialised there, zero here and in the oracle's build of the reference)
+			const double a = (i + 1 < u.L1 - 1) ? c1[(g + 1) * nc + j] : 0.0, b = (i - 1 >= 1) ? c1[(g - 1) * nc + j] : 0.0;
 			if (a != 0) nxt[atomicAdd(&cnt[0], 1)] = a;
 			if (b != 0) prv[atomicAdd(&cnt[1], 1)] = b;
 		}

@@ -36,6 +36,53 @@ def make_utterance(fs: int, seconds: float, seed: int) -> np.ndarray:
     return q.astype(np.float64) / 32768.0
 
 
+SIGNAL_KINDS = ("noise", "chirp", "jumps", "impulses", "duet", "square_dc", "quiet", "loud", "gaps", "low_jitter")
+
+
+def make_signal(fs, seconds, seed):
+    """Float64 test signals of kinds make_utterance never produces (not quantised, not clipped): seed % 10 picks the kind
+    from SIGNAL_KINDS.  Used by tools/parity_sweep.py --zoo and by the fixtures of oracle/gen_golden_harvest.py."""
+    rng = np.random.default_rng(seed)
+    n = int(round(fs * seconds))
+    t = np.arange(n) / fs
+    kind = SIGNAL_KINDS[seed % len(SIGNAL_KINDS)]
+
+    def voice(f0, nh=25, roll=1.0):
+        ph = 2 * np.pi * np.cumsum(f0) / fs
+        x = np.zeros(n)
+        for h in range(1, nh + 1):
+            x += ((h * f0) < 0.45 * fs) * np.sin(h * ph + rng.uniform(0, 2 * np.pi)) / h ** roll
+        return x / max(np.abs(x).max(), 1e-9)
+
+    if kind == "noise":
+        x = 0.3 * rng.normal(size=n)
+    elif kind == "chirp":
+        f = 40.0 + (1200.0 - 40.0) * t / seconds
+        x = 0.6 * np.sin(2 * np.pi * np.cumsum(f) / fs)
+    elif kind == "jumps":
+        seg = int(0.15 * fs)
+        f0 = np.repeat(rng.uniform(60.0, 700.0, n // seg + 1), seg)[:n]
+        x = 0.5 * voice(f0) * np.repeat(rng.uniform(size=n // seg + 1) > 0.25, seg)[:n]
+    elif kind == "impulses":
+        period = int(rng.integers(fs // 400, fs // 80))
+        x = np.zeros(n)
+        x[::period] = 0.9
+    elif kind == "duet":
+        x = 0.35 * voice(np.full(n, rng.uniform(90, 200))) + 0.35 * voice(rng.uniform(210, 500) * (1 + 0.03 * np.sin(2 * np.pi * 5 * t)))
+    elif kind == "square_dc":
+        x = 0.2 + 0.5 * np.sign(voice(150 + 30 * np.sin(2 * np.pi * 2 * t), nh=1))
+    elif kind == "quiet":
+        x = 1e-5 * voice(np.full(n, rng.uniform(100, 300))) + 1e-7 * rng.normal(size=n)
+    elif kind == "loud":
+        x = 3.0 * voice(200 + 50 * np.sin(2 * np.pi * 1.1 * t)) + 0.5 * rng.normal(size=n)
+    elif kind == "gaps":
+        x = 0.5 * voice(np.full(n, rng.uniform(100, 400)), roll=0.5) * (np.sin(2 * np.pi * 1.3 * t) > 0)  # exact zeros in the gaps
+    else:
+        f0 = rng.uniform(45, 90) * (1 + 0.02 * rng.normal(size=n))
+        x = 0.5 * voice(f0, nh=40)
+    return np.ascontiguousarray(x, dtype=np.float64)
+
+
 def make_batch(fs: int, seconds: float, n_utt: int, config: int = 0, first: int = 0):
     """List of utterances with seeds 1000*config + u (u = first .. first+n_utt-1)."""
     return [make_utterance(fs, seconds, 1000 * config + u) for u in range(first, first + n_utt)]
