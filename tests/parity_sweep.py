@@ -1,6 +1,6 @@
 """Parity sweep beyond the committed goldens (development aid, run on a GPU box): N seeded 48 kHz utterances through the fused
 pipeline against the CPU oracle; prints the worst deviations and any voiced/unvoiced disagreement.
-    python tools/parity_sweep.py [--n 32] [--seconds 10] [--fs 48000] [--first-seed 9000] [--floor 71] [--frame-period 5] [--ragged] [--zoo]"""
+    python tests/parity_sweep.py [--n 32] [--seconds 10] [--fs 48000] [--first-seed 9000] [--floor 71] [--frame-period 5] [--ragged] [--zoo]"""
 import argparse
 import os
 import sys
@@ -9,7 +9,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import world_class_amd as w  # noqa: E402
-from oracle import port  # noqa: E402  (tools/ may use the oracle as the checker, like tests/)
+from oracle import port  # noqa: E402  (a checker, which is why it lives under tests/)
 from world_class_amd.synth import SIGNAL_KINDS as ZOO, make_signal as zoo_signal, make_utterance  # noqa: E402
 
 
@@ -35,11 +35,15 @@ def main():
     ap.add_argument("--floor", type=float, default=71.0)
     ap.add_argument("--zoo", action="store_true", help="signals of other kinds (noise, chirps, impulse trains, ...) instead of utterances")
     ap.add_argument("--frame-period", type=float, default=5.0)
+    ap.add_argument("--dither", type=float, default=0.0, help="rms of white noise added to every signal (noise-free bands make "
+                    "CheapTrick and D4C ill-conditioned in any implementation, the reference included)")
     ap.add_argument("--ragged", action="store_true", help="utterance i lasts seconds * (0.2 + 0.8 * ((i * 7) % 10) / 9)")
     a = ap.parse_args()
     dur = [a.seconds * (0.2 + 0.8 * ((i * 7) % 10) / 9) if a.ragged else a.seconds for i in range(a.n)]
     gen = zoo_signal if a.zoo else make_utterance
     xs = [gen(a.fs, dur[i], a.first_seed + i) for i in range(a.n)]
+    if a.dither > 0:
+        xs = [x + a.dither * np.random.default_rng(a.first_seed + i + 10 ** 6).normal(size=len(x)) for i, x in enumerate(xs)]
     res = w.Pipeline(a.fs, frame_period=a.frame_period, harvest_f0_floor=a.floor).run_batch(xs)
     P = port.Port()
     P.set_threads(os.cpu_count() or 1)
