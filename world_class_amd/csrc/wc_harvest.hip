@@ -867,7 +867,7 @@ __global__ __launch_bounds__(128) void hv_unreliable_kernel(const HvUtt *__restr
 	if (interior) {
 		for (int j = threadIdx.x; j < nc; j += blockDim.x) {
 			// the reference's comparison copy holds frames 1 .. L-2 only (:714-715); its rows 0 and L-1 are never written
-			// (uninitialised there, zero here and in the oracle's build of the reference)
+			// (uninitialised there; zero here, as with a zero-filling allocator under the reference)
 			const double a = (i + 1 < u.L1 - 1) ? c1[(g + 1) * nc + j] : 0.0, b = (i - 1 >= 1) ? c1[(g - 1) * nc + j] : 0.0;
 			if (a != 0) nxt[atomicAdd(&cnt[0], 1)] = a;
 			if (b != 0) prv[atomicAdd(&cnt[1], 1)] = b;

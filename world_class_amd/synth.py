@@ -41,7 +41,7 @@ SIGNAL_KINDS = ("noise", "chirp", "jumps", "impulses", "duet", "square_dc", "qui
 
 def make_signal(fs, seconds, seed):
     """Float64 test signals of kinds make_utterance never produces (not quantised, not clipped): seed % 10 picks the kind
-    from SIGNAL_KINDS.  Used by tests/parity_sweep.py --zoo and by the fixtures of oracle/gen_golden_harvest.py."""
+    from SIGNAL_KINDS.  Used by tests/parity_sweep.py --zoo and by the long-utterance F0 fixtures."""
     rng = np.random.default_rng(seed)
     n = int(round(fs * seconds))
     t = np.arange(n) / fs
