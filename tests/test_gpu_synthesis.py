@@ -116,3 +116,29 @@ def test_exact_parallel_phase_accumulation_matches_the_serial_chain(wca, port, f
     port.rng_reset()
     assert np.abs(ys["parallel"][4] - port.synthesis(contours[4], sp, ap, fs, 5.0)).max() < 1e-8
     port.rng_reset()
+
+
+def test_aperiodicity_next_to_its_clamp(wca, port):
+    """Aperiodicity within 1e-12 of one in the top bands of voiced frames (what D4C's band edge at -1e-12 dB produces): the
+    periodic weight 1 - s^2 is 2e-12 there, one ulp of the interpolated s moves it by 1e-4 of itself and the minimum-phase
+    transform spreads that over the whole response -- s has to be rounded exactly as the reference rounds it
+    (reference src/synthesis.cpp:388-390).  A fused multiply-add in that interpolation cost 3e-8 on the waveform."""
+    fs, n, nfr = 16000, 1024, 120
+    rng = np.random.default_rng(99)
+    bins = n // 2 + 1
+    k = np.arange(bins) / (bins - 1.0)
+    f0 = np.full(nfr, 354.7)
+    f0[40:50] = 0.0
+    sp = np.stack([1e-4 + 1e-2 * np.exp(-((k - rng.uniform(0.1, 0.3)) / 0.05) ** 2) for _ in range(nfr)])
+    edge = 10.0 ** (-1e-12 / 20.0)
+    ap = np.stack([np.interp(k, [0.0, 0.3, 0.6, rng.uniform(0.7, 0.9), 1.0], [0.001, rng.uniform(0.05, 0.4), rng.uniform(0.5, 0.99), 1.0, edge])
+                   for _ in range(nfr)])
+    ap[40:50] = 1.0 - 1e-12
+    port.rng_seek(555)
+    ref = port.synthesis(f0, sp, ap, fs, 5.0)
+    wca.rng_set_position(555)
+    y = wca.Synthesis(fs, n, 5.0).compute(f0, sp, ap)
+    assert wca.rng_get_position() == port.rng_position()
+    assert np.abs(ref).max() > 0.01
+    assert np.abs(y - ref).max() < 1e-12
+    port.rng_reset()

@@ -592,7 +592,10 @@ __global__ __launch_bounds__(T) void syn_pulse_kernel(SynArgs a) {
 				ar[e] = s * s;
 			} else {
 				env[e] = fma(1.0 - ipol, fabs(sf[k]), ipol * fabs(sc[k]));
-				double s = fma(1.0 - ipol, safe_ap(af[k]), ipol * safe_ap(ac[k]));
+				// both products rounded as in the reference (:388-390), no fused multiply-add: near the clamp at
+				// 1 - 1e-12 the periodic weight 1 - s^2 is 2e-12, one ulp of s moves it by 1e-4 of itself and the
+				// minimum-phase transform spreads that notch over the whole response (3e-8 on the waveform)
+				double s = (1.0 - ipol) * safe_ap(af[k]) + ipol * safe_ap(ac[k]);
 				ar[e] = s * s;
 			}
 		}
