@@ -761,23 +761,21 @@ __global__ __launch_bounds__(256, 3) void hv_refine_kernel(RefArgs a) {  // 3 wa
 			// (:463-470); running every lane to the longest window in the wavefront made the result depend on the
 			// neighbours through the number of trailing rotations.
 			int Q = 0;
-			for (int n = sub; __ballot(n < bt) != 0ull; n += 16) {
-				if (n < bt) {
-					double xm, xd;
-					sample(n, xm, xd);
+			for (int n = sub; n < bt; n += 16) {
+				double xm, xd;
+				sample(n, xm, xd);
 #pragma unroll
-					for (int h = 0; h < 6; ++h) {
-						sb[2 * h] = fma(c2[h], sa[2 * h], xm) - sb[2 * h];
-						sb[2 * h + 1] = fma(c2[h], sa[2 * h + 1], xd) - sb[2 * h + 1];
-					}
-					sample(n + 8, xm, xd);
-#pragma unroll
-					for (int h = 0; h < 6; ++h) {
-						sa[2 * h] = fma(c2[h], sb[2 * h], xm) - sa[2 * h];
-						sa[2 * h + 1] = fma(c2[h], sb[2 * h + 1], xd) - sa[2 * h + 1];
-					}
-					Q += 2;
+				for (int h = 0; h < 6; ++h) {
+					sb[2 * h] = fma(c2[h], sa[2 * h], xm) - sb[2 * h];
+					sb[2 * h + 1] = fma(c2[h], sa[2 * h + 1], xd) - sb[2 * h + 1];
 				}
+				sample(n + 8, xm, xd);
+#pragma unroll
+				for (int h = 0; h < 6; ++h) {
+					sa[2 * h] = fma(c2[h], sb[2 * h], xm) - sa[2 * h];
+					sa[2 * h + 1] = fma(c2[h], sb[2 * h + 1], xd) - sa[2 * h + 1];
+				}
+				Q += 2;
 			}
 			double v[32];
 #pragma unroll
