@@ -136,3 +136,24 @@ def test_digital_silence(wca, port):
     assert not rz["f0"].any() and np.isfinite(rz["sp"]).all() and np.isfinite(rz["y"]).all()
     oz = port.pipeline(z, fs)
     assert np.abs(rz["y"] - oz["y"]).max() < 1e-8
+
+
+def test_no_voiced_section_and_noise_free_bands(wca, port):
+    """(1) White noise leaves no voiced section after fixStep2: the reference then copies a channel that does not exist
+    (reference src/harvest.cpp:515, a crash); here the contour is all unvoiced, as in the oracle.  (2) A clean synthetic voice
+    with digital-silence gaps has bands without any noise: LinearSmoothing's cumulative sum has to stay non-decreasing there
+    or the logarithm of a negative difference turns whole envelope rows into NaN."""
+    from world_class_amd.synth import make_signal
+    fs = 16000
+    noise = make_signal(fs, 1.0, 50020)
+    (r,) = wca.Pipeline(fs).run_batch([noise])
+    o = port.pipeline(noise, fs)
+    assert not o["f0"][:-1].any()  # (the very last frame is outside every section and keeps its base value)
+    check_f0(r["f0"], o["f0"])
+    assert np.isfinite(r["sp"]).all() and np.isfinite(r["ap"]).all() and np.isfinite(r["y"]).all()
+    assert (np.abs(r["sp"] - o["sp"]) / o["sp"]).max() < 1e-7 and np.abs(r["y"] - o["y"]).max() < 1e-8
+    for seed in (40018, 40022, 40008):  # "gaps" and "jumps"
+        x = make_signal(fs, 3.0, seed)
+        (r,) = wca.Pipeline(fs).run_batch([x])
+        check_f0(r["f0"], port.harvest(x, fs)[1])
+        assert np.isfinite(r["sp"]).all() and np.isfinite(r["ap"]).all() and np.isfinite(r["y"]).all()
