@@ -482,6 +482,9 @@ struct SynArgs {
 // MinimumPhaseAnalysis::compute (reference src/world_common.cpp:196-233) for the block.
 // ls[BPT]: log spectrum of this thread's bins k = tid + e T (k <= M).  On return A[0..M] holds the
 // minimum-phase spectrum (full complex, M+1 entries).  Ends with a __syncthreads().
+#ifndef WC_SYN_MINPHASE_REAL
+#define WC_SYN_MINPHASE_REAL 1
+#endif
 template <int N, int T>
 __device__ __forceinline__ void minimum_phase_lds(double2 *A, const double (&ls)[(N / 2 + T) / T],
 												  const double2 *__restrict__ tw, int tid) {
@@ -501,6 +504,42 @@ __device__ __forceinline__ void minimum_phase_lds(double2 *A, const double (&ls)
 	fft_lds<M, T, +1>(A, tw, tid);
 	r2c_post<M, T>(A, tw, tid);
 	WC_FRESH(tid);
+#if WC_SYN_MINPHASE_REAL
+	// cepstrum folding (reference :207-217): bins 1..M-1 doubled (and conjugated), upper half zeroed.  The cepstrum of a
+	// real even log spectrum is real -- the imaginary parts the reference carries along are its FFT's rounding noise,
+	// 1e-16 of the real parts -- so the second transform is taken as a real one too (an M-point complex FFT and the
+	// unpacking pass instead of an N-point complex FFT; SYN_MINPHASE_REAL=0 keeps the complex transform for comparison).
+	double cr[2 * BPT];  // this thread's real samples n = tid + e T, n < N
+#pragma unroll
+	for (int e = 0; e < 2 * BPT; ++e) {
+		int n = tid + e * T;
+		cr[e] = 0.0;
+		if (n == 0) cr[e] = A[0].x;
+		else if (n == M) cr[e] = A[0].y;
+		else if (n < M) cr[e] = A[n].x * 2.0;
+	}
+	__syncthreads();
+#pragma unroll
+	for (int e = 0; e < 2 * BPT; ++e) {
+		int n = tid + e * T;
+		if (n < N) Ar[n] = cr[e];
+	}
+	__syncthreads();
+	fft_lds<M, T, +1>(A, tw, tid);
+	r2c_post<M, T>(A, tw, tid);
+	WC_FRESH(tid);
+	double2 c[BPT];
+#pragma unroll
+	for (int e = 0; e < BPT; ++e) {
+		int k = tid + e * T;
+		if (k <= M) {
+			double2 m = (k == 0) ? make_double2(A[0].x, 0.0) : (k == M) ? make_double2(A[0].y, 0.0) : A[k];
+			double t = exp(m.x / N), sn, cs;
+			sincos(m.y / N, &sn, &cs);
+			c[e] = make_double2(t * cs, t * sn);
+		}
+	}
+#else
 	// cepstrum folding (reference :207-217): bins 1..M-1 doubled and conjugated, upper half zeroed
 	double2 c[BPT];
 #pragma unroll
@@ -531,6 +570,7 @@ __device__ __forceinline__ void minimum_phase_lds(double2 *A, const double (&ls)
 			c[e] = make_double2(t * cs, t * sn);
 		}
 	}
+#endif
 	__syncthreads();
 #pragma unroll
 	for (int e = 0; e < BPT; ++e) {
