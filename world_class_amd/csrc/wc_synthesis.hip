@@ -587,7 +587,7 @@ __global__ __launch_bounds__(T) void syn_pulse_kernel(SynArgs a) {
 	constexpr int M = N / 2;
 	constexpr int BPT = (M + T) / T;  // bins per thread (k <= M)
 	constexpr int EPT = N / T;        // time samples per thread
-	__shared__ double2 A[fft_lds_size(N)];
+	__shared__ double2 A[WC_SYN_MINPHASE_REAL ? fft_lds_size(N / 2) + 1 : fft_lds_size(N)];  // M + 1 complex bins are the largest array once no N-point transform is left
 	__shared__ double red[2 * (T / 64) + 2];
 	double *Ar = reinterpret_cast<double *>(A);
 	int tid = threadIdx.x;
