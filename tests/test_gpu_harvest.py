@@ -147,3 +147,22 @@ def test_harvest_edges(wca, port):
         h.compute(np.zeros(10))          # shorter than 3 ms
     with pytest.raises(wca.WorldClassError):
         wca.Harvest(fs, f0_floor=10.0)   # band-pass longer than the kernel supports
+
+
+def test_decimation_staged_through_lds_is_bit_identical(wca):
+    """the decimator that stages every lane's stream through LDS (default) against the one that reads the streams directly
+    (WC_HARVEST_DECIMATE=direct): same recursion, same chunk and warm-up boundaries, so the same bits -- at every
+    decimation ratio, for lengths that are not a multiple of anything, and for an utterance shorter than one chunk"""
+    import os
+    for fs, n in ((48000, 100003), (44100, 50001), (22050, 33333), (16000, 20011), (48000, 700)):
+        x = make_utterance(fs, (n + 10) / fs, 4321 + n)[:n]
+        a = wca.Harvest(fs)
+        a.compute(x)
+        ya = a.debug_fetch("y")
+        os.environ["WC_HARVEST_DECIMATE"] = "direct"
+        try:
+            b = wca.Harvest(fs)
+        finally:
+            del os.environ["WC_HARVEST_DECIMATE"]
+        b.compute(x)
+        assert np.array_equal(ya, b.debug_fetch("y")), (fs, n)
