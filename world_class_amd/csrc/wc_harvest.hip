@@ -945,6 +945,14 @@ __global__ __launch_bounds__(128) void hv_unreliable_kernel(const HvUtt *__restr
 	const bool interior = i >= 1 && i < u.L1 - 1;
 	if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
 	if (threadIdx.x == 0) { best = 0ull; best_slot = 0x7fffffff; }
+	// this frame's own candidates are requested together with the neighbours' rows: one memory round trip per workgroup
+	// instead of two (the kernel is a chain of latencies, not of arithmetic)
+	double own_ref[2] = {0.0, 0.0}, own_sc[2] = {0.0, 0.0};
+#pragma unroll
+	for (int q = 0; q < 2; ++q) {
+		const int j = threadIdx.x + q * 128;
+		if (j < nc) { own_ref[q] = c1[g * nc + j]; own_sc[q] = s1[g * nc + j]; }
+	}
 	__syncthreads();
 	if (interior) {
 		for (int j = threadIdx.x; j < nc; j += blockDim.x) {
@@ -963,7 +971,7 @@ __global__ __launch_bounds__(128) void hv_unreliable_kernel(const HvUtt *__restr
 	for (int q = 0; q < 2; ++q) {
 		const int j = threadIdx.x + q * 128;
 		if (j < nc) {
-			double ref = c1[g * nc + j], sc = s1[g * nc + j];
+			double ref = own_ref[q], sc = own_sc[q];
 			if (ref != 0 && interior) {
 				double e1 = 1.0, e2 = 1.0;
 				for (int k = 0; k < n1; ++k) e1 = fmin(e1, fabs(ref - nxt[k]) / ref);
