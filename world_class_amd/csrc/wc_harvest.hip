@@ -1014,6 +1014,7 @@ struct CtrArgs {
 	int max_sec;
 	int nc;
 	int *ibuf;        // [utt][4 * max_sec] position bookkeeping of fixStep3
+	int *nsec;        // [utt] voiced sections after fixStep2, handed from phase to phase
 };
 
 __device__ __forceinline__ void wave_sync() {
@@ -1110,8 +1111,14 @@ __device__ int hv_sections(const double *__restrict__ f0, int n, int *__restrict
 	return nb / 2;
 }
 
+// Three launches: PHASE 0 = fixStep1, fixStep2 and the channels of fixStep3 (one wavefront per utterance); PHASE 1 = the
+// extension walks, which are independent per voiced section and direction (they read the section's original end, write
+// outside it and update their own boundary), one wavefront each; PHASE 2 = extendSub, mergeF0, fixStep4 (one wavefront per
+// utterance).  The walks were 70 % of the former single kernel.
+template <int PHASE>
 __global__ __launch_bounds__(64) void hv_contour_kernel(CtrArgs a) {
-	const HvUtt u = a.utts[blockIdx.x];
+	const int ui = PHASE == 1 ? blockIdx.y : blockIdx.x;
+	const HvUtt u = a.utts[ui];
 	const int lane = threadIdx.x;
 	const int L = u.L1, nc = a.nc;
 	const double *__restrict__ cand = a.cand + u.l1_off * nc;
@@ -1121,9 +1128,24 @@ __global__ __launch_bounds__(64) void hv_contour_kernel(CtrArgs a) {
 	double *__restrict__ s2 = a.s2 + u.l1_off;
 	double *__restrict__ s3 = a.s3 + u.l1_off;
 	double *__restrict__ s4 = a.fixed + u.l1_off;
-	int *__restrict__ sec = a.sec + (long long)blockIdx.x * 2 * a.max_sec;
-	double *__restrict__ chan = a.chan + (long long)blockIdx.x * a.chan_stride;
-
+	int *__restrict__ sec = a.sec + (long long)ui * 2 * a.max_sec;
+	double *__restrict__ chan = a.chan + (long long)ui * a.chan_stride;
+	// channel k keeps frames [clo_k, clo_k + clen_k) around its section (extension moves at most 101 frames);
+	// the reference's full-length rows are zero outside that window
+	int *__restrict__ clo = reinterpret_cast<int *>(chan);
+	int *__restrict__ clen = clo + a.max_sec;
+	int *__restrict__ coff = clen + a.max_sec;
+	int *__restrict__ perm = a.ibuf + (long long)ui * 4 * a.max_sec;  // position -> channel
+	int *__restrict__ bl = perm + a.max_sec;                            // boundaries by position
+	int *__restrict__ order = bl + 2 * a.max_sec;
+	double *__restrict__ cdata = chan + 2 * a.max_sec;  // 3 * max_sec ints fit in 2 * max_sec doubles
+	auto CH = [&](int k, int j) -> double & { return cdata[coff[k] + (j - clo[k])]; };
+	auto chv = [&](int k, int j) -> double {  // value of the full-length row
+		const int d = j - clo[k];
+		return (d >= 0 && d < clen[k]) ? cdata[coff[k] + d] : 0.0;
+	};
+	int ns = 0;
+	if (PHASE == 0) {
 	// searchF0Base (reference :254-272) was evaluated by hv_unreliable_kernel
 	// fixStep1 (reference :277-291; entries the reference never writes are 0)
 	for (int i = lane; i < L; i += 64) {
@@ -1137,7 +1159,7 @@ __global__ __launch_bounds__(64) void hv_contour_kernel(CtrArgs a) {
 	}
 	wave_sync();
 	// fixStep2 (reference :319-334)
-	int ns = hv_sections(s1, L, sec, a.max_sec, lane);
+	ns = hv_sections(s1, L, sec, a.max_sec, lane);
 	wave_sync();
 	ns = min(ns, a.max_sec);
 	for (int k = 0; k < ns; ++k) {
@@ -1151,15 +1173,6 @@ __global__ __launch_bounds__(64) void hv_contour_kernel(CtrArgs a) {
 	ns = hv_sections(s2, L, sec, a.max_sec, lane);
 	wave_sync();
 	ns = min(ns, a.max_sec);
-	// channel k keeps frames [clo_k, clo_k + clen_k) around its section (extension moves at most 101 frames);
-	// the reference's full-length rows are zero outside that window
-	int *__restrict__ clo = reinterpret_cast<int *>(chan);
-	int *__restrict__ clen = clo + a.max_sec;
-	int *__restrict__ coff = clen + a.max_sec;
-	int *__restrict__ perm = a.ibuf + (long long)blockIdx.x * 4 * a.max_sec;  // position -> channel
-	int *__restrict__ bl = perm + a.max_sec;                                    // boundaries by position
-	int *__restrict__ order = bl + 2 * a.max_sec;
-	double *__restrict__ cdata = chan + 2 * a.max_sec;  // 3 * max_sec ints fit in 2 * max_sec doubles
 	{
 		int off = 0;
 		for (int k = 0; k < ns; ++k) {
@@ -1171,15 +1184,16 @@ __global__ __launch_bounds__(64) void hv_contour_kernel(CtrArgs a) {
 			off += hi - lo + 1;
 		}
 	}
-	wave_sync();
-	auto CH = [&](int k, int j) -> double & { return cdata[coff[k] + (j - clo[k])]; };
-	auto chv = [&](int k, int j) -> double {  // value of the full-length row
-		const int d = j - clo[k];
-		return (d >= 0 && d < clen[k]) ? cdata[coff[k] + d] : 0.0;
-	};
+	if (lane == 0) a.nsec[ui] = ns;
+	return;
+	}
+	ns = a.nsec[ui];
+	if (PHASE == 1) {
 	// extend (reference :427-458) with extendF0 (:371-403)
-	for (int k = 0; k < ns; ++k) {
-		for (int dir = 0; dir < 2; ++dir) {
+	for (int pair = blockIdx.x; pair < 2 * ns; pair += gridDim.x) {
+		const int k = pair >> 1;
+		{
+			const int dir = pair & 1;
 			const int shift = dir == 0 ? 1 : -1;
 			const int origin = dir == 0 ? bl[2 * k + 1] : bl[2 * k];
 			const int last_point = dir == 0 ? min(L - 2, origin + 100) : max(1, origin - 100);
@@ -1211,10 +1225,10 @@ __global__ __launch_bounds__(64) void hv_contour_kernel(CtrArgs a) {
 				}
 				if (miss == 4) break;
 			}
-			wave_sync();
 			if (lane == 0) bl[dir == 0 ? 2 * k + 1 : 2 * k] = shifted_origin;
-			wave_sync();
 		}
+	}
+	return;
 	}
 	// extendSub: keep the sections that are long enough for their mean F0 (reference :441-455; mean_f0 is
 	// deliberately not reset between sections)
@@ -1310,6 +1324,7 @@ struct SmArgs {
 	int max_sec;
 };
 
+constexpr int SM_PF = 32;  // steps whose inputs are requested ahead of the dependent recursion (8: 2.9 ms per half batch, memory latency per block)
 __global__ __launch_bounds__(64) void hv_smooth_kernel(SmArgs a) {
 	const HvUtt u = a.utts[blockIdx.x];
 	const int lane = threadIdx.x;
@@ -1342,15 +1357,15 @@ __global__ __launch_bounds__(64) void hv_smooth_kernel(SmArgs a) {
 		if (k < ns) {
 			const int st = sec[2 * k], ed = sec[2 * k + 1];
 			const double xs = f0[st - lag], xe = f0[ed - lag];
-			// forward pass; outputs before the section start are never read back.  Loads are issued eight steps
+			// forward pass; outputs before the section start are never read back.  Loads are issued SM_PF steps
 			// ahead of the dependent recursion.
 			double w0 = 0.0, w1 = 0.0;
-			for (int i0 = 0; i0 < n; i0 += 8) {
-				double xin[8];
+			for (int i0 = 0; i0 < n; i0 += SM_PF) {
+				double xin[SM_PF];
 #pragma unroll
-				for (int e = 0; e < 8; ++e) xin[e] = f0[clampi(i0 + e - lag, 0, L - 1)];
+				for (int e = 0; e < SM_PF; ++e) xin[e] = f0[clampi(i0 + e - lag, 0, L - 1)];
 #pragma unroll
-				for (int e = 0; e < 8; ++e) {
+				for (int e = 0; e < SM_PF; ++e) {
 					const int i = i0 + e;
 					if (i < n) {
 						const double xv = (i < st) ? xs : (i > ed ? xe : xin[e]);
@@ -1363,12 +1378,12 @@ __global__ __launch_bounds__(64) void hv_smooth_kernel(SmArgs a) {
 			// backward pass over the reversed signal, up to the section start
 			w0 = w1 = 0.0;
 			const int kend = n - 1 - st;
-			for (int i0 = 0; i0 <= kend; i0 += 8) {
-				double tin[8];
+			for (int i0 = 0; i0 <= kend; i0 += SM_PF) {
+				double tin[SM_PF];
 #pragma unroll
-				for (int e = 0; e < 8; ++e) tin[e] = (i0 + e <= kend) ? tmp[(long long)(i0 + e) * 64 + lane] : 0.0;
+				for (int e = 0; e < SM_PF; ++e) tin[e] = (i0 + e <= kend) ? tmp[(long long)(i0 + e) * 64 + lane] : 0.0;
 #pragma unroll
-				for (int e = 0; e < 8; ++e) {
+				for (int e = 0; e < SM_PF; ++e) {
 					const int i = i0 + e;
 					if (i <= kend) {
 						const double wt = tin[e] + a0 * w0 + a1 * w1;
@@ -1508,7 +1523,7 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 	if ((rc = h->sec.reserve(sizeof(int) * 2ll * max_sec * n_utt))) return rc;
 	// after fixStep2 a section spans at least 7 frames plus one unvoiced frame
 	const long long chan_stride = 2ll * max_sec + (long long)max_L1 + 209ll * (max_L1 / 8 + 2) + 64;
-	if ((rc = h->ibuf.reserve(sizeof(int) * 4ll * max_sec * n_utt))) return rc;
+	if ((rc = h->ibuf.reserve(sizeof(int) * (4ll * max_sec + 1) * n_utt))) return rc;
 	if ((rc = h->chan.reserve(sizeof(double) * chan_stride * n_utt))) return rc;
 	const long long smooth_stride = (long long)(max_L1 + 600) * 64;
 	if ((rc = h->smooth.reserve(sizeof(double) * smooth_stride * n_utt))) return rc;
@@ -1642,8 +1657,11 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 	ca.s1 = h->s1.as<double>(); ca.s2 = h->s2.as<double>(); ca.s3 = h->s3.as<double>(); ca.fixed = h->fixed.as<double>();
 	ca.sec = h->sec.as<int>(); ca.chan = h->chan.as<double>(); ca.chan_stride = chan_stride; ca.max_sec = max_sec; ca.nc = nc;
 	ca.ibuf = h->ibuf.as<int>();
+	ca.nsec = h->ibuf.as<int>() + 4ll * max_sec * n_utt;
 	if ((rc = dev->time_begin("harvest_contour", s))) return rc;
-	hipLaunchKernelGGL(hv_contour_kernel, dim3(n_utt), dim3(64), 0, s, ca);
+	hipLaunchKernelGGL(hv_contour_kernel<0>, dim3(n_utt), dim3(64), 0, s, ca);
+	hipLaunchKernelGGL(hv_contour_kernel<1>, dim3(96, n_utt), dim3(64), 0, s, ca);  // a 10 s utterance has 20-40 sections
+	hipLaunchKernelGGL(hv_contour_kernel<2>, dim3(n_utt), dim3(64), 0, s, ca);
 	SmArgs sa;
 	sa.utts = du; sa.fixed = h->fixed.as<double>(); sa.f0_1ms = h->f0_1ms.as<double>(); sa.sec = h->sec.as<int>();
 	sa.scratch = h->smooth.as<double>(); sa.scratch_stride = smooth_stride; sa.max_sec = max_sec;
