@@ -15,7 +15,7 @@ typedef struct HarvestOption {
 	double frame_period;
 	double target_fs;
 	double channels_in_octave;
-	bool use_cos_table;  // accepted and ignored: exact cosines are always used
+	bool use_cos_table;  // the refinement window from the reference's 8001-entry cosine table (src/harvest.cpp:152-170)
 
 	// defaults of reference src/harvest.cpp:52-56
 	HarvestOption() : f0_floor(71.0), f0_ceil(800.0), frame_period(5), target_fs(8000.), channels_in_octave(40.), use_cos_table(false) {}

@@ -71,7 +71,7 @@ int wc_synthesis_out_length(int f0_length, double frame_period, int fs);
 
 /* ---- Harvest: include/harvest.hpp:16-44 -------------------------------------------------------- */
 /* HarvestOption fields (include/harvest.hpp:16-28, defaults src/harvest.cpp:52-56: 71, 800, 5, 8000,
- * 40, false).  use_cos_table is accepted and ignored (exact cosines are always used). */
+ * 40, false).  use_cos_table selects the reference's tabulated refinement window (src/harvest.cpp:152-170, :779-787). */
 wc_harvest *wc_harvest_create(int fs, double f0_floor, double f0_ceil, double frame_period,
                               double target_fs, double channels_in_octave, int use_cos_table);
 void wc_harvest_destroy(wc_harvest *h);

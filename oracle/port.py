@@ -76,6 +76,11 @@ class Port:
         L.wco_synthesis_pulses.argtypes = [_dp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, _ip]
         L.wco_set_threads(threads)
 
+    def set_harvest_options(self, target_fs=8000.0, channels_in_octave=40.0, use_cos_table=False):
+        """the HarvestOption fields beyond floor / ceil / frame period, process-wide until set back (call without arguments)"""
+        self.lib.wco_set_harvest_options.argtypes = [C.c_double, C.c_double, C.c_int]
+        self.lib.wco_set_harvest_options(target_fs, channels_in_octave, int(use_cos_table))
+
     # ---- RNG ----------------------------------------------------------------------------
     def rng_reset(self):
         self.lib.wco_rng_reset()

@@ -79,6 +79,17 @@ class Ref:
         self.lib.ref_harvest(_p(x), len(x), fs, f0_floor, f0_ceil, frame_period, _p(tpos), _p(f0))
         return tpos, f0
 
+    def harvest_opt(self, x, fs, f0_floor=71.0, f0_ceil=800.0, frame_period=5.0, target_fs=8000.0, channels_in_octave=40.0,
+                    use_cos_table=False):
+        """every field of HarvestOption (reference include/harvest.hpp:16-24)"""
+        self.lib.ref_harvest_opt.argtypes = [_dp, C.c_int, C.c_int] + [C.c_double] * 5 + [C.c_int, _dp, _dp]
+        x = _c(x)
+        L = self.get_samples(fs, len(x), frame_period)
+        tpos, f0 = np.zeros(L), np.zeros(L)
+        self.lib.ref_harvest_opt(_p(x), len(x), fs, f0_floor, f0_ceil, frame_period, target_fs, channels_in_octave,
+                                 int(use_cos_table), _p(tpos), _p(f0))
+        return tpos, f0
+
     def cheaptrick_fft_size(self, fs, f0_floor=71.0):
         return self.lib.ref_cheaptrick_fft_size(fs, f0_floor)
 

@@ -51,6 +51,20 @@ void ref_harvest(const double *x, int x_length, int fs, double f0_floor, double 
 	h.compute(x, x_length, tpos, f0);
 }
 
+// all six fields of HarvestOption (reference include/harvest.hpp:16-24)
+void ref_harvest_opt(const double *x, int x_length, int fs, double f0_floor, double f0_ceil, double frame_period,
+					 double target_fs, double channels_in_octave, int use_cos_table, double *tpos, double *f0) {
+	HarvestOption opt;
+	opt.f0_floor = f0_floor;
+	opt.f0_ceil = f0_ceil;
+	opt.frame_period = frame_period;
+	opt.target_fs = target_fs;
+	opt.channels_in_octave = channels_in_octave;
+	opt.use_cos_table = use_cos_table != 0;
+	Harvest h(fs, opt);
+	h.compute(x, x_length, tpos, f0);
+}
+
 int ref_cheaptrick_fft_size(int fs, double f0_floor) {
 	CheapTrick c(fs);
 	return c.getFFTSizeForCheapTrick(fs, f0_floor);

@@ -765,6 +765,23 @@ static void synthesis(const double *f0, int L, const double *sp, const double *a
 // ------------------------------------------------------------------------------------------
 // Harvest (reference src/harvest.cpp)
 // ------------------------------------------------------------------------------------------
+// HarvestOption fields beyond floor / ceil / frame period (reference include/harvest.hpp:16-24, defaults src/harvest.cpp:52-56)
+static double g_hv_target_fs = 8000.0, g_hv_channels_in_octave = 40.0;
+static int g_hv_use_cos_table = 0;
+// get_cos_table (:152-170): 8001 entries over one period built from the first quarter
+static const vd &hv_cos_table() {
+	static vd t;
+	if (t.empty()) {
+		const int n = 2000;
+		t.assign(n * 4 + 1, 0.0);
+		double interval = kPi / 2. / n;
+		for (int i = 0; i < n + 1; ++i) t[i] = std::cos(interval * i);
+		for (int i = 0; i < n; ++i) t[i + n + 1] = -t[n - 1 - i];
+		for (int i = 0; i < n; ++i) t[i + n * 2 + 1] = -t[i + 1];
+		for (int i = 0; i < n; ++i) t[i + n * 3 + 1] = t[n - 1 - i];
+	}
+	return t;
+}
 struct Harvest {
 	int fs, decim, y_length, L, n_bands, max_cand, n_cand, fft_size;
 	double fs_d, floor_, ceil_;
@@ -902,10 +919,23 @@ static void hv_refine_one(const Harvest &H, double pos, double f, double *rf, do
 	double bt0 = (-hw) / fs;
 	int basic = mround((pos + bt0) * fs + 0.001);
 	vd mw(bt), dw(bt), wave(N, 0.0);
-	for (int i = 0; i < bt; ++i) {
-		double tmp = (basic + i - 1.0) / fs - pos;
-		double tmp2 = 2.0 * kPi * tmp / wlt;
-		mw[i] = 0.42 + 0.5 * std::cos(tmp2) + 0.08 * std::cos(2 * tmp2);
+	if (!g_hv_use_cos_table) {
+		for (int i = 0; i < bt; ++i) {
+			double tmp = (basic + i - 1.0) / fs - pos;
+			double tmp2 = 2.0 * kPi * tmp / wlt;
+			mw[i] = 0.42 + 0.5 * std::cos(tmp2) + 0.08 * std::cos(2 * tmp2);
+		}
+	} else {  // :779-787
+		const vd &tab = hv_cos_table();
+		const double two_pi = 2.0 * kPi;
+		const int num_div = 2000 * 4;
+		for (int i = 0; i < bt; ++i) {
+			double tmp = (basic + i - 1.0) / fs - pos;
+			double tmp2 = two_pi * (tmp / wlt + 1);
+			double dindex = std::fmod(tmp2, two_pi) / two_pi * num_div;
+			double dindex2 = std::fmod(dindex * 2, num_div);
+			mw[i] = 0.42 + 0.5 * tab[static_cast<int>(std::round(dindex))] + 0.08 * tab[static_cast<int>(std::round(dindex2))];
+		}
 	}
 	dw[0] = -mw[1] / 2.0;
 	dw[bt - 1] = mw[bt - 2] / 2.0;
@@ -1152,7 +1182,7 @@ static void hv_smooth(const Harvest &H, const vd &f0, double *smoothed) {
 // :1380-1453 at frame_period 1 ms
 static void hv_general_body(Harvest &H, const double *x, int x_length, int fs, double floor_, double ceil_,
 							vd &f0_base, vd &f0_fixed, vd &f0_1ms) {
-	const double target_fs = 8000.0, cio = 40.0;
+	const double target_fs = g_hv_target_fs, cio = g_hv_channels_in_octave;
 	H.fs = fs;
 	H.floor_ = floor_;
 	H.ceil_ = ceil_;
@@ -1283,6 +1313,11 @@ uint64_t wco_cheaptrick_draws(int fs, const double *f0, int f0_length, double f0
 	uint64_t t = 0;
 	for (int i = 0; i < f0_length; ++i) t += ct_frame_draws(fs, (f0[i] <= floor_) ? kDefaultF0 : f0[i], N);
 	return t;
+}
+void wco_set_harvest_options(double target_fs, double channels_in_octave, int use_cos_table) {
+	g_hv_target_fs = target_fs;
+	g_hv_channels_in_octave = channels_in_octave;
+	g_hv_use_cos_table = use_cos_table;
 }
 int wco_harvest_debug(const double *x, int x_length, int fs, double f0_floor, double f0_ceil, int *dims,
 					  double *y, double *raw, double *cand, double *score, double *f0_base, double *f0_fixed,

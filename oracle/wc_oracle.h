@@ -42,6 +42,8 @@ void wco_minimum_phase(int n, const double *log_spectrum /* n/2+1 */, double *ou
  *          stream position the serial order would have given it (deterministic, same numbers). */
 void wco_set_threads(int threads);
 int wco_get_samples(int fs, int x_length, double frame_period);
+/* the other three HarvestOption fields (process-wide; defaults 8000, 40, 0) */
+void wco_set_harvest_options(double target_fs, double channels_in_octave, int use_cos_table);
 void wco_harvest(const double *x, int x_length, int fs, double f0_floor, double f0_ceil,
                  double frame_period, double *tpos, double *f0);
 int wco_cheaptrick_fft_size(int fs, double f0_floor);

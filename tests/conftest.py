@@ -76,4 +76,15 @@ def same_candidates(a, b, tol=1e-8):
     return len(a) == len(b) and (len(a) == 0 or np.abs(a - b).max() < tol)
 
 
+def harvest_option_cases():
+    """[(name, x, fs, options, expected F0 of the real reference)] from tests/golden/harvest_options.npz
+    (oracle/gen_golden_harvest_options.py): target_fs, channels_in_octave, use_cos_table"""
+    from world_class_amd.synth import make_utterance
+    d = os.path.join(ROOT, "tests", "golden")
+    z = np.load(os.path.join(d, "harvest_options.npz"))
+    with open(os.path.join(d, "harvest_options.json")) as f:
+        meta = json.load(f)
+    return [(name, make_utterance(m["fs"], m["seconds"], m["seed"]), m["fs"], m["options"], z[name + "/f0"]) for name, m in sorted(meta.items())]
+
+
 PIPELINE_CASES = ["c1_16k_2s_floor71", "c1_16k_2s_floor40", "m48k_1s", "m24k_1s_1ms"]

@@ -3,7 +3,7 @@ reference and against the CPU oracle (final contour and intermediates)."""
 import numpy as np
 import pytest
 
-from conftest import HARVEST_LONG_CASES, PIPELINE_CASES, harvest_edge_rows, harvest_long_case, same_candidates
+from conftest import HARVEST_LONG_CASES, PIPELINE_CASES, harvest_edge_rows, harvest_long_case, harvest_option_cases, same_candidates
 from world_class_amd.synth import make_utterance
 
 pytestmark = pytest.mark.gpu
@@ -71,6 +71,16 @@ def test_refined_candidates_are_equal_where_the_reference_makes_them_equal(wca, 
         assert len(a) == len(b) and len(np.unique(a)) == len(np.unique(b)), "frame %d" % i
         equal_pairs += len(b) - len(np.unique(b))
     assert equal_pairs > 1000  # the case is only worth its name while the reference does produce such candidates
+
+
+def test_harvest_options_golden(wca):
+    """every HarvestOption field: target_fs (other decimation ratios and band-pass lengths), channels_in_octave (other band
+    counts and candidate slots), use_cos_table (the reference's tabulated window, 0.01 Hz away from exact cosines) against
+    contours of the real reference"""
+    for name, x, fs, opts, f0 in harvest_option_cases():
+        _, got = wca.Harvest(fs, **opts).compute(x)
+        assert np.array_equal(got == 0, f0 == 0), name
+        assert np.abs(got - f0).max() < F0_ABS, name
 
 
 def test_harvest_intermediates_vs_oracle(wca, port):

@@ -4,7 +4,7 @@ These pin the oracle that the -m gpu parity tests then use as the checker."""
 import numpy as np
 import pytest
 
-from conftest import HARVEST_LONG_CASES, PIPELINE_CASES, harvest_edge_rows, harvest_long_case, same_candidates
+from conftest import HARVEST_LONG_CASES, PIPELINE_CASES, harvest_edge_rows, harvest_long_case, harvest_option_cases, same_candidates
 from world_class_amd.synth import make_utterance
 
 # tolerances of the restatement vs the reference (FP64; only the FFT rounding differs)
@@ -171,6 +171,23 @@ def test_harvest_stages_against_live_reference(port):
         assert (np.abs(a["score"] - b["score"]) / np.maximum(b["score"], 1.0)).max() < 1e-6
         for k in ("f0_base", "f0_fixed", "f0_1ms"):
             assert np.array_equal(a[k] == 0, b[k] == 0) and np.abs(a[k] - b[k]).max() < 1e-9
+
+
+def test_harvest_options_against_golden(port):
+    """target_fs, channels_in_octave and use_cos_table (reference include/harvest.hpp:16-24): the restatement against contours
+    of the real reference; the cosine table moves the contour by 0.01 Hz, which the fixture also shows"""
+    z = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "harvest_options.npz"))
+    assert 1e-3 < np.abs(z["table_16k/f0"] - z["table_16k/f0_exact_cosines"]).max() < 0.1
+    for name, x, fs, opts, f0 in harvest_option_cases():
+        o = dict(opts)
+        kw = {k: o.pop(k) for k in ("f0_floor", "frame_period") if k in o}
+        port.set_harvest_options(**o)
+        try:
+            _, got = port.harvest(x, fs, **kw)
+        finally:
+            port.set_harvest_options()
+        assert np.array_equal(got == 0, f0 == 0), name
+        assert np.abs(got - f0).max() < F0_ABS, name
 
 
 def test_device_argsort_reproduces_std_sort(tmp_path):

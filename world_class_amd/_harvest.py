@@ -8,7 +8,7 @@ from . import DeviceArray, _c, _check, _handle, _ints, _p, _ptr, get_samples, li
 
 class Harvest:
     """HarvestOption defaults of reference src/harvest.cpp:52-56: f0_floor 71, f0_ceil 800, frame_period 5,
-    target_fs 8000, channels_in_octave 40, use_cos_table False (accepted, ignored)."""
+    target_fs 8000, channels_in_octave 40, use_cos_table False (True: the reference's tabulated refinement window)."""
 
     def __init__(self, fs, f0_floor=71.0, f0_ceil=800.0, frame_period=5.0, target_fs=8000.0,
                  channels_in_octave=40.0, use_cos_table=False):

@@ -752,12 +752,14 @@ struct RefArgs {
 	const double *cand0;
 	const double2 *tw;
 	const double2 *rot;  // per half window length hw: (cos, sin) of 2 pi / (2 hw + 1) and of 8 times that
+	const double *cos_table;  // HarvestOption::use_cos_table: the reference's 8001-entry cosine table (src/harvest.cpp:152-170)
 	double *cand1, *score1;
 	long long total_frames;
 	HvParams p;
 };
 
-constexpr int RF_MAXHW = 320;           // longest half window (f0 = 37.5 Hz at 8 kHz)
+constexpr int RF_MAXHW = 1023;          // longest half window: 2 hw + 1 < 2048 keeps the transform size of reference :962 within the 4096-entry twiddle table
+                                        // (f0 = 37.5 Hz at 8 kHz needs 321; 16 kHz after decimation and a 47 Hz candidate 511)
 constexpr int RF_MAXW = 2 * RF_MAXHW + 1;
 
 // One workgroup per 1 ms frame; a wavefront handles candidate slot j of all 7 overlap blocks at once:
@@ -766,6 +768,10 @@ constexpr int RF_MAXW = 2 * RF_MAXHW + 1;
 // advance by rotation recurrences from exact starting values (one sincos and 6 table twiddles per lane);
 // the 24 partial sums are reduced inside the 8-lane group by a halving butterfly that leaves harmonic h
 // in lane h.
+// TABLE: HarvestOption::use_cos_table -- the main window from the reference's cosine table with its own index arithmetic
+// (getMainWindow, src/harvest.cpp:779-787), the difference window from its neighbours (:792-803); three look-up pairs per
+// sample instead of a rotation, an option nobody takes for speed here but whose results differ from exact cosines by 1e-4.
+template <bool TABLE>
 __global__ __launch_bounds__(256, 3) void hv_refine_kernel(RefArgs a) {  // 3 waves per SIMD (<= 168 VGPRs): measured best
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	const int blk = lane >> 3, sub = lane & 7;
@@ -822,7 +828,28 @@ __global__ __launch_bounds__(256, 3) void hv_refine_kernel(RefArgs a) {  // 3 wa
 			double sa[12], sb[12];  // [2 h] main window, [2 h + 1] difference window; sa = newest after a full trip
 #pragma unroll
 			for (int k = 0; k < 12; ++k) { sa[k] = 0.0; sb[k] = 0.0; }
+			auto table_window = [&](int n) -> double {  // reference :779-787, operation by operation
+				const double two_pi = 2.0 * kPi;
+				const double tmp = (basic + n - 1.0) / fs - pos;
+				const double tmp2 = two_pi * (tmp / wlt + 1);
+				const double dindex = fmod(tmp2, two_pi) / two_pi * 8000;
+				const double dindex2 = fmod(dindex * 2, 8000.0);
+				return 0.42 + 0.5 * a.cos_table[(int)round(dindex)] + 0.08 * a.cos_table[(int)round(dindex2)];
+			};
 			auto sample = [&](int n, double &xm, double &xd) {
+				const double yv = (n < bt) ? y[clampi(basic + n - 1, 0, u.y_len - 1)] : 0.0;
+				if (TABLE) {
+					double m = 0.0, d = 0.0;
+					if (n < bt) {
+						m = table_window(n);
+						if (n == 0) d = -table_window(1) / 2.0;
+						else if (n == bt - 1) d = table_window(bt - 2) / 2.0;
+						else d = -(table_window(n + 1) - table_window(n - 1)) / 2.0;
+					}
+					xm = m * yv;
+					xd = d * yv;
+					return;
+				}
 				// Blackman window 0.42 + 0.5 cos + 0.08 cos 2theta = 0.34 + c (0.5 + 0.16 c); its centred difference
 				// -(w[n+1] - w[n-1]) / 2 = sin theta (0.5 sin beta + 0.16 sin 2beta cos theta) in the interior, the
 				// one-sided forms of reference :797-798 at the two ends
@@ -832,7 +859,6 @@ __global__ __launch_bounds__(256, 3) void hv_refine_kernel(RefArgs a) {  // 3 wa
 				const double mnb = fma(cnb, fma(0.16, cnb, 0.5), 0.34);
 				double d = ws * fma(k2, wc, k1);
 				d = first ? -mnb / 2.0 : (last ? mnb / 2.0 : d);
-				const double yv = (n < bt) ? y[clampi(basic + n - 1, 0, u.y_len - 1)] : 0.0;
 				xm = m * yv;
 				xd = d * yv;
 				const double nc_ = fma(wc, r8.x, -(ws * r8.y));
@@ -1430,6 +1456,8 @@ struct wc_harvest {
 	DevBuf d_taps, d_tap_off, d_half_len, d_band_f0, d_ev_band_off, d_ev_cap, d_rot;
 	DevBuf d_sd_rot, d_sd_p0, d_slot_off, d_slot_cap, slots, slot_count;
 	bool use_fir;  // WC_HARVEST_BANDPASS=fir: the direct FIR band-pass instead of the sliding DFT (A/B and tests)
+	bool use_cos_table;  // HarvestOption::use_cos_table
+	DevBuf d_cos_table;
 	bool direct_decimation;  // WC_HARVEST_DECIMATE=direct: every lane reads its own stream from memory (A/B and the bit-identity test)
 	DevBuf utts, dec, y, events, ev_count, overflow, tile_run, raw, cand0, cand1, score1, cand2, score2;
 	DevBuf base, s1, s2, s3, fixed, f0_1ms, sec, chan, smooth, ibuf;
@@ -1644,7 +1672,9 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 	fa.p.fs = h->fs; fa.p.decim = r; fa.p.n_bands = nb; fa.p.S = S; fa.p.n_cand = nc; fa.p.fs_d = h->fs_d;
 	fa.p.f0_floor = h->f0_floor; fa.p.f0_ceil = h->f0_ceil; fa.p.frame_period = h->frame_period;
 	if ((rc = dev->time_begin("harvest_refine", s))) return rc;
-	hipLaunchKernelGGL(hv_refine_kernel, dim3((unsigned)total_l1), dim3(256), 0, s, fa);
+	fa.cos_table = h->d_cos_table.as<double>();
+	if (h->use_cos_table) hipLaunchKernelGGL(hv_refine_kernel<true>, dim3((unsigned)total_l1), dim3(256), 0, s, fa);
+	else hipLaunchKernelGGL(hv_refine_kernel<false>, dim3((unsigned)total_l1), dim3(256), 0, s, fa);
 	WC_HIP(hipGetLastError());
 	if ((rc = dev->time_end("harvest_refine", s))) return rc;
 	// the ALU-bound part of this chain is enqueued: a staggered twin chain may start its own now, next to our
@@ -1698,7 +1728,6 @@ extern "C" {
 
 wc_harvest *wc_harvest_create(int fs, double f0_floor, double f0_ceil, double frame_period, double target_fs,
 							  double channels_in_octave, int use_cos_table) {
-	(void)use_cos_table;  // reference-only approximation (src/harvest.cpp:152-170); exact cosines are always used
 	if (fs <= 0 || f0_floor <= 0 || f0_ceil <= f0_floor || frame_period <= 0 || target_fs <= 0 || channels_in_octave <= 0) {
 		set_error("harvest: invalid option");
 		return nullptr;
@@ -1708,6 +1737,7 @@ wc_harvest *wc_harvest_create(int fs, double f0_floor, double f0_ceil, double fr
 	wc_harvest *h = new wc_harvest();
 	h->fs = fs; h->f0_floor = f0_floor; h->f0_ceil = f0_ceil; h->frame_period = frame_period; h->target_fs = target_fs;
 	h->channels_in_octave = channels_in_octave; h->dev = dev;
+	h->use_cos_table = use_cos_table != 0;
 	// reference src/harvest.cpp:82-84, :1388-1397, :1418-1419
 	h->decim = std::max(std::min(h_mround(fs / target_fs), 12), 1);
 	h->fs_d = static_cast<double>(fs) / h->decim;
@@ -1791,6 +1821,17 @@ wc_harvest *wc_harvest_create(int fs, double f0_floor, double f0_ceil, double fr
 		ok = ok && h->d_rot.reserve(sizeof(double2) * rot.size()) == 0 &&
 			 hipMemcpy(h->d_rot.p, rot.data(), sizeof(double2) * rot.size(), hipMemcpyHostToDevice) == hipSuccess;
 	}
+	if (h->use_cos_table) {  // get_cos_table (reference src/harvest.cpp:152-170): one period from the first quarter, 8001 entries
+		const int n = 2000;
+		std::vector<double> t(n * 4 + 1, 0.0);
+		const double interval = pi / 2. / n;
+		for (int i = 0; i < n + 1; ++i) t[i] = std::cos(interval * i);
+		for (int i = 0; i < n; ++i) t[i + n + 1] = -t[n - 1 - i];
+		for (int i = 0; i < n; ++i) t[i + n * 2 + 1] = -t[i + 1];
+		for (int i = 0; i < n; ++i) t[i + n * 3 + 1] = t[n - 1 - i];
+		ok = ok && h->d_cos_table.reserve(sizeof(double) * t.size()) == 0 &&
+			 hipMemcpy(h->d_cos_table.p, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice) == hipSuccess;
+	}
 	if (!ok) {
 		set_error("harvest: table upload failed");
 		delete h;
@@ -1802,7 +1843,7 @@ wc_harvest *wc_harvest_create(int fs, double f0_floor, double f0_ceil, double fr
 void wc_harvest_destroy(wc_harvest *h) {
 	if (!h) return;
 	(void)hipStreamSynchronize(h->dev->stream);
-	for (DevBuf *b : {&h->d_sd_rot, &h->d_sd_p0, &h->d_slot_off, &h->d_slot_cap, &h->slots, &h->slot_count, &h->d_rot, &h->d_taps, &h->d_tap_off, &h->d_half_len, &h->d_band_f0, &h->d_ev_band_off, &h->d_ev_cap, &h->utts, &h->dec, &h->y,
+	for (DevBuf *b : {&h->d_cos_table, &h->d_sd_rot, &h->d_sd_p0, &h->d_slot_off, &h->d_slot_cap, &h->slots, &h->slot_count, &h->d_rot, &h->d_taps, &h->d_tap_off, &h->d_half_len, &h->d_band_f0, &h->d_ev_band_off, &h->d_ev_cap, &h->utts, &h->dec, &h->y,
 					  &h->events, &h->ev_count, &h->overflow, &h->tile_run, &h->raw, &h->cand0, &h->cand1, &h->score1, &h->cand2, &h->score2, &h->base,
 					  &h->s1, &h->s2, &h->s3, &h->fixed, &h->f0_1ms, &h->sec, &h->chan, &h->smooth, &h->ibuf, &h->d_x, &h->d_tpos, &h->d_f0})
 		b->release();
