@@ -106,3 +106,15 @@ def test_fails_loudly_on_bad_arguments(wca):
     ct = wca.CheapTrick(16000)
     with pytest.raises(wca.WorldClassError):
         ct.compute(np.zeros(0), [0.0], [100.0])
+
+
+def test_cheaptrick_options_golden(wca):
+    """q1, f0_floor and fft_size away from their defaults (reference include/cheaptrick.hpp) against the real reference's
+    envelopes (tests/golden/stage_options.npz): FFT sizes 512, 1024 (floor 40 -> 2048), 2048 and 4096 at 16 kHz"""
+    from conftest import stage_option_cases
+    x, fs, tpos, f0, stride, ct, _ = stage_option_cases()
+    for name, kw, rows, rowsum in ct:
+        wca.rng_set_position(0)
+        sp = wca.CheapTrick(fs, **kw).compute(x, tpos, f0)
+        assert sp.shape[1] == rows.shape[1], name
+        assert rel(sp[::stride], rows) < SP_REL and rel(sp.sum(1), rowsum) < SP_REL, name

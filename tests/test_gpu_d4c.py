@@ -114,3 +114,13 @@ def test_d4c_fused_and_split_schedules_agree(wca, port, fs):
     port.rng_reset()
     assert np.abs(a - port.d4c(x, fs, tpos, f0, fft)).max() < AP_ABS
     port.rng_reset()
+
+
+def test_d4c_threshold_golden(wca):
+    """D4COption::threshold away from 0.85 (reference include/d4c.hpp) against the real reference's aperiodicity"""
+    from conftest import stage_option_cases
+    x, fs, tpos, f0, stride, _, d4 = stage_option_cases()
+    for name, thr, rows, rowsum in d4:
+        wca.rng_set_position(0)
+        ap = wca.D4C(fs, threshold=thr).compute(x, tpos, f0, 1024)
+        assert np.abs(ap[::stride] - rows).max() < AP_ABS and np.abs(ap.sum(1) - rowsum).max() < AP_ABS * 1024, name

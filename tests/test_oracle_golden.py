@@ -4,7 +4,7 @@ These pin the oracle that the -m gpu parity tests then use as the checker."""
 import numpy as np
 import pytest
 
-from conftest import HARVEST_LONG_CASES, PIPELINE_CASES, harvest_edge_rows, harvest_long_case, harvest_option_cases, same_candidates
+from conftest import HARVEST_LONG_CASES, PIPELINE_CASES, harvest_edge_rows, harvest_long_case, harvest_option_cases, same_candidates, stage_option_cases
 from world_class_amd.synth import make_utterance
 
 # tolerances of the restatement vs the reference (FP64; only the FFT rounding differs)
@@ -188,6 +188,22 @@ def test_harvest_options_against_golden(port):
             port.set_harvest_options()
         assert np.array_equal(got == 0, f0 == 0), name
         assert np.abs(got - f0).max() < F0_ABS, name
+
+
+def test_cheaptrick_and_d4c_options_against_golden(port):
+    """q1, f0_floor, fft_size (reference include/cheaptrick.hpp) and the D4C threshold (include/d4c.hpp) away from their defaults"""
+    x, fs, tpos, f0, stride, ct, d4 = stage_option_cases()
+    assert np.array_equal(port.harvest(x, fs)[0], tpos)
+    for name, kw, rows, rowsum in ct:
+        port.rng_reset()
+        sp = port.cheaptrick(x, fs, tpos, f0, **kw)
+        assert sp.shape[1] == rows.shape[1], name
+        assert (np.abs(sp[::stride] - rows) / rows).max() < SP_REL and (np.abs(sp.sum(axis=1) - rowsum) / rowsum).max() < SP_REL, name
+    for name, thr, rows, rowsum in d4:
+        port.rng_reset()
+        ap = port.d4c(x, fs, tpos, f0, 1024, threshold=thr)
+        assert np.abs(ap[::stride] - rows).max() < AP_ABS and np.abs(ap.sum(axis=1) - rowsum).max() < AP_ABS * 1024, name
+    port.rng_reset()
 
 
 def test_device_argsort_reproduces_std_sort(tmp_path):
