@@ -104,4 +104,11 @@ def stage_option_cases():
             [(n, t, z["d4c/" + n + "/rows"], z["d4c/" + n + "/rowsum"]) for n, t in d4])
 
 
+def rate96k_case():
+    """x, fs and the real reference's outputs for one 96 kHz utterance (tests/golden/rate96k.npz, oracle/gen_golden_96k.py)"""
+    from world_class_amd.synth import make_utterance
+    z = np.load(os.path.join(ROOT, "tests", "golden", "rate96k.npz"))
+    return make_utterance(96000, 0.6, 9600), 96000, 16, z
+
+
 PIPELINE_CASES = ["c1_16k_2s_floor71", "c1_16k_2s_floor40", "m48k_1s", "m24k_1s_1ms"]

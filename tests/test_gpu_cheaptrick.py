@@ -89,7 +89,7 @@ def test_cheaptrick_edges(wca, port):
     port.rng_reset()
 
 
-@pytest.mark.parametrize("fs", [8000, 22050, 44100])
+@pytest.mark.parametrize("fs", [8000, 22050, 44100, 64000, 96000])
 def test_cheaptrick_other_rates(wca, port, fs):
     x = make_utterance(fs, 0.3, fs)
     tpos, f0 = port.harvest(x, fs)

@@ -64,7 +64,7 @@ def test_d4c_ragged_batch_threshold_and_other_grid(wca, port):
     port.rng_reset()
 
 
-@pytest.mark.parametrize("fs", [8000, 22050, 44100])
+@pytest.mark.parametrize("fs", [8000, 22050, 44100, 64000, 88200, 96000])
 def test_d4c_other_rates(wca, port, fs):
     x = make_utterance(fs, 0.3, fs + 1)
     tpos, f0 = port.harvest(x, fs)

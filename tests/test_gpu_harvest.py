@@ -135,7 +135,7 @@ def test_harvest_ragged_batch(wca, port):
         check_f0(f, fr)
 
 
-@pytest.mark.parametrize("fs,fp", [(8000, 5.0), (22050, 5.0), (44100, 10.0), (16000, 1.0)])
+@pytest.mark.parametrize("fs,fp", [(8000, 5.0), (22050, 5.0), (44100, 10.0), (16000, 1.0), (96000, 5.0), (88200, 5.0)])
 def test_harvest_other_rates(wca, port, fs, fp):
     x = make_utterance(fs, 0.8, fs + 7)
     t, f = wca.Harvest(fs, frame_period=fp).compute(x)

@@ -133,3 +133,20 @@ def test_host_batch_front_end_pcm16_and_double(wca):
     for r, g in zip(ref, got):
         assert set(g) == {"f0", "y"} and np.array_equal(g["f0"], r["f0"])
         assert np.abs(g["y"] - r["y"]).max() < 1e-10   # overlap-add order differs between runs at the 1e-16 level
+
+
+def test_pipeline_at_96_khz_golden(wca):
+    """96 kHz: decimation ratio 12, 4096-point CheapTrick / Synthesis, 8192-point D4C and LoveTrain (the unpacking twiddles of
+    the 8192-point real transforms lie between the entries of the 4096-entry table and are computed) against the real
+    reference (tests/golden/rate96k.npz)"""
+    from conftest import rate96k_case
+    x, fs, stride, z = rate96k_case()
+    wca.rng_set_position(0)
+    (r,) = wca.Pipeline(fs).run_batch([x])
+    assert np.array_equal(r["tpos"], z["tpos"]) and np.array_equal(r["f0"] == 0, z["f0"] == 0)
+    assert np.abs(r["f0"] - z["f0"]).max() < 1e-6
+    assert (np.abs(r["sp"][::stride] - z["sp_rows"]) / z["sp_rows"]).max() < 1e-7
+    assert (np.abs(r["sp"].sum(axis=1) - z["sp_rowsum"]) / z["sp_rowsum"]).max() < 1e-7
+    assert np.abs(r["ap"][::stride] - z["ap_rows"]).max() < 1e-7
+    assert np.abs(r["ap"].sum(axis=1) - z["ap_rowsum"]).max() < 1e-7 * r["ap"].shape[1]
+    assert np.abs(r["y"] - z["y"]).max() < 1e-8

@@ -4,7 +4,7 @@ These pin the oracle that the -m gpu parity tests then use as the checker."""
 import numpy as np
 import pytest
 
-from conftest import HARVEST_LONG_CASES, PIPELINE_CASES, harvest_edge_rows, harvest_long_case, harvest_option_cases, same_candidates, stage_option_cases
+from conftest import HARVEST_LONG_CASES, PIPELINE_CASES, harvest_edge_rows, harvest_long_case, harvest_option_cases, rate96k_case, same_candidates, stage_option_cases
 from world_class_amd.synth import make_utterance
 
 # tolerances of the restatement vs the reference (FP64; only the FFT rounding differs)
@@ -204,6 +204,22 @@ def test_cheaptrick_and_d4c_options_against_golden(port):
         ap = port.d4c(x, fs, tpos, f0, 1024, threshold=thr)
         assert np.abs(ap[::stride] - rows).max() < AP_ABS and np.abs(ap.sum(axis=1) - rowsum).max() < AP_ABS * 1024, name
     port.rng_reset()
+
+
+def test_pipeline_at_96_khz_against_golden(port):
+    """decimation ratio 12, 4096-point CheapTrick / Synthesis, 8192-point D4C and LoveTrain"""
+    x, fs, stride, z = rate96k_case()
+    port.set_threads(4)
+    try:
+        r = port.pipeline(x, fs)
+    finally:
+        port.set_threads(0)
+    assert np.array_equal(r["tpos"], z["tpos"]) and np.array_equal(r["f0"] == 0, z["f0"] == 0)
+    assert np.abs(r["f0"] - z["f0"]).max() < F0_ABS
+    assert (np.abs(r["sp"][::stride] - z["sp_rows"]) / z["sp_rows"]).max() < SP_REL
+    assert (np.abs(r["sp"].sum(axis=1) - z["sp_rowsum"]) / z["sp_rowsum"]).max() < SP_REL
+    assert np.abs(r["ap"][::stride] - z["ap_rows"]).max() < AP_ABS
+    assert np.abs(r["y"] - z["y"]).max() < Y_ABS
 
 
 def test_device_argsort_reproduces_std_sort(tmp_path):

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(T, T == 512 ? 6 : 1) void d4c_lovetrain_kernel(D4cA
 #define WC_D4C_FFTSYNC 1  // FFT flags; 0 (no barriers) and 3 (no twiddle loads) are timing ablations with wrong results
 #endif
 template <int N, int T, bool SPLIT>
-__global__ __launch_bounds__(T, (2 * T) / 256) void d4c_frames_kernel(D4cArgs a) {
+__global__ __launch_bounds__(T, T >= 1024 ? 4 : (2 * T) / 256) void d4c_frames_kernel(D4cArgs a) {
 	constexpr int M = N / 2;
 	constexpr int EPT = N / T;
 	constexpr int KPT = (M + 1 + T - 1) / T;  // power-spectrum keys per thread
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(T, (2 * T) / 256) void d4c_frames_kernel(D4cArgs a)
 // d4c_frames_kernel (reference :466-503), with the group delay read back from global memory: 36 KB of LDS and 54
 // registers instead of 64 KB / 128 VGPRs, i.e. four instead of two workgroups per CU.
 template <int N, int T>
-__global__ __launch_bounds__(T, (4 * T) / 256) void d4c_band_kernel(D4cArgs a) {
+__global__ __launch_bounds__(T, T >= 1024 ? 8 : (4 * T) / 256) void d4c_band_kernel(D4cArgs a) {
 	constexpr int M = N / 2;
 	constexpr int EPT = N / T;
 	constexpr int PAIRS = (M / 2) / T;
@@ -700,14 +700,14 @@ struct wc_d4c {
 template <int N>
 static void launch_lt(const D4cArgs &a, hipStream_t s) {
 	long long blocks = ((a.total_frames + 7) / 8) * 8;
-	constexpr int TL = (N >= 4096) ? 512 : 256;
+	constexpr int TL = (N >= 8192) ? 1024 : (N >= 4096) ? 512 : 256;
 	hipLaunchKernelGGL((d4c_lovetrain_kernel<N, TL>), dim3((unsigned)blocks), dim3(TL), 0, s, a);
 }
 // part 0: frames kernel (fused, or up to the group delay when split); part 1: bands + rows of the split schedule
 template <int N>
 static void launch_main(const D4cArgs &a, hipStream_t s, bool split, int part) {
 	long long blocks = ((a.total_frames + 7) / 8) * 8;
-	constexpr int TF = (N >= 4096) ? 512 : 256;  // 8 waves per frame at N = 4096: half the registers per thread, 2 WG/CU
+	constexpr int TF = (N >= 8192) ? 1024 : (N >= 4096) ? 512 : 256;  // 8 waves per frame at N = 4096: half the registers per thread, 2 WG/CU
 	if (part == 0) {
 		if (!split) hipLaunchKernelGGL((d4c_frames_kernel<N, TF, false>), dim3((unsigned)blocks), dim3(TF), 0, s, a);
 		else hipLaunchKernelGGL((d4c_frames_kernel<N, TF, true>), dim3((unsigned)blocks), dim3(TF), 0, s, a);
@@ -777,7 +777,8 @@ int d4c_enqueue(wc_d4c *d, hipStream_t s, int n_utt, const double *d_x, const in
 		case 1024: launch_lt<1024>(a, s); break;
 		case 2048: launch_lt<2048>(a, s); break;
 		case 4096: launch_lt<4096>(a, s); break;
-		default: return fail(WC_ERR_UNSUPPORTED, "d4c: unsupported LoveTrain FFT size (fs must be 8..48 kHz)");
+		case 8192: launch_lt<8192>(a, s); break;
+		default: return fail(WC_ERR_UNSUPPORTED, "d4c: unsupported LoveTrain FFT size (fs must be 8..96 kHz)");
 	}
 	WC_HIP(hipGetLastError());
 	if ((rc = dev->time_end("d4c_lovetrain", s))) return rc;
@@ -791,7 +792,8 @@ int d4c_enqueue(wc_d4c *d, hipStream_t s, int n_utt, const double *d_x, const in
 			case 1024: launch_main<1024>(a, s, split, part); break;
 			case 2048: launch_main<2048>(a, s, split, part); break;
 			case 4096: launch_main<4096>(a, s, split, part); break;
-			default: return fail(WC_ERR_UNSUPPORTED, "d4c: unsupported FFT size (fs must be 8..48 kHz)");
+			case 8192: launch_main<8192>(a, s, split, part); break;
+			default: return fail(WC_ERR_UNSUPPORTED, "d4c: unsupported FFT size (fs must be 8..96 kHz)");
 		}
 		WC_HIP(hipGetLastError());
 		if ((rc = dev->time_end(name, s))) return rc;
@@ -853,9 +855,9 @@ wc_d4c *wc_d4c_create(int fs, double threshold) {
 	d->window_length = static_cast<int>(3000.0 * d->fft_size_d4c / fs) * 2 + 1;
 	d->fft_size_lt = static_cast<int>(std::pow(2.0, 1.0 + static_cast<int>(std::log(3.0 * fs / 40.0 + 1) / 0.69314718055994529)));
 	if (d->n_ap < 0) d->n_ap = 0;
-	if (d->n_ap > kMaxBands || (d->fft_size_d4c != 1024 && d->fft_size_d4c != 2048 && d->fft_size_d4c != 4096) ||
-		(d->fft_size_lt != 1024 && d->fft_size_lt != 2048 && d->fft_size_lt != 4096)) {
-		set_error("d4c: unsupported sampling rate (supported: 8 kHz .. 48 kHz)");
+	if (d->n_ap > kMaxBands || (d->fft_size_d4c != 1024 && d->fft_size_d4c != 2048 && d->fft_size_d4c != 4096 && d->fft_size_d4c != 8192) ||
+		(d->fft_size_lt != 1024 && d->fft_size_lt != 2048 && d->fft_size_lt != 4096 && d->fft_size_lt != 8192)) {
+		set_error("d4c: unsupported sampling rate (supported: 8 kHz .. 96 kHz)");
 		delete d;
 		return nullptr;
 	}

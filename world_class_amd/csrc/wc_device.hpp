@@ -367,12 +367,24 @@ __device__ void fft_lds_tail(double2 *a, const double2 *__restrict__ tw_, int ti
 	fft_chain<M, T, S, NS0, 1>(a, tw, tid, first);
 }
 
+// W_N^k = e^{+2 pi i k / N}, N = 2 M, for the unpacking passes of the real transforms: from the table while it is fine
+// enough, computed where N = 8192 needs odd multiples of half a table step (the 96 kHz D4C transforms; a few per thread)
+template <int M>
+__device__ __forceinline__ double2 tw_real(const double2 *__restrict__ tw, int k) {
+	if constexpr (2 * M <= kTwiddleN) {
+		return tw_load(tw, k * (kTwiddleN / (2 * M)));
+	} else {
+		double sn, cs;
+		sincospi((double)k / M, &sn, &cs);
+		return make_double2(cs, sn);
+	}
+}
+
 // ---- real FFT of N = 2M points held as M interleaved complex (x[2k], x[2k+1]) -----------------------
 // After fft_lds<M,T,+1> on that array, unpack to the spectrum X[0..M] (reference r2c convention).
 // Packed in place: a[0] = (X[0].re, X[M].re); a[k] = X[k] for 0 < k < M.  Ends with a __syncthreads().
 template <int M, int T>
 __device__ void r2c_post(double2 *a, const double2 *__restrict__ tw_, int tid) {
-	constexpr int TS = kTwiddleN / (2 * M);  // W_N^k = tw[k * TS]
 	const double2 *__restrict__ tw = tw_fresh(tw_);
 	// pairs (k, M-k), k = 1 .. M/2-1 ; k = 0 and k = M/2 handled apart
 	for (int k = tid; k <= M / 2; k += T) {
@@ -385,7 +397,7 @@ __device__ void r2c_post(double2 *a, const double2 *__restrict__ tw_, int tid) {
 			double2 zk = a[k], zm = a[M - k];
 			double2 e = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));   // (Zk + conj Zm)/2
 			double2 o = make_double2(0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x));  // (Zk - conj Zm)/(2i)
-			double2 w = tw_load(tw, k * TS);
+			double2 w = tw_real<M>(tw, k);
 			double2 wo = cmul(w, o);
 			a[k] = cadd(e, wo);
 			// X[M-k] = conj(E) + W^{M-k} conj(O),  W^{M-k} = -conj(W^k)  =>  X[M-k] = conj(E - W O)
@@ -400,7 +412,6 @@ __device__ void r2c_post(double2 *a, const double2 *__restrict__ tw_, int tid) {
 template <int M, int T>
 __device__ __forceinline__ void r2c_power(const double2 *a, const double2 *__restrict__ tw_, int tid,
 										  double (&key)[2 * ((M / 2) / T) + 1]) {
-	constexpr int TS = kTwiddleN / (2 * M);
 	const double2 *__restrict__ tw = tw_fresh(tw_);
 	constexpr int PAIRS = (M / 2) / T;
 #pragma unroll
@@ -409,7 +420,7 @@ __device__ __forceinline__ void r2c_power(const double2 *a, const double2 *__res
 		const double2 zk = a[k], zm = a[(M - k) & (M - 1)];
 		const double2 ev = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
 		const double2 od = make_double2(0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x));
-		const double2 wo = cmul(tw_load(tw, k * TS), od);
+		const double2 wo = cmul(tw_real<M>(tw, k), od);
 		const double2 xk = cadd(ev, wo), xm = csub(ev, wo);
 		const double r0 = zk.x + zk.y, rm = zk.x - zk.y;  // k = 0: X[0], X[M] (both real)
 		key[2 * e] = (k == 0) ? r0 * r0 : fma(xk.x, xk.x, xk.y * xk.y);
@@ -422,7 +433,6 @@ __device__ __forceinline__ void r2c_power(const double2 *a, const double2 *__res
 // fft_lds<M,T,-1> yields the real signal y[n] interleaved (reference c2r convention, unnormalised).
 template <int M, int T>
 __device__ void c2r_pre(double2 *a, const double2 *__restrict__ tw_, int tid) {
-	constexpr int TS = kTwiddleN / (2 * M);
 	const double2 *__restrict__ tw = tw_fresh(tw_);
 	for (int k = tid; k <= M / 2; k += T) {
 		if (k == 0) {
@@ -437,7 +447,7 @@ __device__ void c2r_pre(double2 *a, const double2 *__restrict__ tw_, int tid) {
 			double2 yk = a[k], ym = a[M - k];
 			double2 e = make_double2(yk.x + ym.x, yk.y - ym.y);  // Yk + conj Ym
 			double2 d = make_double2(yk.x - ym.x, yk.y + ym.y);  // Yk - conj Ym
-			double2 w = cconj(tw_load(tw, k * TS));
+			double2 w = cconj(tw_real<M>(tw, k));
 			double2 o = cmul(d, w);
 			a[k] = make_double2(e.x - o.y, e.y + o.x);  // E + i O
 			// index M-k: E' = conj(E), D' = -conj(D), conj(W^{M-k}) = -W^k ... O' = conj(D) W^k = conj(D conj W) = conj(O)

@@ -946,7 +946,8 @@ int syn_pulses(wc_synthesis *sy, hipStream_t s, const double *d_f0, const double
 		case 512: launch_pulses<512>(a, s); break;
 		case 1024: launch_pulses<1024>(a, s); break;
 		case 2048: launch_pulses<2048>(a, s); break;
-		default: return fail(WC_ERR_UNSUPPORTED, "synthesis: fft_size must be 512, 1024 or 2048");
+		case 4096: launch_pulses<4096>(a, s); break;
+		default: return fail(WC_ERR_UNSUPPORTED, "synthesis: fft_size must be 512, 1024, 2048 or 4096");
 	}
 	WC_HIP(hipGetLastError());
 	return dev->time_end("synthesis_pulses", s);
@@ -998,8 +999,8 @@ extern "C" {
 
 wc_synthesis *wc_synthesis_create(int fs, int fft_size, double frame_period_ms) {
 	if (fs <= 0 || frame_period_ms <= 0) { set_error("synthesis: fs and frame_period must be positive"); return nullptr; }
-	if (fft_size != 512 && fft_size != 1024 && fft_size != 2048) {
-		set_error("synthesis: fft_size must be 512, 1024 or 2048");
+	if (fft_size != 512 && fft_size != 1024 && fft_size != 2048 && fft_size != 4096) {
+		set_error("synthesis: fft_size must be 512, 1024, 2048 or 4096");
 		return nullptr;
 	}
 	Device *dev = current_device();
