@@ -58,7 +58,7 @@ def test_synthesis_pulse_buffer_overflow_is_retried(wca, port):
     port.rng_reset()
 
 
-@pytest.mark.parametrize("floor,ceil", [(50.0, 600.0), (100.0, 400.0), (71.0, 1000.0)])
+@pytest.mark.parametrize("floor,ceil", [(50.0, 600.0), (100.0, 400.0), (71.0, 1000.0), (20.0, 800.0), (30.0, 1200.0)])
 def test_harvest_option_variations(wca, port, floor, ceil):
     fs = 16000
     x = make_utterance(fs, 1.0, 55)

@@ -38,7 +38,7 @@
 namespace wc {
 
 constexpr double kSafeH = 0.000000000001;
-constexpr int HL_MAX = 512;       // longest supported half filter length (f0_floor >= ~35 Hz at 8 kHz)
+constexpr int HL_MAX = 1024;      // longest supported half filter length (f0_floor >= ~18 Hz at 8 kHz after decimation, ~35 Hz at 16 kHz)
 constexpr int BP_T = 256;         // threads of the band-pass workgroup
 constexpr int BP_R = 8;           // consecutive outputs per thread
 constexpr int BP_TILE = BP_T * BP_R;
@@ -257,7 +257,7 @@ struct BpArgs {
 
 __device__ __forceinline__ int padidx(int m) { return m + (m >> 3); }
 
-__global__ __launch_bounds__(BP_T, 4) void hv_bandpass_kernel(BpArgs a) {
+__global__ __launch_bounds__(BP_T, 3) void hv_bandpass_kernel(BpArgs a) {
 	// 36.5 KB of LDS -> four workgroups per CU; the filtered tile reuses the signal tile's storage
 	__shared__ double Ys[(BP_TILE + 2 * HL_MAX + 32) * 9 / 8 + 16];
 	__shared__ double Tp[2 * HL_MAX + 16];
