@@ -772,7 +772,7 @@ constexpr int RF_MAXW = 2 * RF_MAXHW + 1;
 // (getMainWindow, src/harvest.cpp:779-787), the difference window from its neighbours (:792-803); three look-up pairs per
 // sample instead of a rotation, an option nobody takes for speed here but whose results differ from exact cosines by 1e-4.
 template <bool TABLE>
-__global__ __launch_bounds__(256, 3) void hv_refine_kernel(RefArgs a) {  // 3 waves per SIMD (<= 168 VGPRs): measured best
+__global__ __launch_bounds__(256, 4) void hv_refine_kernel(RefArgs a) {  // 4 waves per SIMD (128 VGPRs, 68 bytes of scratch): 9.5 ms against 9.9 ms at 3 waves / 156 VGPRs since the per-lane loop
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	const int blk = lane >> 3, sub = lane & 7;
 	const long long g = blockIdx.x;
