@@ -3,25 +3,28 @@
 // Restates reference src/harvest.cpp:183-1453 (compute, generalBody and everything they reach) and
 // decimate/FilterForDecimate of src/world_matlabfunctions.cpp:27-125, :184-210 as a chain of kernels:
 //
-//   hv_decimate_kernel   zero-phase order-3 IIR decimation (reference :213-248).  The recursion is
+//   hv_decimate_lds_kernel  zero-phase order-3 IIR decimation (reference :213-248).  The recursion is
 //                        split into independent chunks that warm up on the preceding samples (the
-//                        filter's impulse response is below 1e-20 after 768 samples), two passes.
+//                        filter's impulse response is below 1e-20 after 768 samples), two passes; the
+//                        lanes' streams are staged through LDS in tiles (hv_decimate_kernel reads them
+//                        directly, WC_HARVEST_DECIMATE=direct)
 //   hv_dc_kernel         the reference's int-typed "DC removal" (:239) -- a no-op unless abs(y) >= 1
 //   hv_bandpass_sdft_kernel, hv_compact_kernel
-//                        the band-pass of reference :1261-1305 -- a Nuttall * cosine FIR of <= 2*512+1 taps -- as a
+//                        the band-pass of reference :1261-1305 -- a Nuttall * cosine FIR of <= 2*1024+1 taps -- as a
 //                        sliding DFT (a lane per (band, 2048-sample chunk), seven rotating sums) fused with the four
 //                        zero-crossing detectors of :1179-1255; edges land in per-chunk slots that the second kernel
 //                        packs in time order.  hv_bandpass_kernel is the direct FIR evaluation (one workgroup per
 //                        (utterance, band), register tiled from LDS), kept behind WC_HARVEST_BANDPASS=fir
 //   hv_raw_kernel        interp1 of the four interval series onto the 1 ms grid (:1098-1143)
 //   hv_detect_kernel     per-frame candidate detection over bands (:1005-1083)
-//   hv_refine_kernel     one wavefront per (frame, candidate): overlap (:987-1000) folded into the
-//                        gather, Blackman / differentiated windows, and -- instead of the reference's two
+//   hv_refine_kernel     eight lanes per (frame, candidate): overlap (:987-1000) folded into the
+//                        gather, Blackman / differentiated windows (<true>: from the reference's cosine
+//                        table, HarvestOption::use_cos_table), and -- instead of the reference's two
 //                        full FFTs -- Goertzel recurrences for the <= 6 harmonic bins fixF0 reads (:809-927)
 //   hv_unreliable_kernel (:708-744)
-//   hv_contour_kernel    one wavefront per utterance walks the sequential contour logic
-//                        (:254-634: base contour, fixStep1..4, extend, merge) with the candidate
-//                        searches spread over the lanes
+//   hv_contour_kernel<0/1/2>  the sequential contour logic (:254-634: fixStep1..4, extend, merge): one
+//                        wavefront per utterance with the candidate searches spread over the lanes, except
+//                        the extension walks (<1>), which get a wavefront per (voiced section, direction)
 //   hv_smooth_kernel     zero-lag Butterworth per voiced section, one lane per section (:639-703)
 //   hv_output_kernel     1 ms contour -> frame_period grid (:199-204)
 #include <cmath>
