@@ -150,3 +150,22 @@ def test_pipeline_at_96_khz_golden(wca):
     assert np.abs(r["ap"][::stride] - z["ap_rows"]).max() < 1e-7
     assert np.abs(r["ap"].sum(axis=1) - z["ap_rowsum"]).max() < 1e-7 * r["ap"].shape[1]
     assert np.abs(r["y"] - z["y"]).max() < 1e-8
+
+
+def test_schedules_agree(wca):
+    """the default schedule (two half-batch chains) and WC_PIPELINE_MODE=shared (one set of stage handles, Harvest split
+    over streams): same kernels on the same data, so the same parameters bit for bit and the same waveform up to the
+    order of the overlap-add"""
+    import os
+    fs = 16000
+    xs = [make_utterance(fs, sec, 90 + i) for i, sec in enumerate((0.6, 1.0, 0.25, 0.8, 0.5))]
+    a = wca.Pipeline(fs).run_batch(xs)
+    os.environ["WC_PIPELINE_MODE"] = "shared"
+    try:
+        p = wca.Pipeline(fs)
+    finally:
+        del os.environ["WC_PIPELINE_MODE"]
+    b = p.run_batch(xs)
+    for ra, rb in zip(a, b):
+        assert np.array_equal(ra["f0"], rb["f0"]) and np.array_equal(ra["sp"], rb["sp"]) and np.array_equal(ra["ap"], rb["ap"])
+        assert np.abs(ra["y"] - rb["y"]).max() < 1e-12
