@@ -157,3 +157,31 @@ def test_no_voiced_section_and_noise_free_bands(wca, port):
         (r,) = wca.Pipeline(fs).run_batch([x])
         check_f0(r["f0"], port.harvest(x, fs)[1])
         assert np.isfinite(r["sp"]).all() and np.isfinite(r["ap"]).all() and np.isfinite(r["y"]).all()
+
+
+@pytest.mark.timeout(120)
+def test_non_finite_input_stays_local(wca):
+    """NaN / inf samples (a bad decode upstream) and absurd F0 values: every call returns, nothing non-finite leaks into the
+    frames that do not see the bad samples, and the other utterance of the batch is bit for bit what it is on its own"""
+    fs = 16000
+    good = make_utterance(fs, 0.8, 11)
+    (alone,) = wca.Pipeline(fs).run_batch([good])
+    for bad in (np.nan, np.inf, -np.inf, 1e300):
+        x = make_utterance(fs, 1.0, 12)
+        x[5000:5010] = bad
+        r_bad, r_good = wca.Pipeline(fs).run_batch([x, good])
+        assert np.array_equal(r_good["f0"], alone["f0"]) and np.array_equal(r_good["sp"], alone["sp"]) and np.array_equal(r_good["ap"], alone["ap"])
+        assert np.abs(r_good["y"] - alone["y"]).max() < 1e-12
+        assert np.isfinite(r_bad["f0"]).all()
+        assert np.isfinite(r_bad["sp"]).all(axis=1).sum() >= len(r_bad["f0"]) - 4  # the frames whose window holds the bad samples
+        assert np.isfinite(r_bad["y"]).mean() > 0.85
+    n = (alone["sp"].shape[1] - 1) * 2
+    k = np.arange(len(alone["f0"]))
+    for f0 in (np.where(k % 17 == 3, np.nan, alone["f0"]), -alone["f0"], alone["f0"] * 1e6, np.where(alone["f0"] > 0, np.inf, 0.0)):
+        y = wca.Synthesis(fs, n, 5.0).compute(f0, alone["sp"], alone["ap"])
+        assert np.isfinite(y).all()
+    for f0 in (np.where(k % 13 == 2, np.nan, alone["f0"]), np.where(k % 13 == 2, 1e9, alone["f0"]), np.where(k % 13 == 2, 1e-9, alone["f0"])):
+        sp = wca.CheapTrick(fs).compute(good, alone["tpos"], f0)
+        ap = wca.D4C(fs).compute(good, alone["tpos"], f0, n)
+        ok = np.isfinite(f0)
+        assert np.isfinite(sp[ok]).all() and np.isfinite(ap).all()
