@@ -51,11 +51,21 @@ const char *wc_version(void);
 int wc_device_count(void);            /* number of HIP devices visible, <0 on error */
 int wc_set_device(int device);        /* device used by handles created afterwards (default 0) */
 int wc_get_device(void);
-/* Stream used by handles created afterwards (a hipStream_t passed as void*); NULL = the library's
- * own non-blocking stream.  Lets a caller order our kernels with its own work. */
+/* Stream (a hipStream_t passed as void*) on which the CALLING THREAD's subsequent calls enqueue their
+ * work, whichever handle they go through; NULL = back to the library's own non-blocking stream.  Per host
+ * thread: other threads, existing handles' buffers and the library's stream are unaffected.  Lets a caller
+ * order our kernels with its own work: everything a call launches -- also what the fused pipeline puts on
+ * its internal side streams -- is ordered after the work already on that stream; the pcm / codec /
+ * modify device entry points only enqueue (stream-ordered), the stage and pipeline calls also wait for their
+ * own work before returning (they hand back noise-stream positions and overflow flags).  The stream must
+ * outlive the calls made on it. */
 int wc_set_stream(void *hip_stream);
-/* Blocks until all work submitted by the calling thread's handles on the current stream is done. */
+/* Blocks until all work the calling thread submitted on its current stream is done. */
 int wc_synchronize(void);
+/* Several host threads may drive handles on the same device: public calls on one device are serialised
+ * (they share the noise draw table and the process-wide noise-stream position). */
+/* SHA-256 (hex) of the sources and compiler flags the library was built from; build.py compares it with the tree. */
+const char *wc_build_hash(void);
 uint64_t wc_rng_get_position(void);
 void wc_rng_set_position(uint64_t position);
 

@@ -65,7 +65,7 @@ def main():
     # ---- hand-made variants: extra chunk before "data", 8 / 24 / 32-bit samples, broken headers ----
     def make_wav(name, nbit, samples, extra=b"", fmt_size=16, channels=1, fmt_id=1, riff=b"RIFF"):
         qb = nbit // 8
-        data = b"".join(int(int(s) & ((1 << nbit) - 1)).to_bytes(qb, "little") for s in samples)
+        data = b"".join(int(int(s) & ((1 << (8 * qb)) - 1)).to_bytes(qb, "little") for s in samples)
         fmt = struct.pack("<HHIIHH", fmt_id, channels, 22050, 22050 * qb, qb, nbit)
         body = b"WAVE" + b"fmt " + struct.pack("<I", fmt_size) + fmt + extra + b"data" + struct.pack("<I", len(data)) + data
         with open(os.path.join(OUT, name), "wb") as f:
@@ -84,6 +84,9 @@ def main():
     make_wav("bad_stereo.wav", 16, s16[:8], channels=2)
     make_wav("bad_fmt_size.wav", 16, s16[:8], fmt_size=18)
     make_wav("bad_riff.wav", 16, s16[:8], riff=b"RIFX")
+    # sample sizes the reference must never be shown (it indexes a 4-byte scratch with nbit / 8 - 1): fixtures for OUR reader only
+    make_wav("bad_nbit.wav", 40, s16[:8])
+    make_wav("bad_nbit12.wav", 12, s16[:8])
     for name in ("list_chunk_16bit", "pcm_24bit", "pcm_8bit", "pcm_32bit", "bad_stereo", "bad_fmt_size", "bad_riff"):
         n, fs_r, nb, y = ref_read(name + ".wav")
         g[name + "_len"], g[name + "_fs"], g[name + "_nbit"], g[name + "_x"] = n, fs_r, nb, y

@@ -169,3 +169,57 @@ def test_schedules_agree(wca):
     for ra, rb in zip(a, b):
         assert np.array_equal(ra["f0"], rb["f0"]) and np.array_equal(ra["sp"], rb["sp"]) and np.array_equal(ra["ap"], rb["ap"])
         assert np.abs(ra["y"] - rb["y"]).max() < 1e-12
+
+
+def test_user_stream_orders_our_kernels_with_the_callers_work(wca):
+    """wc_set_stream (include/world_class_c.h): the calling thread's calls run on the caller's stream -- after the work
+    already queued there -- without touching the library's own stream; results equal those on the library stream."""
+    import torch
+    fs = 16000
+    xs = [make_utterance(fs, sec, 80 + i) for i, sec in enumerate((0.8, 0.5, 0.6, 0.4))]
+    x_len = [len(x) for x in xs]
+    f_len = [wca.get_samples(fs, n, 5.0) for n in x_len]
+    y_len = [wca.synthesis_out_length(n, 5.0, fs) for n in f_len]
+    pipe = wca.Pipeline(fs)
+    bins = pipe.bins
+    dev = torch.device("cuda", 0)
+    host = torch.from_numpy(np.concatenate(xs)).pin_memory()
+
+    def run(stream):
+        d_x = torch.zeros(sum(x_len), dtype=torch.float64, device=dev)
+        out = [torch.zeros(n, dtype=torch.float64, device=dev) for n in (sum(f_len), sum(f_len), sum(f_len) * bins, sum(f_len) * bins, sum(y_len))]
+        if stream is None:
+            d_x.copy_(host)
+            torch.cuda.synchronize()
+            pipe.run_device(d_x, x_len, *out)
+        else:
+            torch.cuda.synchronize()
+            assert wca.lib().wc_set_stream(stream.cuda_stream) == 0
+            try:
+                with torch.cuda.stream(stream):
+                    # a long-running kernel, then the upload of the samples: our kernels must wait for both
+                    junk = torch.randn(4096, 4096, device=dev)
+                    for _ in range(20):
+                        junk = junk @ junk * 1e-3
+                    d_x.copy_(host, non_blocking=True)
+                pipe.run_device(d_x, x_len, *out)
+                # stages through the same stream: CheapTrick on the freshly written F0
+                sp2 = torch.zeros_like(out[2])
+                wca.CheapTrick(fs).compute_device(d_x, x_len, out[0], out[1], f_len, sp2, rng_pos=[0] * len(xs))
+                assert wca.lib().wc_synchronize() == 0
+                assert torch.equal(sp2, out[2])
+            finally:
+                assert wca.lib().wc_set_stream(None) == 0
+        torch.cuda.synchronize()
+        return [o.cpu().numpy() for o in out]
+
+    ref = run(None)
+    s = torch.cuda.Stream()
+    got = run(s)
+    for a, b in zip(ref[:4], got[:4]):
+        assert np.array_equal(a, b)
+    assert np.abs(ref[4] - got[4]).max() < 1e-12  # atomic overlap-add order
+    # and back on the library's stream afterwards, with the caller's stream gone
+    del s
+    again = run(None)
+    assert np.array_equal(again[1], ref[1])

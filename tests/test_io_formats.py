@@ -44,6 +44,14 @@ def test_rejected_and_missing_files_behave_like_the_reference(g, wio):
     assert wio.audio_length(os.path.join(IO, "does_not_exist.wav")) == int(g["missing_len"]) == 0
 
 
+def test_sample_sizes_other_than_1_to_4_bytes_are_rejected(wio):
+    # the header's bits-per-sample is a free byte; 40 would index past a 4-byte sample scratch, 12 is not whole bytes
+    for name in ("bad_nbit", "bad_nbit12"):
+        assert wio.audio_length(os.path.join(IO, name + ".wav")) == -1
+        with pytest.raises(wio.WorldClassError):
+            wio.wavread(os.path.join(IO, name + ".wav"))
+
+
 def test_wavwrite_is_byte_identical(g, wio, tmp_path):
     out = tmp_path / "ours.wav"
     wio.wavwrite(g["wav_x"], 16000, out)

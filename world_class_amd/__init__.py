@@ -23,6 +23,7 @@ _vp = C.c_void_p
 _SIGNATURES = {
     "wc_last_error": (C.c_char_p, []),
     "wc_version": (C.c_char_p, []),
+    "wc_build_hash": (C.c_char_p, []),
     "wc_device_count": (C.c_int, []),
     "wc_set_device": (C.c_int, [C.c_int]),
     "wc_get_device": (C.c_int, []),

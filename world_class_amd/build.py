@@ -2,8 +2,16 @@
 
 hipcc cross-compiles without a GPU, so this runs in the build container as well as on the GPU box.
 The built .so is git-ignored but travels with the tree to the GPU box.
+
+A shipped library is reused only when it provably belongs to the sources and flags in the tree: the SHA-256 of
+every source, header and the compiler flags is compiled into the library (wc_core.hip, `wc_build_hash()`, found
+here by scanning the file for its marker -- no dlopen) and must equal the hash of what is on disk now; file
+times play no part in that decision.  Anything else (edited source, other flags, WC_EXTRA_FLAGS experiments,
+a library from an older tree) rebuilds.
 """
+import hashlib
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -15,10 +23,39 @@ OBJ = os.path.join(HERE, "_obj")
 EXTRA = os.environ.get("WC_EXTRA_FLAGS", "").split()
 FLAGS = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics", "-Wall",
          "-Wno-unused-function", "-Wno-unused-result"]
+HASH_MARKER = b"WC_SOURCE_HASH="
 
 
 def sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def headers():
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    hs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp"))
+    hs += [os.path.join(inc, f) for f in ("world_class_c.h", "world_class_io.h", "world_class_codec.h", "world_class_stream.h",
+                                          "world_matlabfunctions.hpp", "world_fft.hpp") if os.path.exists(os.path.join(inc, f))]
+    return hs
+
+
+def source_hash():
+    """SHA-256 over the flags and the bytes of every translation unit and header the library is built from"""
+    h = hashlib.sha256()
+    h.update(" ".join(FLAGS).encode())
+    for path in [os.path.join(CSRC, f) for f in sources()] + headers():
+        h.update(b"\0" + os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def embedded_hash(path=OUT):
+    """the source hash compiled into a built library, or None"""
+    if not os.path.exists(path):
+        return None
+    with open(path, "rb") as f:
+        m = re.search(HASH_MARKER + rb"([0-9a-f]{64})", f.read())
+    return m.group(1).decode() if m else None
 
 
 def _stale(out, deps):
@@ -30,15 +67,8 @@ def _stale(out, deps):
 
 def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
-    headers.append(os.path.join(os.path.dirname(HERE), "include", "world_class_c.h"))
-    headers.append(os.path.join(os.path.dirname(HERE), "include", "world_class_io.h"))
-    headers.append(os.path.join(os.path.dirname(HERE), "include", "world_class_codec.h"))
-    headers.append(os.path.join(os.path.dirname(HERE), "include", "world_matlabfunctions.hpp"))
-    headers.append(os.path.join(os.path.dirname(HERE), "include", "world_fft.hpp"))
-    # a shipped library that is newer than every source is used as is (the object directory does not travel to
-    # the GPU box); experimental flags always rebuild
-    if not force and not EXTRA and not _stale(OUT, [os.path.join(CSRC, f) for f in sources()] + headers):
+    want = source_hash()
+    if not force and embedded_hash() == want:
         return OUT
     os.makedirs(OBJ, exist_ok=True)
     # objects depend on the flags too: a flags stamp forces a full rebuild when they change
@@ -48,12 +78,17 @@ def build(force=False, verbose=False):
         force = True
     jobs = []
     objs = []
+    hs = headers()
     for src in sources():
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src[:-4] + ".o")
         objs.append(o)
-        if force or _stale(o, [s] + headers):
-            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+        cmd = [hipcc] + FLAGS
+        if src == "wc_core.hip":  # carries the hash: recompiled whenever anything changed
+            cmd += ['-DWC_SOURCE_HASH="%s"' % want]
+            jobs.append(cmd + ["-c", s, "-o", o])
+        elif force or _stale(o, [s] + hs):
+            jobs.append(cmd + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -69,12 +104,13 @@ def build(force=False, verbose=False):
                 raise RuntimeError("hipcc failed")
     with open(stamp, "w") as f:
         f.write(flags_now)
-    if jobs or force or _stale(OUT, objs):
-        rc, out = run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
-        if out.strip():
-            print(out)
-        if rc != 0:
-            raise RuntimeError("link failed")
+    rc, out = run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
+    if out.strip():
+        print(out)
+    if rc != 0:
+        raise RuntimeError("link failed")
+    if embedded_hash() != want:
+        raise RuntimeError("built library does not carry the expected source hash")
     return OUT
 
 

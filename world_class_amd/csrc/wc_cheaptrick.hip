@@ -345,7 +345,7 @@ const unsigned long long *ct_end_positions(const wc_cheaptrick *c) { return c->e
 static int ct_run_device(wc_cheaptrick *c, int n_utt, const double *d_x, const int *x_length, const double *d_tpos,
 						 const double *d_f0, const int *f0_length, double *d_sp, uint64_t *rng_pos) {
 	Device *dev = c->dev;
-	hipStream_t s = dev->stream;
+	hipStream_t s = dev->active();
 	long long total = 0;
 	uint64_t min_pos = 0, max_end = 0;
 	int rc;
@@ -399,7 +399,7 @@ wc_cheaptrick *wc_cheaptrick_create(int fs, double q1, double f0_floor, int fft_
 }
 void wc_cheaptrick_destroy(wc_cheaptrick *c) {
 	if (!c) return;
-	(void)hipStreamSynchronize(c->dev->stream);
+	c->dev->quiesce();
 	c->utts.release(); c->cnt.release(); c->off.release(); c->endpos.release();
 	c->d_x.release(); c->d_tpos.release(); c->d_f0.release(); c->d_sp.release();
 	c->h_stage.release();
@@ -413,6 +413,7 @@ int wc_cheaptrick_compute_device(wc_cheaptrick *c, int n_utt, const double *d_x,
 	if (!c || n_utt <= 0 || !d_x || !x_length || !d_tpos || !d_f0 || !f0_length || !d_sp)
 		return fail(WC_ERR_INVALID, "cheaptrick: null argument");
 	WC_HIP(hipSetDevice(c->dev->id));
+	DeviceLock lock(c->dev);
 	return ct_run_device(c, n_utt, d_x, x_length, d_tpos, d_f0, f0_length, d_sp, rng_pos);
 }
 
@@ -423,7 +424,8 @@ int wc_cheaptrick_compute(wc_cheaptrick *c, const double *x, int x_length, const
 	if (x_length <= 0 || f0_length < 0) return fail(WC_ERR_INVALID, "cheaptrick: bad length");
 	if (f0_length == 0) return WC_OK;
 	WC_HIP(hipSetDevice(c->dev->id));
-	hipStream_t s = c->dev->stream;
+	DeviceLock lock(c->dev);
+	hipStream_t s = c->dev->active();
 	const int bins = c->fft_size / 2 + 1;
 	int rc;
 	if ((rc = c->d_x.reserve(sizeof(double) * x_length))) return rc;
@@ -437,7 +439,7 @@ int wc_cheaptrick_compute(wc_cheaptrick *c, const double *x, int x_length, const
 	rc = ct_run_device(c, 1, c->d_x.as<double>(), &x_length, c->d_tpos.as<double>(), c->d_f0.as<double>(), &f0_length,
 					   c->d_sp.as<double>(), &pos);
 	if (rc) return rc;
-	global_rng_position() = pos;
+	set_global_rng_position(pos);
 	std::vector<double> host((size_t)f0_length * bins);
 	WC_HIP(hipMemcpyAsync(host.data(), c->d_sp.p, sizeof(double) * host.size(), hipMemcpyDeviceToHost, s));
 	WC_HIP(hipStreamSynchronize(s));

@@ -192,10 +192,10 @@ int upload_plan(Device *dev, PlanBufs &b, const std::vector<int> &k, const std::
 	if ((rc = b.k.reserve(sizeof(int) * k.size()))) return rc;
 	if ((rc = b.s.reserve(sizeof(double) * s.size()))) return rc;
 	if ((rc = b.w.reserve(sizeof(double2) * w.size()))) return rc;
-	WC_HIP(hipMemcpyAsync(b.k.p, k.data(), sizeof(int) * k.size(), hipMemcpyHostToDevice, dev->stream));
-	WC_HIP(hipMemcpyAsync(b.s.p, s.data(), sizeof(double) * s.size(), hipMemcpyHostToDevice, dev->stream));
-	WC_HIP(hipMemcpyAsync(b.w.p, w.data(), sizeof(double2) * w.size(), hipMemcpyHostToDevice, dev->stream));
-	WC_HIP(hipStreamSynchronize(dev->stream));  // the host vectors go out of scope with the caller
+	WC_HIP(hipMemcpyAsync(b.k.p, k.data(), sizeof(int) * k.size(), hipMemcpyHostToDevice, dev->active()));
+	WC_HIP(hipMemcpyAsync(b.s.p, s.data(), sizeof(double) * s.size(), hipMemcpyHostToDevice, dev->active()));
+	WC_HIP(hipMemcpyAsync(b.w.p, w.data(), sizeof(double2) * w.size(), hipMemcpyHostToDevice, dev->active()));
+	WC_HIP(hipStreamSynchronize(dev->active()));  // the host vectors go out of scope with the caller
 	out.k = b.k.as<int>();
 	out.s = b.s.as<double>();
 	out.w = b.w.as<double2>();
@@ -238,6 +238,7 @@ int wc_code_spectral_envelope_device(int fs, int fft_size, long long n_frames, i
 		return fail(WC_ERR_INVALID, "code_spectral_envelope: fft_size must be 512..4096 and 1 <= number_of_dimensions <= fft_size/4+1");
 	Device *dev = current_device();
 	if (!dev) return WC_ERR_DEVICE;
+	DeviceLock lock(dev);
 	if (n_frames == 0) return WC_OK;
 	const int md = fft_size / 2;
 	// GetParametersForCoding, reference :125-142
@@ -264,13 +265,13 @@ int wc_code_spectral_envelope_device(int fs, int fft_size, long long n_frames, i
 	if ((rc = upload_plan(dev, bufs, k, s, w, plan))) return rc;
 	const dim3 grid((unsigned)n_frames), block(256);
 	switch (md) {
-		case 256: hipLaunchKernelGGL(code_sp_kernel<256>, grid, block, 0, dev->stream, d_sp, d_coded, nd, plan, dev->twiddle); break;
-		case 512: hipLaunchKernelGGL(code_sp_kernel<512>, grid, block, 0, dev->stream, d_sp, d_coded, nd, plan, dev->twiddle); break;
-		case 1024: hipLaunchKernelGGL(code_sp_kernel<1024>, grid, block, 0, dev->stream, d_sp, d_coded, nd, plan, dev->twiddle); break;
-		default: hipLaunchKernelGGL(code_sp_kernel<2048>, grid, block, 0, dev->stream, d_sp, d_coded, nd, plan, dev->twiddle); break;
+		case 256: hipLaunchKernelGGL(code_sp_kernel<256>, grid, block, 0, dev->active(), d_sp, d_coded, nd, plan, dev->twiddle); break;
+		case 512: hipLaunchKernelGGL(code_sp_kernel<512>, grid, block, 0, dev->active(), d_sp, d_coded, nd, plan, dev->twiddle); break;
+		case 1024: hipLaunchKernelGGL(code_sp_kernel<1024>, grid, block, 0, dev->active(), d_sp, d_coded, nd, plan, dev->twiddle); break;
+		default: hipLaunchKernelGGL(code_sp_kernel<2048>, grid, block, 0, dev->active(), d_sp, d_coded, nd, plan, dev->twiddle); break;
 	}
 	WC_HIP(hipGetLastError());
-	WC_HIP(hipStreamSynchronize(dev->stream));  // the plan buffers are freed on return
+	WC_HIP(hipStreamSynchronize(dev->active()));  // the plan buffers are freed on return
 	return WC_OK;
 }
 
@@ -279,6 +280,7 @@ int wc_decode_spectral_envelope_device(int fs, int fft_size, long long n_frames,
 		return fail(WC_ERR_INVALID, "decode_spectral_envelope: fft_size must be 512..4096 and 1 <= number_of_dimensions <= fft_size/2");
 	Device *dev = current_device();
 	if (!dev) return WC_ERR_DEVICE;
+	DeviceLock lock(dev);
 	if (n_frames == 0) return WC_OK;
 	const int md = fft_size / 2;
 	// GetParametersForDecoding, reference :144-166
@@ -302,13 +304,13 @@ int wc_decode_spectral_envelope_device(int fs, int fft_size, long long n_frames,
 	if ((rc = upload_plan(dev, bufs, k, s, w, plan))) return rc;
 	const dim3 grid((unsigned)n_frames), block(256);
 	switch (md) {
-		case 256: hipLaunchKernelGGL(decode_sp_kernel<256>, grid, block, 0, dev->stream, d_coded, d_sp, nd, plan, dev->twiddle); break;
-		case 512: hipLaunchKernelGGL(decode_sp_kernel<512>, grid, block, 0, dev->stream, d_coded, d_sp, nd, plan, dev->twiddle); break;
-		case 1024: hipLaunchKernelGGL(decode_sp_kernel<1024>, grid, block, 0, dev->stream, d_coded, d_sp, nd, plan, dev->twiddle); break;
-		default: hipLaunchKernelGGL(decode_sp_kernel<2048>, grid, block, 0, dev->stream, d_coded, d_sp, nd, plan, dev->twiddle); break;
+		case 256: hipLaunchKernelGGL(decode_sp_kernel<256>, grid, block, 0, dev->active(), d_coded, d_sp, nd, plan, dev->twiddle); break;
+		case 512: hipLaunchKernelGGL(decode_sp_kernel<512>, grid, block, 0, dev->active(), d_coded, d_sp, nd, plan, dev->twiddle); break;
+		case 1024: hipLaunchKernelGGL(decode_sp_kernel<1024>, grid, block, 0, dev->active(), d_coded, d_sp, nd, plan, dev->twiddle); break;
+		default: hipLaunchKernelGGL(decode_sp_kernel<2048>, grid, block, 0, dev->active(), d_coded, d_sp, nd, plan, dev->twiddle); break;
 	}
 	WC_HIP(hipGetLastError());
-	WC_HIP(hipStreamSynchronize(dev->stream));
+	WC_HIP(hipStreamSynchronize(dev->active()));
 	return WC_OK;
 }
 
@@ -318,9 +320,10 @@ int wc_code_aperiodicity_device(int fs, int fft_size, long long n_frames, const 
 	if (kFrequencyInterval * n_ap / (static_cast<double>(fs) / fft_size) >= fft_size / 2 + 1) return fail(WC_ERR_INVALID, "code_aperiodicity: fft_size too small");
 	Device *dev = current_device();
 	if (!dev) return WC_ERR_DEVICE;
+	DeviceLock lock(dev);
 	if (n_frames == 0) return WC_OK;
 	const long long total = n_frames * n_ap;
-	hipLaunchKernelGGL(code_ap_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, dev->stream, d_ap, d_coded, n_frames, n_ap, fs, fft_size);
+	hipLaunchKernelGGL(code_ap_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, dev->active(), d_ap, d_coded, n_frames, n_ap, fs, fft_size);
 	WC_HIP(hipGetLastError());
 	return WC_OK;
 }
@@ -330,8 +333,9 @@ int wc_decode_aperiodicity_device(int fs, int fft_size, long long n_frames, cons
 	if (fs <= 0 || fft_size < 2 || n_frames < 0 || n_ap < 1) return fail(WC_ERR_INVALID, "decode_aperiodicity: bad argument (fs must exceed 12 kHz)");
 	Device *dev = current_device();
 	if (!dev) return WC_ERR_DEVICE;
+	DeviceLock lock(dev);
 	if (n_frames == 0) return WC_OK;
-	hipLaunchKernelGGL(decode_ap_kernel, dim3((unsigned)n_frames), dim3(256), 0, dev->stream, d_coded, d_ap, n_ap, fs, fft_size);
+	hipLaunchKernelGGL(decode_ap_kernel, dim3((unsigned)n_frames), dim3(256), 0, dev->active(), d_coded, d_ap, n_ap, fs, fft_size);
 	WC_HIP(hipGetLastError());
 	return WC_OK;
 }
@@ -342,10 +346,10 @@ void CodeSpectralEnvelope(const double *const *spectrogram, int f0_length, int f
 	if (!dev) { report(WC_ERR_DEVICE); return; }
 	if (f0_length <= 0) return;
 	ScopedBuf in, out;
-	int rc = rows_to_device(spectrogram, f0_length, fft_size / 2 + 1, in, dev->stream);
+	int rc = rows_to_device(spectrogram, f0_length, fft_size / 2 + 1, in, dev->active());
 	if (!rc) rc = out.reserve(sizeof(double) * (size_t)f0_length * number_of_dimensions);
 	if (!rc) rc = wc_code_spectral_envelope_device(fs, fft_size, f0_length, number_of_dimensions, in.as<double>(), out.as<double>());
-	if (!rc) rc = device_to_rows(out, f0_length, number_of_dimensions, coded_spectral_envelope, dev->stream);
+	if (!rc) rc = device_to_rows(out, f0_length, number_of_dimensions, coded_spectral_envelope, dev->active());
 	report(rc);
 }
 
@@ -355,10 +359,10 @@ void DecodeSpectralEnvelope(const double *const *coded_spectral_envelope, int f0
 	if (!dev) { report(WC_ERR_DEVICE); return; }
 	if (f0_length <= 0) return;
 	ScopedBuf in, out;
-	int rc = rows_to_device(coded_spectral_envelope, f0_length, number_of_dimensions, in, dev->stream);
+	int rc = rows_to_device(coded_spectral_envelope, f0_length, number_of_dimensions, in, dev->active());
 	if (!rc) rc = out.reserve(sizeof(double) * (size_t)f0_length * (fft_size / 2 + 1));
 	if (!rc) rc = wc_decode_spectral_envelope_device(fs, fft_size, f0_length, number_of_dimensions, in.as<double>(), out.as<double>());
-	if (!rc) rc = device_to_rows(out, f0_length, fft_size / 2 + 1, spectrogram, dev->stream);
+	if (!rc) rc = device_to_rows(out, f0_length, fft_size / 2 + 1, spectrogram, dev->active());
 	report(rc);
 }
 
@@ -368,10 +372,10 @@ void CodeAperiodicity(const double *const *aperiodicity, int f0_length, int fs, 
 	if (f0_length <= 0) return;
 	const int n_ap = GetNumberOfAperiodicities(fs);
 	ScopedBuf in, out;
-	int rc = rows_to_device(aperiodicity, f0_length, fft_size / 2 + 1, in, dev->stream);
+	int rc = rows_to_device(aperiodicity, f0_length, fft_size / 2 + 1, in, dev->active());
 	if (!rc) rc = out.reserve(sizeof(double) * (size_t)f0_length * (n_ap > 0 ? n_ap : 1));
 	if (!rc) rc = wc_code_aperiodicity_device(fs, fft_size, f0_length, in.as<double>(), out.as<double>());
-	if (!rc) rc = device_to_rows(out, f0_length, n_ap, coded_aperiodicity, dev->stream);
+	if (!rc) rc = device_to_rows(out, f0_length, n_ap, coded_aperiodicity, dev->active());
 	report(rc);
 }
 
@@ -381,10 +385,10 @@ void DecodeAperiodicity(const double *const *coded_aperiodicity, int f0_length, 
 	if (f0_length <= 0) return;
 	const int n_ap = GetNumberOfAperiodicities(fs);
 	ScopedBuf in, out;
-	int rc = n_ap >= 1 ? rows_to_device(coded_aperiodicity, f0_length, n_ap, in, dev->stream) : fail(WC_ERR_INVALID, "decode_aperiodicity: fs must exceed 12 kHz");
+	int rc = n_ap >= 1 ? rows_to_device(coded_aperiodicity, f0_length, n_ap, in, dev->active()) : fail(WC_ERR_INVALID, "decode_aperiodicity: fs must exceed 12 kHz");
 	if (!rc) rc = out.reserve(sizeof(double) * (size_t)f0_length * (fft_size / 2 + 1));
 	if (!rc) rc = wc_decode_aperiodicity_device(fs, fft_size, f0_length, in.as<double>(), out.as<double>());
-	if (!rc) rc = device_to_rows(out, f0_length, fft_size / 2 + 1, aperiodicity, dev->stream);
+	if (!rc) rc = device_to_rows(out, f0_length, fft_size / 2 + 1, aperiodicity, dev->active());
 	report(rc);
 }
 

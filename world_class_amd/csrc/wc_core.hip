@@ -1,5 +1,6 @@
 // Library-wide plumbing of the C-ABI: error state, per-device state (stream, twiddle table, RNG draw
 // table), device buffers, size helpers.  No signal-path arithmetic lives here except the RNG table.
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -152,6 +153,7 @@ int launch_rng_fill(Device *dev, uint32_t *table, uint64_t first, uint64_t count
 }
 
 int Device::ensure_rng(uint64_t first, uint64_t last) {
+	std::lock_guard<std::recursive_mutex> lk(mu);
 	if (last <= first) return WC_OK;
 	if (rng_count > 0 && first >= rng_base && last <= rng_base + rng_count) return WC_OK;
 	uint64_t nb = (first / kRngChunk) * kRngChunk;
@@ -162,7 +164,7 @@ int Device::ensure_rng(uint64_t first, uint64_t last) {
 	cnt += cnt / 8;  // slack so slightly longer batches do not regenerate
 	cnt = ((cnt + kRngChunk - 1) / kRngChunk) * kRngChunk;
 	if (cnt > (1ull << 33)) return fail(WC_ERR_UNSUPPORTED, "RNG table request too large");
-	WC_HIP(hipStreamSynchronize(stream));  // previous kernels may still read the old table
+	quiesce();  // earlier kernels -- on whichever stream -- may still read the old table
 	rng_count = 0;
 	int rc = rng_table.reserve(cnt * sizeof(uint32_t));
 	if (rc) return rc;
@@ -175,7 +177,7 @@ int Device::ensure_rng(uint64_t first, uint64_t last) {
 
 int Device::time_begin(const char *name, hipStream_t s) {
 	if (!timing) return WC_OK;
-	if (!s) s = stream;
+	if (!s) s = active();
 	const std::string key = time_tag >= 0 ? std::string(name) + "#" + std::to_string(time_tag) : std::string(name);
 	auto it = events.find(key);
 	if (it == events.end()) {
@@ -189,7 +191,7 @@ int Device::time_begin(const char *name, hipStream_t s) {
 }
 int Device::time_end(const char *name, hipStream_t s) {
 	if (!timing) return WC_OK;
-	if (!s) s = stream;
+	if (!s) s = active();
 	const std::string key = time_tag >= 0 ? std::string(name) + "#" + std::to_string(time_tag) : std::string(name);
 	auto it = events.find(key);
 	if (it == events.end()) return WC_OK;
@@ -201,11 +203,19 @@ int Device::time_end(const char *name, hipStream_t s) {
 static std::mutex g_mu;
 static std::map<int, std::unique_ptr<Device>> g_devices;
 static thread_local int g_device_id = 0;
-static thread_local void *g_user_stream = nullptr;
-static thread_local bool g_has_user_stream = false;
-static uint64_t g_rng_position = 0;
+static thread_local void *g_user_stream = nullptr;  // wc_set_stream: per host thread, never stored in the shared Device
+static std::atomic<uint64_t> g_rng_position{0};
 
-uint64_t &global_rng_position() { return g_rng_position; }
+uint64_t global_rng_position() { return g_rng_position.load(); }
+void set_global_rng_position(uint64_t position) { g_rng_position.store(position); }
+
+hipStream_t Device::active() const { return g_user_stream ? (hipStream_t)g_user_stream : stream; }
+void Device::quiesce() const {
+	int cur = -1;
+	if (hipGetDevice(&cur) == hipSuccess && cur != id) (void)hipSetDevice(id);
+	(void)hipDeviceSynchronize();
+	if (cur >= 0 && cur != id) (void)hipSetDevice(cur);
+}
 
 Device *current_device() {
 	std::lock_guard<std::mutex> lk(g_mu);
@@ -249,12 +259,7 @@ Device *current_device() {
 		}
 		it = g_devices.emplace(g_device_id, std::move(d)).first;
 	}
-	Device *d = it->second.get();
-	if (g_has_user_stream) {
-		d->stream = (hipStream_t)g_user_stream;
-		d->user_stream = true;
-	}
-	return d;
+	return it->second.get();
 }
 
 }  // namespace wc
@@ -264,7 +269,15 @@ using namespace wc;
 extern "C" {
 
 const char *wc_last_error(void) { return g_error.c_str(); }
-const char *wc_version(void) { return "world_class_amd 0.1 (gfx950)"; }
+const char *wc_version(void) { return "world_class_amd 0.2 (gfx950)"; }
+// SHA-256 of the sources and flags this library was built from (world_class_amd/build.py checks it against the tree)
+#ifndef WC_SOURCE_HASH
+#define WC_SOURCE_HASH "unstamped"
+#endif
+const char *wc_build_hash(void) {
+	static const char stamp[] = "WC_SOURCE_HASH=" WC_SOURCE_HASH;
+	return stamp + 15;
+}
 int wc_device_count(void) {
 	int n = 0;
 	hipError_t e = hipGetDeviceCount(&n);
@@ -278,40 +291,34 @@ int wc_set_device(int device) {
 }
 int wc_get_device(void) { return g_device_id; }
 int wc_set_stream(void *hip_stream) {
-	g_user_stream = hip_stream;
-	g_has_user_stream = hip_stream != nullptr;
-	if (!g_has_user_stream) {
-		std::lock_guard<std::mutex> lk(g_mu);
-		auto it = g_devices.find(g_device_id);
-		if (it != g_devices.end() && it->second->user_stream) {
-			it->second->user_stream = false;
-			if (hipStreamCreateWithFlags(&it->second->stream, hipStreamNonBlocking) != hipSuccess)
-				return fail(WC_ERR_DEVICE, "hipStreamCreate failed");
-		}
-	}
+	g_user_stream = hip_stream;  // thread-local: other threads and the library's own stream are untouched
 	return WC_OK;
 }
 int wc_synchronize(void) {
 	Device *d = current_device();
 	if (!d) return WC_ERR_DEVICE;
-	WC_HIP(hipStreamSynchronize(d->stream));
+	WC_HIP(hipStreamSynchronize(d->active()));
 	return WC_OK;
 }
-uint64_t wc_rng_get_position(void) { return g_rng_position; }
-void wc_rng_set_position(uint64_t position) { g_rng_position = position; }
+uint64_t wc_rng_get_position(void) { return g_rng_position.load(); }
+void wc_rng_set_position(uint64_t position) { g_rng_position.store(position); }
 
 // reference src/world_matlabfunctions.cpp:243-264 as a host function on the same process-wide stream the stages
 // use: draws at the current position and advances it by one (declared in include/world_matlabfunctions.hpp)
 double randn(void) {
+	static std::mutex mu;
 	static uint64_t cached_pos = ~0ull;
 	static XorShift cached;
-	if (cached_pos != g_rng_position) {  // someone moved the stream (a stage ran, or wc_rng_set_position): jump there
+	std::lock_guard<std::mutex> lk(mu);
+	const uint64_t now = g_rng_position.load();
+	if (cached_pos != now) {  // someone moved the stream (a stage ran, or wc_rng_set_position): jump there
 		uint32_t st[4];
-		rng_state_at(g_rng_position, st);
+		rng_state_at(now, st);
 		cached = XorShift{st[0], st[1], st[2], st[3]};
 	}
 	const uint32_t raw = cached.draw();
-	cached_pos = ++g_rng_position;
+	cached_pos = now + 1;
+	g_rng_position.store(cached_pos);
 	return raw / 268435456.0 - 6.0;
 }
 
@@ -345,15 +352,15 @@ void wc_device_free(void *p) {
 int wc_memcpy_h2d(void *dst, const void *src, uint64_t bytes) {
 	Device *d = current_device();
 	if (!d) return WC_ERR_DEVICE;
-	WC_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, d->stream));
-	WC_HIP(hipStreamSynchronize(d->stream));
+	WC_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, d->active()));
+	WC_HIP(hipStreamSynchronize(d->active()));
 	return WC_OK;
 }
 int wc_memcpy_d2h(void *dst, const void *src, uint64_t bytes) {
 	Device *d = current_device();
 	if (!d) return WC_ERR_DEVICE;
-	WC_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, d->stream));
-	WC_HIP(hipStreamSynchronize(d->stream));
+	WC_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, d->active()));
+	WC_HIP(hipStreamSynchronize(d->active()));
 	return WC_OK;
 }
 int wc_set_kernel_timing(int enable) {

@@ -813,7 +813,7 @@ uint64_t d4c_draw_bound(const wc_d4c *d, int f0_length) {
 static int d4c_run_device(wc_d4c *d, int n_utt, const double *d_x, const int *x_length, const double *d_tpos,
 						  const double *d_f0, const int *f0_length, int fft_size, double *d_ap, uint64_t *rng_pos) {
 	Device *dev = d->dev;
-	hipStream_t s = dev->stream;
+	hipStream_t s = dev->active();
 	int rc;
 	uint64_t lo = ~0ull, hi = 0;
 	long long total = 0;
@@ -877,7 +877,7 @@ wc_d4c *wc_d4c_create(int fs, double threshold) {
 }
 void wc_d4c_destroy(wc_d4c *d) {
 	if (!d) return;
-	(void)hipStreamSynchronize(d->dev->stream);
+	d->dev->quiesce();
 	d->nuttall.release(); d->utts.release(); d->cnt.release(); d->off.release(); d->endpos.release(); d->endpos2.release();
 	d->ap0.release(); d->sgd.release(); d->coarse.release(); d->d_x.release(); d->d_tpos.release(); d->d_f0.release(); d->d_ap.release(); d->h_stage.release();
 	delete d;
@@ -888,6 +888,7 @@ int wc_d4c_compute_device(wc_d4c *d, int n_utt, const double *d_x, const int *x_
 	if (!d || n_utt <= 0 || !d_x || !x_length || !d_tpos || !d_f0 || !f0_length || !d_ap)
 		return fail(WC_ERR_INVALID, "d4c: null argument");
 	WC_HIP(hipSetDevice(d->dev->id));
+	DeviceLock lock(d->dev);
 	return d4c_run_device(d, n_utt, d_x, x_length, d_tpos, d_f0, f0_length, fft_size, d_ap, rng_pos);
 }
 
@@ -897,7 +898,8 @@ int wc_d4c_compute(wc_d4c *d, const double *x, int x_length, const double *tempo
 	if (x_length <= 0 || f0_length < 0) return fail(WC_ERR_INVALID, "d4c: bad length");
 	if (f0_length == 0) return WC_OK;
 	WC_HIP(hipSetDevice(d->dev->id));
-	hipStream_t s = d->dev->stream;
+	DeviceLock lock(d->dev);
+	hipStream_t s = d->dev->active();
 	const int bins = fft_size / 2 + 1;
 	int rc;
 	if ((rc = d->d_x.reserve(sizeof(double) * x_length))) return rc;
@@ -911,7 +913,7 @@ int wc_d4c_compute(wc_d4c *d, const double *x, int x_length, const double *tempo
 	rc = d4c_run_device(d, 1, d->d_x.as<double>(), &x_length, d->d_tpos.as<double>(), d->d_f0.as<double>(), &f0_length,
 						fft_size, d->d_ap.as<double>(), &pos);
 	if (rc) return rc;
-	global_rng_position() = pos;
+	set_global_rng_position(pos);
 	std::vector<double> host((size_t)f0_length * bins);
 	WC_HIP(hipMemcpyAsync(host.data(), d->d_ap.p, sizeof(double) * host.size(), hipMemcpyDeviceToHost, s));
 	WC_HIP(hipStreamSynchronize(s));

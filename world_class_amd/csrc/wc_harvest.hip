@@ -1458,6 +1458,7 @@ struct wc_harvest {
 	std::vector<int> half_len, tap_off;
 	DevBuf d_taps, d_tap_off, d_half_len, d_band_f0, d_ev_band_off, d_ev_cap, d_rot;
 	DevBuf d_sd_rot, d_sd_p0, d_slot_off, d_slot_cap, slots, slot_count;
+	bool debug_small_caps;  // WC_DEBUG_SMALL_CAPS, read once at creation: tiny rate-bounded buffers, so that the overflow retry runs (tests)
 	bool use_fir;  // WC_HARVEST_BANDPASS=fir: the direct FIR band-pass instead of the sliding DFT (A/B and tests)
 	bool use_cos_table;  // HarvestOption::use_cos_table
 	DevBuf d_cos_table;
@@ -1564,7 +1565,7 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 		for (int b = 0; b < nb; ++b) {
 			int hard = max_ylen / 2 + 4;
 			int soft = static_cast<int>(2.5 * h->band_f0[b] * (max_ylen / h->fs_d)) + 64;
-			if (getenv("WC_DEBUG_SMALL_CAPS")) soft = 24;  // test hook: forces the overflow-and-retry path
+			if (h->debug_small_caps) soft = 24;  // test hook: forces the overflow-and-retry path
 			ev_cap[b] = full ? hard : std::min(hard, soft);
 			ev_band_off[b] = per_utt;
 			per_utt += 4ll * ev_cap[b];
@@ -1580,7 +1581,7 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 		for (int b = 0; b < nb; ++b) {
 			const int hard = SD_CH / 2 + 2;
 			int soft = static_cast<int>(2.5 * h->band_f0[b] * (SD_CH / h->fs_d)) + 16;
-			if (getenv("WC_DEBUG_SMALL_CAPS")) soft = 3;
+			if (h->debug_small_caps) soft = 3;
 			slot_cap[b] = full ? hard : std::min(hard, soft);
 			slot_off[b] = slots_per_utt;
 			slots_per_utt += 4ll * n_tiles * slot_cap[b];
@@ -1716,7 +1717,7 @@ int hv_overflowed(wc_harvest *h, hipStream_t s, bool *overflow) {
 }
 
 static int hv_run_device(wc_harvest *h, int n_utt, const double *d_x, const int *x_length, double *d_tpos, double *d_f0) {
-	hipStream_t s = h->dev->stream;
+	hipStream_t s = h->dev->active();
 	int rc;
 	for (int attempt = 0; attempt < 2; ++attempt) {
 		if ((rc = hv_enqueue(h, s, n_utt, d_x, x_length, d_tpos, d_f0, attempt == 1, nullptr, nullptr))) return rc;
@@ -1811,6 +1812,7 @@ wc_harvest *wc_harvest_create(int fs, double f0_floor, double f0_ceil, double fr
 			 hipMemcpy(h->d_sd_p0.p, sd_p0.data(), sizeof(double2) * sd_p0.size(), hipMemcpyHostToDevice) == hipSuccess;
 		const char *bp = getenv("WC_HARVEST_BANDPASS");
 		h->use_fir = bp && std::strcmp(bp, "fir") == 0;
+		h->debug_small_caps = getenv("WC_DEBUG_SMALL_CAPS") != nullptr;
 		const char *dm = getenv("WC_HARVEST_DECIMATE");
 		h->direct_decimation = dm && std::strcmp(dm, "direct") == 0;
 	}
@@ -1845,7 +1847,7 @@ wc_harvest *wc_harvest_create(int fs, double f0_floor, double f0_ceil, double fr
 
 void wc_harvest_destroy(wc_harvest *h) {
 	if (!h) return;
-	(void)hipStreamSynchronize(h->dev->stream);
+	h->dev->quiesce();
 	for (DevBuf *b : {&h->d_cos_table, &h->d_sd_rot, &h->d_sd_p0, &h->d_slot_off, &h->d_slot_cap, &h->slots, &h->slot_count, &h->d_rot, &h->d_taps, &h->d_tap_off, &h->d_half_len, &h->d_band_f0, &h->d_ev_band_off, &h->d_ev_cap, &h->utts, &h->dec, &h->y,
 					  &h->events, &h->ev_count, &h->overflow, &h->tile_run, &h->raw, &h->cand0, &h->cand1, &h->score1, &h->cand2, &h->score2, &h->base,
 					  &h->s1, &h->s2, &h->s3, &h->fixed, &h->f0_1ms, &h->sec, &h->chan, &h->smooth, &h->ibuf, &h->d_x, &h->d_tpos, &h->d_f0})
@@ -1857,6 +1859,7 @@ void wc_harvest_destroy(wc_harvest *h) {
 int wc_harvest_compute_device(wc_harvest *h, int n_utt, const double *d_x, const int *x_length, double *d_tpos, double *d_f0) {
 	if (!h || n_utt <= 0 || !d_x || !x_length || !d_tpos || !d_f0) return fail(WC_ERR_INVALID, "harvest: null argument");
 	WC_HIP(hipSetDevice(h->dev->id));
+	DeviceLock lock(h->dev);
 	return hv_run_device(h, n_utt, d_x, x_length, d_tpos, d_f0);
 }
 
@@ -1864,7 +1867,8 @@ int wc_harvest_compute(wc_harvest *h, const double *x, int x_length, double *tem
 	if (!h || !x || !temporal_positions || !f0) return fail(WC_ERR_INVALID, "harvest: null argument");
 	if (x_length <= 0) return fail(WC_ERR_INVALID, "harvest: bad length");
 	WC_HIP(hipSetDevice(h->dev->id));
-	hipStream_t s = h->dev->stream;
+	DeviceLock lock(h->dev);
+	hipStream_t s = h->dev->active();
 	const int L = wc_get_samples(h->fs, x_length, h->frame_period);
 	int rc;
 	if ((rc = h->d_x.reserve(sizeof(double) * x_length))) return rc;
@@ -1902,8 +1906,8 @@ long long wc_harvest_debug_fetch(wc_harvest *h, const char *name, int utt, doubl
 	else if (nm == "f0_1ms") { src = h->f0_1ms.as<double>() + u.l1_off; n = u.L1; }
 	else return fail(WC_ERR_INVALID, "harvest debug: unknown name");
 	if (dst) {
-		WC_HIP(hipMemcpyAsync(dst, src, sizeof(double) * n, hipMemcpyDeviceToHost, h->dev->stream));
-		WC_HIP(hipStreamSynchronize(h->dev->stream));
+		WC_HIP(hipMemcpyAsync(dst, src, sizeof(double) * n, hipMemcpyDeviceToHost, h->dev->active()));
+		WC_HIP(hipStreamSynchronize(h->dev->active()));
 	}
 	return n;
 }

@@ -46,9 +46,15 @@ struct HostBuf {
 // Per-device shared state.
 struct Device {
 	int id = 0;
-	hipStream_t stream = nullptr;  // library-owned non-blocking stream (or user stream)
-	bool user_stream = false;
-	std::mutex mu;
+	hipStream_t stream = nullptr;  // library-owned non-blocking stream: created once, never replaced
+	// the stream this thread's calls enqueue on: the calling thread's wc_set_stream() stream, else `stream`
+	hipStream_t active() const;
+	// waits for everything on the device (handles are destroyed / the RNG table is replaced behind it: work that uses
+	// their buffers may sit on the library stream, on a caller's stream or on the pipeline's side streams)
+	void quiesce() const;
+	// One public call at a time per device: the calls of several host threads that drive handles on the same device
+	// are serialised (they share the RNG draw table, the timing events and the noise-stream position).
+	std::recursive_mutex mu;
 	double2 *twiddle = nullptr;  // kTwiddleN entries, e^{+2 pi i k / kTwiddleN}
 	// RNG draw table: raw 12-step sums (uint32) of the reference's randn() for stream positions
 	// [rng_base, rng_base + rng_count)
@@ -59,12 +65,19 @@ struct Device {
 	bool timing = false;
 	int time_tag = -1;  // >= 0: events are keyed "name#tag" (the pipeline runs each kernel once per utterance group)
 	std::map<std::string, std::pair<hipEvent_t, hipEvent_t>> events;
-	int time_begin(const char *name, hipStream_t s = nullptr);  // nullptr = this->stream
+	int time_begin(const char *name, hipStream_t s = nullptr);  // nullptr = active()
 	int time_end(const char *name, hipStream_t s = nullptr);
 };
 
 Device *current_device();  // creates the state on first use; nullptr + error on failure
-uint64_t &global_rng_position();
+// process-wide noise-stream position of the host-pointer calls (atomic: handles on different devices share it)
+uint64_t global_rng_position();
+void set_global_rng_position(uint64_t position);
+// RAII: serialises the public calls on one device
+struct DeviceLock {
+	std::unique_lock<std::recursive_mutex> lk;
+	explicit DeviceLock(Device *d) : lk(d->mu) {}
+};
 
 // utterance descriptors uploaded per batch call
 struct UttDesc {

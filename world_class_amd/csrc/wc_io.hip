@@ -117,7 +117,9 @@ int wav_parse(const char *filename, std::vector<unsigned char> &buf, WavInfo &w,
 	c.skip(1);
 	if (!wav_find_data(c)) { complain("data error."); return -1; }
 	const int bytes = c.le(4);
-	if (w.nbit < 8) { complain("data error."); return -1; }  // (the reference would divide by zero)
+	// whole-byte PCM of 1 to 4 bytes only: the reference divides by zero below 8 bits and, like any reader that sizes its
+	// sample scratch for 32 bits, runs off it above (the header field is one byte: up to 255)
+	if (w.nbit != 8 && w.nbit != 16 && w.nbit != 24 && w.nbit != 32) { complain("data error."); return -1; }
 	w.length = bytes / (w.nbit / 8);
 	w.data_pos = c.pos;
 	return 1;
@@ -368,9 +370,10 @@ int wc_pcm16_to_double_device(const int16_t *d_pcm, long long n, double *d_x) {
 	if (n < 0 || (n > 0 && (!d_pcm || !d_x))) return fail(WC_ERR_INVALID, "pcm16_to_double: bad argument");
 	Device *dev = current_device();
 	if (!dev) return WC_ERR_DEVICE;
+	DeviceLock lock(dev);
 	if (n == 0) return WC_OK;
 	const unsigned blocks = static_cast<unsigned>(std::min<long long>((n + 255) / 256, 65536));
-	hipLaunchKernelGGL(pcm16_to_double_kernel, dim3(blocks), dim3(256), 0, dev->stream, d_pcm, n, d_x);
+	hipLaunchKernelGGL(pcm16_to_double_kernel, dim3(blocks), dim3(256), 0, dev->active(), d_pcm, n, d_x);
 	WC_HIP(hipGetLastError());
 	return WC_OK;
 }
@@ -379,9 +382,10 @@ int wc_double_to_pcm16_device(const double *d_y, long long n, int16_t *d_pcm) {
 	if (n < 0 || (n > 0 && (!d_pcm || !d_y))) return fail(WC_ERR_INVALID, "double_to_pcm16: bad argument");
 	Device *dev = current_device();
 	if (!dev) return WC_ERR_DEVICE;
+	DeviceLock lock(dev);
 	if (n == 0) return WC_OK;
 	const unsigned blocks = static_cast<unsigned>(std::min<long long>((n + 255) / 256, 65536));
-	hipLaunchKernelGGL(double_to_pcm16_kernel, dim3(blocks), dim3(256), 0, dev->stream, d_y, n, d_pcm);
+	hipLaunchKernelGGL(double_to_pcm16_kernel, dim3(blocks), dim3(256), 0, dev->active(), d_y, n, d_pcm);
 	WC_HIP(hipGetLastError());
 	return WC_OK;
 }
@@ -392,13 +396,14 @@ int wc_modify_parameters_device(int fs, int fft_size, long long n_frames, double
 		return fail(WC_ERR_INVALID, "modify_parameters: bad argument (fft_size <= 4096, ratio >= 0)");
 	Device *dev = current_device();
 	if (!dev) return WC_ERR_DEVICE;
+	DeviceLock lock(dev);
 	if (n_frames == 0) return WC_OK;
 	if (d_f0 && f0_scale != 1.0) {
 		const unsigned blocks = static_cast<unsigned>(std::min<long long>((n_frames + 255) / 256, 65536));
-		hipLaunchKernelGGL(scale_f0_kernel, dim3(blocks), dim3(256), 0, dev->stream, d_f0, n_frames, f0_scale);
+		hipLaunchKernelGGL(scale_f0_kernel, dim3(blocks), dim3(256), 0, dev->active(), d_f0, n_frames, f0_scale);
 	}
 	if (d_sp && spectral_ratio != 0.0)
-		hipLaunchKernelGGL(stretch_kernel, dim3(static_cast<unsigned>(n_frames)), dim3(256), 0, dev->stream, d_sp, fs, fft_size, spectral_ratio);
+		hipLaunchKernelGGL(stretch_kernel, dim3(static_cast<unsigned>(n_frames)), dim3(256), 0, dev->active(), d_sp, fs, fft_size, spectral_ratio);
 	WC_HIP(hipGetLastError());
 	return WC_OK;
 }

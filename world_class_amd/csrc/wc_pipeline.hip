@@ -107,7 +107,7 @@ wc_pipeline *wc_pipeline_create(int fs, double frame_period, double harvest_f0_f
 			G.d4 = G.ct ? wc_d4c_create(fs, d4c_threshold) : nullptr;
 			G.sy = G.d4 ? wc_synthesis_create(fs, p->fft_size, frame_period) : nullptr;
 			ok = G.sy != nullptr;
-			if (g == 0) { G.main = dev->stream; G.aux = p->s1; }
+			if (g == 0) { G.main = dev->active(); G.aux = p->s1; }
 			else { G.main = p->n_split > 1 ? p->hs[1] : p->s2; G.aux = p->s2; }
 			ok = ok && hipEventCreateWithFlags(&G.e0, hipEventDisableTiming) == hipSuccess;
 			ok = ok && hipEventCreateWithFlags(&G.e_aux, hipEventDisableTiming) == hipSuccess;
@@ -126,7 +126,7 @@ wc_pipeline *wc_pipeline_create(int fs, double frame_period, double harvest_f0_f
 
 void wc_pipeline_destroy(wc_pipeline *p) {
 	if (!p) return;
-	if (p->dev) (void)hipStreamSynchronize(p->dev->stream);
+	if (p->dev) p->dev->quiesce();
 	for (DevBuf *b : {&p->b_x, &p->b_pcm, &p->b_t, &p->b_f, &p->b_sp, &p->b_ap, &p->b_y, &p->b_ypcm}) b->release();
 	p->st_in.release();
 	p->st_out.release();
@@ -163,8 +163,9 @@ int wc_pipeline_run_device(wc_pipeline *p, int n_utt, const double *d_x, const i
 	if (!p || n_utt <= 0 || !d_x || !x_length || !d_tpos || !d_f0 || !d_sp || !d_ap || !d_y)
 		return fail(WC_ERR_INVALID, "pipeline: null argument");
 	WC_HIP(hipSetDevice(p->dev->id));
+	DeviceLock lock(p->dev);
 	Device *dev = p->dev;
-	hipStream_t s0 = dev->stream;
+	hipStream_t s0 = dev->active();
 	std::vector<int> f_len(n_utt), y_len(n_utt);
 	uint64_t lo = ~0ull, hi = 0;
 	const int bins = p->fft_size / 2 + 1;
@@ -191,6 +192,7 @@ int wc_pipeline_run_device(wc_pipeline *p, int n_utt, const double *d_x, const i
 		// runs in the shadow of an ALU-bound one:
 		//   Harvest_A heavy | tail_A next to Harvest_B heavy | tail_B next to CheapTrick/D4C_A | pulses_A | D4C_B | pulses_B
 		// (tail = unreliable-candidate test, contour logic, smoothing; the Synthesis time bases hide the same way)
+		p->grp[0].main = s0;  // chain A runs on the calling thread's stream (wc_set_stream) -- resolved per call, not at creation
 		bool full[2][2] = {{false, false}, {false, false}};
 		for (int attempt = 0; attempt < 3; ++attempt) {
 			const int bins_ = p->fft_size / 2 + 1;
@@ -204,6 +206,10 @@ int wc_pipeline_run_device(wc_pipeline *p, int n_utt, const double *d_x, const i
 					for (int u = sl[g].u0; u < sl[g].u0 + sl[g].nu; ++u) { xo += x_length[u]; fo += f_len[u]; yo += y_len[u]; }
 				}
 			}
+			// 0. chain B's own stream starts behind whatever already sits on the caller's stream (an upload of the samples, the
+			//    caller's kernels): its decimation reads d_x right away.  (The aux streams follow their main streams through e0.)
+			WC_HIP(hipEventRecord(p->e1, s0));
+			WC_HIP(hipStreamWaitEvent(p->grp[1].main, p->e1, 0));
 			// 1. both Harvest chains; B's starts when A's refinement kernel is done
 			for (int g = 0; g < 2; ++g) {
 				PipeGroup &G = p->grp[g];
@@ -310,7 +316,8 @@ int wc_pipeline_run_batch_host(wc_pipeline *p, int n_utt, const void *const *x, 
 							   uint64_t *rng_pos) {
 	if (!p || n_utt <= 0 || !x || !x_length) return fail(WC_ERR_INVALID, "pipeline batch: null argument");
 	WC_HIP(hipSetDevice(p->dev->id));
-	hipStream_t s = p->dev->stream;
+	DeviceLock lock(p->dev);
+	hipStream_t s = p->dev->active();
 	const int bins = p->fft_size / 2 + 1;
 	std::vector<int> f_len(n_utt), y_len(n_utt);
 	long long nx = 0, nf = 0, ny = 0;

@@ -474,7 +474,7 @@ struct SynArgs {
 	double *out;
 	long long total_pulses;  // launch size (capacity); the real count is pulse_prefix[n_utt]
 	const unsigned long long *rng_start;  // per-utterance stream position (device), NULL = utts[u].rng_pos
-	long long only_pulse;  // debugging aid (env WC_DEBUG_ONLY_PULSE): synthesise only this pulse, -1 = all
+	long long only_pulse;  // debugging aid (builds with -DWC_DEBUG_HOOKS, env WC_DEBUG_ONLY_PULSE): synthesise only this pulse, -1 = all
 	int fs;
 	double frame_period;
 };
@@ -937,10 +937,14 @@ int syn_pulses(wc_synthesis *sy, hipStream_t s, const double *d_f0, const double
 	a.rng_table = dev->rng_table.as<uint32_t>(); a.rng_base = dev->rng_base; a.tw = dev->twiddle;
 	a.dc_remover = sy->dc_remover.as<double>(); a.out = d_out; a.total_pulses = co; a.fs = sy->fs;
 	a.frame_period = sy->frame_period; a.rng_start = d_start;
+#ifdef WC_DEBUG_HOOKS  // output-altering debugging aid: compiled in only on request (WC_EXTRA_FLAGS=-DWC_DEBUG_HOOKS)
 	{
 		const char *dbg = getenv("WC_DEBUG_ONLY_PULSE");
 		a.only_pulse = dbg ? atoll(dbg) : -1;
 	}
+#else
+	a.only_pulse = -1;
+#endif
 	if ((rc = dev->time_begin("synthesis_pulses", s))) return rc;
 	switch (sy->fft_size) {
 		case 512: launch_pulses<512>(a, s); break;
@@ -975,7 +979,7 @@ int syn_finish(wc_synthesis *sy, hipStream_t s, uint64_t *rng_pos_out, bool *ove
 static int syn_run_device(wc_synthesis *sy, int n_utt, const double *d_f0, const int *f0_length, const double *d_sp,
 						  const double *d_ap, const int *out_length, double *d_out, uint64_t *rng_pos) {
 	Device *dev = sy->dev;
-	hipStream_t s = dev->stream;
+	hipStream_t s = dev->active();
 	int rc;
 	uint64_t lo = ~0ull, hi = 0;
 	for (int u = 0; u < n_utt; ++u) {
@@ -1032,7 +1036,7 @@ wc_synthesis *wc_synthesis_create(int fs, int fft_size, double frame_period_ms) 
 }
 void wc_synthesis_destroy(wc_synthesis *s) {
 	if (!s) return;
-	(void)hipStreamSynchronize(s->dev->stream);
+	s->dev->quiesce();
 	s->dc_remover.release(); s->utts.release(); s->meta.release(); s->pulses.release(); s->incs.release(); s->phase.release();
 	s->d_f0.release(); s->d_sp.release(); s->d_ap.release(); s->d_out.release(); s->h_stage.release();
 	delete s;
@@ -1043,6 +1047,7 @@ int wc_synthesis_compute_device(wc_synthesis *s, int n_utt, const double *d_f0, 
 	if (!s || n_utt <= 0 || !d_f0 || !f0_length || !d_sp || !d_ap || !out_length || !d_out)
 		return fail(WC_ERR_INVALID, "synthesis: null argument");
 	WC_HIP(hipSetDevice(s->dev->id));
+	DeviceLock lock(s->dev);
 	return syn_run_device(s, n_utt, d_f0, f0_length, d_sp, d_ap, out_length, d_out, rng_pos);
 }
 
@@ -1052,7 +1057,8 @@ int wc_synthesis_compute(wc_synthesis *s, const double *f0, int f0_length, const
 	if (f0_length < 2) return fail(WC_ERR_INVALID, "synthesis: f0_length must be at least 2");
 	if (out_length <= 0) return WC_OK;
 	WC_HIP(hipSetDevice(s->dev->id));
-	hipStream_t st = s->dev->stream;
+	DeviceLock lock(s->dev);
+	hipStream_t st = s->dev->active();
 	const int bins = s->fft_size / 2 + 1;
 	int rc;
 	if ((rc = s->d_f0.reserve(sizeof(double) * f0_length))) return rc;
@@ -1071,7 +1077,7 @@ int wc_synthesis_compute(wc_synthesis *s, const double *f0, int f0_length, const
 	rc = syn_run_device(s, 1, s->d_f0.as<double>(), &f0_length, s->d_sp.as<double>(), s->d_ap.as<double>(), &out_length,
 						s->d_out.as<double>(), &pos);
 	if (rc) return rc;
-	global_rng_position() = pos;
+	set_global_rng_position(pos);
 	WC_HIP(hipMemcpyAsync(out, s->d_out.p, sizeof(double) * out_length, hipMemcpyDeviceToHost, st));
 	WC_HIP(hipStreamSynchronize(st));
 	return WC_OK;
