@@ -112,3 +112,37 @@ def rate96k_case():
 
 
 PIPELINE_CASES = ["c1_16k_2s_floor71", "c1_16k_2s_floor40", "m48k_1s", "m24k_1s_1ms"]
+
+
+def headline_case(u):
+    """utterance u (0, 1) of the benchmark's workload at its full size, 48 kHz x 10 s, with what the real reference's full
+    pipeline returns for it (tests/golden/headline_48k_10s.npz, oracle/gen_golden_headline.py): x and a dict of f0, sp/ap row
+    sums and every `stride`-th row, block sums and windows of the waveform"""
+    import hashlib
+    from world_class_amd.synth import make_utterance
+    z = np.load(os.path.join(ROOT, "tests", "golden", "headline_48k_10s.npz"))
+    k = "u%d/" % u
+    fs, sec, seed, stride, block, win = z[k + "meta"]
+    x = make_utterance(int(fs), float(sec), int(seed))
+    assert hashlib.sha256(x.tobytes()).digest() == z[k + "x_sha256"].tobytes(), "synthetic generator drifted"
+    g = {n: z[k + n] for n in ("f0", "sp_rowsum", "ap_rowsum", "sp_rows", "ap_rows", "y_blocksum", "y_win_start", "y_win")}
+    g.update(fs=int(fs), stride=int(stride), block=int(block), win=int(win), y_len=int(z[k + "y_len"][0]))
+    return x, g
+
+
+def check_headline(r, g, f0_abs, sp_rel, ap_abs, y_abs):
+    """outputs of a full-size pipeline run against headline_case's expectations"""
+    assert np.array_equal(r["f0"] == 0, g["f0"] == 0)
+    assert np.abs(r["f0"] - g["f0"]).max() < f0_abs
+    s = g["stride"]
+    assert (np.abs(r["sp"][::s] - g["sp_rows"]) / g["sp_rows"]).max() < sp_rel
+    assert np.abs(r["ap"][::s] - g["ap_rows"]).max() < ap_abs
+    bins = r["sp"].shape[1]
+    assert (np.abs(r["sp"].sum(1) - g["sp_rowsum"]) / g["sp_rowsum"]).max() < sp_rel  # every row, through its sum
+    assert np.abs(r["ap"].sum(1) - g["ap_rowsum"]).max() < ap_abs * bins
+    y = r["y"]
+    assert len(y) == g["y_len"]
+    for st, w in zip(g["y_win_start"], g["y_win"]):
+        assert np.abs(y[st:st + g["win"]] - w).max() < y_abs
+    nb = len(y) // g["block"]
+    assert np.abs(y[:nb * g["block"]].reshape(nb, g["block"]).sum(1) - g["y_blocksum"]).max() < y_abs * g["block"]

@@ -1,0 +1,126 @@
+"""-m gpu: bounded subsets of the development sweeps (tests/parity_sweep.py, tests/stage_sweep.py) as gated tests, so that
+inputs OUTSIDE the committed fixtures hold the stated tolerances too (f0 1e-6 Hz with identical V/UV, sp 1e-7 relative,
+ap 1e-7, y 1e-8): undithered signals of ten other kinds (noise, chirps, pitch jumps, two voices, clipped squares with DC,
+1e-5 and 4.0 amplitudes, digital-silence gaps, 45 Hz voices) -- whose noise-free bands make LinearSmoothing's result a matter
+of how every single addition of its cumulative sum rounded (reference src/world_common.cpp:47-51; reproduced bit for bit,
+wc_device.hpp seq_cumsum_nonneg) -- seeded utterances at 48 kHz, and stage-level runs on F0 contours Harvest never produces.
+The checker is the CPU oracle (oracle/port.py), pinned to the real reference by tests/test_oracle_golden.py."""
+import os
+
+import numpy as np
+import pytest
+
+from parity_sweep import dev
+from stage_sweep import contour
+from world_class_amd.synth import SIGNAL_KINDS, make_signal, make_utterance
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def wca():
+    import world_class_amd as w
+    w.lib()
+    return w
+
+
+@pytest.fixture(scope="module")
+def P():
+    from oracle import port
+    p = port.Port()
+    p.set_threads(os.cpu_count() or 1)
+    yield p
+    p.set_threads(0)
+    p.rng_reset()
+
+
+def check(r, o, x, what, f0_only=False):
+    assert np.array_equal(r["f0"] == 0, o["f0"] == 0), what + ": voiced/unvoiced decisions differ"
+    assert dev(r["f0"], o["f0"]) < 1e-6, what
+    if f0_only:
+        return
+    assert dev(r["sp"], o["sp"], rel=True) < 1e-7, what
+    assert dev(r["ap"], o["ap"]) < 1e-7, what
+    assert dev(r["y"], o["y"]) / max(1.0, float(np.abs(x).max())) < 1e-8, what
+
+
+def test_other_signal_kinds_16k(wca, P):
+    """two signals of every kind except impulse trains (below), no dither"""
+    fs = 16000
+    seeds = [230000 + i for i in range(20) if SIGNAL_KINDS[(230000 + i) % len(SIGNAL_KINDS)] != "impulses"]
+    xs = [make_signal(fs, 1.5, s) for s in seeds]
+    res = wca.Pipeline(fs).run_batch(xs)
+    for s, x, r in zip(seeds, xs, res):
+        check(r, P.pipeline(x, fs), x, "seed %d (%s)" % (s, SIGNAL_KINDS[s % len(SIGNAL_KINDS)]))
+
+
+def test_impulse_trains_agree_in_voicing_and_within_a_window_length_step(wca, P):
+    """A train whose period is a whole number of samples at the decimated rate puts 1.5 fs / f0 + 1 exactly on an integer
+    (reference src/harvest.cpp:950): the refinement window is 45 or 46 samples long depending on the last bits of the raw
+    candidate, in any implementation -- the reference's own choice is made by the rounding of its FFT convolution.  The
+    contour then moves by a few mHz on those frames; voicing decisions must still agree."""
+    fs = 16000
+    seeds = [230003, 230013, 230023, 230033]
+    xs = [make_signal(fs, 1.5, s) for s in seeds]
+    assert all(SIGNAL_KINDS[s % len(SIGNAL_KINDS)] == "impulses" for s in seeds)
+    res = wca.Pipeline(fs).run_batch(xs)
+    for s, x, r in zip(seeds, xs, res):
+        o = P.pipeline(x, fs)
+        assert np.array_equal(r["f0"] == 0, o["f0"] == 0), s
+        assert dev(r["f0"], o["f0"]) < 0.1, s
+        assert np.mean(np.abs(r["f0"] - o["f0"]) > 1e-6) < 0.25, s
+
+
+def test_seeded_utterances_48k(wca, P):
+    fs = 48000
+    seeds = [200240 + i for i in range(6)]
+    xs = [make_utterance(fs, 2.0, s) for s in seeds]
+    res = wca.Pipeline(fs).run_batch(xs)
+    for s, x, r in zip(seeds, xs, res):
+        check(r, P.pipeline(x, fs), x, "seed %d" % s)
+
+
+def test_other_signal_kinds_48k_1ms_hop(wca, P):
+    fs = 48000
+    seeds = [230101, 230104, 230108]  # chirp, duet, gaps
+    xs = [make_signal(fs, 1.0, s) for s in seeds]
+    res = wca.Pipeline(fs, frame_period=1.0).run_batch(xs)
+    for s, x, r in zip(seeds, xs, res):
+        check(r, P.pipeline(x, fs, frame_period=1.0), x, "seed %d (%s)" % (s, SIGNAL_KINDS[s % len(SIGNAL_KINDS)]))
+
+
+def test_stages_on_arbitrary_contours(wca, P):
+    """CheapTrick, D4C and Synthesis through the C-ABI on contours between 30 and 1300 Hz, six rates, three hops; the oracle's
+    parameters go into Synthesis on both sides, and the noise-stream positions must agree after every stage"""
+    worst = dict(sp=0.0, ap=0.0, y=0.0)
+    for c in range(16):
+        seed = 70000 + c
+        rng = np.random.default_rng(seed)
+        fs = int(rng.choice([8000, 16000, 22050, 24000, 44100, 48000]))
+        fp = float(rng.choice([1.0, 5.0, 5.0, 10.0]))
+        x = make_utterance(fs, float(rng.uniform(0.3, 1.5)), seed)
+        nfr = wca.get_samples(fs, len(x), fp)
+        tpos = np.arange(nfr) * fp / 1000.0
+        f0 = contour(rng, nfr)
+        start = int(rng.integers(0, 10 ** 6))
+        P.rng_seek(start)
+        sp_o = P.cheaptrick(x, fs, tpos, f0)
+        wca.rng_set_position(start)
+        sp_g = wca.CheapTrick(fs).compute(x, tpos, f0)
+        assert wca.rng_get_position() == P.rng_position()
+        n = (sp_o.shape[1] - 1) * 2
+        P.rng_seek(start)
+        ap_o = P.d4c(x, fs, tpos, f0, n)
+        wca.rng_set_position(start)
+        ap_g = wca.D4C(fs).compute(x, tpos, f0, n)
+        assert wca.rng_get_position() == P.rng_position()
+        P.rng_seek(start)
+        y_o = P.synthesis(f0, sp_o, ap_o, fs, fp)
+        wca.rng_set_position(start)
+        y_g = wca.Synthesis(fs, n, fp).compute(f0, sp_o, ap_o)
+        assert wca.rng_get_position() == P.rng_position()
+        worst["sp"] = max(worst["sp"], dev(sp_g, sp_o, rel=True))
+        worst["ap"] = max(worst["ap"], dev(ap_g, ap_o))
+        worst["y"] = max(worst["y"], dev(y_g, y_o))
+    wca.rng_set_position(0)
+    assert worst["sp"] < 1e-7 and worst["ap"] < 1e-7 and worst["y"] < 1e-8, worst

@@ -4,7 +4,7 @@ These pin the oracle that the -m gpu parity tests then use as the checker."""
 import numpy as np
 import pytest
 
-from conftest import HARVEST_LONG_CASES, PIPELINE_CASES, harvest_edge_rows, harvest_long_case, harvest_option_cases, rate96k_case, same_candidates, stage_option_cases
+from conftest import HARVEST_LONG_CASES, PIPELINE_CASES, check_headline, headline_case, harvest_edge_rows, harvest_long_case, harvest_option_cases, rate96k_case, same_candidates, stage_option_cases
 from world_class_amd.synth import make_utterance
 
 # tolerances of the restatement vs the reference (FP64; only the FFT rounding differs)
@@ -220,6 +220,17 @@ def test_pipeline_at_96_khz_against_golden(port):
     assert (np.abs(r["sp"].sum(axis=1) - z["sp_rowsum"]) / z["sp_rowsum"]).max() < SP_REL
     assert np.abs(r["ap"][::stride] - z["ap_rows"]).max() < AP_ABS
     assert np.abs(r["y"] - z["y"]).max() < Y_ABS
+
+
+def test_headline_utterance_against_golden(port):
+    """the benchmark's utterance size (48 kHz, 10 s): the restatement against the real reference on every frame"""
+    x, g = headline_case(0)
+    port.set_threads(8)
+    try:
+        r = port.pipeline(x, g["fs"])
+    finally:
+        port.set_threads(0)
+    check_headline(r, g, F0_ABS, SP_REL, AP_ABS, Y_ABS)
 
 
 def test_device_argsort_reproduces_std_sort(tmp_path):

@@ -48,7 +48,8 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 	constexpr int EPT = (N + T - 1) / T;       // window elements per thread
 	constexpr int BPT = (M + 1 + T - 1) / T;   // bins per thread
 	__shared__ double2 A[fft_lds_size(M)];
-	__shared__ double P[M + 2];
+	constexpr int SCR = T + 2 * (T / 64);  // scratch of the exact cumulative sum: it reuses P once the terms are formed
+	__shared__ double P[(M + 2 > SCR) ? M + 2 : SCR];
 	__shared__ double red[2 * (T / 64) + 2];
 	double *Ar = reinterpret_cast<double *>(A);
 
@@ -166,23 +167,12 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 			if (i < M + b) return P[i - b];
 			return P[M - (i - (M + b))];
 		};
-		const int ch = (len + T - 1) / T;
-		const int lo = tid * ch, hi = min(len, lo + ch);
-		double loc = 0.0;
-		for (int i = lo; i < hi; ++i) loc += mir(i) * fs / N;
-		double base = block_excl_scan<T>(loc, red, tid);
-		// Ar is free (the spectrum has been consumed): it now holds the cumulative segment
+		// Ar is free (the spectrum has been consumed): it receives the terms, then their cumulative sum in the reference's
+		// own sequential rounding (seq_cumsum_nonneg, wc_device.hpp) -- non-decreasing like the reference's, which matters
+		// because the smoothed value below is a difference of two neighbourhoods of it and goes into a logarithm
+		for (int i = tid; i < len; i += T) Ar[i] = mir(i) * fs / N;
 		__syncthreads();
-		double run = base;
-		for (int i = lo; i < hi; ++i) {
-			run = mir(i) * fs / N + run;
-			Ar[i] = run;
-		}
-		// non-decreasing like the reference's sequential sum (the smoothed value below is a difference of two
-		// neighbourhoods of it and goes into a logarithm): clamp every segment to the largest value before it
-		const double floor_v = block_excl_max_scan<T>(run, red, tid);
-		for (int i = lo; i < hi; ++i) Ar[i] = fmax(Ar[i], floor_v);
-		__syncthreads();
+		seq_cumsum_nonneg<T>(Ar, len, P, red, tid);
 		const double origin_axis = -(b - 0.5) * fs / N;
 		const double step = (double)fs / N, rstep = 1.0 / step;
 		auto seg = [&](int i) -> double { return Ar[min(max(i, 0), len - 1)]; };

@@ -147,22 +147,27 @@ __device__ __forceinline__ void linear_smoothing_lds(const double *P, double *S,
 		if (i < M + b) return P[i - b];
 		return P[M - (i - (M + b))];
 	};
-	const int ch = (len + T - 1) / T;
-	const int lo = tid * ch, hi = min(len, lo + ch);
-	double loc = 0.0;
-	for (int i = lo; i < hi; ++i) loc += mir(i) * fs / N;
-	double run = block_excl_scan<T>(loc, red, tid);
-	for (int i = lo; i < hi; ++i) {
-		run = mir(i) * fs / N + run;
-		S[i] = run;
-	}
 	if (NONNEG) {
-		// a power spectrum: keep the cumulative sum non-decreasing like the reference's sequential one (the smoothed
-		// spectrum becomes a divisor); every segment is clamped to the largest value before it
-		const double floor_v = block_excl_max_scan<T>(run, red, tid);
-		for (int i = lo; i < hi; ++i) S[i] = fmax(S[i], floor_v);
+		// a power spectrum (the smoothed spectrum becomes a divisor): the cumulative sum in the reference's own sequential
+		// rounding, seq_cumsum_nonneg of wc_device.hpp.  Once the terms stand in S, P is free until `out` rewrites it and
+		// serves as the scratch of the sum.
+		static_assert(M + 2 >= T + 2 * (T / 64), "P doubles as the scratch of the cumulative sum");
+		for (int i = tid; i < len; i += T) S[i] = mir(i) * fs / N;
+		__syncthreads();
+		seq_cumsum_nonneg<T>(S, len, const_cast<double *>(P), red, tid);
+	} else {
+		// signed input (the group-delay numerator): block-scanned, re-associated sum
+		const int ch = (len + T - 1) / T;
+		const int lo = tid * ch, hi = min(len, lo + ch);
+		double loc = 0.0;
+		for (int i = lo; i < hi; ++i) loc += mir(i) * fs / N;
+		double run = block_excl_scan<T>(loc, red, tid);
+		for (int i = lo; i < hi; ++i) {
+			run = mir(i) * fs / N + run;
+			S[i] = run;
+		}
+		__syncthreads();
 	}
-	__syncthreads();
 	const double origin_axis = -(b - 0.5) * fs / N;
 	const double step = (double)fs / N, rstep = 1.0 / step;
 	auto seg = [&](int i) -> double { return S[min(max(i, 0), len - 1)]; };

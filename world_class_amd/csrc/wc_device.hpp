@@ -157,6 +157,122 @@ __device__ __forceinline__ double block_excl_max_scan(double v, double *scratch,
 	return m;
 }
 
+// ---- the reference's sequential cumulative sum, bit for bit, in parallel ------------------------------------------
+// c[i] = fl(v[i] + c[i-1]), strictly left to right, is what reference src/world_common.cpp:47-51 computes for
+// LinearSmoothing, and the smoothed value is a DIFFERENCE of two neighbourhoods of c: where the terms are small against
+// the running sum (noise-free bands of a clean chirp, the gaps between the harmonics of a synthetic voice) the result is
+// decided by how each single addition rounded -- a tree-ordered prefix sum is more accurate and exactly therefore
+// 1e-6 away from the reference.  The sequential rounding is reproduced instead:
+//   * while the running sum c stays inside one binade [2^e, 2^(e+1)), every addition of a term v >= 0 adds the integer
+//     rn(v / ulp) ulps, whatever c is -- unless v / ulp lies exactly half way (round-to-even then looks at c's parity).
+//     A thread whose CH consecutive terms provably stay inside one binade (decided from a tree-ordered estimate of c,
+//     good to 1e-13, with a 2^-30 margin either side) and contain no tie is "clean": its exact increment d is obtained
+//     by adding its terms to 2^e; sums of such increments of one binade are exact in any order (segmented scan).
+//   * the remaining threads (binade crossings, ties, the very first terms; a handful per spectrum) are walked in order
+//     by one wavefront with the reference's own floating-point additions, hopping over the clean runs in between.
+//     (it writes their partial sums itself)
+//   * every clean thread then re-adds its terms from its exact start value.
+// In: S[0 .. len) = the terms (non-negative).  Out: S[i] = c[i].  scr: >= T + 2 (T / 64) doubles of LDS, red: >= T / 64.
+// Ends with a __syncthreads().
+template <int T>
+__device__ __forceinline__ void seq_cumsum_nonneg(double *S, int len, double *scr, double *red, int tid) {
+	constexpr int W = T / 64;
+	double *pre = scr, *wt = scr + T + W;  // pre[t]: inclusive run prefix of a clean thread / sum behind a dirty thread's terms
+	unsigned long long *msk = reinterpret_cast<unsigned long long *>(scr + T);
+	const int lane = tid & 63, w = tid >> 6;
+	const int ch = (len + T - 1) / T;
+	const int lo = min(tid * ch, len), hi = min(len, lo + ch);
+	double loc = 0.0;
+	bool bad = false;
+	for (int i = lo; i < hi; ++i) {
+		const double v = S[i];
+		loc += v;
+		bad = bad || !(v >= 0.0);
+	}
+	const double base_a = block_excl_scan<T>(loc, red, tid);
+	const double lower = base_a * (1.0 - 0x1p-30), upper = (base_a + loc) * (1.0 + 0x1p-30);
+	const int E = (__double2hiint(lower) >> 20) & 0x7ff;
+	bool dirty = tid == 0 || bad || !(lower > 0.0) || E != ((__double2hiint(upper) >> 20) & 0x7ff) || E < 64 || E > 1984;
+	double d = 0.0;
+	if (lo >= hi) {
+		dirty = tid == 0;
+	} else if (!dirty) {
+		const double C = __hiloint2double(E << 20, 0);               // 2^e, the start of the binade
+		const double rulp = __hiloint2double((2098 - E) << 20, 0);   // 2^(52 - e) = 1 / ulp
+		double r = C;
+		for (int i = lo; i < hi; ++i) {
+			const double v = S[i], t = v * rulp;
+			dirty = dirty || (t - floor(t)) == 0.5;
+			r = v + r;
+		}
+		d = dirty ? 0.0 : r - C;
+	}
+	// inclusive segmented scan of d over the threads, restarting behind every dirty thread
+	double x = d;
+	int f = dirty ? 1 : 0;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const double xo = __shfl_up(x, o, 64);
+		const int fo = __shfl_up(f, o, 64);
+		if (lane >= o) {
+			if (!f) x += xo;
+			f |= fo;
+		}
+	}
+	const unsigned long long m = __ballot(dirty);
+	if (lane == 63) wt[w] = x;
+	if (lane == 0) msk[w] = m;
+	__syncthreads();
+	if (!f)
+		for (int k = w - 1; k >= 0; --k) {
+			x += wt[k];
+			if (msk[k]) break;
+		}
+	pre[tid] = x;
+	__syncthreads();
+	if (w == 0) {  // the walk: wave-uniform, every lane computes the same values
+		double so = 0.0;
+		int prev = -1;
+		for (int k = 0; k < W; ++k) {
+			unsigned long long mk = msk[k];
+			mk = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(mk >> 32)) << 32) |
+				 (unsigned)__builtin_amdgcn_readfirstlane((int)(mk & 0xffffffffull));
+			while (mk) {
+				const int t = k * 64 + __ffsll((long long)mk) - 1;
+				mk &= mk - 1;
+				const double si = prev < 0 ? 0.0 : (t == prev + 1 ? so : so + pre[t - 1]);
+				const int l2 = min(t * ch, len), h2 = min(len, l2 + ch);
+				double run = si;
+				for (int i = l2; i < h2; ++i) {
+					run = S[i] + run;
+					if (lane == 0) S[i] = run;
+				}
+				if (lane == 0) pre[t] = run;
+				so = run;
+				prev = t;
+			}
+		}
+	}
+	__syncthreads();
+	if (!dirty) {
+		const unsigned long long below = m & ((1ull << lane) - 1ull);
+		int j;
+		if (below) {
+			j = w * 64 + 63 - __clzll((long long)below);
+		} else {  // (thread 0 is always dirty: the search ends in wave 0 at the latest)
+			int k = w - 1;
+			while (k > 0 && msk[k] == 0ull) --k;
+			j = k * 64 + 63 - __clzll((long long)msk[k]);
+		}
+		double run = pre[j] + (x - d);
+		for (int i = lo; i < hi; ++i) {
+			run = S[i] + run;
+			S[i] = run;
+		}
+	}
+	__syncthreads();
+}
+
 // ---- complex helpers ----------------------------------------------------------------------------
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
 	return make_double2(fma(a.x, b.x, -(a.y * b.y)), fma(a.x, b.y, a.y * b.x));
@@ -350,7 +466,7 @@ __device__ __forceinline__ void fft_chain(double2 *a, const double2 *__restrict_
 }
 
 template <int M, int T, int S, int FL = 1>
-__device__ void fft_lds(double2 *a, const double2 *__restrict__ tw_, int tid) {
+__device__ __forceinline__ void fft_lds(double2 *a, const double2 *__restrict__ tw_, int tid) {
 	static_assert((M & (M - 1)) == 0 && M >= 16 && M <= kTwiddleN, "M must be a power of two in [16, 4096]");
 	const double2 *__restrict__ tw = tw_fresh(tw_);
 	FftTw<M, T, fft_radix<M, 1>(), 1> first;  // the first pass has no twiddles (Ns = 1)
@@ -360,7 +476,7 @@ __device__ void fft_lds(double2 *a, const double2 *__restrict__ tw_, int tid) {
 // The passes from Ns = NS0 on, for callers that can write the state after the first passes directly (an input that is
 // zero beyond its first M / NS0 entries makes those passes pure replication).
 template <int M, int T, int S, int NS0>
-__device__ void fft_lds_tail(double2 *a, const double2 *__restrict__ tw_, int tid) {
+__device__ __forceinline__ void fft_lds_tail(double2 *a, const double2 *__restrict__ tw_, int tid) {
 	const double2 *__restrict__ tw = tw_fresh(tw_);
 	FftTw<M, T, fft_radix<M, NS0>(), NS0> first;
 	fft_load_tw<M, T, S, fft_radix<M, NS0>(), NS0, 1>(first, tw, tid);
@@ -384,7 +500,7 @@ __device__ __forceinline__ double2 tw_real(const double2 *__restrict__ tw, int k
 // After fft_lds<M,T,+1> on that array, unpack to the spectrum X[0..M] (reference r2c convention).
 // Packed in place: a[0] = (X[0].re, X[M].re); a[k] = X[k] for 0 < k < M.  Ends with a __syncthreads().
 template <int M, int T>
-__device__ void r2c_post(double2 *a, const double2 *__restrict__ tw_, int tid) {
+__device__ __forceinline__ void r2c_post(double2 *a, const double2 *__restrict__ tw_, int tid) {
 	const double2 *__restrict__ tw = tw_fresh(tw_);
 	// pairs (k, M-k), k = 1 .. M/2-1 ; k = 0 and k = M/2 handled apart
 	for (int k = tid; k <= M / 2; k += T) {
@@ -432,7 +548,7 @@ __device__ __forceinline__ void r2c_power(const double2 *a, const double2 *__res
 // Inverse of the above: a holds the packed spectrum Y (a[0] = (Y[0].re, Y[M].re)); produce Z so that
 // fft_lds<M,T,-1> yields the real signal y[n] interleaved (reference c2r convention, unnormalised).
 template <int M, int T>
-__device__ void c2r_pre(double2 *a, const double2 *__restrict__ tw_, int tid) {
+__device__ __forceinline__ void c2r_pre(double2 *a, const double2 *__restrict__ tw_, int tid) {
 	const double2 *__restrict__ tw = tw_fresh(tw_);
 	for (int k = tid; k <= M / 2; k += T) {
 		if (k == 0) {

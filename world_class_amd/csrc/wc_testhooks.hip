@@ -1,0 +1,161 @@
+// Development / test hooks (not part of include/world_class_c.h): the device building blocks of wc_device.hpp run on
+// their own, so that -m gpu tests can pin them directly -- the in-LDS FFT against the reference's transform conventions
+// (reference src/world_fft.cpp:31-167; goldens fft/* made by the real reference), the order-faithful cumulative sum
+// against a sequential loop.  One workgroup per transform / sequence; nothing here is on the product path.
+#include <vector>
+
+#include "wc_device.hpp"
+#include "wc_internal.hpp"
+
+namespace wc {
+
+// kind 0: r2c, in N doubles, out (N/2+1) complex.  kind 1: c2r, in (N/2+1) complex, out N doubles (imaginary parts of
+// bins 0 and N/2 ignored, unnormalised).  One transform per block.
+// (the direction is a template parameter: the FFT launders its table pointer through a scalar register per call, which the
+// compiler cannot do under a run-time branch)
+template <int N, int T, int KIND>
+__global__ __launch_bounds__(T) void hook_real_fft_kernel(const double *__restrict__ in, double *__restrict__ out,
+														  const double2 *__restrict__ tw) {
+	constexpr int M = N / 2;
+	__shared__ double2 A[fft_lds_size(M)];
+	double *Ar = reinterpret_cast<double *>(A);
+	const int tid = threadIdx.x;
+	if constexpr (KIND == 0) {
+		const double *x = in + (size_t)blockIdx.x * N;
+		double2 *X = reinterpret_cast<double2 *>(out) + (size_t)blockIdx.x * (M + 1);
+		for (int i = tid; i < N; i += T) Ar[i] = x[i];
+		__syncthreads();
+		fft_lds<M, T, +1>(A, tw, tid);
+		r2c_post<M, T>(A, tw, tid);
+		for (int k = tid; k <= M; k += T) X[k] = k == 0 ? make_double2(A[0].x, 0.0) : k == M ? make_double2(A[0].y, 0.0) : A[k];
+	} else {
+		const double2 *Y = reinterpret_cast<const double2 *>(in) + (size_t)blockIdx.x * (M + 1);
+		double *y = out + (size_t)blockIdx.x * N;
+		for (int k = tid; k < M; k += T) A[k] = k == 0 ? make_double2(Y[0].x, Y[M].x) : Y[k];
+		__syncthreads();
+		c2r_pre<M, T>(A, tw, tid);
+		fft_lds<M, T, -1>(A, tw, tid);
+		for (int i = tid; i < N; i += T) y[i] = Ar[i];
+	}
+}
+
+// complex transform of N points, sign +1 (the reference's FFT_FORWARD, e^{+i}) or -1 (FFT_BACKWARD)
+template <int N, int T, int SIGN>
+__global__ __launch_bounds__(T) void hook_complex_fft_kernel(const double2 *__restrict__ in, double2 *__restrict__ out,
+															 const double2 *__restrict__ tw) {
+	__shared__ double2 A[fft_lds_size(N)];
+	const int tid = threadIdx.x;
+	const double2 *x = in + (size_t)blockIdx.x * N;
+	double2 *X = out + (size_t)blockIdx.x * N;
+	for (int i = tid; i < N; i += T) A[i] = x[i];
+	__syncthreads();
+	fft_lds<N, T, SIGN>(A, tw, tid);
+	for (int i = tid; i < N; i += T) X[i] = A[i];
+}
+
+template <int T>
+__global__ __launch_bounds__(T) void hook_cumsum_kernel(const double *__restrict__ v, int n, double *__restrict__ out) {
+	__shared__ double S[4096];
+	__shared__ double scr[T + 2 * (T / 64)];
+	__shared__ double red[T / 64 + 2];
+	const int tid = threadIdx.x;
+	const double *src = v + (size_t)blockIdx.x * n;
+	for (int i = tid; i < n; i += T) S[i] = src[i];
+	__syncthreads();
+	seq_cumsum_nonneg<T>(S, n, scr, red, tid);
+	for (int i = tid; i < n; i += T) out[(size_t)blockIdx.x * n + i] = S[i];
+}
+
+}  // namespace wc
+
+using namespace wc;
+
+namespace {
+struct Scoped {
+	void *p = nullptr;
+	~Scoped() { if (p) (void)hipFree(p); }
+};
+template <int N>
+void launch_real(int kind, int batch, const double *in, double *out, const double2 *tw, hipStream_t s) {
+	if (kind == 0) hipLaunchKernelGGL((hook_real_fft_kernel<N, 256, 0>), dim3(batch), dim3(256), 0, s, in, out, tw);
+	else hipLaunchKernelGGL((hook_real_fft_kernel<N, 256, 1>), dim3(batch), dim3(256), 0, s, in, out, tw);
+}
+template <int N>
+void launch_complex(int sign, int batch, const double2 *in, double2 *out, const double2 *tw, hipStream_t s) {
+	if (sign > 0) hipLaunchKernelGGL((hook_complex_fft_kernel<N, 256, +1>), dim3(batch), dim3(256), 0, s, in, out, tw);
+	else hipLaunchKernelGGL((hook_complex_fft_kernel<N, 256, -1>), dim3(batch), dim3(256), 0, s, in, out, tw);
+}
+}  // namespace
+
+extern "C" {
+
+// kind 0 r2c, 1 c2r, 2 c2c forward (e^{+i}), 3 c2c backward; host pointers; `batch` transforms back to back.
+// doubles in: N / N+2 / 2N / 2N per transform, doubles out: N+2 / N / 2N / 2N.
+int wc_debug_fft(int kind, int n, int batch, const double *in, double *out) {
+	if (kind < 0 || kind > 3 || batch <= 0 || !in || !out) return fail(WC_ERR_INVALID, "debug fft: bad argument");
+	Device *dev = current_device();
+	if (!dev) return WC_ERR_DEVICE;
+	DeviceLock lock(dev);
+	hipStream_t s = dev->active();
+	const size_t n_in = (kind == 0 ? n : kind == 1 ? n + 2 : 2 * n) * (size_t)batch;
+	const size_t n_out = (kind == 0 ? n + 2 : kind == 1 ? n : 2 * n) * (size_t)batch;
+	Scoped d_in, d_out;
+	WC_HIP(hipMalloc(&d_in.p, sizeof(double) * n_in));
+	WC_HIP(hipMalloc(&d_out.p, sizeof(double) * n_out));
+	WC_HIP(hipMemcpyAsync(d_in.p, in, sizeof(double) * n_in, hipMemcpyHostToDevice, s));
+	const double *di = static_cast<const double *>(d_in.p);
+	double *dout = static_cast<double *>(d_out.p);
+	if (kind < 2) {
+		switch (n) {
+			case 128: launch_real<128>(kind, batch, di, dout, dev->twiddle, s); break;
+			case 256: launch_real<256>(kind, batch, di, dout, dev->twiddle, s); break;
+			case 512: launch_real<512>(kind, batch, di, dout, dev->twiddle, s); break;
+			case 1024: launch_real<1024>(kind, batch, di, dout, dev->twiddle, s); break;
+			case 2048: launch_real<2048>(kind, batch, di, dout, dev->twiddle, s); break;
+			case 4096: launch_real<4096>(kind, batch, di, dout, dev->twiddle, s); break;
+			case 8192: launch_real<8192>(kind, batch, di, dout, dev->twiddle, s); break;
+			default: return fail(WC_ERR_UNSUPPORTED, "debug fft: real sizes 128 .. 8192");
+		}
+	} else {
+		const int sign = kind == 2 ? +1 : -1;
+		const double2 *ci = reinterpret_cast<const double2 *>(di);
+		double2 *co = reinterpret_cast<double2 *>(dout);
+		switch (n) {
+			case 64: launch_complex<64>(sign, batch, ci, co, dev->twiddle, s); break;
+			case 128: launch_complex<128>(sign, batch, ci, co, dev->twiddle, s); break;
+			case 256: launch_complex<256>(sign, batch, ci, co, dev->twiddle, s); break;
+			case 512: launch_complex<512>(sign, batch, ci, co, dev->twiddle, s); break;
+			case 1024: launch_complex<1024>(sign, batch, ci, co, dev->twiddle, s); break;
+			case 2048: launch_complex<2048>(sign, batch, ci, co, dev->twiddle, s); break;
+			case 4096: launch_complex<4096>(sign, batch, ci, co, dev->twiddle, s); break;
+			default: return fail(WC_ERR_UNSUPPORTED, "debug fft: complex sizes 64 .. 4096");
+		}
+	}
+	WC_HIP(hipGetLastError());
+	WC_HIP(hipMemcpyAsync(out, d_out.p, sizeof(double) * n_out, hipMemcpyDeviceToHost, s));
+	WC_HIP(hipStreamSynchronize(s));
+	return WC_OK;
+}
+
+// `batch` sequences of n (<= 4096) non-negative terms each: out = their cumulative sums as seq_cumsum_nonneg forms them
+// (threads: 256 or 512, the two block sizes the stages use)
+int wc_debug_seq_cumsum(const double *v, int n, int batch, int threads, double *out) {
+	if (!v || !out || n <= 0 || n > 4096 || batch <= 0 || (threads != 256 && threads != 512)) return fail(WC_ERR_INVALID, "debug cumsum: bad argument");
+	Device *dev = current_device();
+	if (!dev) return WC_ERR_DEVICE;
+	DeviceLock lock(dev);
+	hipStream_t s = dev->active();
+	Scoped d_in, d_out;
+	const size_t total = (size_t)n * batch;
+	WC_HIP(hipMalloc(&d_in.p, sizeof(double) * total));
+	WC_HIP(hipMalloc(&d_out.p, sizeof(double) * total));
+	WC_HIP(hipMemcpyAsync(d_in.p, v, sizeof(double) * total, hipMemcpyHostToDevice, s));
+	if (threads == 256) hipLaunchKernelGGL(hook_cumsum_kernel<256>, dim3(batch), dim3(256), 0, s, static_cast<const double *>(d_in.p), n, static_cast<double *>(d_out.p));
+	else hipLaunchKernelGGL(hook_cumsum_kernel<512>, dim3(batch), dim3(512), 0, s, static_cast<const double *>(d_in.p), n, static_cast<double *>(d_out.p));
+	WC_HIP(hipGetLastError());
+	WC_HIP(hipMemcpyAsync(out, d_out.p, sizeof(double) * total, hipMemcpyDeviceToHost, s));
+	WC_HIP(hipStreamSynchronize(s));
+	return WC_OK;
+}
+
+}  // extern "C"
