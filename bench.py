@@ -1,21 +1,34 @@
 #!/usr/bin/env python
 """Headline benchmark: analysis+synthesis frames/sec, 48 kHz, 5 ms hop (BASELINE.json `metric`).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--gather f0|y]
 
 One "step" = one pass of the whole hot path Harvest -> CheapTrick -> D4C -> Synthesis (demo order of
 reference test/test.cpp:288-384) over this rank's batch of synthetic 48 kHz 10 s utterances, inputs
-already resident in HBM, every stage on the device through the C-ABI (libworldclass_hip.so).  Utterances
-are independent, so ranks shard them with no data-path collective (weak scaling: every rank gets its own
-`--utts` utterances); the only collective is the final RCCL all-gather of the F0 contours and per-rank
-output checksums.  `value` = frames of all ranks / max-over-ranks wall time.
+already resident in HBM, every stage on the device through the C-ABI (libworldclass_hip.so).
 
-Rank 0 at N=1 also times the CPU path on a bounded sample of the same workload: the real reference's
-OpenMP build (oracle/_ref, kind "reference") when it is present, else our CPU restatement (kind "port").
+Multi-GPU: one process per GPU over RCCL.  Started under torch.distributed.run the ranks come from the
+environment; started plainly with --gpus N > 1 the script re-executes itself under torch.distributed.run
+with N ranks (and fails loudly when the box has fewer than N devices).  The global list of N x --utts
+utterances is dealt to the ranks by world_class_amd.shard.partition; utterances are independent, so there is
+no data-path collective (weak scaling), and the only collective is the final RCCL all-gather of the F0
+contours and output checksums (--gather y: of the waveforms too, BASELINE config 4's gather), timed inside
+the measured region and reported separately as `gather_ms`.  `value` = frames of all ranks / max-over-ranks
+wall time.
+
+At N = 1 rank 0 adds, outside the timed region:
+  stages          BASELINE config 3: 256 x 48 kHz 10 s, CheapTrick only, against the HBM roofline on B_ct
+  with_transfers  the same batch through the host front-end (wc_pipeline_run_batch_host): H2D of x and D2H of
+                  the outputs inside the clock; never reported as `value`
+  cpu_baseline    the real reference's OpenMP build (oracle/_ref, kind "reference") on a bounded sample of the
+                  same workload, as many concurrent processes as the host's cores allow; our CPU restatement
+                  (kind "port") when the reference build is absent
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -42,50 +55,66 @@ KERNEL_STAGE = {
 }
 SEQUENTIAL_SCANS = ("synthesis_timebase", "harvest_contour")
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
-VALU_PEAK_GINSTR = 614.4  # wave-level f64 vector instructions per second: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles
-VALU_SUSTAINED_GINSTR = 420.0  # what a pure FP64 FMA stream sustains on this part (tools/fp64_issue_rate.hip, profiles/r01_fp64_issue_rate.txt)
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
+
+
+def _ref_call(args):
+    """one fresh reference process; returns (frames, seconds)"""
+    from oracle import ref
+    x, threads, method = args
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    t0 = time.perf_counter()
+    if method == "pipeline":
+        r = ref.run_fresh("pipeline", x, FS, harvest_floor=71.0, omp=True)
+        n = len(r["f0"])
+    else:
+        ref.run_fresh("randn", 1, omp=True)
+        n = 0
+    return n, time.perf_counter() - t0
 
 
 def cpu_baseline(xs, budget_s=24.0):
     """CPU path on a bounded sample (whole utterances of the same workload), rank 0 / N=1 only.
 
-    The reference's OpenMP build is tried at several thread counts on the first utterance (it does not scale to
-    all cores of a large host: its parallel loops allocate and plan FFTs per iteration) and the best count is
-    used for the rest of the sample.  Each run is a fresh process: the reference's noise state is process-global,
-    and its Synthesis overflows its pulse arrays on some inputs, which a subprocess isolates.
+    The reference's OpenMP build does not scale to all cores of a large host inside one process (its parallel
+    loops allocate and plan FFTs per iteration), but utterances are as independent on the CPU as on the GPU: the
+    best thread count T of one process is found first, then floor(cores / T) processes run concurrently on
+    distinct utterances, and THAT whole-host rate is the baseline.  Every run is a fresh process: the reference's
+    noise state is process-global, and its Synthesis overflows its pulse arrays on some inputs,
+    which a subprocess isolates.  Process start-up (measured with a no-op call) is subtracted.
     """
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import port, ref
     cores = os.cpu_count() or 1
 
-    def ref_once(x, threads):
-        os.environ["OMP_NUM_THREADS"] = str(threads)
-        t0 = time.perf_counter()
-        r = ref.run_fresh("pipeline", x, FS, harvest_floor=71.0, omp=True)
-        dt = time.perf_counter() - t0
-        t1 = time.perf_counter()
-        ref.run_fresh("randn", 1, omp=True)  # process start-up + library load, subtracted
-        return len(r["f0"]), max(dt - (time.perf_counter() - t1), 1e-3)
-
     if ref.available(omp=True):
         try:
-            best = None
-            for th in sorted({min(cores, t) for t in (8, 16, 32, 64, cores)}):
-                n, dt = ref_once(xs[0], th)
-                if best is None or dt < best[1]:
-                    best = (th, dt, n)
-            threads, t_used, frames, n_done = best[0], best[1], best[2], 1
-            for x in xs[1:]:
-                if t_used > budget_s * 0.5:
-                    break
-                n, dt = ref_once(x, threads)
-                frames += n
-                t_used += dt
-                n_done += 1
-            return {"value": frames / t_used, "unit": "frames/s", "cores": threads, "kind": "reference",
-                    "sample": f"{n_done} x 48 kHz 10 s utterance(s) of the same synthetic workload, full pipeline, OpenMP build "
-                              f"of the reference (oracle/_ref), best of 8/16/32/64/{cores} threads = {threads} (host has {cores})"}
-        except Exception:
-            pass
+            _, t_start = _ref_call((None, 1, "noop"))
+            best = None  # (threads, frames/s of one process): the count with the best rate per thread fills the host best
+            for th in sorted({min(cores, t) for t in (4, 8, 16, 32)}):
+                n, dt = _ref_call((xs[0], th, "pipeline"))
+                rate = n / max(dt - t_start, 1e-3)
+                if best is None or rate / th > best[1] / best[0]:
+                    best = (th, rate)
+            threads, one_rate = best
+            procs = max(1, min(64, cores // threads))
+            # all processes at once, each on its own utterance of the workload (tiled when there are more processes than
+            # distinct signals: the run time does not depend on which utterance it is)
+            jobs = [(xs[i % len(xs)], threads, "pipeline") for i in range(procs)]
+            with ThreadPoolExecutor(procs) as ex:
+                t0 = time.perf_counter()
+                list(ex.map(_ref_call, [(None, threads, "noop")] * procs))
+                t_noop = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                res = list(ex.map(_ref_call, jobs))
+                wall = max(time.perf_counter() - t0 - t_noop, 1e-3)
+            frames = sum(n for n, _ in res)
+            return {"value": frames / wall, "unit": "frames/s", "cores": procs * threads, "kind": "reference",
+                    "sample": f"{procs} x 48 kHz 10 s utterance(s) of the same synthetic workload, full pipeline, OpenMP build of the "
+                              f"reference (oracle/_ref): {procs} concurrent processes x {threads} threads on a host with {cores} cores",
+                    "one_process": {"value": one_rate, "threads": threads}, "host_cores": cores}
+        except Exception as e:  # fall through to the restatement
+            sys.stderr.write(f"cpu_baseline: reference run failed ({e}); using the restatement\n")
     P = port.Port()
     P.set_threads(cores)
     frames, t_used, n_done = 0, 0.0, 0
@@ -103,6 +132,74 @@ def cpu_baseline(xs, budget_s=24.0):
                       f"(oracle/), OpenMP, {cores} threads"}
 
 
+def spawn_ranks(a, argv):
+    """plain `python bench.py --gpus N`, N > 1: re-execute under torch.distributed.run with one rank per GPU"""
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus}: this box has {have} HIP device(s); refusing to report a {a.gpus}-GPU number")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def stage_cheaptrick(w, L, torch, dev, d_x64, x_len64, d_t64, d_f64, f_len64, reps=4, iters=5):
+    """BASELINE config 3: 256 x 48 kHz x 10 s, CheapTrick only (contour = this batch's own Harvest output), resident in HBM"""
+    ct = w.CheapTrick(FS)
+    d_x = d_x64.repeat(reps)
+    d_t, d_f = d_t64.repeat(reps), d_f64.repeat(reps)
+    xl, fl = list(x_len64) * reps, list(f_len64) * reps
+    frames = sum(fl)
+    d_sp = torch.empty(frames * ct.bins, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    ct.compute_device(d_x, xl, d_t, d_f, fl, d_sp)
+    L.wc_synchronize()
+    L.wc_set_kernel_timing(1)
+    wall, kern = [], []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        ct.compute_device(d_x, xl, d_t, d_f, fl, d_sp)
+        L.wc_synchronize()
+        wall.append(time.perf_counter() - t0)
+        kern.append(float(L.wc_last_kernel_ms(b"cheaptrick_frames")) * 1e-3)
+    L.wc_set_kernel_timing(0)
+    t, k = float(np.median(wall)), float(np.mean(kern))
+    b_ct = STAGE_BYTES["cheaptrick"]
+    return {"workload": f"{len(xl)} x 48 kHz 10 s, CheapTrick only (2048-point FFT), contour given, resident in HBM (BASELINE config 3)",
+            "frames": frames, "ms": t * 1e3, "frames_per_s": frames / t, "kernel": "ct_frames_kernel<2048, 256>",
+            "kernel_ms": k * 1e3, "bytes_per_frame": b_ct, "achieved_GBps": frames * b_ct / k / 1e9,
+            "hbm_frac": frames * b_ct / k / (HBM_PEAK_GBS * 1e9)}
+
+
+def with_transfers(w, pipe, xs, frames, iters=3):
+    """the host front-end on the same batch: H2D of x and D2H of the outputs inside the clock"""
+    out = {}
+    pcm = [np.clip(np.round(x * 32768.0), -32768, 32767).astype(np.int16) for x in xs[:8]]
+    pcm = [pcm[i % len(pcm)] for i in range(len(xs))]
+    for key, inp, want, ypcm, label in (
+            ("f64_in_all_five_out", xs, ("tpos", "f0", "sp", "ap", "y"), False,
+             "x as float64 from host memory, tpos + f0 + spectrogram + aperiodicity + waveform back as float64 (section 8(d) to the letter)"),
+            ("pcm16_in_f0_pcm16_out", pcm, ("f0", "y"), True,
+             "x as the int16 PCM of a WAV file, F0 + int16 waveform back; spectrogram and aperiodicity stay in HBM")):
+        res = pipe.run_batch_host(inp, want=want, y_pcm16=ypcm)  # warm-up: pinned staging, device buffers, result arrays
+        ts = []
+        for _ in range(iters):
+            t0 = time.perf_counter()
+            pipe.run_batch_host(inp, want=want, y_pcm16=ypcm, out=res)
+            ts.append(time.perf_counter() - t0)
+        t = float(np.median(ts))
+        out[key] = {"what": label, "ms": t * 1e3, "frames_per_s": frames / t,
+                    "host_bytes_in": int(sum(v.nbytes for v in inp)),
+                    "host_bytes_out": int(sum(a.nbytes for r in res for a in r.values()))}
+        del res
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,35 +207,59 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--utts", type=int, default=64, help="utterances per GPU")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic utterances per GPU (tiled to --utts)")
+    ap.add_argument("--gather", choices=("f0", "y"), default="f0", help="what the final RCCL all-gather collects besides the checksums")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the stages / with_transfers blocks (N = 1)")
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        spawn_ranks(a, sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus}")
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} wants device {local_rank} but only {torch.cuda.device_count()} are visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+        # RCCL really spans `world` ranks on distinct devices
+        probe = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(probe)
+        ids = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(ids, torch.tensor([local_rank], dtype=torch.int64, device=dev))
+        if int(probe.item()) != world or dist.get_backend() != "nccl" or len({int(t.item()) for t in ids}) != world:
+            raise SystemExit("bench.py: the RCCL group does not span --gpus distinct devices")
 
     import world_class_amd as w
+    from world_class_amd.shard import ShardLayout
     from world_class_amd.synth import make_utterance
     L = w.lib()
     L.wc_set_device(local_rank)
 
-    # ---- synthetic workload: seeds 3000 + rank * utts + u (config 3 family of SURVEY 8(d)) ----
-    n_utt = a.utts
-    distinct = max(1, min(a.distinct, n_utt))
-    base = [make_utterance(FS, SECONDS, 3000 + rank * n_utt + u) for u in range(distinct)]
-    xs = [base[u % distinct] for u in range(n_utt)]
-    x_len = [len(x) for x in xs]
-    f_len = [w.get_samples(FS, n, FRAME_PERIOD) for n in x_len]
-    y_len = [w.synthesis_out_length(n, FRAME_PERIOD, FS) for n in f_len]
+    # ---- synthetic workload: world x utts utterances of 10 s; utterance i is seed 3000 + i % (distinct x world); the ranks
+    # take their shares by the static longest-first partition of world_class_amd.shard (equal lengths: round robin) ----
+    n_total = a.utts * world
+    cache = {3000: make_utterance(FS, SECONDS, 3000)}
+    n_samples = len(cache[3000])  # every utterance of the workload has this length
+    lay = ShardLayout([n_samples] * n_total, FS, FRAME_PERIOD, world, rank)
+    n_utt = len(lay.mine)
+    distinct = max(1, min(a.distinct, n_utt)) * world
+    xs = []
+    for i in lay.mine:
+        seed = 3000 + i % distinct
+        if seed not in cache:
+            cache[seed] = make_utterance(FS, SECONDS, seed)
+        xs.append(cache[seed])
+    assert [len(x) for x in xs] == lay.x_len, "utterance length differs from the layout's"
+    x_len, f_len, y_len = lay.x_len, lay.f_len, lay.y_len
     frames = sum(f_len)
     pipe = w.Pipeline(FS, frame_period=FRAME_PERIOD)  # Harvest -> CheapTrick -> D4C -> Synthesis, reference defaults
     bins = pipe.bins
@@ -160,15 +281,23 @@ def main():
         if world > 1:
             dist.barrier()
 
+    gather_s = [0.0]
+
     def final_gather():
-        # the path's only collective: F0 contours + output checksums of every rank
+        # the path's only collective: the F0 contours (and, --gather y, the waveforms) of every utterance in the original
+        # utterance order on every rank, plus the output checksums
         L.wc_synchronize()
         summary = torch.stack([d_sp.sum(), d_ap.sum(), d_y.abs().sum()])
         if world > 1:
-            f0_all = [torch.empty_like(d_f) for _ in range(world)]
-            dist.all_gather(f0_all, d_f)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            f0_all = lay.gather_frames(d_f)
+            y_all = lay.gather_samples(d_y) if a.gather == "y" else None
             sums = [torch.empty_like(summary) for _ in range(world)]
             dist.all_gather(sums, summary)
+            torch.cuda.synchronize()
+            gather_s[0] = time.perf_counter() - t0
+            assert len(f0_all) == n_total and (y_all is None or len(y_all) == n_total)
         return summary
 
     for _ in range(a.warmup):
@@ -184,11 +313,16 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed, gather_s[0]], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        elapsed, gather_s[0] = float(tmax[0].item()), float(tmax[1].item())
+        tot = torch.tensor([frames], dtype=torch.int64, device=dev)
+        dist.all_reduce(tot)
+        total_frames = int(tot.item())
+    else:
+        total_frames = frames
 
-    # per-kernel time of the last timed step, HIP events on the library's own stream
+    # per-kernel time of the last timed step, HIP events on the library's own streams
     kern = {}
     for name in KERNEL_STAGE:
         ms = float(L.wc_last_kernel_ms(name.encode()))
@@ -197,7 +331,6 @@ def main():
     L.wc_set_kernel_timing(0)
 
     if rank == 0:
-        total_frames = frames * world
         ms_per_step = elapsed / a.steps * 1e3
         value = total_frames * a.steps / elapsed
         # dominant = longest of the full-grid kernels.  The two one-wavefront-per-utterance sequential scans (Synthesis time
@@ -209,36 +342,50 @@ def main():
         if dom:
             stage = KERNEL_STAGE[dom]
             achieved = frames * STAGE_BYTES[stage] / (kern[dom] * 1e-3) / 1e9
-            traffic, valu = None, None
+            traffic, fp64 = None, None
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tpath):
                 with open(tpath) as f:
                     pmc = json.load(f)
                 traffic = pmc.get(dom)  # HBM bytes per step (PMC, see the file's _note)
-                insts = pmc.get("_valu_insts_per_step", {}).get(dom)
-                if insts:  # the ceiling that actually binds: FP64 vector issue
-                    rate = insts / (kern[dom] * 1e-3) / 1e9
-                    valu = {"insts_per_step": insts, "ginstr_per_s": rate, "peak_ginstr_per_s": VALU_PEAK_GINSTR,
-                            "issue_frac": rate / VALU_PEAK_GINSTR, "sustained_fma_ginstr_per_s": VALU_SUSTAINED_GINSTR,
-                            "frac_of_sustained": rate / VALU_SUSTAINED_GINSTR}
+                flops = pmc.get("_fp64_flops_per_step", {}).get(dom)
+                if flops:  # FP64 FLOP/s from SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 x 64 lanes (FMA counted twice)
+                    rate = flops / (kern[dom] * 1e-3) / 1e12
+                    fp64 = {"flops_per_step": flops, "tflops": rate, "peak_tflops": FP64_VECTOR_PEAK_TFLOPS, "frac": rate / FP64_VECTOR_PEAK_TFLOPS}
             roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                         "kernel_ms": kern[dom], "bytes_per_frame": STAGE_BYTES[stage],
-                        "fp64_vector_issue": valu, "all_kernels_ms": kern}
+                        "fp64_vector": fp64, "all_kernels_ms": kern,
+                        "pipeline": {"bytes_per_frame": 20248, "achieved": frames * 20248 / (ms_per_step * 1e-3) / 1e9,
+                                     "frac": frames * 20248 / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}}
         out = {
             "metric": "analysis+synthesis frames/sec (whole node), 48 kHz 5 ms hop",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{n_utt} synthetic 48 kHz 10 s utterances per GPU ({distinct} distinct, tiled), 5 ms hop, "
+            "config": {"workload": f"{n_utt} synthetic 48 kHz 10 s utterances per GPU ({distinct // world} distinct, tiled), 5 ms hop, "
                                    "Harvest->CheapTrick->D4C->Synthesis, inputs resident in HBM",
                        "utterances_per_gpu": n_utt, "frames_per_gpu": frames, "fs": FS, "frame_period_ms": FRAME_PERIOD,
-                       "fft_size": pipe.fft_size, "parallelism": f"utterance-sharded x{world}, final RCCL all-gather of F0 + checksums"},
+                       "fft_size": pipe.fft_size,
+                       "parallelism": f"utterance-sharded x{world} (shard.partition), final RCCL all-gather of "
+                                      + ("F0 + waveforms + checksums" if a.gather == "y" else "F0 + checksums")},
             "roofline": roofline,
         }
+        if world > 1:
+            out["gather_ms"] = gather_s[0] * 1e3
+            out["gather"] = a.gather
+        if world == 1 and not a.no_extras:
+            try:
+                out["stages"] = {"cheaptrick_config3": stage_cheaptrick(w, L, torch, dev, d_x, x_len, d_t, d_f, f_len)}
+            except Exception as e:
+                out["stages"] = {"error": str(e)}
+            try:
+                out["with_transfers"] = with_transfers(w, pipe, xs, frames)
+            except Exception as e:
+                out["with_transfers"] = {"error": str(e)}
         if world == 1 and not a.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(base)
+                out["cpu_baseline"] = cpu_baseline(list(cache.values()))
             except Exception as e:  # the GPU number stays valid without it
                 out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {e}"}

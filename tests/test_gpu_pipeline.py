@@ -133,6 +133,19 @@ def test_host_batch_front_end_pcm16_and_double(wca):
     for r, g in zip(ref, got):
         assert set(g) == {"f0", "y"} and np.array_equal(g["f0"], r["f0"])
         assert np.abs(g["y"] - r["y"]).max() < 1e-10   # overlap-add order differs between runs at the 1e-16 level
+    # the caller's own buffers written again (out=), larger batch so that the half-batch copies overlap the second half
+    many = [xq[i % 3] for i in range(10)]
+    ref = p.run_batch(many)
+    first = p.run_batch_host(many)
+    for g in first:
+        for v in g.values():
+            v.fill(-1.0)
+    again = p.run_batch_host(many, out=first)
+    for r, g, h in zip(ref, first, again):
+        assert all(g[k] is h[k] for k in g)
+        assert np.array_equal(g["tpos"], r["tpos"]) and np.array_equal(g["f0"], r["f0"])
+        assert np.array_equal(g["sp"], r["sp"]) and np.array_equal(g["ap"], r["ap"])
+        assert np.abs(g["y"] - r["y"]).max() < 1e-10
 
 
 def test_pipeline_at_96_khz_golden(wca):

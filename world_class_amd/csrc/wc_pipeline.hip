@@ -19,9 +19,11 @@
 // Measured on MI355X: overlapping two ALU-bound kernels (refinement next to D4C) gains nothing -- they time-share
 // the CUs -- while the tails and time bases (64 wavefronts each) disappear behind the heavy kernels.
 // WC_PIPELINE_MODE=shared selects the older schedule: one set of stages, Harvest split over two streams.
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "wc_stages.hpp"
@@ -39,6 +41,42 @@ struct PipeGroup {
 	hipEvent_t e0 = nullptr, e_aux = nullptr, e_mid = nullptr;
 };
 
+// Host-side copies of the batch front-end, spread over a few threads: one thread moves 5-10 GB/s, the 2.1 GB of
+// spectrogram + aperiodicity rows of a 64 x 10 s batch would take a quarter of a second on one.
+struct CopyJob { void *dst; const void *src; size_t bytes; };
+static void parallel_copy(const std::vector<CopyJob> &jobs) {
+	constexpr size_t kPiece = 2u << 20;
+	struct Piece { char *dst; const char *src; size_t bytes; };
+	std::vector<Piece> pieces;
+	size_t total = 0;
+	for (const CopyJob &j : jobs)
+		for (size_t o = 0; o < j.bytes; o += kPiece) {
+			pieces.push_back({static_cast<char *>(j.dst) + o, static_cast<const char *>(j.src) + o, std::min(kPiece, j.bytes - o)});
+			total += pieces.back().bytes;
+		}
+	unsigned hw = std::thread::hardware_concurrency();
+	size_t nt = std::min<size_t>({hw ? hw : 4u, 16u, total / (8u << 20) + 1, pieces.size()});
+	std::atomic<size_t> next{0};
+	auto work = [&]() {
+		for (size_t i = next.fetch_add(1); i < pieces.size(); i = next.fetch_add(1)) std::memcpy(pieces[i].dst, pieces[i].src, pieces[i].bytes);
+	};
+	std::vector<std::thread> th;
+	for (size_t t = 1; t < nt; ++t) th.emplace_back(work);
+	work();
+	for (std::thread &t : th) t.join();
+}
+
+// What wc_pipeline_run_batch_host asks of a run: the spectrogram / aperiodicity rows of each half batch start their way
+// to the host as soon as that half's D4C is through (copy stream, pinned staging), and are handed to the caller's
+// per-utterance buffers while the other half still computes.
+struct HostSink {
+	char *stage_sp = nullptr, *stage_ap = nullptr;  // pinned, packed [frames][bins] like the device arrays; nullptr = not wanted
+	double *const *sp = nullptr, *const *ap = nullptr;  // the caller's per-utterance destinations
+	const int *f_len = nullptr;
+	int bins = 0;
+	bool overlapped[2] = {false, false};  // group g was copied and scattered during the run (first attempt only)
+};
+
 struct wc_pipeline {
 	int mode;  // 0: shared stages, Harvest split over streams; 1: independent staggered chains per utterance group
 	PipeGroup grp[2];
@@ -52,8 +90,8 @@ struct wc_pipeline {
 	wc_cheaptrick *ct;
 	wc_d4c *d4;
 	wc_synthesis *sy;
-	hipStream_t s1, s2;
-	hipEvent_t e0, e1, e2;
+	hipStream_t s1, s2, s_copy;
+	hipEvent_t e0, e1, e2, e_copy[2];
 	// host batch front-end (wc_pipeline_run_batch_host): device-resident batch + pinned staging, grow-only
 	DevBuf b_x, b_pcm, b_t, b_f, b_sp, b_ap, b_y, b_ypcm;
 	HostBuf st_in, st_out;
@@ -99,6 +137,9 @@ wc_pipeline *wc_pipeline_create(int fs, double frame_period, double harvest_f0_f
 	ok = ok && hipEventCreateWithFlags(&p->e0, hipEventDisableTiming) == hipSuccess;
 	ok = ok && hipEventCreateWithFlags(&p->e1, hipEventDisableTiming) == hipSuccess;
 	ok = ok && hipEventCreateWithFlags(&p->e2, hipEventDisableTiming) == hipSuccess;
+	ok = ok && hipStreamCreateWithFlags(&p->s_copy, hipStreamNonBlocking) == hipSuccess;
+	ok = ok && hipEventCreateWithFlags(&p->e_copy[0], hipEventDisableTiming) == hipSuccess;
+	ok = ok && hipEventCreateWithFlags(&p->e_copy[1], hipEventDisableTiming) == hipSuccess;
 	if (ok && p->mode == 1) {
 		for (int g = 0; g < 2 && ok; ++g) {
 			PipeGroup &G = p->grp[g];
@@ -135,6 +176,8 @@ void wc_pipeline_destroy(wc_pipeline *p) {
 	if (p->e0) (void)hipEventDestroy(p->e0);
 	if (p->e1) (void)hipEventDestroy(p->e1);
 	if (p->e2) (void)hipEventDestroy(p->e2);
+	if (p->s_copy) (void)hipStreamDestroy(p->s_copy);
+	for (int g = 0; g < 2; ++g) if (p->e_copy[g]) (void)hipEventDestroy(p->e_copy[g]);
 	for (int g = 0; g < 2; ++g) {
 		PipeGroup &G = p->grp[g];
 		if (G.e0) (void)hipEventDestroy(G.e0);
@@ -158,8 +201,8 @@ void wc_pipeline_destroy(wc_pipeline *p) {
 
 int wc_pipeline_get_fft_size(const wc_pipeline *p) { return p ? p->fft_size : WC_ERR_INVALID; }
 
-int wc_pipeline_run_device(wc_pipeline *p, int n_utt, const double *d_x, const int *x_length, double *d_tpos, double *d_f0,
-						   double *d_sp, double *d_ap, double *d_y, uint64_t *rng_pos) {
+static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int *x_length, double *d_tpos, double *d_f0,
+						double *d_sp, double *d_ap, double *d_y, uint64_t *rng_pos, HostSink *sink) {
 	if (!p || n_utt <= 0 || !d_x || !x_length || !d_tpos || !d_f0 || !d_sp || !d_ap || !d_y)
 		return fail(WC_ERR_INVALID, "pipeline: null argument");
 	WC_HIP(hipSetDevice(p->dev->id));
@@ -197,6 +240,7 @@ int wc_pipeline_run_device(wc_pipeline *p, int n_utt, const double *d_x, const i
 		for (int attempt = 0; attempt < 3; ++attempt) {
 			const int bins_ = p->fft_size / 2 + 1;
 			struct Slice { int u0, nu; long long xo, fo, yo; } sl[2];
+			long long fo_end[2];
 			{
 				long long xo = 0, fo = 0, yo = 0;
 				for (int g = 0; g < 2; ++g) {
@@ -204,6 +248,7 @@ int wc_pipeline_run_device(wc_pipeline *p, int n_utt, const double *d_x, const i
 					sl[g].nu = (g == 0 ? n_utt / 2 : n_utt) - sl[g].u0;
 					sl[g].xo = xo; sl[g].fo = fo; sl[g].yo = yo;
 					for (int u = sl[g].u0; u < sl[g].u0 + sl[g].nu; ++u) { xo += x_length[u]; fo += f_len[u]; yo += y_len[u]; }
+					fo_end[g] = fo;
 				}
 			}
 			// 0. chain B's own stream starts behind whatever already sits on the caller's stream (an upload of the samples, the
@@ -238,11 +283,34 @@ int wc_pipeline_run_device(wc_pipeline *p, int n_utt, const double *d_x, const i
 									  ct_end_positions(G.ct))))
 					return rc;
 				WC_HIP(hipEventRecord(G.e_aux, G.aux));
+				if (sink && attempt == 0 && (sink->stage_sp || sink->stage_ap)) {
+					const size_t off = sizeof(double) * (size_t)sl[g].fo * bins_, len = sizeof(double) * (size_t)(fo_end[g] - sl[g].fo) * bins_;
+					WC_HIP(hipStreamWaitEvent(p->s_copy, G.e_aux, 0));
+					if (sink->stage_sp) WC_HIP(hipMemcpyAsync(sink->stage_sp + off, gsp, len, hipMemcpyDeviceToHost, p->s_copy));
+					if (sink->stage_ap) WC_HIP(hipMemcpyAsync(sink->stage_ap + off, gap, len, hipMemcpyDeviceToHost, p->s_copy));
+					WC_HIP(hipEventRecord(p->e_copy[g], p->s_copy));
+				}
 				if ((rc = syn_prepare(G.sy, G.main, nu, gf, f_len.data() + u0, y_len.data() + u0, gy, nullptr, full[g][1]))) return rc;
 				WC_HIP(hipStreamWaitEvent(G.main, G.e_aux, 0));
 				if ((rc = syn_pulses(G.sy, G.main, gf, gsp, gap, gy, d4c_end_positions(G.d4)))) return rc;
 			}
 			dev->time_tag = -1;
+			if (sink && attempt == 0 && (sink->stage_sp || sink->stage_ap)) {
+				// the rows of each half batch go to the caller's buffers as soon as their copy has landed: half A's while B computes
+				for (int g = 0; g < 2; ++g) {
+					WC_HIP(hipEventSynchronize(p->e_copy[g]));
+					std::vector<CopyJob> jobs;
+					long long fo = sl[g].fo;
+					for (int u = sl[g].u0; u < sl[g].u0 + sl[g].nu; ++u) {
+						const size_t off = sizeof(double) * (size_t)fo * bins_, len = sizeof(double) * (size_t)f_len[u] * bins_;
+						if (sink->stage_sp && sink->sp[u]) jobs.push_back({sink->sp[u], sink->stage_sp + off, len});
+						if (sink->stage_ap && sink->ap[u]) jobs.push_back({sink->ap[u], sink->stage_ap + off, len});
+						fo += f_len[u];
+					}
+					parallel_copy(jobs);
+					sink->overlapped[g] = true;
+				}
+			}
 			bool again = false;
 			for (int g = 0; g < 2; ++g) {
 				PipeGroup &G = p->grp[g];
@@ -254,6 +322,7 @@ int wc_pipeline_run_device(wc_pipeline *p, int n_utt, const double *d_x, const i
 				full[g][1] = full[g][1] || o2;
 				again = again || o1 || o2;
 			}
+			if (again && sink) sink->overlapped[0] = sink->overlapped[1] = false;  // the re-run rewrites the rows
 			if (!again) return WC_OK;
 		}
 		return fail(WC_ERR_DEVICE, "pipeline: buffer overflow");
@@ -308,6 +377,11 @@ int wc_pipeline_run_device(wc_pipeline *p, int n_utt, const double *d_x, const i
 	return fail(WC_ERR_DEVICE, "pipeline: buffer overflow");
 }
 
+int wc_pipeline_run_device(wc_pipeline *p, int n_utt, const double *d_x, const int *x_length, double *d_tpos, double *d_f0,
+						   double *d_sp, double *d_ap, double *d_y, uint64_t *rng_pos) {
+	return pipeline_run(p, n_utt, d_x, x_length, d_tpos, d_f0, d_sp, d_ap, d_y, rng_pos, nullptr);
+}
+
 // Host batch front-end: ragged utterances as 16-bit PCM (as stored in a WAV file) or as doubles,
 // gathered into pinned memory, one H2D copy, expanded on the device, fused pipeline, outputs packed into pinned memory with
 // one D2H copy per requested array, scattered to the caller's per-utterance buffers.  Any output table may be NULL.
@@ -337,12 +411,14 @@ int wc_pipeline_run_batch_host(wc_pipeline *p, int n_utt, const void *const *x, 
 	if ((rc = p->b_sp.reserve(sizeof(double) * nf * bins))) return rc;
 	if ((rc = p->b_ap.reserve(sizeof(double) * nf * bins))) return rc;
 	if ((rc = p->b_y.reserve(sizeof(double) * ny))) return rc;
-	{
+	{  // gather the utterances into pinned memory (a few threads: 245 MB of doubles take 40 ms on one)
+		std::vector<CopyJob> jobs(n_utt);
 		char *dst = static_cast<char *>(p->st_in.p);
 		for (int u = 0; u < n_utt; ++u) {
-			std::memcpy(dst, x[u], in_elem * x_length[u]);
+			jobs[u] = {dst, x[u], in_elem * x_length[u]};
 			dst += in_elem * x_length[u];
 		}
+		parallel_copy(jobs);
 	}
 	if (x_is_pcm16) {
 		WC_HIP(hipMemcpyAsync(p->b_pcm.p, p->st_in.p, sizeof(int16_t) * nx, hipMemcpyHostToDevice, s));
@@ -351,21 +427,28 @@ int wc_pipeline_run_batch_host(wc_pipeline *p, int n_utt, const void *const *x, 
 		WC_HIP(hipMemcpyAsync(p->b_x.p, p->st_in.p, sizeof(double) * nx, hipMemcpyHostToDevice, s));
 	}
 	if ((rc = p->st_in.mark(s))) return rc;
-	if ((rc = wc_pipeline_run_device(p, n_utt, p->b_x.as<double>(), x_length, p->b_t.as<double>(), p->b_f.as<double>(),
-									 p->b_sp.as<double>(), p->b_ap.as<double>(), p->b_y.as<double>(), rng_pos)))
-		return rc;
 	// outputs: one packed region of pinned memory, [tpos | f0 | sp | ap | y]
 	const size_t y_elem = y_is_pcm16 ? sizeof(int16_t) : sizeof(double);
 	size_t off_t = 0, off_f = off_t + (tpos ? sizeof(double) * nf : 0), off_sp = off_f + (f0 ? sizeof(double) * nf : 0);
 	size_t off_ap = off_sp + (sp ? sizeof(double) * nf * bins : 0), off_y = off_ap + (ap ? sizeof(double) * nf * bins : 0);
 	const size_t total = off_y + (y ? y_elem * ny : 0);
-	if (total == 0) return WC_OK;
-	if ((rc = p->st_out.reserve(total))) return rc;
+	if (total > 0 && (rc = p->st_out.reserve(total))) return rc;
 	char *out = static_cast<char *>(p->st_out.p);
+	// The big arrays (spectrogram, aperiodicity) leave per half batch while the rest of the batch still computes, and are
+	// handed to the caller's rows by several threads (pipeline_run, HostSink).
+	HostSink sink;
+	sink.stage_sp = sp ? out + off_sp : nullptr;
+	sink.stage_ap = ap ? out + off_ap : nullptr;
+	sink.sp = sp; sink.ap = ap; sink.f_len = f_len.data(); sink.bins = bins;
+	if ((rc = pipeline_run(p, n_utt, p->b_x.as<double>(), x_length, p->b_t.as<double>(), p->b_f.as<double>(),
+						   p->b_sp.as<double>(), p->b_ap.as<double>(), p->b_y.as<double>(), rng_pos, &sink)))
+		return rc;
+	if (total == 0) return WC_OK;
+	const bool rows_done = sink.overlapped[0] && sink.overlapped[1];
 	if (tpos) WC_HIP(hipMemcpyAsync(out + off_t, p->b_t.p, sizeof(double) * nf, hipMemcpyDeviceToHost, s));
 	if (f0) WC_HIP(hipMemcpyAsync(out + off_f, p->b_f.p, sizeof(double) * nf, hipMemcpyDeviceToHost, s));
-	if (sp) WC_HIP(hipMemcpyAsync(out + off_sp, p->b_sp.p, sizeof(double) * nf * bins, hipMemcpyDeviceToHost, s));
-	if (ap) WC_HIP(hipMemcpyAsync(out + off_ap, p->b_ap.p, sizeof(double) * nf * bins, hipMemcpyDeviceToHost, s));
+	if (sp && !rows_done) WC_HIP(hipMemcpyAsync(out + off_sp, p->b_sp.p, sizeof(double) * nf * bins, hipMemcpyDeviceToHost, s));
+	if (ap && !rows_done) WC_HIP(hipMemcpyAsync(out + off_ap, p->b_ap.p, sizeof(double) * nf * bins, hipMemcpyDeviceToHost, s));
 	if (y) {
 		if (y_is_pcm16) {
 			if ((rc = p->b_ypcm.reserve(sizeof(int16_t) * ny))) return rc;
@@ -376,16 +459,20 @@ int wc_pipeline_run_batch_host(wc_pipeline *p, int n_utt, const void *const *x, 
 		}
 	}
 	WC_HIP(hipStreamSynchronize(s));
+	std::vector<CopyJob> jobs;
 	long long fo = 0, yo = 0;
 	for (int u = 0; u < n_utt; ++u) {
-		if (tpos && tpos[u]) std::memcpy(tpos[u], out + off_t + sizeof(double) * fo, sizeof(double) * f_len[u]);
-		if (f0 && f0[u]) std::memcpy(f0[u], out + off_f + sizeof(double) * fo, sizeof(double) * f_len[u]);
-		if (sp && sp[u]) std::memcpy(sp[u], out + off_sp + sizeof(double) * fo * bins, sizeof(double) * f_len[u] * bins);
-		if (ap && ap[u]) std::memcpy(ap[u], out + off_ap + sizeof(double) * fo * bins, sizeof(double) * f_len[u] * bins);
-		if (y && y[u]) std::memcpy(y[u], out + off_y + y_elem * yo, y_elem * y_len[u]);
+		if (tpos && tpos[u]) jobs.push_back({tpos[u], out + off_t + sizeof(double) * fo, sizeof(double) * f_len[u]});
+		if (f0 && f0[u]) jobs.push_back({f0[u], out + off_f + sizeof(double) * fo, sizeof(double) * f_len[u]});
+		if (!rows_done) {
+			if (sp && sp[u]) jobs.push_back({sp[u], out + off_sp + sizeof(double) * fo * bins, sizeof(double) * f_len[u] * bins});
+			if (ap && ap[u]) jobs.push_back({ap[u], out + off_ap + sizeof(double) * fo * bins, sizeof(double) * f_len[u] * bins});
+		}
+		if (y && y[u]) jobs.push_back({y[u], out + off_y + y_elem * yo, y_elem * y_len[u]});
 		fo += f_len[u];
 		yo += y_len[u];
 	}
+	parallel_copy(jobs);
 	return WC_OK;
 }
 

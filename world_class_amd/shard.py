@@ -51,3 +51,30 @@ def scatter_back(parts: List[List[int]], gathered: List[torch.Tensor], lengths_p
             out[i] = gathered[r][o:o + n]
             o += n
     return out
+
+
+class ShardLayout:
+    """What one rank holds of a sharded batch: the utterance indices `partition` dealt to it and the packed layout of their
+    samples, frames and output samples (include/world_class_c.h: utterance u's samples start at sum(x_length[<u]), its frames at
+    row sum(f0_length[<u]), its output at sum(out_length[<u])).  Sizes come from the library's own host arithmetic
+    (wc_get_samples = Harvest::getSamples, wc_synthesis_out_length), so the gloo tests shard exactly what the GPUs shard."""
+
+    def __init__(self, x_lengths: Sequence[int], fs: int, frame_period: float, world: int, rank: int):
+        from . import get_samples, synthesis_out_length
+        self.world, self.rank = world, rank
+        self.parts = partition(x_lengths, world)
+        self.all_x_len = [int(n) for n in x_lengths]
+        self.all_f_len = [get_samples(fs, n, frame_period) for n in self.all_x_len]
+        self.all_y_len = [synthesis_out_length(f, frame_period, fs) for f in self.all_f_len]
+        self.mine = self.parts[rank]
+        self.x_len = [self.all_x_len[i] for i in self.mine]
+        self.f_len = [self.all_f_len[i] for i in self.mine]
+        self.y_len = [self.all_y_len[i] for i in self.mine]
+
+    def gather_frames(self, local: torch.Tensor, width: int = 1, group=None) -> List[torch.Tensor]:
+        """per-frame rows of `width` values of every rank -> list over ALL utterances in their original order"""
+        return scatter_back(self.parts, gather_ragged(local.reshape(-1), group), [f * width for f in self.all_f_len])
+
+    def gather_samples(self, local: torch.Tensor, group=None) -> List[torch.Tensor]:
+        """output waveforms of every rank -> list over all utterances in their original order"""
+        return scatter_back(self.parts, gather_ragged(local.reshape(-1), group), self.all_y_len)
