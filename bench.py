@@ -73,6 +73,30 @@ def _ref_call(args):
     return n, time.perf_counter() - t0
 
 
+def usable_cores():
+    """cores this process may actually run on: the affinity mask, cut down by a cgroup CPU quota if there is one (a container on
+    a 256-core host often owns far fewer; os.cpu_count() reports the host's)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                        n = min(n, max(1, q // int(g.read())))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(xs, budget_s=24.0):
     """CPU path on a bounded sample (whole utterances of the same workload), rank 0 / N=1 only.
 
@@ -85,7 +109,7 @@ def cpu_baseline(xs, budget_s=24.0):
     """
     from concurrent.futures import ThreadPoolExecutor
     from oracle import port, ref
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
 
     if ref.available(omp=True):
         try:

@@ -47,6 +47,9 @@ def test_library_exports_every_declared_symbol(built_lib):
     fft_declared = io_header_symbols("world_fft.hpp")
     assert {"fft_plan_dft_r2c_1d", "fft_execute", "fft_destroy_plan"} <= set(fft_declared)
     assert not [s for s in fft_declared if s not in exported_all]
+    stream_declared = [n for n in io_header_symbols("world_class_stream.h") if n.startswith("wc_")]
+    assert {"wc_stream_create", "wc_stream_push_device", "wc_stream_reset"} <= set(stream_declared)
+    assert not [s for s in stream_declared if s not in exported_all]
     codec_declared = io_header_symbols("world_class_codec.h")
     assert {"CodeSpectralEnvelope", "DecodeAperiodicity", "GetNumberOfAperiodicities"} <= set(codec_declared)
     assert not [s for s in codec_declared if s not in exported_all]
@@ -59,6 +62,8 @@ def test_python_mirror_binds_the_header(built_lib):
     assert sorted(wio.IO_SIGNATURES) == io_header_symbols()
     from world_class_amd import codec
     assert sorted(codec.CODEC_SIGNATURES) == io_header_symbols("world_class_codec.h")
+    from world_class_amd import stream
+    assert sorted(stream.STREAM_SIGNATURES) == [n for n in io_header_symbols("world_class_stream.h") if n.startswith("wc_")]
     lib = w.lib()  # loads and sets every prototype
     assert lib.wc_version().startswith(b"world_class_amd")
     # pure host helpers work without a device and match the reference's formulas (goldens in test_oracle_golden)

@@ -1,0 +1,127 @@
+"""-m gpu: chunked Harvest + CheapTrick (include/world_class_stream.h, BASELINE config 5) against ONE whole-utterance call of
+the same stages on the complete signal.  The reference has no streaming mode (Harvest is non-causal, reference
+src/harvest.cpp:431-440, :676-703); the parity claim is the one the header makes: with lookahead and lookback of 400 ms the
+committed frames equal the whole-utterance result -- identical voicing decisions, F0 within 1e-9 Hz (last-bit differences
+from the smoothing filter's backward limit cycle), spectrogram within 1e-7 relative, the noise draws being the very same
+stream positions."""
+import numpy as np
+import pytest
+
+from world_class_amd.synth import make_utterance
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def wca():
+    import world_class_amd as w
+    w.lib()
+    return w
+
+
+def whole(wca, x, fs, fp):
+    wca.rng_set_position(0)
+    tpos, f0 = wca.Harvest(fs, frame_period=fp).compute(x)
+    sp = wca.CheapTrick(fs).compute(x, tpos, f0)
+    wca.rng_set_position(0)
+    return tpos, f0, sp
+
+
+def compare(got, want, what):
+    tpos, f0, sp = want
+    assert len(got["f0"]) == len(f0), what
+    assert np.array_equal(got["tpos"], tpos), what
+    assert np.array_equal(got["f0"] == 0, f0 == 0), what + ": voicing"
+    assert np.abs(got["f0"] - f0).max() < 1e-9, what
+    assert (np.abs(got["sp"] - sp) / sp).max() < 1e-7, what
+    return float(np.mean(got["f0"] == f0)), float(np.abs(got["f0"] - f0).max()), float((np.abs(got["sp"] - sp) / sp).max())
+
+
+def test_streams_equal_whole_utterances_24k_1ms(wca):
+    """BASELINE config 5's shape: 24 kHz, 1 ms frames; ragged lengths, one of them not a whole number of chunks or ms"""
+    from world_class_amd.stream import StreamAnalyzer
+    fs = 24000
+    xs = [make_utterance(fs, sec, 5000 + i) for i, sec in enumerate((3.0, 2.2, 4.1, 0.9))]
+    xs[2] = xs[2][:-377]
+    sa = StreamAnalyzer(fs, len(xs), frame_period=1.0, chunk_ms=200, lookback_ms=400, lookahead_ms=400)
+    assert sa.latency_ms == 600 and sa.chunk_samples == 4800
+    res = sa.run_whole(xs)
+    stats = [compare(r, whole(wca, x, fs, 1.0), "stream %d" % u) for u, (x, r) in enumerate(zip(xs, res))]
+    # most frames are bit-equal; the rest differ in the last bits only
+    assert min(s[0] for s in stats) > 0.5 and max(s[1] for s in stats) < 1e-11, stats
+    for u, x in enumerate(xs):
+        assert sa.frames_committed(u) == wca.get_samples(fs, len(x), 1.0)
+
+
+def test_streams_equal_whole_utterances_48k_5ms(wca):
+    from world_class_amd.stream import StreamAnalyzer
+    fs = 48000
+    xs = [make_utterance(fs, sec, 5100 + i) for i, sec in enumerate((2.5, 1.7))]
+    sa = StreamAnalyzer(fs, len(xs), frame_period=5.0, chunk_ms=200, lookback_ms=400, lookahead_ms=400)
+    res = sa.run_whole(xs)
+    for u, (x, r) in enumerate(zip(xs, res)):
+        compare(r, whole(wca, x, fs, 5.0), "stream %d" % u)
+
+
+def test_idle_streams_resets_and_frame_accounting(wca):
+    """streams need not move in lockstep: one idles, one is reset and starts a new signal; every absolute frame is committed
+    exactly once, `chunk / frame_period` per push in the steady state, the rest at the flush"""
+    from world_class_amd.stream import StreamAnalyzer
+    fs = 16000
+    a, b, c = (make_utterance(fs, sec, 5200 + i) for i, sec in enumerate((1.6, 1.2, 1.0)))
+    sa = StreamAnalyzer(fs, 2, frame_period=1.0, chunk_ms=160, lookback_ms=400, lookahead_ms=400)
+    cs = sa.chunk_samples
+    acc = {0: [], 1: []}
+
+    def push(c0, c1, f0=0, f1=0):
+        r = sa.push([c0, c1], [f0, f1])
+        acc[0].append(r[0])
+        acc[1].append(r[1])
+        return [len(v["f0"]) for v in r]
+
+    counts = []
+    na, nb = 0, 0
+    # stream 0 gets `a`; stream 1 idles for three pushes, then gets `b`
+    for k in range(3):
+        counts.append(push(a[na:na + cs], np.zeros(0)))
+        na += cs
+    assert [c[1] for c in counts] == [0, 0, 0] and counts[0][0] == 0 and counts[2][0] == 3 * 160 - 400
+    while na + cs < len(a):
+        n = push(a[na:na + cs], b[nb:nb + cs])
+        assert n[0] == 160
+        na += cs
+        nb += cs
+    push(a[na:], b[nb:nb + cs], 1, 0)
+    nb += cs
+    while nb + cs < len(b):
+        push(np.zeros(0), b[nb:nb + cs])
+        nb += cs
+    push(np.zeros(0), b[nb:], 0, 1)
+    got = {u: {k: np.concatenate([r[k] for r in acc[u]]) for k in ("tpos", "f0", "sp")} for u in (0, 1)}
+    compare(got[0], whole(wca, a, fs, 1.0), "a")
+    compare(got[1], whole(wca, b, fs, 1.0), "b")
+    with pytest.raises(wca.WorldClassError, match="flushed"):
+        sa.push([a[:cs], np.zeros(0)])
+    # a new signal on stream 0 after a reset
+    sa.reset(0)
+    acc[0] = []
+    nc = 0
+    while nc + cs < len(c):
+        push(c[nc:nc + cs], np.zeros(0))
+        nc += cs
+    push(c[nc:], np.zeros(0), 1, 0)
+    got0 = {k: np.concatenate([r[k] for r in acc[0]]) for k in ("tpos", "f0", "sp")}
+    compare(got0, whole(wca, c, fs, 1.0), "c after reset")
+
+
+def test_stream_arguments_are_checked(wca):
+    from world_class_amd.stream import StreamAnalyzer
+    with pytest.raises(wca.WorldClassError, match="multiple of 1000"):
+        StreamAnalyzer(44100, 2)
+    with pytest.raises(wca.WorldClassError, match="multiples of lcm"):
+        StreamAnalyzer(24000, 2, chunk_ms=100)
+    with pytest.raises(wca.WorldClassError, match="multiples of lcm"):
+        StreamAnalyzer(24000, 2, frame_period=5.0, chunk_ms=200, lookback_ms=400, lookahead_ms=408)
+    sa = StreamAnalyzer(24000, 2)
+    with pytest.raises(wca.WorldClassError, match="short chunk"):
+        sa.push([np.zeros(100), np.zeros(sa.chunk_samples)])

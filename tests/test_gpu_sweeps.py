@@ -68,7 +68,6 @@ def test_impulse_trains_agree_in_voicing_and_within_a_window_length_step(wca, P)
         o = P.pipeline(x, fs)
         assert np.array_equal(r["f0"] == 0, o["f0"] == 0), s
         assert dev(r["f0"], o["f0"]) < 0.1, s
-        assert np.mean(np.abs(r["f0"] - o["f0"]) > 1e-6) < 0.25, s
 
 
 def test_seeded_utterances_48k(wca, P):

@@ -107,8 +107,38 @@ def main():
                           "frames": sum(fl), "ms": t * 1e3, "frames_per_s": sum(fl) / t}))
         del d_f, d_sp, d_ap, d_y, sy, sp4, ap4
 
-    if 5 in todo:  # 1 ms hop Harvest + CheapTrick at 24 kHz; per-GPU share of 4096 streams = 512, whole utterances of 2 s
+    if 5 in todo:  # streaming 1 ms hop Harvest + CheapTrick at 24 kHz; per-GPU share of 4096 streams = 512
+        from world_class_amd.stream import StreamAnalyzer
         fs, n = 24000, max(2, int(512 * a.scale))
+        sig = [make_utterance(fs, 4.0, 5000 + u) for u in range(8)]
+        for chunk_ms, back_ms, ahead_ms in ((200, 400, 400), (400, 400, 400), (80, 400, 400)):
+            sa = StreamAnalyzer(fs, n, frame_period=1.0, chunk_ms=chunk_ms, lookback_ms=back_ms, lookahead_ms=ahead_ms)
+            cs = sa.chunk_samples
+            cap = n * sa.max_frames
+            d_t = torch.empty(cap, dtype=torch.float64, device=dev)
+            d_f = torch.empty(cap, dtype=torch.float64, device=dev)
+            d_sp = torch.empty(cap * sa.bins, dtype=torch.float64, device=dev)
+            n_push = len(sig[0]) // cs
+            chunks = [torch.from_numpy(np.concatenate([sig[u % 8][k * cs:(k + 1) * cs] for u in range(n)])).to(dev) for k in range(n_push)]
+            torch.cuda.synchronize()
+            times, frames = [], []
+            for k in range(n_push):
+                t0 = time.perf_counter()
+                counts = sa.push_device(chunks[k], None, None, d_t, d_f, d_sp)
+                L.wc_synchronize()
+                times.append(time.perf_counter() - t0)
+                frames.append(sum(counts))
+            full = (back_ms + chunk_ms + ahead_ms) // chunk_ms + 1  # pushes until the history window is full
+            steady = times[full:]
+            t = float(np.median(steady))
+            print(json.dumps({"config": 5, "what": f"{n} concurrent 24 kHz streams (1/8 of 4096), 1 ms frames, chunked Harvest + CheapTrick "
+                                                    f"(include/world_class_stream.h): chunk {chunk_ms} ms, lookback {back_ms} ms, lookahead {ahead_ms} ms, 1 GPU",
+                              "frames_per_push": frames[-1], "push_ms": t * 1e3, "push_ms_max": max(steady) * 1e3,
+                              "frames_per_s": frames[-1] / t, "algorithmic_latency_ms": ahead_ms + chunk_ms,
+                              "latency_ms_incl_compute": ahead_ms + chunk_ms + t * 1e3, "real_time_factor": chunk_ms / (t * 1e3),
+                              "streams_sustainable_in_real_time": int(n * chunk_ms / (t * 1e3))}))
+            del sa, chunks, d_t, d_f, d_sp
+        # for comparison: the same streams as whole 2 s utterances in one batch (no chunking)
         xs = tile([make_utterance(fs, 2.0, 5000 + u) for u in range(8)], n)
         hv, ct = w.Harvest(fs, frame_period=1.0), w.CheapTrick(fs)
         xl = [len(x) for x in xs]
@@ -123,9 +153,8 @@ def main():
             hv.compute_device(d_x, xl, d_t, d_f)
             ct.compute_device(d_x, xl, d_t, d_f, fl, d_sp)
         t = timed(run, L)
-        print(json.dumps({"config": 5, "what": f"{n} x 24 kHz 2 s (1/8 of 4096 streams), 1 ms hop, Harvest + CheapTrick on whole "
-                                                "utterances (Harvest is non-causal: no streaming semantics in the reference), 1 GPU",
-                          "frames": sum(fl), "ms": t * 1e3, "frames_per_s": sum(fl) / t, "batch_latency_ms": t * 1e3}))
+        print(json.dumps({"config": "5-whole", "what": f"{n} x 24 kHz 2 s as whole utterances in one batch, 1 ms hop, Harvest + CheapTrick, 1 GPU",
+                          "frames": sum(fl), "ms": t * 1e3, "frames_per_s": sum(fl) / t}))
 
     if 7 in todo:  # PCIe-inclusive: host batch front-end, int16 PCM in, f0 + int16 waveform out (and everything out)
         fs, n = 48000, max(2, int(64 * a.scale))
