@@ -15,8 +15,16 @@
  *   steady state.  CheapTrick then runs on the committed frames only, reading the samples from the history and taking
  *   its noise draws from the stream's own position in the reference's xorshift128 sequence, which is carried from push to
  *   push -- exactly the draws the frames would have got in one whole-utterance call.
- *   A stream is closed by a push with flush[u] != 0 (its last chunk may be shorter): all remaining frames up to
- *   wc_get_samples(fs, total samples, frame_period) are committed, the window ending where the signal ends.
+ *   A stream is closed by a push with flush[u] != 0 (its last chunk may be shorter): all remaining frames are committed,
+ *   the window ending where the signal ends.
+ *   One property of the reference has to be pinned for this to be well defined: its decimator aligns the sampling phase to
+ *   the END of the signal (reference src/world_matlabfunctions.cpp:201-206, nbeg = length mod ratio, MATLAB's decimate), so
+ *   the contour of a whole-utterance call changes by tenths of a Hz with (total length mod decimation ratio) -- one or two
+ *   trailing samples -- which no stream can know in advance.  Harvest therefore always sees windows that are a multiple of
+ *   the ratio long: full chunks are, and of a short final chunk the last (length mod ratio) samples are used by CheapTrick
+ *   only.  The stream equals the whole-utterance call exactly for totals that are multiples of the ratio; for others it
+ *   equals Harvest on the signal without those trailing samples (frame count wc_get_samples of that length) followed by
+ *   CheapTrick on the complete signal.
  *
  *   Result: the committed (tpos, f0, spectrogram rows) equal those of ONE whole-utterance Harvest + CheapTrick call on
  *   the complete signal wherever the influence of the window edges has died out: lookahead and lookback of >= 400 ms

@@ -16,7 +16,9 @@ struct StreamDesc {
 	long long src_off;    // first kept sample of the old history row (row start + dropped samples)
 	long long dst_off;    // start of the new history row
 	long long chunk_off;  // first new sample in the packed chunk array
-	long long batch_off;  // start of this stream's window in the packed batch handed to the stages
+	long long batch_off;  // start of this stream's window in the packed batch handed to CheapTrick
+	long long hbatch_off; // ... and in the packed batch handed to Harvest (windows cut to a multiple of the decimation ratio)
+	int h_len, pad_;      // samples of the window Harvest sees
 	int keep, n_new;      // old samples kept, new samples appended (window length = keep + n_new)
 	// commit: `count` frames from window row `row0` (packed Harvest output offset hf_off) to packed output offset out_off
 	long long hf_off, out_off, first_frame;
@@ -25,13 +27,15 @@ struct StreamDesc {
 
 // new history row = kept tail of the old one followed by the new chunk; the same samples also go to the packed batch
 __global__ void stream_update_kernel(const StreamDesc *__restrict__ desc, const double *__restrict__ old_hist,
-									 const double *__restrict__ chunk, double *__restrict__ new_hist, double *__restrict__ batch) {
+									 const double *__restrict__ chunk, double *__restrict__ new_hist, double *__restrict__ batch,
+									 double *__restrict__ hbatch) {
 	const StreamDesc d = desc[blockIdx.y];
 	const int n = d.keep + d.n_new;
 	for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
 		const double v = j < d.keep ? old_hist[d.src_off + j] : chunk[d.chunk_off + (j - d.keep)];
 		new_hist[d.dst_off + j] = v;
 		batch[d.batch_off + j] = v;
+		if (hbatch != batch && j < d.h_len) hbatch[d.hbatch_off + j] = v;
 	}
 }
 
@@ -54,7 +58,7 @@ __global__ void stream_commit_kernel(const StreamDesc *__restrict__ desc, const 
 using namespace wc;
 
 struct wc_stream {
-	int fs, n_streams, fp_ms, chunk_ms, back_ms, ahead_ms, align_ms;
+	int fs, n_streams, fp_ms, chunk_ms, back_ms, ahead_ms, align_ms, decim;
 	int chunk_s, win_s;  // samples of a chunk / of the longest history
 	double frame_period;
 	Device *dev;
@@ -66,7 +70,7 @@ struct wc_stream {
 	std::vector<int> hist_len, parity;                         // samples in the history, which of the two history buffers holds it
 	std::vector<char> closed;
 	std::vector<uint64_t> rng_pos;
-	DevBuf hist[2], batch, win_tpos, win_f0, tpos_rel, desc;
+	DevBuf hist[2], batch, hbatch, win_tpos, win_f0, tpos_rel, desc;
 	HostBuf h_desc;
 };
 
@@ -95,6 +99,7 @@ wc_stream *wc_stream_create(int fs, int n_streams, double frame_period_ms, int c
 	if (!dev) return nullptr;
 	wc_stream *s = new wc_stream();
 	s->fs = fs; s->n_streams = n_streams; s->fp_ms = fp; s->frame_period = frame_period_ms;
+	s->decim = decim;
 	s->chunk_ms = chunk_ms; s->back_ms = lookback_ms; s->ahead_ms = lookahead_ms; s->align_ms = align;
 	s->chunk_s = fs / 1000 * chunk_ms;
 	s->win_s = fs / 1000 * (lookback_ms + chunk_ms + lookahead_ms);
@@ -120,7 +125,7 @@ void wc_stream_destroy(wc_stream *s) {
 	s->dev->quiesce();
 	wc_cheaptrick_destroy(s->ct);
 	wc_harvest_destroy(s->hv);
-	for (DevBuf *b : {&s->hist[0], &s->hist[1], &s->batch, &s->win_tpos, &s->win_f0, &s->tpos_rel, &s->desc}) b->release();
+	for (DevBuf *b : {&s->hist[0], &s->hist[1], &s->batch, &s->hbatch, &s->win_tpos, &s->win_f0, &s->tpos_rel, &s->desc}) b->release();
 	s->h_desc.release();
 	delete s;
 }
@@ -150,8 +155,8 @@ int wc_stream_push_device(wc_stream *s, const double *d_chunk, const int *n_new,
 	// ---- bookkeeping on the host: which streams take part, what their windows are, which frames they commit ----
 	std::vector<int> act;       // streams that take part in this push
 	std::vector<StreamDesc> desc;
-	std::vector<int> win_len, count;
-	long long chunk_off = 0, batch_off = 0, hf_off = 0, out_off = 0;
+	std::vector<int> win_len, h_len, count;
+	long long chunk_off = 0, batch_off = 0, hbatch_off = 0, hf_off = 0, out_off = 0;
 	for (int u = 0; u < n; ++u) {
 		frames_out[u] = 0;
 		const int nn = n_new ? n_new[u] : s->chunk_s;
@@ -174,10 +179,17 @@ int wc_stream_push_device(wc_stream *s, const double *d_chunk, const int *n_new,
 		d.batch_off = batch_off;
 		const int wl = d.keep + nn;
 		const long long start = s->hist_start[u] + drop, recv = s->n_recv[u] + nn;
-		const int L = wc_get_samples(s->fs, wl, s->frame_period);
+		// Harvest's decimator aligns its sampling phase to the END of what it is given (reference src/world_matlabfunctions.cpp:201-206:
+		// nbeg = length mod ratio), so the contour of a whole-utterance call depends on (total length mod ratio) -- which a stream
+		// cannot know in advance.  Every window Harvest sees is a multiple of the ratio long: full chunks are, and of a final
+		// short chunk the last (length mod ratio) samples are left to CheapTrick alone.
+		d.h_len = wl - wl % s->decim;
+		d.hbatch_off = hbatch_off;
+		if (d.h_len < 3 * spm) return fail(WC_ERR_INVALID, "stream push: a stream needs at least 3 ms of signal");
+		const int L = wc_get_samples(s->fs, d.h_len, s->frame_period);
 		// frames committed: all whose time lies more than `lookahead` before the newest sample; everything on a flush
 		long long c1;
-		if (fl) c1 = wc_get_samples(s->fs, (int)recv, s->frame_period);
+		if (fl) c1 = wc_get_samples(s->fs, (int)(recv - recv % s->decim), s->frame_period);
 		else c1 = (recv / spm - s->ahead_ms) / s->fp_ms;  // frames k with k * fp < T - lookahead (T a whole number of ms here)
 		if (!fl && recv / spm < s->ahead_ms) c1 = 0;
 		if (c1 < s->next_frame[u]) c1 = s->next_frame[u];
@@ -191,8 +203,9 @@ int wc_stream_push_device(wc_stream *s, const double *d_chunk, const int *n_new,
 		desc.push_back(d);
 		act.push_back(u);
 		win_len.push_back(wl);
+		h_len.push_back(d.h_len);
 		count.push_back(d.count);
-		chunk_off += nn; batch_off += wl; hf_off += L; out_off += d.count;
+		chunk_off += nn; batch_off += wl; hbatch_off += d.h_len; hf_off += L; out_off += d.count;
 		// state after this push
 		s->hist_start[u] = start; s->hist_len[u] = wl; s->n_recv[u] = recv; s->next_frame[u] = c1;
 		if (fl) s->closed[u] = 1;
@@ -203,6 +216,9 @@ int wc_stream_push_device(wc_stream *s, const double *d_chunk, const int *n_new,
 	const size_t hist_bytes = sizeof(double) * (size_t)n * s->win_s;
 	if ((rc = s->hist[0].reserve(hist_bytes)) || (rc = s->hist[1].reserve(hist_bytes))) return rc;
 	if ((rc = s->batch.reserve(sizeof(double) * (size_t)batch_off))) return rc;
+	const bool cut = hbatch_off != batch_off;  // some window ends on a short final chunk
+	if (cut && (rc = s->hbatch.reserve(sizeof(double) * (size_t)hbatch_off))) return rc;
+	double *d_hbatch = cut ? s->hbatch.as<double>() : s->batch.as<double>();
 	if ((rc = s->win_tpos.reserve(sizeof(double) * (size_t)hf_off)) || (rc = s->win_f0.reserve(sizeof(double) * (size_t)hf_off))) return rc;
 	if ((rc = s->tpos_rel.reserve(sizeof(double) * (size_t)std::max<long long>(out_off, 1)))) return rc;
 	if ((rc = s->desc.reserve(sizeof(StreamDesc) * na)) || (rc = s->h_desc.reserve(sizeof(StreamDesc) * na))) return rc;
@@ -232,12 +248,12 @@ int wc_stream_push_device(wc_stream *s, const double *d_chunk, const int *n_new,
 		for (int a = 0; a < na; ++a) max_len = std::max(max_len, win_len[a]);
 		dim3 grid((unsigned)std::min(64, (max_len + 255) / 256), (unsigned)na);
 		hipLaunchKernelGGL(stream_update_kernel, grid, dim3(256), 0, st, s->desc.as<StreamDesc>(), s->hist[par].as<double>(), d_chunk,
-						   s->hist[1 - par].as<double>(), s->batch.as<double>());
+						   s->hist[1 - par].as<double>(), s->batch.as<double>(), d_hbatch);
 		WC_HIP(hipGetLastError());
 		for (int a = 0; a < na; ++a) s->parity[act[a]] = 1 - par;
 	}
 	// ---- Harvest on every window (the whole-utterance kernels; host-synchronous) ----
-	if ((rc = wc_harvest_compute_device(s->hv, na, s->batch.as<double>(), win_len.data(), s->win_tpos.as<double>(), s->win_f0.as<double>())))
+	if ((rc = wc_harvest_compute_device(s->hv, na, d_hbatch, h_len.data(), s->win_tpos.as<double>(), s->win_f0.as<double>())))
 		return rc;
 	// ---- commit ----
 	for (int a = 0; a < na; ++a) frames_out[act[a]] = count[a];
