@@ -51,8 +51,10 @@ def test_streams_equal_whole_utterances_24k_1ms(wca):
     assert sa.latency_ms == 600 and sa.chunk_samples == 4800
     res = sa.run_whole(xs)
     stats = [compare(r, whole(wca, x, fs, 1.0), "stream %d" % u) for u, (x, r) in enumerate(zip(xs, res))]
-    # most frames are bit-equal; the rest differ in the last bits only
-    assert min(s[0] for s in stats) > 0.5 and max(s[1] for s in stats) < 1e-11, stats
+    # 40-100 % of the frames are bit-equal; the rest differ in the last bits only (1e-14 relative: the smoothing filter's backward
+    # pass starts where the window ends and runs into its last-bit limit cycle with another phase)
+    assert max(s[1] for s in stats) < 1e-11 and max(s[2] for s in stats) < 1e-9, stats
+    assert stats[3][0] == 1.0  # a stream shorter than one window IS the whole-utterance call
     for u, x in enumerate(xs):
         assert sa.frames_committed(u) == wca.get_samples(fs, len(x) - len(x) % 3, 1.0)
     assert len(xs[2]) % 3 != 0 and len(xs[0]) % 3 == 0  # both cases of the decimation-phase rule are in the batch
