@@ -761,6 +761,9 @@ struct RefArgs {
 	HvParams p;
 };
 
+#ifndef WC_REFINE_FENCE
+#define WC_REFINE_FENCE 1
+#endif
 constexpr int RF_MAXHW = 1023;          // longest half window: 2 hw + 1 < 2048 keeps the transform size of reference :962 within the 4096-entry twiddle table
                                         // (f0 = 37.5 Hz at 8 kHz needs 321; 16 kHz after decimation and a 47 Hz candidate 511)
 constexpr int RF_MAXW = 2 * RF_MAXHW + 1;
@@ -789,9 +792,32 @@ __global__ __launch_bounds__(256, 4) void hv_refine_kernel(RefArgs a) {  // 4 wa
 	const double *__restrict__ y = a.y + u.y_off;
 	const int src = (blk == 0) ? i : (blk <= 3 ? i - blk : i + (blk - 3));  // overlap (reference :987-1000)
 	const bool src_ok = blk < 7 && src >= 0 && src < u.L1;
-	for (int j = wv; j < S; j += 4) {
+	const double *__restrict__ crow = a.cand0 + (u.l1_off + i) * S;  // wave-uniform row of this frame; the lane's source frame is doff away
+	const int doff = (src - i) * S;
+	// Phase 1: the window phase at every lane's first sample, exactly as the reference evaluates it (:762-788), for all the
+	// candidates this wavefront will take (slots wv, wv + 4, ...), parked in LDS.  Kept apart from the recurrences of phase 2
+	// because the polynomial coefficients of sincos are loop invariant: inside the candidate loop the compiler holds their 18
+	// registers across the whole body and, at 128 registers, spills them -- 84 bytes of scratch per thread, written by every
+	// one of the 164 M threads of a batch (7 GB of HBM writes per step in round 1's profile).
+	__shared__ double2 start_phase[MAX_SLOTS / 4][256];
+	__shared__ double row_f[7 * MAX_SLOTS], row_s[7 * MAX_SLOTS];
+	for (int j = wv, q = 0; j < S; j += 4, ++q) {
 		double f = 0.0;
-		if (src_ok) f = a.cand0[(u.l1_off + src) * S + j];
+		if (src_ok) f = crow[doff + j];
+		const double fc = f > 0.0 ? f : 100.0;
+		const int hw = min((int)(1.5 * fs / fc + 1.0), RF_MAXHW);
+		const double wlt = (2.0 * hw + 1.0) / fs;
+		const double bt0 = (-hw) / fs;
+		const int basic = mround((pos + bt0) * fs + 0.001);
+		const double tmp = (basic + sub - 1.0) / fs - pos;
+		const double tmp2 = 2.0 * kPi * tmp / wlt;
+		double wc, ws;
+		sincos(tmp2, &ws, &wc);
+		start_phase[q][threadIdx.x] = make_double2(wc, ws);
+	}
+	for (int j = wv, q = 0; j < S; j += 4, ++q) {
+		double f = 0.0;
+		if (src_ok) f = crow[doff + j];
 		const bool live = f > 0.0;
 		double rf = 0.0, rs = 0.0;
 		if (__ballot(live) != 0ull) {
@@ -811,13 +837,7 @@ __global__ __launch_bounds__(256, 4) void hv_refine_kernel(RefArgs a) {  // 4 wa
 			int idx[6];
 #pragma unroll
 			for (int h = 0; h < 6; ++h) idx[h] = mround(fc * N / fs * (h + 1));
-			// window phase at this lane's first sample, exactly as the reference evaluates it (:762-788)
-			double wc, ws;
-			{
-				const double tmp = (basic + sub - 1.0) / fs - pos;
-				const double tmp2 = 2.0 * kPi * tmp / wlt;
-				sincos(tmp2, &ws, &wc);
-			}
+			double wc = start_phase[q][threadIdx.x].x, ws = start_phase[q][threadIdx.x].y;  // phase 1
 			const double2 r1 = a.rot[2 * hw], r8 = a.rot[2 * hw + 1];  // (cos, sin) of beta and 8 beta, beta = 2 pi / (2 hw + 1)
 			const double k1 = 0.5 * r1.y, k2 = 0.16 * (2.0 * r1.y * r1.x);
 			// DFT bins of the lane's sub-sequence n = sub + 8 q by Goertzel's recurrence s_q = x_q + 2 cos(w) s_{q-1} - s_{q-2}
@@ -890,25 +910,34 @@ __global__ __launch_bounds__(256, 4) void hv_refine_kernel(RefArgs a) {  // 4 wa
 				}
 				Q += 2;
 			}
-			double v[32];
-#pragma unroll
-			for (int k = 24; k < 32; ++k) v[k] = 0.0;
-#pragma unroll
-			for (int h = 0; h < 6; ++h) {
+			// The 24 partial sums (6 harmonics x {re, im} x {main, difference window}) are reduced inside the 8-lane group by a
+			// halving butterfly that leaves harmonic h in lane h.  Its first stage pairs harmonic p with harmonic p + 4 (nothing
+			// for p = 2, 3) and is fused with the closing twiddles pair by pair: the recurrence states of a harmonic die as soon
+			// as its pair has been exchanged, which keeps the kernel inside 128 registers without scratch.
+			double v[16];
+			auto closing = [&](int h, double (&o)[4]) {
 				const double2 e1 = a.tw[((idx[h] * (sub + 8 * (Q - 1))) & (N - 1)) * tsh];  // conj = e^{-i phi (sub + 8 (Q-1))}
 				const double2 e2 = a.tw[((idx[h] * (sub + 8 * Q)) & (N - 1)) * tsh];
-				v[4 * h + 0] = sa[2 * h] * e1.x - sb[2 * h] * e2.x;
-				v[4 * h + 1] = sb[2 * h] * e2.y - sa[2 * h] * e1.y;
-				v[4 * h + 2] = sa[2 * h + 1] * e1.x - sb[2 * h + 1] * e2.x;
-				v[4 * h + 3] = sb[2 * h + 1] * e2.y - sa[2 * h + 1] * e1.y;
-			}
-			// halving butterfly inside the 8-lane group: afterwards lane `sub` holds v[4 sub .. 4 sub + 3]
+				o[0] = sa[2 * h] * e1.x - sb[2 * h] * e2.x;
+				o[1] = sb[2 * h] * e2.y - sa[2 * h] * e1.y;
+				o[2] = sa[2 * h + 1] * e1.x - sb[2 * h + 1] * e2.x;
+				o[3] = sb[2 * h + 1] * e2.y - sa[2 * h + 1] * e1.y;
+			};
 #pragma unroll
-			for (int k = 0; k < 16; ++k) {
+			for (int p = 0; p < 4; ++p) {
+				double lo[4], hi[4] = {0.0, 0.0, 0.0, 0.0};
+				closing(p, lo);
+				if (p < 2) closing(p + 4, hi);
 				const bool up = (sub & 4) != 0;
-				const double send = up ? v[k] : v[16 + k];
-				const double keep = up ? v[16 + k] : v[k];
-				v[k] = keep + __shfl_xor(send, 4, 64);
+#pragma unroll
+				for (int c = 0; c < 4; ++c) {
+					const double send = up ? lo[c] : hi[c];
+					const double keep = up ? hi[c] : lo[c];
+					v[4 * p + c] = keep + __shfl_xor(send, 4, 64);
+				}
+#if WC_REFINE_FENCE
+				asm volatile("" ::: "memory");  // keeps the next pair's table loads behind this pair's exchange
+#endif
 			}
 #pragma unroll
 			for (int k = 0; k < 8; ++k) {
@@ -950,9 +979,16 @@ __global__ __launch_bounds__(256, 4) void hv_refine_kernel(RefArgs a) {  // 4 wa
 			}
 		}
 		if (sub == 0 && blk < 7) {
-			a.cand1[g * a.p.n_cand + j + S * blk] = rf;
-			a.score1[g * a.p.n_cand + j + S * blk] = rs;
+			row_f[j + S * blk] = rf;
+			row_s[j + S * blk] = rs;
 		}
+	}
+	// the frame's 7 S (candidate, score) pairs leave as two contiguous rows instead of 2 x 7 scattered 8-byte stores per
+	// wavefront and slot
+	__syncthreads();
+	for (int k = threadIdx.x; k < 7 * S; k += 256) {
+		a.cand1[g * a.p.n_cand + k] = row_f[k];
+		a.score1[g * a.p.n_cand + k] = row_s[k];
 	}
 }
 
