@@ -176,3 +176,30 @@ def test_decimation_staged_through_lds_is_bit_identical(wca):
             del os.environ["WC_HARVEST_DECIMATE"]
         b.compute(x)
         assert np.array_equal(ya, b.debug_fetch("y")), (fs, n)
+
+
+def test_smoothing_that_skips_settled_stretches_is_bit_identical(wca):
+    """smoothF0Contour (reference src/harvest.cpp:639-703) filters the whole padded contour once per voiced section.  The default
+    kernel skips whole periods of eight steps wherever the input is constant and the filter state has repeated bit for bit; the
+    walk over every step (WC_HARVEST_SMOOTH=full) is the reference's loop as written.  Same bits on every frame -- long and
+    short sections, sections touching both ends of the utterance, 1 ms and 5 ms hops, a batch of ragged lengths."""
+    import os
+    from world_class_amd.synth import make_signal
+    fs = 16000
+    xs = [make_utterance(fs, 10.0, 12003), make_utterance(fs, 0.31, 7), make_signal(fs, 3.0, 40004), make_signal(fs, 2.0, 230002),
+          np.sin(2 * np.pi * 180.0 * np.arange(3 * fs) / fs) * 0.4,   # one section from the first frame to the last
+          make_utterance(fs, 4.0, 99)]
+    for fp in (1.0, 5.0):
+        a = wca.Harvest(fs, frame_period=fp)
+        ra = a.compute_batch(xs)
+        sm_a = [a.debug_fetch("f0_1ms", u) for u in range(len(xs))]
+        os.environ["WC_HARVEST_SMOOTH"] = "full"
+        try:
+            b = wca.Harvest(fs, frame_period=fp)
+        finally:
+            del os.environ["WC_HARVEST_SMOOTH"]
+        rb = b.compute_batch(xs)
+        for u, ((_, fa), (_, fb)) in enumerate(zip(ra, rb)):
+            assert np.array_equal(fa, fb), (fp, u)
+            assert np.array_equal(sm_a[u], b.debug_fetch("f0_1ms", u)), (fp, u)
+        assert sum(int((f > 0).sum()) for _, f in ra) > 1000

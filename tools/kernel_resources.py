@@ -12,7 +12,7 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 
 
 def main():
-    so = os.path.join(ROOT, "world_class_amd", "libworldclass_hip.so")
+    so = os.environ.get("WC_LIB_PATH") or os.path.join(ROOT, "world_class_amd", "libworldclass_hip.so")
     flt = sys.argv[1] if len(sys.argv) > 1 else ""
     notes = ""
     with tempfile.TemporaryDirectory() as d:

@@ -13,7 +13,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libworldclass_hip.so")
+# WC_LIB_PATH: another build of the same library (development: A/B runs of kernel variants, tools/ab_build.py)
+LIB_PATH = os.environ.get("WC_LIB_PATH") or os.path.join(_HERE, "libworldclass_hip.so")
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)

@@ -49,8 +49,9 @@ def source_hash():
     return h.hexdigest()
 
 
-def embedded_hash(path=OUT):
+def embedded_hash(path=None):
     """the source hash compiled into a built library, or None"""
+    path = path or OUT
     if not os.path.exists(path):
         return None
     with open(path, "rb") as f:

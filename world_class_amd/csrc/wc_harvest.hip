@@ -761,6 +761,9 @@ struct RefArgs {
 	HvParams p;
 };
 
+#ifndef WC_REFINE_WAVES
+#define WC_REFINE_WAVES 4
+#endif
 #ifndef WC_REFINE_FENCE
 #define WC_REFINE_FENCE 1
 #endif
@@ -778,7 +781,7 @@ constexpr int RF_MAXW = 2 * RF_MAXHW + 1;
 // (getMainWindow, src/harvest.cpp:779-787), the difference window from its neighbours (:792-803); three look-up pairs per
 // sample instead of a rotation, an option nobody takes for speed here but whose results differ from exact cosines by 1e-4.
 template <bool TABLE>
-__global__ __launch_bounds__(256, 4) void hv_refine_kernel(RefArgs a) {  // 4 waves per SIMD (128 VGPRs, 68 bytes of scratch): 9.5 ms against 9.9 ms at 3 waves / 156 VGPRs since the per-lane loop
+__global__ __launch_bounds__(256, WC_REFINE_WAVES) void hv_refine_kernel(RefArgs a) {  // 4 waves per SIMD (128 VGPRs, 68 bytes of scratch): 9.5 ms against 9.9 ms at 3 waves / 156 VGPRs since the per-lane loop
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	const int blk = lane >> 3, sub = lane & 7;
 	const long long g = blockIdx.x;
@@ -804,6 +807,7 @@ __global__ __launch_bounds__(256, 4) void hv_refine_kernel(RefArgs a) {  // 4 wa
 	for (int j = wv, q = 0; j < S; j += 4, ++q) {
 		double f = 0.0;
 		if (src_ok) f = crow[doff + j];
+		if (__ballot(f > 0.0) == 0ull) continue;  // an empty slot (most are) is skipped in phase 2 as well
 		const double fc = f > 0.0 ? f : 100.0;
 		const int hw = min((int)(1.5 * fs / fc + 1.0), RF_MAXHW);
 		const double wlt = (2.0 * hw + 1.0) / fs;
@@ -1387,6 +1391,7 @@ struct SmArgs {
 	double *scratch;  // [utt][(L1max + 600) * 64]
 	long long scratch_stride;
 	int max_sec;
+	int full_walk;    // WC_HARVEST_SMOOTH=full: every step of both passes over the whole padded contour (A/B and the bit-identity test)
 };
 
 constexpr int SM_PF = 32;  // steps whose inputs are requested ahead of the dependent recursion (8: 2.9 ms per half batch, memory latency per block)
@@ -1417,45 +1422,152 @@ __global__ __launch_bounds__(64) void hv_smooth_kernel(SmArgs a) {
 	const int ns = min(nb / 2, a.max_sec);
 	const double b0 = 0.0078202080334971724, b1 = 0.015640416066994345;
 	const double a0 = 1.7347257688092754, a1 = -0.76600660094326412;
+	if (a.full_walk) {
+		for (int s0 = 0; s0 < ns; s0 += 64) {
+			const int k = s0 + lane;
+			if (k < ns) {
+				const int st = sec[2 * k], ed = sec[2 * k + 1];
+				const double xs = f0[st - lag], xe = f0[ed - lag];
+				// forward pass; outputs before the section start are never read back.  Loads are issued SM_PF steps
+				// ahead of the dependent recursion.
+				double w0 = 0.0, w1 = 0.0;
+				for (int i0 = 0; i0 < n; i0 += SM_PF) {
+					double xin[SM_PF];
+	#pragma unroll
+					for (int e = 0; e < SM_PF; ++e) xin[e] = f0[clampi(i0 + e - lag, 0, L - 1)];
+	#pragma unroll
+					for (int e = 0; e < SM_PF; ++e) {
+						const int i = i0 + e;
+						if (i < n) {
+							const double xv = (i < st) ? xs : (i > ed ? xe : xin[e]);
+							const double wt = xv + a0 * w0 + a1 * w1;
+							if (i >= st) tmp[(long long)(n - i - 1) * 64 + lane] = b0 * wt + b1 * w0 + b0 * w1;
+							w1 = w0; w0 = wt;
+						}
+					}
+				}
+				// backward pass over the reversed signal, up to the section start
+				w0 = w1 = 0.0;
+				const int kend = n - 1 - st;
+				for (int i0 = 0; i0 <= kend; i0 += SM_PF) {
+					double tin[SM_PF];
+	#pragma unroll
+					for (int e = 0; e < SM_PF; ++e) tin[e] = (i0 + e <= kend) ? tmp[(long long)(i0 + e) * 64 + lane] : 0.0;
+	#pragma unroll
+					for (int e = 0; e < SM_PF; ++e) {
+						const int i = i0 + e;
+						if (i <= kend) {
+							const double wt = tin[e] + a0 * w0 + a1 * w1;
+							const double yv = b0 * wt + b1 * w0 + b0 * w1;
+							w1 = w0; w0 = wt;
+							const int j = n - i - 1;
+							if (j <= ed) out[j - lag] = yv;
+						}
+					}
+				}
+			}
+			__syncthreads();
+		}
+		return;
+	}
+	// The reference runs both passes over the whole padded contour for every section (2 x 10 600 dependent steps for a 10 s
+	// utterance).  Outside the section the input is constant -- the section's first value before it, its last value behind it
+	// (:646-647) -- and the recursion is a deterministic map of its two state words, so once the state after a step equals,
+	// bit for bit, the state eight steps earlier, every further block of eight steps under that input leaves it unchanged and
+	// can be skipped.  (The filter settles within ~300 steps: exactly in three cases of four, else into a last-bit limit cycle
+	// of period 4 or 8 -- which is why whole periods are skipped, and why the comparison is on the bits, not on a tolerance.
+	// A state that never repeats -- NaN input -- simply walks every step, as the reference does.)
+	//   forward:  constant lead-in (skipped up to a multiple of 8), the section, then the constant tail until its outputs
+	//             repeat with period 8 (index `pend`: outputs beyond it are copies of the last eight);
+	//   backward: the periodic tail from the far end (periodic input, same argument with the phase kept), the explicit tail,
+	//             the section.
+	// Every step that is executed is the reference's own arithmetic, in its order.
+	__shared__ double per[8 * 64];  // the last period of the forward tail, [phase][lane]
+	auto bits = [](double v) { return __double_as_longlong(v); };
 	for (int s0 = 0; s0 < ns; s0 += 64) {
 		const int k = s0 + lane;
 		if (k < ns) {
 			const int st = sec[2 * k], ed = sec[2 * k + 1];
 			const double xs = f0[st - lag], xe = f0[ed - lag];
-			// forward pass; outputs before the section start are never read back.  Loads are issued SM_PF steps
-			// ahead of the dependent recursion.
 			double w0 = 0.0, w1 = 0.0;
-			for (int i0 = 0; i0 < n; i0 += SM_PF) {
+			auto step = [&](double xv) -> double {
+				const double wt = xv + a0 * w0 + a1 * w1;
+				const double yv = b0 * wt + b1 * w0 + b0 * w1;
+				w1 = w0; w0 = wt;
+				return yv;
+			};
+			// ---- forward, lead-in: i = 0 .. st - 1 under the constant xs ----
+			{
+				int i = 0;
+				double p0 = w0, p1 = w1;
+				bool periodic = false;
+				while (i < st) {
+					if ((i & 7) == 0 && i > 0) {
+						if (bits(w0) == bits(p0) && bits(w1) == bits(p1)) { periodic = true; break; }
+						p0 = w0; p1 = w1;
+					}
+					(void)step(xs);
+					++i;
+				}
+				if (periodic) i += ((st - i) / 8) * 8;
+				for (; i < st; ++i) (void)step(xs);
+			}
+			// ---- forward, section: outputs to tmp[i - st] ----
+			for (int i0 = st; i0 <= ed; i0 += SM_PF) {
 				double xin[SM_PF];
 #pragma unroll
 				for (int e = 0; e < SM_PF; ++e) xin[e] = f0[clampi(i0 + e - lag, 0, L - 1)];
 #pragma unroll
 				for (int e = 0; e < SM_PF; ++e) {
 					const int i = i0 + e;
-					if (i < n) {
-						const double xv = (i < st) ? xs : (i > ed ? xe : xin[e]);
-						const double wt = xv + a0 * w0 + a1 * w1;
-						if (i >= st) tmp[(long long)(n - i - 1) * 64 + lane] = b0 * wt + b1 * w0 + b0 * w1;
-						w1 = w0; w0 = wt;
+					if (i <= ed) tmp[(long long)(i - st) * 64 + lane] = step(xin[e]);
+				}
+			}
+			// ---- forward, tail: constant xe until the outputs repeat with period 8 (or the array ends) ----
+			int pend = ed + 1;
+			{
+				double q0 = w0, q1 = w1;
+				int c = 0;
+				while (pend < n) {
+					tmp[(long long)(pend - st) * 64 + lane] = step(xe);
+					++pend;
+					if ((++c & 7) == 0) {
+						if (bits(w0) == bits(q0) && bits(w1) == bits(q1)) break;
+						q0 = w0; q1 = w1;
 					}
 				}
 			}
-			// backward pass over the reversed signal, up to the section start
+			// ---- backward, periodic part of the tail: j = n - 1 .. pend, input y[j] = y[pend - 8 + ((j - pend) & 7)] ----
 			w0 = w1 = 0.0;
-			const int kend = n - 1 - st;
-			for (int i0 = 0; i0 <= kend; i0 += SM_PF) {
+			int j = n - 1;
+			if (j >= pend) {
+#pragma unroll
+				for (int m = 0; m < 8; ++m) per[m * 64 + lane] = tmp[(long long)(pend - 8 + m - st) * 64 + lane];
+				double p0 = w0, p1 = w1;
+				int c = 0;
+				bool periodic = false;
+				while (j >= pend) {
+					(void)step(per[((j - pend) & 7) * 64 + lane]);
+					--j;
+					if ((++c & 7) == 0) {
+						if (bits(w0) == bits(p0) && bits(w1) == bits(p1)) { periodic = true; break; }
+						p0 = w0; p1 = w1;
+					}
+				}
+				if (periodic) j -= ((j - pend + 1) / 8) * 8;
+				for (; j >= pend; --j) (void)step(per[((j - pend) & 7) * 64 + lane]);
+			}
+			// ---- backward, explicit tail and section: j = pend - 1 .. st ----
+			for (int j0 = j; j0 >= st; j0 -= SM_PF) {
 				double tin[SM_PF];
 #pragma unroll
-				for (int e = 0; e < SM_PF; ++e) tin[e] = (i0 + e <= kend) ? tmp[(long long)(i0 + e) * 64 + lane] : 0.0;
+				for (int e = 0; e < SM_PF; ++e) tin[e] = (j0 - e >= st) ? tmp[(long long)(j0 - e - st) * 64 + lane] : 0.0;
 #pragma unroll
 				for (int e = 0; e < SM_PF; ++e) {
-					const int i = i0 + e;
-					if (i <= kend) {
-						const double wt = tin[e] + a0 * w0 + a1 * w1;
-						const double yv = b0 * wt + b1 * w0 + b0 * w1;
-						w1 = w0; w0 = wt;
-						const int j = n - i - 1;
-						if (j <= ed) out[j - lag] = yv;
+					const int jj = j0 - e;
+					if (jj >= st) {
+						const double yv = step(tin[e]);
+						if (jj <= ed) out[jj - lag] = yv;
 					}
 				}
 			}
@@ -1498,6 +1610,7 @@ struct wc_harvest {
 	bool use_fir;  // WC_HARVEST_BANDPASS=fir: the direct FIR band-pass instead of the sliding DFT (A/B and tests)
 	bool use_cos_table;  // HarvestOption::use_cos_table
 	DevBuf d_cos_table;
+	bool smooth_full_walk;  // WC_HARVEST_SMOOTH=full: the smoothing filter without the skipping of settled stretches (A/B and the bit-identity test)
 	bool direct_decimation;  // WC_HARVEST_DECIMATE=direct: every lane reads its own stream from memory (A/B and the bit-identity test)
 	DevBuf utts, dec, y, events, ev_count, overflow, tile_run, raw, cand0, cand1, score1, cand2, score2;
 	DevBuf base, s1, s2, s3, fixed, f0_1ms, sec, chan, smooth, ibuf;
@@ -1735,6 +1848,7 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 	SmArgs sa;
 	sa.utts = du; sa.fixed = h->fixed.as<double>(); sa.f0_1ms = h->f0_1ms.as<double>(); sa.sec = h->sec.as<int>();
 	sa.scratch = h->smooth.as<double>(); sa.scratch_stride = smooth_stride; sa.max_sec = max_sec;
+	sa.full_walk = h->smooth_full_walk ? 1 : 0;
 	hipLaunchKernelGGL(hv_smooth_kernel, dim3(n_utt), dim3(64), 0, s, sa);
 	hipLaunchKernelGGL(hv_output_kernel, dim3((max_L + 255) / 256, n_utt), dim3(256), 0, s, du, h->f0_1ms.as<double>(), d_tpos, d_f0, h->frame_period);
 	WC_HIP(hipGetLastError());
@@ -1851,6 +1965,8 @@ wc_harvest *wc_harvest_create(int fs, double f0_floor, double f0_ceil, double fr
 		h->debug_small_caps = getenv("WC_DEBUG_SMALL_CAPS") != nullptr;
 		const char *dm = getenv("WC_HARVEST_DECIMATE");
 		h->direct_decimation = dm && std::strcmp(dm, "direct") == 0;
+		const char *sm = getenv("WC_HARVEST_SMOOTH");
+		h->smooth_full_walk = sm && std::strcmp(sm, "full") == 0;
 	}
 	{
 		std::vector<double2> rot(2 * (RF_MAXHW + 1));
