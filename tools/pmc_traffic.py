@@ -44,6 +44,7 @@ def main():
     ap.add_argument("fetch_dir")
     ap.add_argument("write_dir")
     ap.add_argument("--valu-dir", default=None, help="pass with SQ_INSTS_VALU (vector instructions issued, per wave)")
+    ap.add_argument("--f64-dir", default=None, help="pass with SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64")
     ap.add_argument("--steps", type=int, required=True, help="warmup + timed steps of the profiled bench run")
     ap.add_argument("-o", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json"))
     a = ap.parse_args()
@@ -65,6 +66,17 @@ def main():
                              "cycles, so the chip issues at most 1024 SIMDs x 2.4 GHz / 4 = 614.4 G of them per second; bench.py divides "
                              "by the live kernel time to report the vector-issue utilisation next to the HBM fraction.")
         out["_valu_insts_per_step"] = {k: v / a.steps for k, v in sorted(valu.items())}
+    if a.f64_dir:
+        parts = {c: total_kib(a.f64_dir, c) for c in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64")}
+        names = sorted(set().union(*[set(v) for v in parts.values()]))
+        if names:
+            out["_fp64_note"] = ("FP64 floating-point operations per bench step from SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 (wave-level "
+                                 "instruction counts) x 64 lanes, a fused multiply-add counted as two; an upper bound where lanes are masked off. "
+                                 "Peak: 78.6 TFLOP/s (256 CUs x 4 SIMDs x 16 lanes x 2 x 2.4 GHz).")
+            out["_fp64_insts_per_step"] = {n: {c[14:]: parts[c].get(n, 0.0) / a.steps for c in parts} for n in names}
+            out["_fp64_flops_per_step"] = {n: 64.0 * (parts["SQ_INSTS_VALU_ADD_F64"].get(n, 0.0) + parts["SQ_INSTS_VALU_MUL_F64"].get(n, 0.0)
+                                                      + 2.0 * parts["SQ_INSTS_VALU_FMA_F64"].get(n, 0.0) + parts["SQ_INSTS_VALU_TRANS_F64"].get(n, 0.0)) / a.steps
+                                           for n in names}
     with open(a.o, "w") as fh:
         json.dump(out, fh, indent=1)
     print(json.dumps({k: v for k, v in out.items() if not k.startswith("_")}))
