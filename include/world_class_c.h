@@ -138,8 +138,9 @@ int wc_pipeline_get_fft_size(const wc_pipeline *p);
 int wc_pipeline_run_device(wc_pipeline *p, int n_utt, const double *d_x, const int *x_length, double *d_tpos, double *d_f0,
                            double *d_sp, double *d_ap, double *d_y, uint64_t *rng_pos);
 
-/* Host batch front-end: n_utt ragged utterances given by host pointers, either doubles (x_is_pcm16 = 0) or the 16-bit PCM
- * samples of a WAV file (x_is_pcm16 = 1: expanded on the device as sample / 32768, what the reference's wavread returns).
+/* Host batch front-end: n_utt ragged utterances given by host pointers: doubles (x_is_pcm16 = 0), the 16-bit PCM samples of a
+ * WAV file (x_is_pcm16 = 1: expanded on the device as sample / 32768, what the reference's wavread returns) or 32-bit floats
+ * (x_is_pcm16 = 2: widened on the device, exactly).
  * Inputs are gathered into pinned memory and cross PCIe in one copy; the fused pipeline runs; the requested outputs come back
  * in one packed pinned region and are scattered to the caller's per-utterance buffers: tpos[u], f0[u] (frames doubles),
  * sp[u], ap[u] (frames x (fft_size/2+1) doubles, contiguous), y[u] (out_length doubles, or int16 quantised like the

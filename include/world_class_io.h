@@ -50,6 +50,8 @@ int ReadAperiodicity(const char *filename, double **aperiodicity);
 int wc_wavread_pcm16(const char *filename, int *fs, int16_t *pcm, int capacity);
 /* d_x[i] = d_pcm[i] / 32768.0 (wavread's scaling) on the current device / stream; pointers are device pointers */
 int wc_pcm16_to_double_device(const int16_t *d_pcm, long long n, double *d_x);
+/* d_x[i] = (double)d_f[i]: 32-bit float samples (the other common in-memory format) widened on the device, exactly */
+int wc_float_to_double_device(const float *d_f, long long n, double *d_x);
 /* d_pcm[i] = wavwrite's quantisation of d_y[i] */
 int wc_double_to_pcm16_device(const double *d_y, long long n, int16_t *d_pcm);
 

@@ -21,6 +21,11 @@ def test_partition_is_balanced_and_deterministic():
     assert parts == partition(lengths, 4)
     assert partition([5, 5, 5], 1) == [[0, 1, 2]]
     assert partition([], 2) == [[], []]
+    # the C-ABI twin for hosts without Python (include/world_class_shard.h) deals identically
+    from world_class_amd.shard import partition_c
+    for world in (1, 2, 3, 8):
+        assert partition_c(lengths, world) == partition(lengths, world)
+    assert partition_c([7, 7, 7, 7, 7], 2) == partition([7, 7, 7, 7, 7], 2)
 
 
 def _stage(x):

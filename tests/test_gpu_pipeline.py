@@ -133,6 +133,12 @@ def test_host_batch_front_end_pcm16_and_double(wca):
     for r, g in zip(ref, got):
         assert set(g) == {"f0", "y"} and np.array_equal(g["f0"], r["f0"])
         assert np.abs(g["y"] - r["y"]).max() < 1e-10   # overlap-add order differs between runs at the 1e-16 level
+    # 32-bit float samples: widened on the device, exactly
+    x32 = [v.astype(np.float32) for v in xq]
+    ref32 = p.run_batch([v.astype(np.float64) for v in x32])
+    got = p.run_batch_host(x32, want=("f0", "sp"))
+    for r, g in zip(ref32, got):
+        assert np.array_equal(g["f0"], r["f0"]) and np.array_equal(g["sp"], r["sp"])
     # the caller's own buffers written again (out=), larger batch so that the half-batch copies overlap the second half
     many = [xq[i % 3] for i in range(10)]
     ref = p.run_batch(many)
@@ -246,3 +252,37 @@ def test_headline_workload_against_the_reference(wca):
     res = wca.Pipeline(48000).run_batch([x for x, _ in cases] * 2)  # both halves of the batch schedule see both utterances
     for (x, g), r in zip(cases * 2, res):
         check_headline(r, g, 1e-6, 1e-7, 1e-7, 1e-8)
+
+
+def test_c_abi_gather_over_rccl(wca):
+    """wc_gather_device (include/world_class_shard.h) on a communicator the caller owns.  One GPU here, so the group has one rank
+    -- what this pins is the binding: RCCL found in the process, the grouped broadcasts enqueued on the caller's stream behind
+    the pipeline's work, the block landing at its offset."""
+    import ctypes as C
+    import os
+    import torch
+    from world_class_amd.shard import SHARD_SIGNATURES, partition_c
+    partition_c([3, 2, 1], 2)  # binds the prototypes
+    rccl = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+    comm = C.c_void_p()
+    assert rccl.ncclCommInitAll(C.byref(comm), 1, (C.c_int * 1)(0)) == 0
+    try:
+        fs = 16000
+        x = make_utterance(fs, 0.6, 77)
+        pipe = wca.Pipeline(fs)
+        dev = torch.device("cuda", 0)
+        f_len, y_len = pipe.lengths([len(x)])
+        d_x = torch.from_numpy(x).to(dev)
+        out = [torch.zeros(n, dtype=torch.float64, device=dev) for n in (f_len[0], f_len[0], f_len[0] * pipe.bins, f_len[0] * pipe.bins, y_len[0])]
+        torch.cuda.synchronize()
+        pipe.run_device(d_x, [len(x)], *out)
+        d_all = torch.zeros(y_len[0], dtype=torch.float64, device=dev)
+        counts = (C.c_longlong * 1)(y_len[0])
+        rc = wca.lib().wc_gather_device(comm, 1, 0, out[4].data_ptr(), counts, d_all.data_ptr())
+        assert rc == 0, wca.last_error()
+        assert wca.lib().wc_synchronize() == 0
+        torch.cuda.synchronize()
+        assert torch.equal(d_all, out[4]) and float(d_all.abs().sum()) > 0
+        assert wca.lib().wc_gather_device(comm, 1, 3, out[4].data_ptr(), counts, d_all.data_ptr()) != 0  # rank outside the group
+    finally:
+        rccl.ncclCommDestroy(comm)

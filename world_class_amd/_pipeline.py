@@ -50,8 +50,8 @@ class Pipeline:
         out: a result of an earlier call with the same lengths and `want` whose arrays are written again (a caller
         that reuses its buffers spares the page faults of 2 GB of fresh memory per batch)."""
         import ctypes as C
-        pcm = xs[0].dtype == np.int16
-        xs = [np.ascontiguousarray(v, dtype=np.int16 if pcm else np.float64) for v in xs]
+        fmt = {np.dtype(np.int16): 1, np.dtype(np.float32): 2}.get(xs[0].dtype, 0)  # 0 float64, 1 int16 PCM, 2 float32
+        xs = [np.ascontiguousarray(v, dtype=(np.float64, np.int16, np.float32)[fmt]) for v in xs]
         n = len(xs)
         xl = [len(v) for v in xs]
         fl, yl = self.lengths(xl)
@@ -72,7 +72,7 @@ class Pipeline:
                 outs[k] = [np.empty(m, dtype=np.int16 if y_pcm16 else np.float64) for m in yl]
             tabs[k] = VP(*[a.ctypes.data for a in outs[k]])
         arr, arg = _rng_arg(rng_pos, n)
-        _check(lib().wc_pipeline_run_batch_host(self._h, n, VP(*[v.ctypes.data for v in xs]), 1 if pcm else 0, _ints(xl), tabs["tpos"],
+        _check(lib().wc_pipeline_run_batch_host(self._h, n, VP(*[v.ctypes.data for v in xs]), fmt, _ints(xl), tabs["tpos"],
                                                 tabs["f0"], tabs["sp"], tabs["ap"], tabs["y"], 1 if y_pcm16 else 0, arg))
         res = [{k: outs[k][u] for k in outs if outs[k] is not None} for u in range(n)]
         return (res, list(arr)) if rng_pos is not None else res

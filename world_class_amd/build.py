@@ -33,7 +33,7 @@ def sources():
 def headers():
     inc = os.path.join(os.path.dirname(HERE), "include")
     hs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp"))
-    hs += [os.path.join(inc, f) for f in ("world_class_c.h", "world_class_io.h", "world_class_codec.h", "world_class_stream.h",
+    hs += [os.path.join(inc, f) for f in ("world_class_c.h", "world_class_io.h", "world_class_codec.h", "world_class_stream.h", "world_class_shard.h",
                                           "world_matlabfunctions.hpp", "world_fft.hpp") if os.path.exists(os.path.join(inc, f))]
     return hs
 
@@ -105,7 +105,7 @@ def build(force=False, verbose=False):
                 raise RuntimeError("hipcc failed")
     with open(stamp, "w") as f:
         f.write(flags_now)
-    rc, out = run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
+    rc, out = run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl"])
     if out.strip():
         print(out)
     if rc != 0:

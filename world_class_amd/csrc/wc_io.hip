@@ -190,6 +190,10 @@ __global__ void pcm16_to_double_kernel(const int16_t *__restrict__ p, long long 
 	for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
 		x[i] = static_cast<double>(p[i]) / 32768.0;
 }
+__global__ void float_to_double_kernel(const float *__restrict__ p, long long n, double *__restrict__ x) {
+	for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+		x[i] = static_cast<double>(p[i]);
+}
 __global__ void double_to_pcm16_kernel(const double *__restrict__ y, long long n, int16_t *__restrict__ p) {
 	for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
 		p[i] = static_cast<int16_t>(pcm16_of(y[i]));
@@ -374,6 +378,18 @@ int wc_pcm16_to_double_device(const int16_t *d_pcm, long long n, double *d_x) {
 	if (n == 0) return WC_OK;
 	const unsigned blocks = static_cast<unsigned>(std::min<long long>((n + 255) / 256, 65536));
 	hipLaunchKernelGGL(pcm16_to_double_kernel, dim3(blocks), dim3(256), 0, dev->active(), d_pcm, n, d_x);
+	WC_HIP(hipGetLastError());
+	return WC_OK;
+}
+
+int wc_float_to_double_device(const float *d_f, long long n, double *d_x) {
+	if (n < 0 || (n > 0 && (!d_f || !d_x))) return fail(WC_ERR_INVALID, "float_to_double: bad argument");
+	Device *dev = current_device();
+	if (!dev) return WC_ERR_DEVICE;
+	DeviceLock lock(dev);
+	if (n == 0) return WC_OK;
+	const unsigned blocks = static_cast<unsigned>(std::min<long long>((n + 255) / 256, 65536));
+	hipLaunchKernelGGL(float_to_double_kernel, dim3(blocks), dim3(256), 0, dev->active(), d_f, n, d_x);
 	WC_HIP(hipGetLastError());
 	return WC_OK;
 }

@@ -402,10 +402,11 @@ int wc_pipeline_run_batch_host(wc_pipeline *p, int n_utt, const void *const *x, 
 		nx += x_length[u]; nf += f_len[u]; ny += y_len[u];
 	}
 	int rc;
-	const size_t in_elem = x_is_pcm16 ? sizeof(int16_t) : sizeof(double);
+	if (x_is_pcm16 < 0 || x_is_pcm16 > 2) return fail(WC_ERR_INVALID, "pipeline batch: input format must be 0 (float64), 1 (int16 PCM) or 2 (float32)");
+	const size_t in_elem = x_is_pcm16 == 1 ? sizeof(int16_t) : x_is_pcm16 == 2 ? sizeof(float) : sizeof(double);
 	if ((rc = p->st_in.reserve(in_elem * nx))) return rc;
 	if ((rc = p->b_x.reserve(sizeof(double) * nx))) return rc;
-	if (x_is_pcm16 && (rc = p->b_pcm.reserve(sizeof(int16_t) * nx))) return rc;
+	if (x_is_pcm16 && (rc = p->b_pcm.reserve(in_elem * nx))) return rc;
 	if ((rc = p->b_t.reserve(sizeof(double) * nf))) return rc;
 	if ((rc = p->b_f.reserve(sizeof(double) * nf))) return rc;
 	if ((rc = p->b_sp.reserve(sizeof(double) * nf * bins))) return rc;
@@ -420,9 +421,12 @@ int wc_pipeline_run_batch_host(wc_pipeline *p, int n_utt, const void *const *x, 
 		}
 		parallel_copy(jobs);
 	}
-	if (x_is_pcm16) {
+	if (x_is_pcm16 == 1) {
 		WC_HIP(hipMemcpyAsync(p->b_pcm.p, p->st_in.p, sizeof(int16_t) * nx, hipMemcpyHostToDevice, s));
 		if ((rc = wc_pcm16_to_double_device(p->b_pcm.as<int16_t>(), nx, p->b_x.as<double>()))) return rc;
+	} else if (x_is_pcm16 == 2) {
+		WC_HIP(hipMemcpyAsync(p->b_pcm.p, p->st_in.p, sizeof(float) * nx, hipMemcpyHostToDevice, s));
+		if ((rc = wc_float_to_double_device(p->b_pcm.as<float>(), nx, p->b_x.as<double>()))) return rc;
 	} else {
 		WC_HIP(hipMemcpyAsync(p->b_x.p, p->st_in.p, sizeof(double) * nx, hipMemcpyHostToDevice, s));
 	}

@@ -23,6 +23,7 @@ IO_SIGNATURES = {
     "ReadAperiodicity": (C.c_int, [C.c_char_p, _rows_t]),
     "wc_wavread_pcm16": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), _i16p, C.c_int]),
     "wc_pcm16_to_double_device": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p]),
+    "wc_float_to_double_device": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p]),
     "wc_double_to_pcm16_device": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p]),
     "wc_modify_parameters_device": (C.c_int, [C.c_int, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p, C.c_double, C.c_double]),
 }
@@ -136,6 +137,10 @@ def read_aperiodicity(filename):
 
 def pcm16_to_double_device(d_pcm, n, d_x):
     _check(_io().wc_pcm16_to_double_device(_ptr(d_pcm), int(n), _ptr(d_x)))
+
+
+def float_to_double_device(d_f, n, d_x):
+    _check(_io().wc_float_to_double_device(_ptr(d_f), int(n), _ptr(d_x)))
 
 
 def double_to_pcm16_device(d_y, n, d_pcm):

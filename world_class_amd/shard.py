@@ -4,10 +4,34 @@ Every utterance is independent in all four stages, so ranks never exchange data 
 only collective is the gather of results at the end; it is written against torch.distributed so the same
 code runs over RCCL ("nccl" backend on ROCm, xGMI links) on the GPUs and over gloo in the CPU tests.
 """
+import ctypes as C
 from typing import List, Sequence
 
 import torch
 import torch.distributed as dist
+
+# the C-ABI of include/world_class_shard.h (C / C++ hosts shard and gather through it; this module is the torch.distributed twin)
+SHARD_SIGNATURES = {
+    "wc_shard_partition": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "wc_gather_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_longlong), C.c_void_p]),
+}
+
+
+def partition_c(lengths: Sequence[int], world: int) -> List[List[int]]:
+    """`partition` through the C-ABI (wc_shard_partition): the same deal, for hosts without Python"""
+    from . import _check, lib
+    L = lib()
+    for name, (res, args) in SHARD_SIGNATURES.items():
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = res, args
+    n = len(lengths)
+    arr = (C.c_int * max(n, 1))(*[int(v) for v in lengths])
+    out = (C.c_int * max(n, 1))()
+    _check(L.wc_shard_partition(arr, n, world, out))
+    parts: List[List[int]] = [[] for _ in range(world)]
+    for i in range(n):
+        parts[out[i]].append(i)
+    return parts
 
 
 def partition(lengths: Sequence[int], world: int) -> List[List[int]]:
