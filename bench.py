@@ -255,12 +255,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
         # RCCL really spans `world` ranks on distinct devices
-        probe = torch.ones(1, dtype=torch.float64, device=dev)
-        dist.all_reduce(probe)
-        ids = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(ids, torch.tensor([local_rank], dtype=torch.int64, device=dev))
-        if int(probe.item()) != world or dist.get_backend() != "nccl" or len({int(t.item()) for t in ids}) != world:
-            raise SystemExit("bench.py: the RCCL group does not span --gpus distinct devices")
+        from world_class_amd.shard import verify_group
+        if dist.get_backend() != "nccl":
+            raise SystemExit("bench.py: the process group is not RCCL")
+        try:
+            verify_group(world, local_rank, dev)
+        except RuntimeError as e:
+            raise SystemExit(f"bench.py: {e}")
 
     import world_class_amd as w
     from world_class_amd.shard import ShardLayout
@@ -337,12 +338,9 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed, gather_s[0]], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed, gather_s[0] = float(tmax[0].item()), float(tmax[1].item())
-        tot = torch.tensor([frames], dtype=torch.int64, device=dev)
-        dist.all_reduce(tot)
-        total_frames = int(tot.item())
+        from world_class_amd.shard import max_over_ranks, sum_over_ranks
+        elapsed, gather_s[0] = max_over_ranks([elapsed, gather_s[0]], dev)
+        total_frames = sum_over_ranks(frames, dev)
     else:
         total_frames = frames
 

@@ -83,7 +83,16 @@ def _layout_worker(rank, world, port, x_lengths, width, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    from world_class_amd.shard import max_over_ranks, sum_over_ranks, verify_group
+    verify_group(world, rank, torch.device("cpu"))          # the checks bench.py makes on its RCCL group
+    try:
+        verify_group(world, 0, torch.device("cpu"))         # every rank claiming device 0: must be refused
+        raise AssertionError("duplicate local ids went unnoticed")
+    except RuntimeError:
+        pass
+    assert max_over_ranks([float(rank), 1.5], torch.device("cpu")) == [float(world - 1), 1.5]
     lay = ShardLayout(x_lengths, FS, HOP, world, rank)
+    assert sum_over_ranks(sum(lay.f_len), torch.device("cpu")) == sum(lay.all_f_len)
     outs = [_fake_outputs(i, f, y, width) for i, f, y in zip(lay.mine, lay.f_len, lay.y_len)]
     cat = lambda k, shape: torch.from_numpy(np.concatenate([o[k].ravel() for o in outs])) if outs else torch.zeros(shape, dtype=torch.float64)
     f0_all = lay.gather_frames(cat(0, 0))

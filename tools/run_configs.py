@@ -162,11 +162,12 @@ def main():
         pcm = [np.clip(np.round(x * 32768), -32768, 32767).astype(np.int16) for x in xs]
         p = w.Pipeline(fs)
         frames = sum(p.lengths([len(v) for v in pcm])[0])
-        p.run_batch_host(pcm, want=("f0", "y"), y_pcm16=True)
         for want, label in ((("f0", "y"), "f0 + int16 waveform back"), (("tpos", "f0", "sp", "ap", "y"), "all five outputs back (2.1 GB of sp + ap)")):
+            res = p.run_batch_host(pcm, want=want, y_pcm16=True)  # the caller's result buffers, written again below (no fresh pages)
             t0 = time.perf_counter()
-            p.run_batch_host(pcm, want=want, y_pcm16=True)
+            p.run_batch_host(pcm, want=want, y_pcm16=True, out=res)
             t = time.perf_counter() - t0
+            del res
             print(json.dumps({"config": "host", "what": f"{n} x 48 kHz 10 s from host int16 PCM through pinned staging, full pipeline, {label}",
                               "frames": frames, "ms": t * 1e3, "frames_per_s": frames / t}))
         del p

@@ -102,3 +102,28 @@ class ShardLayout:
     def gather_samples(self, local: torch.Tensor, group=None) -> List[torch.Tensor]:
         """output waveforms of every rank -> list over all utterances in their original order"""
         return scatter_back(self.parts, gather_ragged(local.reshape(-1), group), self.all_y_len)
+
+
+# ---- the few collectives of a sharded run besides the final gather: used by bench.py over RCCL and by the gloo tests ----------
+def verify_group(world: int, local_id: int, device, group=None) -> None:
+    """the process group really spans `world` ranks, each with its own device / local id (a launcher mistake would otherwise
+    produce an N-GPU-labelled number from fewer GPUs)"""
+    probe = torch.ones(1, dtype=torch.float64, device=device)
+    dist.all_reduce(probe, group=group)
+    ids = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(ids, torch.tensor([local_id], dtype=torch.int64, device=device), group=group)
+    seen = {int(t.item()) for t in ids}
+    if int(probe.item()) != world or dist.get_world_size(group) != world or len(seen) != world:
+        raise RuntimeError(f"process group does not span {world} distinct devices (ranks answering: {int(probe.item())}, local ids: {sorted(seen)})")
+
+
+def max_over_ranks(values: Sequence[float], device, group=None) -> List[float]:
+    t = torch.tensor(list(values), dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return [float(v) for v in t.tolist()]
+
+
+def sum_over_ranks(value: int, device, group=None) -> int:
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, group=group)
+    return int(t.item())
