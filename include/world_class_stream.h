@@ -65,6 +65,11 @@ int wc_stream_reset(wc_stream *s, int stream);
  * frames_out: host array [n_streams], frames committed by this push. */
 int wc_stream_push_device(wc_stream *s, const double *d_chunk, const int *n_new, const int *flush, double *d_tpos, double *d_f0,
                           double *d_sp, int *frames_out);
+/* Position of stream u in the reference's noise sequence (reference src/world_matlabfunctions.cpp:243-264): where CheapTrick's next
+ * committed frame takes its draws.  0 after creation and after wc_stream_reset -- the position a fresh reference process starts
+ * from; set it to continue the numbering of an earlier analysis (e.g. the value wc_rng_get_position() reports after one). */
+unsigned long long wc_stream_rng_position(const wc_stream *s, int stream);
+int wc_stream_set_rng_position(wc_stream *s, int stream, unsigned long long position);
 /* frames committed so far / samples received so far for stream u */
 long long wc_stream_frames_committed(const wc_stream *s, int stream);
 long long wc_stream_samples_received(const wc_stream *s, int stream);

@@ -132,3 +132,26 @@ def test_stream_arguments_are_checked(wca):
     sa = StreamAnalyzer(24000, 2)
     with pytest.raises(wca.WorldClassError, match="short chunk"):
         sa.push([np.zeros(100), np.zeros(sa.chunk_samples)])
+
+
+def test_noise_positions_are_carried_and_may_lie_far_apart(wca):
+    """CheapTrick's draws come from the stream's own position in the reference's sequence; a stream may continue the numbering of
+    an earlier analysis, and streams whose positions lie further apart than one draw table covers are served one by one"""
+    from world_class_amd.stream import StreamAnalyzer
+    fs = 16000
+    x = make_utterance(fs, 1.3, 5300)
+    x = x[:len(x) - len(x) % 2]
+    far = (1 << 30) + 12345
+    sa = StreamAnalyzer(fs, 2, frame_period=5.0, chunk_ms=200, lookback_ms=400, lookahead_ms=400)
+    sa.set_rng_position(1, far)
+    res = sa.run_whole([x, x])
+    t, f0, sp0 = whole(wca, x, fs, 5.0)
+    wca.rng_set_position(far)
+    sp1 = wca.CheapTrick(fs).compute(x, t, f0)
+    end1 = wca.rng_get_position()
+    wca.rng_set_position(0)
+    assert np.array_equal(res[0]["f0"] == 0, f0 == 0) and np.array_equal(res[1]["f0"], res[0]["f0"])
+    assert (np.abs(res[0]["sp"] - sp0) / sp0).max() < 1e-9
+    assert (np.abs(res[1]["sp"] - sp1) / sp1).max() < 1e-9
+    assert not np.array_equal(res[0]["sp"], res[1]["sp"])       # other draws, other last bits
+    assert sa.rng_position(1) == end1 and sa.rng_position(0) == end1 - far

@@ -138,6 +138,14 @@ int wc_stream_max_frames_per_push(const wc_stream *s) {
 long long wc_stream_frames_committed(const wc_stream *s, int u) { return (s && u >= 0 && u < s->n_streams) ? s->next_frame[u] : -1; }
 long long wc_stream_samples_received(const wc_stream *s, int u) { return (s && u >= 0 && u < s->n_streams) ? s->n_recv[u] : -1; }
 
+unsigned long long wc_stream_rng_position(const wc_stream *s, int u) { return (s && u >= 0 && u < s->n_streams) ? s->rng_pos[u] : 0ull; }
+int wc_stream_set_rng_position(wc_stream *s, int u, unsigned long long position) {
+	if (!s || u < 0 || u >= s->n_streams) return fail(WC_ERR_INVALID, "stream: bad stream index");
+	DeviceLock lock(s->dev);
+	s->rng_pos[u] = position;
+	return WC_OK;
+}
+
 int wc_stream_reset(wc_stream *s, int u) {
 	if (!s || u < 0 || u >= s->n_streams) return fail(WC_ERR_INVALID, "stream reset: bad stream index");
 	DeviceLock lock(s->dev);
@@ -189,7 +197,9 @@ int wc_stream_push_device(wc_stream *s, const double *d_chunk, const int *n_new,
 		const int L = wc_get_samples(s->fs, d.h_len, s->frame_period);
 		// frames committed: all whose time lies more than `lookahead` before the newest sample; everything on a flush
 		long long c1;
-		if (fl) c1 = wc_get_samples(s->fs, (int)(recv - recv % s->decim), s->frame_period);
+		// (Harvest::getSamples, reference src/harvest.cpp:173-181, in integer arithmetic: samples per ms and frame period are whole
+		// numbers here, and a stream may have received more samples than an int holds)
+		if (fl) c1 = (recv - recv % s->decim) / ((long long)spm * s->fp_ms) + 1;
 		else c1 = (recv / spm - s->ahead_ms) / s->fp_ms;  // frames k with k * fp < T - lookahead (T a whole number of ms here)
 		if (!fl && recv / spm < s->ahead_ms) c1 = 0;
 		if (c1 < s->next_frame[u]) c1 = s->next_frame[u];
@@ -265,10 +275,27 @@ int wc_stream_push_device(wc_stream *s, const double *d_chunk, const int *n_new,
 	WC_HIP(hipGetLastError());
 	// ---- CheapTrick on the committed frames, noise positions carried per stream ----
 	std::vector<uint64_t> pos(na);
-	for (int a = 0; a < na; ++a) pos[a] = s->rng_pos[act[a]];
-	if ((rc = wc_cheaptrick_compute_device(s->ct, na, s->batch.as<double>(), win_len.data(), s->tpos_rel.as<double>(), d_f0, count.data(), d_sp,
-										   pos.data())))
-		return rc;
+	uint64_t lo = ~0ull, hi = 0;
+	for (int a = 0; a < na; ++a) {
+		pos[a] = s->rng_pos[act[a]];
+		if (count[a] > 0) { lo = std::min(lo, pos[a]); hi = std::max(hi, pos[a]); }
+	}
+	const int bins = s->fft_size / 2 + 1;
+	if (hi - lo <= (1ull << 28)) {
+		if ((rc = wc_cheaptrick_compute_device(s->ct, na, s->batch.as<double>(), win_len.data(), s->tpos_rel.as<double>(), d_f0, count.data(),
+											   d_sp, pos.data())))
+			return rc;
+	} else {
+		// streams whose noise positions lie further apart than one draw table covers (one of them was reset hours after the
+		// others started): one call per stream, each with its own stretch of the table
+		for (int a = 0; a < na; ++a) {
+			if (count[a] == 0) continue;
+			if ((rc = wc_cheaptrick_compute_device(s->ct, 1, s->batch.as<double>() + desc[a].batch_off, &win_len[a],
+												   s->tpos_rel.as<double>() + desc[a].out_off, d_f0 + desc[a].out_off, &count[a],
+												   d_sp + desc[a].out_off * bins, &pos[a])))
+				return rc;
+		}
+	}
 	for (int a = 0; a < na; ++a) s->rng_pos[act[a]] = pos[a];
 	return WC_OK;
 }

@@ -17,6 +17,8 @@ STREAM_SIGNATURES = {
     "wc_stream_max_frames_per_push": (C.c_int, [_vp]),
     "wc_stream_reset": (C.c_int, [_vp, C.c_int]),
     "wc_stream_push_device": (C.c_int, [_vp, _vp, _ip, _ip, _vp, _vp, _vp, _ip]),
+    "wc_stream_rng_position": (C.c_ulonglong, [_vp, C.c_int]),
+    "wc_stream_set_rng_position": (C.c_int, [_vp, C.c_int, C.c_ulonglong]),
     "wc_stream_frames_committed": (C.c_longlong, [_vp, C.c_int]),
     "wc_stream_samples_received": (C.c_longlong, [_vp, C.c_int]),
 }
@@ -84,6 +86,12 @@ class StreamAnalyzer:
 
     def reset(self, stream):
         _check(_lib().wc_stream_reset(self._h, stream))
+
+    def rng_position(self, stream):
+        return int(_lib().wc_stream_rng_position(self._h, stream))
+
+    def set_rng_position(self, stream, position):
+        _check(_lib().wc_stream_set_rng_position(self._h, stream, int(position)))
 
     def frames_committed(self, stream):
         return int(_lib().wc_stream_frames_committed(self._h, stream))
