@@ -54,6 +54,15 @@ typedef struct wc_stream wc_stream;
 wc_stream *wc_stream_create(int fs, int n_streams, double frame_period_ms, int chunk_ms, int lookback_ms, int lookahead_ms,
                             double harvest_f0_floor, double harvest_f0_ceil, double q1, double cheaptrick_f0_floor, int fft_size);
 void wc_stream_destroy(wc_stream *s);
+/* Incremental mode (call before the first push; 0 switches back).  Harvest's front -- decimation, band-pass, zero crossings, raw
+ * candidates, refinement -- is local: what it yields for a 1 ms frame depends on +-`context_ms` of signal (160 ms covers the
+ * longest band-pass, the lowest band's periods, the refinement window and the +-3-frame overlap with room to spare).  In this mode
+ * a push runs the front on the newest chunk + 2 context only and appends the refined candidate / score rows of the frames that
+ * have their full context to a per-stream ring; only Harvest's tail (unreliable-candidate test, contour logic, smoothing) runs over
+ * the window, on rows from the ring.  The context is part of the lookahead (rows exist up to `context` behind the newest sample, the
+ * tail looks `lookahead - context` ahead of the newest committed frame): lookahead 560 ms with context 160 ms gives the tail the
+ * same 400 ms it has with whole windows.  Same committed frames, same parity bar; about half the work per push. */
+int wc_stream_set_incremental(wc_stream *s, int context_ms);
 int wc_stream_get_fft_size(const wc_stream *s);
 int wc_stream_chunk_samples(const wc_stream *s);        /* samples per stream of a full chunk */
 int wc_stream_max_frames_per_push(const wc_stream *s);  /* most frames one push can commit for one stream (a flush) */

@@ -41,42 +41,51 @@ def compare(got, want, what):
     return float(np.mean(got["f0"] == f0)), float(np.abs(got["f0"] - f0).max()), float((np.abs(got["sp"] - sp) / sp).max())
 
 
-def test_streams_equal_whole_utterances_24k_1ms(wca):
+# whole windows (lookahead 400 ms) and the incremental mode (context 160 ms inside a lookahead of 560 ms: the tail sees the same 400)
+MODES = [dict(lookahead_ms=400, context_ms=0), dict(lookahead_ms=560, context_ms=160)]
+
+
+@pytest.mark.parametrize("mode", MODES, ids=["whole_windows", "incremental"])
+def test_streams_equal_whole_utterances_24k_1ms(wca, mode):
     """BASELINE config 5's shape: 24 kHz, 1 ms frames; ragged lengths, one of them not a whole number of chunks or ms"""
     from world_class_amd.stream import StreamAnalyzer
     fs = 24000
     xs = [make_utterance(fs, sec, 5000 + i) for i, sec in enumerate((3.0, 2.2, 4.1, 0.9))]
     xs[2] = xs[2][:-377]
-    sa = StreamAnalyzer(fs, len(xs), frame_period=1.0, chunk_ms=200, lookback_ms=400, lookahead_ms=400)
-    assert sa.latency_ms == 600 and sa.chunk_samples == 4800
+    sa = StreamAnalyzer(fs, len(xs), frame_period=1.0, chunk_ms=200, lookback_ms=400, **mode)
+    assert sa.latency_ms == 200 + mode["lookahead_ms"] and sa.chunk_samples == 4800
     res = sa.run_whole(xs)
     stats = [compare(r, whole(wca, x, fs, 1.0), "stream %d" % u) for u, (x, r) in enumerate(zip(xs, res))]
     # 40-100 % of the frames are bit-equal; the rest differ in the last bits only (1e-14 relative: the smoothing filter's backward
     # pass starts where the window ends and runs into its last-bit limit cycle with another phase)
     assert max(s[1] for s in stats) < 1e-11 and max(s[2] for s in stats) < 1e-9, stats
-    assert stats[3][0] == 1.0  # a stream shorter than one window IS the whole-utterance call
+    if not mode["context_ms"]:
+        assert stats[3][0] == 1.0  # a stream shorter than one window IS the whole-utterance call
     for u, x in enumerate(xs):
         assert sa.frames_committed(u) == wca.get_samples(fs, len(x) - len(x) % 3, 1.0)
     assert len(xs[2]) % 3 != 0 and len(xs[0]) % 3 == 0  # both cases of the decimation-phase rule are in the batch
 
 
-def test_streams_equal_whole_utterances_48k_5ms(wca):
+@pytest.mark.parametrize("mode", MODES, ids=["whole_windows", "incremental"])
+def test_streams_equal_whole_utterances_48k_5ms(wca, mode):
     from world_class_amd.stream import StreamAnalyzer
     fs = 48000
     xs = [make_utterance(fs, sec, 5100 + i) for i, sec in enumerate((2.5, 1.7))]
-    sa = StreamAnalyzer(fs, len(xs), frame_period=5.0, chunk_ms=200, lookback_ms=400, lookahead_ms=400)
+    sa = StreamAnalyzer(fs, len(xs), frame_period=5.0, chunk_ms=200, lookback_ms=400, **mode)
     res = sa.run_whole(xs)
     for u, (x, r) in enumerate(zip(xs, res)):
         compare(r, whole(wca, x, fs, 5.0), "stream %d" % u)
 
 
-def test_idle_streams_resets_and_frame_accounting(wca):
+@pytest.mark.parametrize("mode", MODES, ids=["whole_windows", "incremental"])
+def test_idle_streams_resets_and_frame_accounting(wca, mode):
     """streams need not move in lockstep: one idles, one is reset and starts a new signal; every absolute frame is committed
     exactly once, `chunk / frame_period` per push in the steady state, the rest at the flush"""
     from world_class_amd.stream import StreamAnalyzer
     fs = 16000
     a, b, c = (make_utterance(fs, sec, 5200 + i) for i, sec in enumerate((1.6, 1.2, 1.0)))
-    sa = StreamAnalyzer(fs, 2, frame_period=1.0, chunk_ms=160, lookback_ms=400, lookahead_ms=400)
+    sa = StreamAnalyzer(fs, 2, frame_period=1.0, chunk_ms=160, lookback_ms=400, **mode)
+    ahead = mode["lookahead_ms"]
     cs = sa.chunk_samples
     acc = {0: [], 1: []}
 
@@ -89,10 +98,10 @@ def test_idle_streams_resets_and_frame_accounting(wca):
     counts = []
     na, nb = 0, 0
     # stream 0 gets `a`; stream 1 idles for three pushes, then gets `b`
-    for k in range(3):
+    for k in range(4):
         counts.append(push(a[na:na + cs], np.zeros(0)))
         na += cs
-    assert [c[1] for c in counts] == [0, 0, 0] and counts[0][0] == 0 and counts[2][0] == 3 * 160 - 400
+    assert [c[1] for c in counts] == [0, 0, 0, 0] and counts[0][0] == 0 and sum(c[0] for c in counts) == 4 * 160 - ahead
     while na + cs < len(a):
         n = push(a[na:na + cs], b[nb:nb + cs])
         assert n[0] == 160

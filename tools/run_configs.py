@@ -111,8 +111,9 @@ def main():
         from world_class_amd.stream import StreamAnalyzer
         fs, n = 24000, max(2, int(512 * a.scale))
         sig = [make_utterance(fs, 4.0, 5000 + u) for u in range(8)]
-        for chunk_ms, back_ms, ahead_ms in ((200, 400, 400), (400, 400, 400), (80, 400, 400)):
-            sa = StreamAnalyzer(fs, n, frame_period=1.0, chunk_ms=chunk_ms, lookback_ms=back_ms, lookahead_ms=ahead_ms)
+        for chunk_ms, back_ms, ahead_ms, ctx_ms in ((200, 400, 400, 0), (200, 400, 560, 160), (400, 400, 400, 0), (400, 400, 560, 160),
+                                                      (80, 400, 400, 0), (80, 400, 560, 160)):
+            sa = StreamAnalyzer(fs, n, frame_period=1.0, chunk_ms=chunk_ms, lookback_ms=back_ms, lookahead_ms=ahead_ms, context_ms=ctx_ms)
             cs = sa.chunk_samples
             cap = n * sa.max_frames
             d_t = torch.empty(cap, dtype=torch.float64, device=dev)
@@ -132,7 +133,8 @@ def main():
             steady = times[full:]
             t = float(np.median(steady))
             print(json.dumps({"config": 5, "what": f"{n} concurrent 24 kHz streams (1/8 of 4096), 1 ms frames, chunked Harvest + CheapTrick "
-                                                    f"(include/world_class_stream.h): chunk {chunk_ms} ms, lookback {back_ms} ms, lookahead {ahead_ms} ms, 1 GPU",
+                                                    f"(include/world_class_stream.h): chunk {chunk_ms} ms, lookback {back_ms} ms, lookahead {ahead_ms} ms, "
+                                                    + (f"incremental (context {ctx_ms} ms)" if ctx_ms else "whole windows") + ", 1 GPU",
                               "frames_per_push": frames[-1], "push_ms": t * 1e3, "push_ms_max": max(steady) * 1e3,
                               "frames_per_s": frames[-1] / t, "algorithmic_latency_ms": ahead_ms + chunk_ms,
                               "latency_ms_incl_compute": ahead_ms + chunk_ms + t * 1e3, "real_time_factor": chunk_ms / (t * 1e3),

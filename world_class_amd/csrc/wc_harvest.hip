@@ -1610,6 +1610,7 @@ struct wc_harvest {
 	bool use_fir;  // WC_HARVEST_BANDPASS=fir: the direct FIR band-pass instead of the sliding DFT (A/B and tests)
 	bool use_cos_table;  // HarvestOption::use_cos_table
 	DevBuf d_cos_table;
+	int phases = 3;  // hv_set_phases: 1 = front (decimation .. refinement), 2 = tail (unreliable-candidate test .. output), 3 = both
 	bool smooth_full_walk;  // WC_HARVEST_SMOOTH=full: the smoothing filter without the skipping of settled stretches (A/B and the bit-identity test)
 	bool direct_decimation;  // WC_HARVEST_DECIMATE=direct: every lane reads its own stream from memory (A/B and the bit-identity test)
 	DevBuf utts, dec, y, events, ev_count, overflow, tile_run, raw, cand0, cand1, score1, cand2, score2;
@@ -1760,7 +1761,7 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 		if ((rc = h->h_stage.mark(s))) return rc;
 		WC_HIP(hipMemsetAsync(h->overflow.p, 0, sizeof(int), s));
 		const HvUtt *du = h->utts.as<HvUtt>();
-		{
+		if (h->phases & 1) {
 			WC_HIP(hipMemsetAsync(h->y.p, 0, sizeof(double) * yo, s));
 			if ((rc = dev->time_begin("harvest_decimate", s))) return rc;
 			if (r == 1) {
@@ -1784,6 +1785,7 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 		// a staggered twin chain holds its ALU-bound kernels back until the other chain's are through; the latency-bound
 		// decimation above may run underneath them
 		if (start_after) WC_HIP(hipStreamWaitEvent(s, start_after, 0));
+		if (h->phases & 1) {
 		BpArgs ba;
 		ba.utts = du; ba.y = h->y.as<double>(); ba.taps = h->d_taps.as<double>(); ba.tap_off = h->d_tap_off.as<int>();
 		ba.half_len = h->d_half_len.as<int>(); ba.ev_band_off = h->d_ev_band_off.as<long long>(); ba.ev_cap = h->d_ev_cap.as<int>();
@@ -1807,8 +1809,10 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 		}
 		WC_HIP(hipGetLastError());
 		if ((rc = dev->time_end("harvest_bandpass", s))) return rc;
+		}
 	}
 	const HvUtt *du = h->utts.as<HvUtt>();
+	if (h->phases & 1) {
 	RawArgs ra;
 	ra.utts = du; ra.events = h->events.as<double>(); ra.ev_band_off = h->d_ev_band_off.as<long long>(); ra.ev_cap = h->d_ev_cap.as<int>();
 	ra.ev_count = h->ev_count.as<int>(); ra.band_f0 = h->d_band_f0.as<double>(); ra.raw = h->raw.as<double>(); ra.n_bands = nb;
@@ -1830,9 +1834,14 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 	else hipLaunchKernelGGL(hv_refine_kernel<false>, dim3((unsigned)total_l1), dim3(256), 0, s, fa);
 	WC_HIP(hipGetLastError());
 	if ((rc = dev->time_end("harvest_refine", s))) return rc;
+	}
 	// the ALU-bound part of this chain is enqueued: a staggered twin chain may start its own now, next to our
 	// latency-bound tail (contour logic, smoothing) and whatever the caller runs after us
 	if (mid_event) WC_HIP(hipEventRecord(mid_event, s));
+	if (!(h->phases & 2)) {
+		h->last_utts = utts;
+		return WC_OK;
+	}
 	hipLaunchKernelGGL(hv_unreliable_kernel, dim3((unsigned)total_l1), dim3(128), 0, s, du, n_utt, h->cand1.as<double>(), h->score1.as<double>(),
 					   h->cand2.as<double>(), h->score2.as<double>(), h->base.as<double>(), total_l1, nc);
 	CtrArgs ca;
@@ -1856,6 +1865,20 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 	h->last_utts = utts;
 	return WC_OK;
 }
+
+// Harvest in two parts (the incremental stream path, wc_stream.hip): a handle restricted to the front leaves the refined
+// candidate and score rows of its batch ([1 ms frame][7 S], packed by utterance) in hv_candidate_rows / hv_score_rows; a handle
+// restricted to the tail runs the unreliable-candidate test, the contour logic and the smoothing on rows the caller has put there
+// (hv_reserve_rows first, so that hv_enqueue does not move the buffers).
+void hv_set_phases(wc_harvest *h, int mask) { h->phases = mask & 3; }
+int hv_row_width(const wc_harvest *h) { return 7 * h->S; }
+int hv_reserve_rows(wc_harvest *h, long long total_l1) {
+	int rc;
+	if ((rc = h->cand1.reserve(sizeof(double) * total_l1 * 7 * h->S))) return rc;
+	return h->score1.reserve(sizeof(double) * total_l1 * 7 * h->S);
+}
+double *hv_candidate_rows(wc_harvest *h) { return h->cand1.as<double>(); }
+double *hv_score_rows(wc_harvest *h) { return h->score1.as<double>(); }
 
 // after hv_enqueue: synchronises the stream and reports whether the zero-crossing buffers overflowed
 int hv_overflowed(wc_harvest *h, hipStream_t s, bool *overflow) {

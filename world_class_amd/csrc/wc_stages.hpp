@@ -6,6 +6,12 @@
 int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const int *x_length, double *d_tpos, double *d_f0,
 			   bool full, hipEvent_t mid_event, hipEvent_t start_after);
 int hv_overflowed(wc_harvest *h, hipStream_t s, bool *overflow);
+// Harvest in two parts (incremental streams): phases 1 = front (decimation .. refinement), 2 = tail (unreliable .. output), 3 = both
+void hv_set_phases(wc_harvest *h, int mask);
+int hv_row_width(const wc_harvest *h);
+int hv_reserve_rows(wc_harvest *h, long long total_1ms_frames);
+double *hv_candidate_rows(wc_harvest *h);
+double *hv_score_rows(wc_harvest *h);
 
 int ct_prepare(wc_cheaptrick *c, hipStream_t s, int n_utt, const int *x_length, const double *d_f0, const int *f0_length,
 			   const uint64_t *rng_pos, long long *total_out, uint64_t *min_pos_out, uint64_t *max_end_out);

@@ -12,6 +12,7 @@ _vp = C.c_void_p
 STREAM_SIGNATURES = {
     "wc_stream_create": (_vp, [C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int]),
     "wc_stream_destroy": (None, [_vp]),
+    "wc_stream_set_incremental": (C.c_int, [_vp, C.c_int]),
     "wc_stream_get_fft_size": (C.c_int, [_vp]),
     "wc_stream_chunk_samples": (C.c_int, [_vp]),
     "wc_stream_max_frames_per_push": (C.c_int, [_vp]),
@@ -42,11 +43,13 @@ class StreamAnalyzer:
     (absolute times, F0, spectrogram rows), `lookahead_ms` behind the newest sample."""
 
     def __init__(self, fs, n_streams, frame_period=1.0, chunk_ms=200, lookback_ms=400, lookahead_ms=400, harvest_f0_floor=71.0,
-                 harvest_f0_ceil=800.0, q1=-0.15, cheaptrick_f0_floor=71.0, fft_size=0):
+                 harvest_f0_ceil=800.0, q1=-0.15, cheaptrick_f0_floor=71.0, fft_size=0, context_ms=0):
         L = _lib()
         self.fs, self.n_streams, self.frame_period = fs, n_streams, float(frame_period)
         self._h = _handle(L.wc_stream_create(fs, n_streams, float(frame_period), chunk_ms, lookback_ms, lookahead_ms, harvest_f0_floor,
                                              harvest_f0_ceil, q1, cheaptrick_f0_floor, fft_size))
+        if context_ms:  # incremental mode: Harvest's front on the newest chunk + 2 context only (see the header)
+            _check(L.wc_stream_set_incremental(self._h, context_ms))
         self.fft_size = L.wc_stream_get_fft_size(self._h)
         self.bins = self.fft_size // 2 + 1
         self.chunk_samples = L.wc_stream_chunk_samples(self._h)
