@@ -37,6 +37,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--configs", default="2,3,4,5,6,7")
     ap.add_argument("--scale", type=float, default=1.0, help="scale the utterance counts (for quick runs)")
+    ap.add_argument("--stream-modes", default="", help="config 5: only these variants, e.g. 200:560:160 (chunk:lookahead:context ms)")
     a = ap.parse_args()
     import torch
     dev = torch.device("cuda", 0)
@@ -111,8 +112,10 @@ def main():
         from world_class_amd.stream import StreamAnalyzer
         fs, n = 24000, max(2, int(512 * a.scale))
         sig = [make_utterance(fs, 4.0, 5000 + u) for u in range(8)]
-        for chunk_ms, back_ms, ahead_ms, ctx_ms in ((200, 400, 400, 0), (200, 400, 560, 160), (400, 400, 400, 0), (400, 400, 560, 160),
-                                                      (80, 400, 400, 0), (80, 400, 560, 160)):
+        variants = ((200, 400, 400, 0), (200, 400, 560, 160), (400, 400, 400, 0), (400, 400, 560, 160), (80, 400, 400, 0), (80, 400, 560, 160))
+        if a.stream_modes:
+            variants = tuple((int(c), 400, int(ah), int(cx)) for c, ah, cx in (m.split(":") for m in a.stream_modes.split(",")))
+        for chunk_ms, back_ms, ahead_ms, ctx_ms in variants:
             sa = StreamAnalyzer(fs, n, frame_period=1.0, chunk_ms=chunk_ms, lookback_ms=back_ms, lookahead_ms=ahead_ms, context_ms=ctx_ms)
             cs = sa.chunk_samples
             cap = n * sa.max_frames

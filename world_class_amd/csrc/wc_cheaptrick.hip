@@ -258,10 +258,19 @@ struct wc_cheaptrick {
 	HostBuf h_stage;
 };
 
+// Threads per frame: eight samples per thread up to N = 2048 (one radix-4 butterfly per thread and pass, nobody idle): 256
+// threads at N = 1024 / 512 left half / three quarters of them idle in every FFT pass while barriers, reductions and the
+// cumulative sum's walk cost the same -- 2.20 -> 1.85 ms per 128 k frames at N = 1024, 1.54 -> 0.86 ms at N = 512.  Above that
+// the thread count stays at 256: 128 threads per 2048-point frame (two butterflies each) was slower, 14.2 against 12.9 ms per
+// 512 k frames, as halving D4C's threads was in round 1.
+#ifndef WC_CT_THREADS
+#define WC_CT_THREADS 256
+#endif
 template <int N>
 static void launch_ct(const CtArgs &a, hipStream_t s) {
 	long long blocks = ((a.total_frames + 7) / 8) * 8;
-	hipLaunchKernelGGL((ct_frames_kernel<N, 256>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+	constexpr int T = (N >= 2048) ? WC_CT_THREADS : (N / 8 < 64 ? 64 : N / 8);
+	hipLaunchKernelGGL((ct_frames_kernel<N, T>), dim3((unsigned)blocks), dim3(T), 0, s, a);
 }
 
 // Enqueue-only building blocks (no host synchronisation), shared with the fused pipeline (wc_pipeline.hip):

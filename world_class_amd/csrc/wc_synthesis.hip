@@ -792,7 +792,10 @@ struct wc_synthesis {
 
 template <int N>
 static void launch_pulses(const SynArgs &a, hipStream_t s) {
-	constexpr int TP = 256;  // 512 threads per pulse measured slower (13.2 vs 10.0 ms per 64 x 10 s batch)
+	// eight samples per thread up to N = 2048 (at N = 1024 / 512 a 256-thread block idles half / three quarters of its threads in
+	// every FFT pass: 3.53 -> 3.35 ms per 64 x 10 s at 16 kHz, 2.08 -> 1.53 ms at 8 kHz); 512 threads per 2048-point pulse measured
+	// slower (13.2 vs 10.0 ms per 64 x 10 s batch)
+	constexpr int TP = (N >= 2048) ? 256 : (N / 8 < 64 ? 64 : N / 8);
 	hipLaunchKernelGGL((syn_pulse_kernel<N, TP>), dim3((unsigned)a.total_pulses), dim3(TP), 0, s, a);
 }
 
