@@ -164,3 +164,25 @@ def test_noise_positions_are_carried_and_may_lie_far_apart(wca):
     assert (np.abs(res[1]["sp"] - sp1) / sp1).max() < 1e-9
     assert not np.array_equal(res[0]["sp"], res[1]["sp"])       # other draws, other last bits
     assert sa.rng_position(1) == end1 and sa.rng_position(0) == end1 - far
+
+
+@pytest.mark.parametrize("mode", MODES, ids=["whole_windows", "incremental"])
+def test_non_finite_samples_stay_in_their_stream(wca, mode):
+    """a burst of NaN / inf samples in one stream never hangs a push, never reaches the other stream, and the damaged stream is
+    accounted for frame by frame and recovers once the burst has left its window"""
+    from world_class_amd.stream import StreamAnalyzer
+    fs = 16000
+    x = make_utterance(fs, 3.0, 5400)
+    x = x[:len(x) - len(x) % 2]
+    bad = x.copy()
+    bad[9000:9040] = np.nan
+    bad[9100] = np.inf
+    sa = StreamAnalyzer(fs, 2, frame_period=5.0, chunk_ms=200, lookback_ms=400, **mode)
+    res = sa.run_whole([x, bad])
+    want = whole(wca, x, fs, 5.0)
+    compare(res[0], want, "clean stream next to a damaged one")
+    assert len(res[1]["f0"]) == len(want[1]) and np.array_equal(res[1]["tpos"], want[0])
+    # far behind the burst (0.57 s + window) the damaged stream is the clean one again
+    late = res[1]["tpos"] > 2.2
+    assert np.array_equal(res[1]["f0"][late] == 0, want[1][late] == 0)
+    assert np.abs(res[1]["f0"][late] - want[1][late]).max() < 1e-9
