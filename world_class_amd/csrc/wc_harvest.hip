@@ -838,9 +838,10 @@ __global__ __launch_bounds__(256, WC_REFINE_WAVES) void hv_refine_kernel(RefArgs
 			const double bt0 = (-hw) / fs;
 			const int basic = mround((pos + bt0) * fs + 0.001);
 			const int nh = min((int)(fs / 2.0 / fc), 6);
-			int idx[6];
-#pragma unroll
-			for (int h = 0; h < 6; ++h) idx[h] = mround(fc * N / fs * (h + 1));
+			// harmonic bins (reference :853-861).  Formed twice -- here for the recurrence coefficients, again behind the sample loop
+			// for the closing twiddles -- because six registers held across the loop are six too many at 128
+			double bin_unit = fc * N / fs;
+			auto bin_of = [&](int h) { return mround(bin_unit * (h + 1)); };
 			double wc = start_phase[q][threadIdx.x].x, ws = start_phase[q][threadIdx.x].y;  // phase 1
 			const double2 r1 = a.rot[2 * hw], r8 = a.rot[2 * hw + 1];  // (cos, sin) of beta and 8 beta, beta = 2 pi / (2 hw + 1)
 			const double k1 = 0.5 * r1.y, k2 = 0.16 * (2.0 * r1.y * r1.x);
@@ -851,7 +852,7 @@ __global__ __launch_bounds__(256, WC_REFINE_WAVES) void hv_refine_kernel(RefArgs
 			// (s_{q-1}, s_{q-2}) pair alternates between two register sets; trailing zero samples are harmless.
 			double c2[6];
 #pragma unroll
-			for (int h = 0; h < 6; ++h) c2[h] = 2.0 * a.tw[((idx[h] * 8) & (N - 1)) * tsh].x;
+			for (int h = 0; h < 6; ++h) c2[h] = 2.0 * a.tw[((bin_of(h) * 8) & (N - 1)) * tsh].x;
 			double sa[12], sb[12];  // [2 h] main window, [2 h + 1] difference window; sa = newest after a full trip
 #pragma unroll
 			for (int k = 0; k < 12; ++k) { sa[k] = 0.0; sb[k] = 0.0; }
@@ -897,16 +898,33 @@ __global__ __launch_bounds__(256, WC_REFINE_WAVES) void hv_refine_kernel(RefArgs
 			// that share them (the window length is quantised, :950-958) and mergeF0's searchScore compares with ==
 			// (:463-470); running every lane to the longest window in the wavefront made the result depend on the
 			// neighbours through the number of trailing rotations.
+			// Interior samples take the short form of the same arithmetic (no one-sided differences, no range checks): only
+			// the first trip (sample 0) and a lane's last trip can hold an end of the window, and the lanes of a wavefront
+			// reach their last trips together, give or take one (the seven blocks hold the same slot of neighbouring frames).
+			auto interior = [&](int n, double &xm, double &xd) {
+				const double yv = y[clampi(basic + n - 1, 0, u.y_len - 1)];
+				const double m = fma(wc, fma(0.16, wc, 0.5), 0.34);
+				const double d = ws * fma(k2, wc, k1);
+				xm = m * yv;
+				xd = d * yv;
+				const double nc_ = fma(wc, r8.x, -(ws * r8.y));
+				ws = fma(ws, r8.x, wc * r8.y);
+				wc = nc_;
+			};
 			int Q = 0;
 			for (int n = sub; n < bt; n += 16) {
+				const bool ends = TABLE || n == sub || n + 9 >= bt;
+				const bool any_end = __ballot(ends) != 0ull;  // wave-uniform: the recurrences below stay outside the branch
 				double xm, xd;
-				sample(n, xm, xd);
+				if (any_end) sample(n, xm, xd);
+				else interior(n, xm, xd);
 #pragma unroll
 				for (int h = 0; h < 6; ++h) {
 					sb[2 * h] = fma(c2[h], sa[2 * h], xm) - sb[2 * h];
 					sb[2 * h + 1] = fma(c2[h], sa[2 * h + 1], xd) - sb[2 * h + 1];
 				}
-				sample(n + 8, xm, xd);
+				if (any_end) sample(n + 8, xm, xd);
+				else interior(n + 8, xm, xd);
 #pragma unroll
 				for (int h = 0; h < 6; ++h) {
 					sa[2 * h] = fma(c2[h], sb[2 * h], xm) - sa[2 * h];
@@ -918,6 +936,10 @@ __global__ __launch_bounds__(256, WC_REFINE_WAVES) void hv_refine_kernel(RefArgs
 			// halving butterfly that leaves harmonic h in lane h.  Its first stage pairs harmonic p with harmonic p + 4 (nothing
 			// for p = 2, 3) and is fused with the closing twiddles pair by pair: the recurrence states of a harmonic die as soon
 			// as its pair has been exchanged, which keeps the kernel inside 128 registers without scratch.
+			asm volatile("" : "+v"(bin_unit));  // (keeps the bins from being carried across the loop instead of re-formed)
+			int idx[6];
+#pragma unroll
+			for (int h = 0; h < 6; ++h) idx[h] = bin_of(h);
 			double v[16];
 			auto closing = [&](int h, double (&o)[4]) {
 				const double2 e1 = a.tw[((idx[h] * (sub + 8 * (Q - 1))) & (N - 1)) * tsh];  // conj = e^{-i phi (sub + 8 (Q-1))}
