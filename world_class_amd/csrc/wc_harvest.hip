@@ -835,9 +835,8 @@ __global__ __launch_bounds__(256, WC_REFINE_WAVES) void hv_refine_kernel(RefArgs
 			const int fft_index = 2 + (31 - __clz(hw * 2 + 1));
 			const int N = 1 << fft_index;
 			const int tsh = kTwiddleN / N;
-			// matlab_round((pos - hw / fs) fs + 0.001) of reference :760: pos fs is a whole number (or a multiple of 0.05 at the rates
-			// whose decimated rate is not a multiple of 1 kHz) plus rounding noise, so the 0.001 decides and the quotient is not needed
-			const int basic = mround(pos * fs - hw + 0.001);
+			const double bt0 = (-hw) / fs;
+			const int basic = mround((pos + bt0) * fs + 0.001);
 			const int nh = min((int)(fs / 2.0 / fc), 6);
 			// harmonic bins (reference :853-861).  Formed twice -- here for the recurrence coefficients, again behind the sample loop
 			// for the closing twiddles -- because six registers held across the loop are six too many at 128
@@ -988,24 +987,9 @@ __global__ __launch_bounds__(256, WC_REFINE_WAVES) void hv_refine_kernel(RefArgs
 			const double mr = v[0], mi = v[1], dr = v[2], di = v[3];
 			const double pw = mr * mr + mi * mi;
 			const double ni = mr * di - mi * dr;
-			// The quotients from here on only scale values (none decides an index): reciprocal, two Newton steps and one
-			// residual correction -- within an ulp of the division at a third of its instructions, 8 of them per candidate.
-			auto rdiv = [](double n, double d) -> double {
-				double r = __builtin_amdgcn_rcp(d);
-				r = fma(fma(-d, r, 1.0), r, r);
-				r = fma(fma(-d, r, 1.0), r, r);
-				const double q = n * r;
-				return fma(fma(-d, q, n), r, q);
-			};
-			double ratio = rdiv(ni, pw);
-			if (!(pw > 1e-200)) ratio = (pw == 0.0) ? 0.0 : ni / pw;  // (a spectrum down among the denormals: the exact quotient)
-			constexpr double kInvPi = 0.31830988618379067154;
-			const double t_if = ratio * fs * 0.5;
-			double q_if = t_if * kInvPi;
-			q_if = fma(fma(-kPi, q_if, t_if), kInvPi, q_if);  // t / pi
-			const double inst = (pw == 0.0) ? 0.0 : (double)myidx * fs * (1.0 / N) + q_if;  // (N is a power of two)
+			const double inst = (pw == 0.0) ? 0.0 : (double)myidx * fs / N + ni / pw * fs / 2.0 / kPi;
 			const double amp = sqrt(pw);
-			const double e_num = amp * inst, e_den = amp * (h + 1.0), e_sc = fabs(rdiv(rdiv(inst, h + 1.0) - fc, fc));
+			const double e_num = amp * inst, e_den = amp * (h + 1.0), e_sc = fabs((inst / (h + 1.0) - fc) / fc);
 			double num = 0.0, den = 0.0, sc = 0.0;
 #pragma unroll
 			for (int q = 0; q < 6; ++q) {  // the reference's summation order over harmonics
@@ -1015,8 +999,8 @@ __global__ __launch_bounds__(256, WC_REFINE_WAVES) void hv_refine_kernel(RefArgs
 				if (q < nh) { num += x1; den += x2; sc += x3; }
 			}
 			if (live) {
-				rf = rdiv(num, den + kSafeH);
-				rs = rdiv(1.0, rdiv(sc, (double)nh) + kSafeH);
+				rf = num / (den + kSafeH);
+				rs = 1.0 / (sc / nh + kSafeH);
 				if (rf < a.p.f0_floor || rf > a.p.f0_ceil || rs < 2.5) { rf = 0.0; rs = 0.0; }  // reference :974-979
 			}
 		}
