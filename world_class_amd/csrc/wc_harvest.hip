@@ -1018,77 +1018,70 @@ __global__ __launch_bounds__(256, WC_REFINE_WAVES) void hv_refine_kernel(RefArgs
 	}
 }
 
-// reference :708-744.  One workgroup per frame: the non-zero candidates of the two neighbouring frames are
-// compacted into LDS first (a zero candidate yields the error 1.0, which selectBestF0's allowed range of 1.0
-// already is), then every candidate of this frame scans the two short lists.
-__global__ __launch_bounds__(128) void hv_unreliable_kernel(const HvUtt *__restrict__ utts, int n_utt, const double *__restrict__ c1,
+// reference :708-744.  One workgroup per UNR_F consecutive frames of an utterance: the rows of the UNR_F + 2 frames involved are
+// compacted into LDS once (non-zero candidates in slot order; a zero candidate yields the error 1.0, which selectBestF0's allowed
+// range of 1.0 already is), then a wavefront per frame lets every candidate scan the lists of the two neighbouring frames.
+// min_k fl(|ref - x_k| / ref) = fl((min_k |ref - x_k|) / ref) -- rounding is monotone -- so the scan takes differences only and
+// divides once.  searchF0Base (:254-272) on the surviving candidates is a wave reduction (highest score, first slot on ties).
+// (Round 1 ran one workgroup per frame: three row reads, four barriers and two LDS-atomic compactions per frame.)
+constexpr int UNR_F = 8;
+__global__ __launch_bounds__(256) void hv_unreliable_kernel(const HvUtt *__restrict__ utts, const double *__restrict__ c1,
 									 const double *__restrict__ s1, double *__restrict__ c2, double *__restrict__ s2,
-									 double *__restrict__ base, long long total_frames, int nc) {
-	__shared__ double nxt[7 * MAX_SLOTS], prv[7 * MAX_SLOTS];
-	__shared__ int cnt[2];
-	__shared__ unsigned long long best;  // searchF0Base: bit pattern of the highest score (positive doubles order like their bits)
-	__shared__ int best_slot;
-	const long long g = blockIdx.x;
-	if (g >= total_frames) return;
-	const int ui = hv_find(utts, n_utt, g, &HvUtt::l1_off);
-	const HvUtt u = utts[ui];
-	const int i = (int)(g - u.l1_off);
-	const bool interior = i >= 1 && i < u.L1 - 1;
-	if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
-	if (threadIdx.x == 0) { best = 0ull; best_slot = 0x7fffffff; }
-	// this frame's own candidates are requested together with the neighbours' rows: one memory round trip per workgroup
-	// instead of two (the kernel is a chain of latencies, not of arithmetic)
-	double own_ref[2] = {0.0, 0.0}, own_sc[2] = {0.0, 0.0};
-#pragma unroll
-	for (int q = 0; q < 2; ++q) {
-		const int j = threadIdx.x + q * 128;
-		if (j < nc) { own_ref[q] = c1[g * nc + j]; own_sc[q] = s1[g * nc + j]; }
-	}
-	__syncthreads();
-	if (interior) {
-		for (int j = threadIdx.x; j < nc; j += blockDim.x) {
-			// the reference's comparison copy holds frames 1 .. L-2 only (:714-715); its rows 0 and L-1 are never written
-			// (uninitialised there; zero here, as with a zero-filling allocator under the reference)
-			const double a = (i + 1 < u.L1 - 1) ? c1[(g + 1) * nc + j] : 0.0, b = (i - 1 >= 1) ? c1[(g - 1) * nc + j] : 0.0;
-			if (a != 0) nxt[atomicAdd(&cnt[0], 1)] = a;
-			if (b != 0) prv[atomicAdd(&cnt[1], 1)] = b;
+									 double *__restrict__ base, int nc) {
+	__shared__ double lst[UNR_F + 2][7 * MAX_SLOTS];
+	__shared__ int cnt[UNR_F + 2];
+	const HvUtt u = utts[blockIdx.y];
+	const int first = blockIdx.x * UNR_F;
+	if (first >= u.L1) return;
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	for (int r = wv; r < UNR_F + 2; r += 4) {
+		const int i = first - 1 + r;
+		// the reference's comparison copy holds frames 1 .. L-2 only (:714-715); its rows 0 and L-1 are never written
+		// (uninitialised there; zero here, as with a zero-filling allocator under the reference)
+		const bool held = i >= 1 && i <= u.L1 - 2;
+		int n = 0;
+		for (int j0 = 0; j0 < nc; j0 += 64) {
+			const int j = j0 + lane;
+			const double v = (held && j < nc) ? c1[(u.l1_off + i) * nc + j] : 0.0;
+			const unsigned long long m = __ballot(v != 0.0);
+			if (v != 0.0) lst[r][n + __popcll(m & ((1ull << lane) - 1ull))] = v;
+			n += __popcll(m);
 		}
+		if (lane == 0) cnt[r] = n;
 	}
 	__syncthreads();
-	const int n1 = cnt[0], n2 = cnt[1];
-	// (one slot per thread: nc <= 7 * MAX_SLOTS = 224 <= 2 * blockDim.x, so at most two slots each)
-	double my_ref[2] = {0.0, 0.0}, my_sc[2] = {0.0, 0.0};
-#pragma unroll
-	for (int q = 0; q < 2; ++q) {
-		const int j = threadIdx.x + q * 128;
-		if (j < nc) {
-			double ref = own_ref[q], sc = own_sc[q];
-			if (ref != 0 && interior) {
-				double e1 = 1.0, e2 = 1.0;
-				for (int k = 0; k < n1; ++k) e1 = fmin(e1, fabs(ref - nxt[k]) / ref);
-				for (int k = 0; k < n2; ++k) e2 = fmin(e2, fabs(ref - prv[k]) / ref);
-				if (fmin(e1, e2) > 0.05) { ref = 0; sc = 0; }
+	for (int k = wv; k < UNR_F; k += 4) {
+		const int i = first + k;
+		if (i >= u.L1) break;
+		const bool interior = i >= 1 && i < u.L1 - 1;
+		const long long g = u.l1_off + i;
+		const int n_prev = cnt[k], n_next = cnt[k + 2];
+		const double *__restrict__ prv = lst[k], *__restrict__ nxt = lst[k + 2];
+		double top_sc = 0.0, top_ref = 0.0;
+		int top_slot = 0x7fffffff;
+		for (int j0 = 0; j0 < nc; j0 += 64) {
+			const int j = j0 + lane;
+			double ref = 0.0, sc = 0.0;
+			if (j < nc) { ref = c1[g * nc + j]; sc = s1[g * nc + j]; }
+			if (ref != 0.0 && interior) {
+				double dmin = ref;  // |ref - 0| / ref = 1.0, the allowed range
+				for (int q = 0; q < n_next; ++q) dmin = fmin(dmin, fabs(ref - nxt[q]));
+				for (int q = 0; q < n_prev; ++q) dmin = fmin(dmin, fabs(ref - prv[q]));
+				if (fmin(1.0, dmin / ref) > 0.05) { ref = 0.0; sc = 0.0; }
 			}
-			c2[g * nc + j] = ref;
-			s2[g * nc + j] = sc;
-			my_ref[q] = ref;
-			my_sc[q] = sc;
-			if (sc > 0.0) atomicMax(&best, (unsigned long long)__double_as_longlong(sc));
+			if (j < nc) {
+				c2[g * nc + j] = ref;
+				s2[g * nc + j] = sc;
+				if (sc > top_sc) { top_sc = sc; top_ref = ref; top_slot = j; }  // (a lane's slots come in ascending order)
+			}
 		}
-	}
-	__syncthreads();
-	// searchF0Base (reference :254-272): highest score, the first slot on ties
-	const unsigned long long top = best;
 #pragma unroll
-	for (int q = 0; q < 2; ++q)
-		if (my_sc[q] > 0.0 && (unsigned long long)__double_as_longlong(my_sc[q]) == top) atomicMin(&best_slot, (int)(threadIdx.x + q * 128));
-	__syncthreads();
-	if (top == 0ull) {
-		if (threadIdx.x == 0) base[g] = 0.0;
-	} else {
-#pragma unroll
-		for (int q = 0; q < 2; ++q)
-			if ((int)(threadIdx.x + q * 128) == best_slot) base[g] = my_ref[q];
+		for (int o = 32; o > 0; o >>= 1) {
+			const double osc = __shfl_xor(top_sc, o, 64), oref = __shfl_xor(top_ref, o, 64);
+			const int oslot = __shfl_xor(top_slot, o, 64);
+			if (osc > top_sc || (osc == top_sc && oslot < top_slot)) { top_sc = osc; top_ref = oref; top_slot = oslot; }
+		}
+		if (lane == 0) base[g] = top_sc > 0.0 ? top_ref : 0.0;
 	}
 }
 
@@ -1864,8 +1857,8 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 		h->last_utts = utts;
 		return WC_OK;
 	}
-	hipLaunchKernelGGL(hv_unreliable_kernel, dim3((unsigned)total_l1), dim3(128), 0, s, du, n_utt, h->cand1.as<double>(), h->score1.as<double>(),
-					   h->cand2.as<double>(), h->score2.as<double>(), h->base.as<double>(), total_l1, nc);
+	hipLaunchKernelGGL(hv_unreliable_kernel, dim3((unsigned)((max_L1 + UNR_F - 1) / UNR_F), n_utt), dim3(256), 0, s, du, h->cand1.as<double>(),
+					   h->score1.as<double>(), h->cand2.as<double>(), h->score2.as<double>(), h->base.as<double>(), nc);
 	CtrArgs ca;
 	ca.utts = du; ca.cand = h->cand2.as<double>(); ca.score = h->score2.as<double>(); ca.base = h->base.as<double>();
 	ca.s1 = h->s1.as<double>(); ca.s2 = h->s2.as<double>(); ca.s3 = h->s3.as<double>(); ca.fixed = h->fixed.as<double>();
