@@ -74,6 +74,10 @@ int wc_stream_reset(wc_stream *s, int stream);
  * frames_out: host array [n_streams], frames committed by this push. */
 int wc_stream_push_device(wc_stream *s, const double *d_chunk, const int *n_new, const int *flush, double *d_tpos, double *d_f0,
                           double *d_sp, int *frames_out);
+/* The same with the new samples as int16 PCM (chunk_format 1: sample / 32768, the reference's wavread scaling) or float32 (2),
+ * widened on the device; 0 = float64. */
+int wc_stream_push_device_fmt(wc_stream *s, const void *d_chunk, int chunk_format, const int *n_new, const int *flush, double *d_tpos,
+                              double *d_f0, double *d_sp, int *frames_out);
 /* Position of stream u in the reference's noise sequence (reference src/world_matlabfunctions.cpp:243-264): where CheapTrick's next
  * committed frame takes its draws.  0 after creation and after wc_stream_reset -- the position a fresh reference process starts
  * from; set it to continue the numbering of an earlier analysis (e.g. the value wc_rng_get_position() reports after one). */

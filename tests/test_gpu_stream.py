@@ -186,3 +186,17 @@ def test_non_finite_samples_stay_in_their_stream(wca, mode):
     late = res[1]["tpos"] > 2.2
     assert np.array_equal(res[1]["f0"][late] == 0, want[1][late] == 0)
     assert np.abs(res[1]["f0"][late] - want[1][late]).max() < 1e-9
+
+
+def test_chunks_as_int16_pcm_and_float32(wca):
+    """new samples as they come off a WAV file or a capture device: widened on the device, same frames as float64 chunks"""
+    from world_class_amd.stream import StreamAnalyzer
+    fs = 16000
+    x = make_utterance(fs, 1.2, 5500)             # int16-quantised by construction: x * 32768 is a whole number
+    x = x[:len(x) - len(x) % 2]
+    pcm = np.round(x * 32768.0).astype(np.int16)
+    assert np.array_equal(pcm.astype(np.float64) / 32768.0, x)
+    want = StreamAnalyzer(fs, 1, frame_period=5.0).run_whole([x])[0]
+    for src in (pcm, x.astype(np.float32)):
+        got = StreamAnalyzer(fs, 1, frame_period=5.0).run_whole([src])[0]
+        assert np.array_equal(got["f0"], want["f0"]) and np.array_equal(got["sp"], want["sp"])

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "wc_stages.hpp"
+#include "../../include/world_class_io.h"
 #include "../../include/world_class_stream.h"
 
 namespace wc {
@@ -115,7 +116,7 @@ struct wc_stream {
 	std::vector<int> hist_len, parity, rows_len, rparity;      // samples in the history / rows in the ring, which ping-pong buffer holds them
 	std::vector<char> closed;
 	std::vector<uint64_t> rng_pos;
-	DevBuf hist[2], rows_c[2], rows_s[2], batch, hbatch, win_tpos, win_f0, tpos_rel, desc;
+	DevBuf hist[2], rows_c[2], rows_s[2], batch, hbatch, win_tpos, win_f0, tpos_rel, desc, chunk_f64;
 	HostBuf h_desc;
 	// harvest option copies for the handles created on demand
 	double hv_floor, hv_ceil;
@@ -195,7 +196,7 @@ void wc_stream_destroy(wc_stream *s) {
 	wc_harvest_destroy(s->hv_front);
 	wc_harvest_destroy(s->hv_tail);
 	for (DevBuf *b : {&s->hist[0], &s->hist[1], &s->rows_c[0], &s->rows_c[1], &s->rows_s[0], &s->rows_s[1], &s->batch, &s->hbatch, &s->win_tpos,
-					  &s->win_f0, &s->tpos_rel, &s->desc})
+					  &s->win_f0, &s->tpos_rel, &s->desc, &s->chunk_f64})
 		b->release();
 	s->h_desc.release();
 	delete s;
@@ -472,6 +473,29 @@ int wc_stream_push_device(wc_stream *s, const double *d_chunk, const int *n_new,
 	}
 	for (int a = 0; a < na; ++a) s->rng_pos[act[a]] = pos[a];
 	return WC_OK;
+}
+
+// The same with the new samples as they come off a capture device or a WAV file: chunk_format 0 = float64, 1 = int16 PCM
+// (sample / 32768, the reference's wavread scaling), 2 = float32; widened on the device into a staging buffer.
+int wc_stream_push_device_fmt(wc_stream *s, const void *d_chunk, int chunk_format, const int *n_new, const int *flush, double *d_tpos,
+							  double *d_f0, double *d_sp, int *frames_out) {
+	if (!s || !d_chunk) return fail(WC_ERR_INVALID, "stream push: null argument");
+	if (chunk_format == 0) return wc_stream_push_device(s, static_cast<const double *>(d_chunk), n_new, flush, d_tpos, d_f0, d_sp, frames_out);
+	if (chunk_format != 1 && chunk_format != 2) return fail(WC_ERR_INVALID, "stream push: chunk format must be 0 (float64), 1 (int16 PCM) or 2 (float32)");
+	WC_HIP(hipSetDevice(s->dev->id));
+	DeviceLock lock(s->dev);
+	long long total = 0;
+	for (int u = 0; u < s->n_streams; ++u) {
+		const int nn = n_new ? n_new[u] : s->chunk_s;
+		if (nn < 0 || nn > s->chunk_s) return fail(WC_ERR_INVALID, "stream push: n_new out of range");
+		total += nn;
+	}
+	int rc;
+	if ((rc = s->chunk_f64.reserve(sizeof(double) * (size_t)std::max<long long>(total, 1)))) return rc;
+	if (chunk_format == 1) rc = wc_pcm16_to_double_device(static_cast<const int16_t *>(d_chunk), total, s->chunk_f64.as<double>());
+	else rc = wc_float_to_double_device(static_cast<const float *>(d_chunk), total, s->chunk_f64.as<double>());
+	if (rc) return rc;
+	return wc_stream_push_device(s, s->chunk_f64.as<double>(), n_new, flush, d_tpos, d_f0, d_sp, frames_out);
 }
 
 }  // extern "C"

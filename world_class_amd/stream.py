@@ -18,6 +18,7 @@ STREAM_SIGNATURES = {
     "wc_stream_max_frames_per_push": (C.c_int, [_vp]),
     "wc_stream_reset": (C.c_int, [_vp, C.c_int]),
     "wc_stream_push_device": (C.c_int, [_vp, _vp, _ip, _ip, _vp, _vp, _vp, _ip]),
+    "wc_stream_push_device_fmt": (C.c_int, [_vp, _vp, C.c_int, _ip, _ip, _vp, _vp, _vp, _ip]),
     "wc_stream_rng_position": (C.c_ulonglong, [_vp, C.c_int]),
     "wc_stream_set_rng_position": (C.c_int, [_vp, C.c_int, C.c_ulonglong]),
     "wc_stream_frames_committed": (C.c_longlong, [_vp, C.c_int]),
@@ -58,11 +59,12 @@ class StreamAnalyzer:
         cap = n_streams * self.max_frames
         self._d_t, self._d_f, self._d_sp = DeviceArray(cap), DeviceArray(cap), DeviceArray(cap * self.bins)
 
-    def push_device(self, d_chunk, n_new=None, flush=None, d_tpos=None, d_f0=None, d_sp=None):
-        """device pointers in and out (packed layouts of the header); returns frames committed per stream"""
+    def push_device(self, d_chunk, n_new=None, flush=None, d_tpos=None, d_f0=None, d_sp=None, chunk_format=0):
+        """device pointers in and out (packed layouts of the header); chunk_format 0 = float64, 1 = int16 PCM, 2 = float32;
+        returns frames committed per stream"""
         n = self.n_streams
         out = (C.c_int * n)()
-        _check(_lib().wc_stream_push_device(self._h, _ptr(d_chunk), _ints(n_new) if n_new is not None else None,
+        _check(_lib().wc_stream_push_device_fmt(self._h, _ptr(d_chunk), chunk_format, _ints(n_new) if n_new is not None else None,
                                             _ints(flush) if flush is not None else None,
                                             _ptr(d_tpos if d_tpos is not None else self._d_t), _ptr(d_f0 if d_f0 is not None else self._d_f),
                                             _ptr(d_sp if d_sp is not None else self._d_sp), out))
@@ -71,11 +73,15 @@ class StreamAnalyzer:
     def push(self, chunks, flush=None):
         """chunks: list of n_streams float64 arrays (length chunk_samples; empty = idle; shorter only with flush[u]).
         Returns a list of dicts (tpos, f0, sp) with the frames committed for every stream."""
-        chunks = [np.ascontiguousarray(c, dtype=np.float64) for c in chunks]
+        filled = [np.asarray(c) for c in chunks if len(c)]  # (idle streams pass empty chunks of any type)
+        dt = filled[0].dtype if filled and filled[0].dtype in (np.int16, np.float32) else np.dtype(np.float64)
+        assert all(c.dtype == dt or dt == np.float64 for c in filled), "chunks of one push share a sample format"
+        fmt = {np.dtype(np.int16): 1, np.dtype(np.float32): 2}.get(np.dtype(dt), 0)
+        chunks = [np.ascontiguousarray(c, dtype=dt) for c in chunks]
         n_new = [len(c) for c in chunks]
-        flat = np.concatenate(chunks) if sum(n_new) else np.zeros(1)
-        d = DeviceArray.from_host(flat)
-        counts = self.push_device(d, n_new, flush)
+        flat = np.concatenate(chunks) if sum(n_new) else np.zeros(1, dtype=dt)
+        d = DeviceArray.from_host(flat, dtype=dt)
+        counts = self.push_device(d, n_new, flush, chunk_format=fmt)
         d.free()
         tot = sum(counts)
         t = self._d_t.to_host()[:tot]
