@@ -140,7 +140,9 @@ def test_stream_arguments_are_checked(wca):
         StreamAnalyzer(24000, 2, frame_period=5.0, chunk_ms=200, lookback_ms=400, lookahead_ms=408)
     sa = StreamAnalyzer(24000, 2)
     with pytest.raises(wca.WorldClassError, match="short chunk"):
-        sa.push([np.zeros(100), np.zeros(sa.chunk_samples)])
+        sa.push([np.zeros(sa.chunk_samples), np.zeros(100)])
+    # the refused push left both streams where they were (the first one's chunk was fine and must not have been taken)
+    assert int(wca.lib().wc_stream_samples_received(sa._h, 0)) == 0 and sa.frames_committed(0) == 0
 
 
 def test_noise_positions_are_carried_and_may_lie_far_apart(wca):

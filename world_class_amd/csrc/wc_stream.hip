@@ -122,6 +122,24 @@ struct wc_stream {
 	double hv_floor, hv_ceil;
 };
 
+// A push that fails half way (bad argument for a later stream, a device error) leaves every stream where it was.
+struct StreamStateGuard {
+	wc_stream *s;
+	std::vector<long long> n_recv, hist_start, next_frame, rows_start;
+	std::vector<int> hist_len, parity, rows_len, rparity;
+	std::vector<char> closed;
+	std::vector<uint64_t> rng_pos;
+	bool keep = false;
+	explicit StreamStateGuard(wc_stream *st)
+		: s(st), n_recv(st->n_recv), hist_start(st->hist_start), next_frame(st->next_frame), rows_start(st->rows_start), hist_len(st->hist_len),
+		  parity(st->parity), rows_len(st->rows_len), rparity(st->rparity), closed(st->closed), rng_pos(st->rng_pos) {}
+	~StreamStateGuard() {
+		if (keep) return;
+		s->n_recv = n_recv; s->hist_start = hist_start; s->next_frame = next_frame; s->rows_start = rows_start; s->hist_len = hist_len;
+		s->parity = parity; s->rows_len = rows_len; s->rparity = rparity; s->closed = closed; s->rng_pos = rng_pos;
+	}
+};
+
 static long long gcd_ll(long long a, long long b) { return b ? gcd_ll(b, a % b) : a; }
 static long long floor_to(long long v, long long unit) { return v <= 0 ? 0 : v / unit * unit; }
 
@@ -260,6 +278,7 @@ int wc_stream_push_device(wc_stream *s, const double *d_chunk, const int *n_new,
 	DeviceLock lock(s->dev);
 	hipStream_t st = s->dev->active();
 	s->started = true;
+	StreamStateGuard guard(s);
 	const bool inc = s->ctx_ms > 0;
 	const int n = s->n_streams, spm = s->fs / 1000, align_s = spm * s->align_ms, nc = s->nc;
 	// ---- bookkeeping on the host: which streams take part, what their windows are, which frames they commit ----
@@ -379,7 +398,7 @@ int wc_stream_push_device(wc_stream *s, const double *d_chunk, const int *n_new,
 		if (fl) s->closed[u] = 1;
 	}
 	const int na = (int)act.size();
-	if (na == 0) return WC_OK;
+	if (na == 0) { guard.keep = true; return WC_OK; }
 	int rc;
 	const size_t hist_bytes = sizeof(double) * (size_t)n * s->win_s;
 	if ((rc = s->hist[0].reserve(hist_bytes)) || (rc = s->hist[1].reserve(hist_bytes))) return rc;
@@ -442,7 +461,7 @@ int wc_stream_push_device(wc_stream *s, const double *d_chunk, const int *n_new,
 	}
 	// ---- commit ----
 	for (int a = 0; a < na; ++a) frames_out[act[a]] = count[a];
-	if (out_off == 0) return WC_OK;
+	if (out_off == 0) { guard.keep = true; return WC_OK; }
 	int max_count = 0;
 	for (int a = 0; a < na; ++a) max_count = std::max(max_count, count[a]);
 	hipLaunchKernelGGL(stream_commit_kernel, dim3((unsigned)((max_count + 127) / 128), (unsigned)na), dim3(128), 0, st, s->desc.as<StreamDesc>(),
@@ -472,6 +491,7 @@ int wc_stream_push_device(wc_stream *s, const double *d_chunk, const int *n_new,
 		}
 	}
 	for (int a = 0; a < na; ++a) s->rng_pos[act[a]] = pos[a];
+	guard.keep = true;
 	return WC_OK;
 }
 
