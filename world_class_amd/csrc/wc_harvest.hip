@@ -1857,6 +1857,7 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 		h->last_utts = utts;
 		return WC_OK;
 	}
+	if ((rc = dev->time_begin("harvest_contour", s))) return rc;  // the per-utterance tail: unreliable-candidate test, contour logic, smoothing
 	hipLaunchKernelGGL(hv_unreliable_kernel, dim3((unsigned)((max_L1 + UNR_F - 1) / UNR_F), n_utt), dim3(256), 0, s, du, h->cand1.as<double>(),
 					   h->score1.as<double>(), h->cand2.as<double>(), h->score2.as<double>(), h->base.as<double>(), nc);
 	CtrArgs ca;
@@ -1865,7 +1866,6 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 	ca.sec = h->sec.as<int>(); ca.chan = h->chan.as<double>(); ca.chan_stride = chan_stride; ca.max_sec = max_sec; ca.nc = nc;
 	ca.ibuf = h->ibuf.as<int>();
 	ca.nsec = h->ibuf.as<int>() + 4ll * max_sec * n_utt;
-	if ((rc = dev->time_begin("harvest_contour", s))) return rc;
 	hipLaunchKernelGGL(hv_contour_kernel<0>, dim3(n_utt), dim3(64), 0, s, ca);
 	hipLaunchKernelGGL(hv_contour_kernel<1>, dim3(96, n_utt), dim3(64), 0, s, ca);  // a 10 s utterance has 20-40 sections
 	hipLaunchKernelGGL(hv_contour_kernel<2>, dim3(n_utt), dim3(64), 0, s, ca);
