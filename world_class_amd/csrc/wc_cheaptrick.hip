@@ -48,8 +48,10 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 	constexpr int EPT = (N + T - 1) / T;       // window elements per thread
 	constexpr int BPT = (M + 1 + T - 1) / T;   // bins per thread
 	__shared__ double2 A[fft_lds_size(M)];
-	constexpr int SCR = T + 2 * (T / 64);  // scratch of the exact cumulative sum: it reuses P once the terms are formed
-	__shared__ double P[(M + 2 > SCR) ? M + 2 : SCR];
+	// LDS: the FFT workspace and the scratch of the cumulative sum only (18.3 KB at N = 2048: eight workgroups per CU).  The power
+	// spectrum has no array of its own: it lives in the workspace until it has been DC-corrected, goes through registers and
+	// comes back as the mirrored terms of the cumulative sum.
+	__shared__ double scr[T + 2 * (T / 64)];
 	__shared__ double red[2 * (T / 64) + 2];
 	double *Ar = reinterpret_cast<double *>(A);
 
@@ -121,18 +123,27 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 	WC_FRESH(tid);
 	fft_lds<M, T, +1>(A, a.tw, tid);
 	r2c_post<M, T>(A, a.tw, tid);
-	for (int k = tid; k <= M; k += T) {
-		double2 v = A[k == M ? 0 : k];
-		double p;
-		if (k == 0) p = v.x * v.x;
-		else if (k == M) p = v.y * v.y;
-		else p = fma(v.x, v.x, v.y * v.y);
-		P[k] = p;
+	double pw[BPT];
+#pragma unroll
+	for (int e = 0; e < BPT; ++e) {
+		const int k = tid + e * T;
+		pw[e] = 0.0;
+		if (k <= M) {
+			const double2 v = A[k == M ? 0 : k];
+			pw[e] = (k == 0) ? v.x * v.x : (k == M) ? v.y * v.y : fma(v.x, v.x, v.y * v.y);
+		}
+	}
+	__syncthreads();  // the spectrum has been read: the workspace becomes P[0 .. M]
+#pragma unroll
+	for (int e = 0; e < BPT; ++e) {
+		const int k = tid + e * T;
+		if (k <= M) Ar[k] = pw[e];
 	}
 	__syncthreads();
 	// DC correction (reference src/world_common.cpp:61-80)
 	WC_FRESH(tid);
 	{
+		double *P = Ar;
 		const int upper = 2 + (int)(f0c * N / fs);
 		const double dx = -(double)fs / N, rdx = 1.0 / dx;
 		double rep[2];
@@ -153,6 +164,12 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 		}
 		__syncthreads();
 	}
+#pragma unroll
+	for (int e = 0; e < BPT; ++e) {
+		const int k = tid + e * T;
+		if (k <= M) pw[e] = Ar[k];
+	}
+	__syncthreads();  // the corrected spectrum is in registers: the workspace becomes the mirrored segment
 
 	// ---- linear smoothing, width 2 f0 / 3 (reference src/world_common.cpp:27-52, :82-116) ----
 	double lp[BPT];
@@ -162,17 +179,23 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 		int b = (int)(width * N / fs) + 1;
 		if (M + 2 * b + 1 > N) b = (N - M - 1) / 2;  // cannot happen for f0 < 3 fs / 8
 		const int len = M + 2 * b + 1;
-		auto mir = [&](int i) -> double {
-			if (i < b) return P[b - i];
-			if (i < M + b) return P[i - b];
-			return P[M - (i - (M + b))];
-		};
-		// Ar is free (the spectrum has been consumed): it receives the terms, then their cumulative sum in the reference's
-		// own sequential rounding (seq_cumsum_nonneg, wc_device.hpp) -- non-decreasing like the reference's, which matters
-		// because the smoothed value below is a difference of two neighbourhoods of it and goes into a logarithm
-		for (int i = tid; i < len; i += T) Ar[i] = mir(i) * fs / N;
+		// mirrored segment (reference src/world_common.cpp:33-44): position i holds bin b - i (i < b), bin i - b (b <= i < M + b),
+		// bin 2 M + b - i (M + b <= i <= M + 2 b); every thread scatters the terms of its own bins.  The cumulative sum is then
+		// formed in the reference's own sequential rounding (seq_cumsum_nonneg, wc_device.hpp) -- non-decreasing like the
+		// reference's, which matters because the smoothed value below is a difference of two neighbourhoods of it and goes into
+		// a logarithm
+#pragma unroll
+		for (int e = 0; e < BPT; ++e) {
+			const int k = tid + e * T;
+			if (k <= M) {
+				const double v = pw[e] * fs / N;
+				if (k < M) Ar[k + b] = v;
+				if (k >= 1 && k <= b) Ar[b - k] = v;
+				if (k >= M - b) Ar[2 * M + b - k] = v;
+			}
+		}
 		__syncthreads();
-		seq_cumsum_nonneg<T>(Ar, len, P, red, tid);
+		seq_cumsum_nonneg<T>(Ar, len, scr, red, tid);
 		const double origin_axis = -(b - 0.5) * fs / N;
 		const double step = (double)fs / N, rstep = 1.0 / step;
 		auto seg = [&](int i) -> double { return Ar[min(max(i, 0), len - 1)]; };
@@ -215,6 +238,8 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 		double c, sn, cd, sd;
 		sincospi(f0c / fs * tid, &sn, &c);
 		sincospi(f0c / fs * T, &sd, &cd);
+		// every thread reads and rewrites its own bins only; bin M travels in the imaginary slot of bin 0, and both are thread 0's
+		double bin0 = 0.0, binM = 0.0;
 		for (int k = tid; k <= M; k += T) {
 			double sl, cl;
 			if (k == 0) {
@@ -225,17 +250,18 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 				cl = fma(2.0 * q1, fma(-2.0 * sn, sn, 1.0), 1.0 - 2.0 * q1);
 			}
 			if (k == M) {
-				P[M] = A[0].y * sl * cl / N;  // parked until every thread has read its own bin
+				binM = A[0].y * sl * cl / N;
 			} else {
-				double re = (k == 0) ? A[0].x : A[k].x;
-				P[k] = re * sl * cl / N;
+				const double re = (k == 0) ? A[0].x : A[k].x;
+				const double v = re * sl * cl / N;
+				if (k == 0) bin0 = v;
+				else A[k] = make_double2(v, 0.0);
 			}
 			const double cn = fma(c, cd, -(sn * sd));
 			sn = fma(sn, cd, c * sd);
 			c = cn;
 		}
-		__syncthreads();
-		for (int k = tid; k < M; k += T) A[k] = make_double2(P[k], k == 0 ? P[M] : 0.0);
+		if (tid == 0) A[0] = make_double2(bin0, binM);
 		__syncthreads();
 	}
 	WC_FRESH(tid);
