@@ -614,7 +614,7 @@ __device__ __forceinline__ int hv_count_le(E e, int lo, int hi, double fs, doubl
 }
 
 constexpr int RAW_T = 256;      // frames per workgroup
-constexpr int RAW_LDS = 512;    // staged intervals per type
+constexpr int RAW_LDS = 304;    // staged intervals per type: 256 ms of a 968 Hz band hold 248 (+ 8 of margin); 19.5 KB per workgroup, 7 per CU (512: 4 per CU)
 
 // One workgroup per (utterance, band, 256 consecutive 1 ms frames).  The fine edges that can matter for these
 // frames form a short contiguous slice of each of the four event lists; wave `ty` locates the slice of type `ty`
