@@ -406,7 +406,13 @@ struct SdArgs {
 	int n_bands, n_chunks;
 };
 
-__global__ __launch_bounds__(64) void hv_bandpass_sdft_kernel(SdArgs a) {
+#ifndef WC_SDFT_U
+#define WC_SDFT_U 4      // outputs per trip = depth of the sample prefetch
+#endif
+#ifndef WC_SDFT_WAVES
+#define WC_SDFT_WAVES 1  // minimum wavefronts per SIMD asked of the register allocator
+#endif
+__global__ __launch_bounds__(64, WC_SDFT_WAVES) void hv_bandpass_sdft_kernel(SdArgs a) {
 	const int lane = threadIdx.x;
 	const HvUtt u = a.utts[blockIdx.y];
 	const int item = blockIdx.x * 64 + lane;  // (chunk, band), band fastest: a wave holds neighbouring bands
@@ -483,7 +489,7 @@ __global__ __launch_bounds__(64) void hv_bandpass_sdft_kernel(SdArgs a) {
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) steps = max(steps, __shfl_xor(steps, o, 64));
 	// four outputs per trip; the samples of a trip are requested one trip ahead of their use
-	constexpr int U = 4;
+	constexpr int U = WC_SDFT_U;
 	double yn[U], yo[U];
 #pragma unroll
 	for (int k = 0; k < U; ++k) { yn[k] = pn[1 + k]; yo[k] = po[1 + k]; }
