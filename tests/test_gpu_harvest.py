@@ -203,3 +203,31 @@ def test_smoothing_that_skips_settled_stretches_is_bit_identical(wca):
             assert np.array_equal(fa, fb), (fp, u)
             assert np.array_equal(sm_a[u], b.debug_fetch("f0_1ms", u)), (fp, u)
         assert sum(int((f > 0).sum()) for _, f in ra) > 1000
+
+
+def test_packed_refinement_is_bit_identical(wca):
+    """getRefinedF0 (reference src/harvest.cpp:944-982) runs once per candidate of the overlapped rows.  The default kernel packs
+    a frame's live candidates eight to a wavefront and computes the harmonics of candidates that share window length and bins
+    once; WC_HARVEST_REFINE=slots is the plain layout, a wavefront per candidate slot.  Same bits in every refined candidate
+    and score -- speech, two voices, other band counts (more slots), the tabulated window, a ragged batch."""
+    import os
+    from world_class_amd.synth import make_signal
+    fs = 16000
+    xs = [make_utterance(fs, 3.0, 515), make_signal(fs, 2.0, 40004), make_utterance(fs, 0.2, 9), make_signal(fs, 1.5, 230002)]
+    x2, fs2, floor2, _ = harvest_long_case("equal_refined_16k_3s_loud")
+    for fs_, batch, opts in ((fs, xs, {}), (fs, xs, dict(channels_in_octave=80.0)), (fs, xs[:2], dict(use_cos_table=True)),
+                             (fs2, [x2], dict(f0_floor=floor2)), (48000, [make_utterance(48000, 2.0, 31)], dict(f0_floor=40.0))):
+        a = wca.Harvest(fs_, **opts)
+        ra = a.compute_batch(batch)
+        got = [(a.debug_fetch("cand1", k), a.debug_fetch("score1", k)) for k in range(len(batch))]
+        os.environ["WC_HARVEST_REFINE"] = "slots"
+        try:
+            b = wca.Harvest(fs_, **opts)
+        finally:
+            del os.environ["WC_HARVEST_REFINE"]
+        rb = b.compute_batch(batch)
+        for k in range(len(batch)):
+            assert np.array_equal(got[k][0], b.debug_fetch("cand1", k)), (opts, k)
+            assert np.array_equal(got[k][1], b.debug_fetch("score1", k)), (opts, k)
+            assert np.array_equal(ra[k][1], rb[k][1])
+        assert sum(int((c != 0).sum()) for c, _ in got) > 500

@@ -43,7 +43,7 @@ class Harvest:
         return out
 
     def debug_fetch(self, name, utt=0):
-        """Development hook: an intermediate of the most recent call (y, raw, cand0, cand1, cand, score, base,
+        """Development hook: an intermediate of the most recent call (y, raw, cand0, cand1, score1, cand, score, base,
         s1, s2, s3, fixed, f0_1ms) as a flat float64 array."""
         fn = lib().wc_harvest_debug_fetch
         fn.restype = C.c_longlong
