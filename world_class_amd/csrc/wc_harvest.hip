@@ -1038,9 +1038,9 @@ __global__ __launch_bounds__(256, WC_REFINE_WAVES) void hv_refine_kernel(RefArgs
 // A candidate's refined F0 and score are the values the kernel above computes, bit for bit: the arithmetic of a group of eight
 // lanes never depended on what else ran in the wavefront, and candidates with equal keys got equal harmonics there as well.
 // 39 % fewer passes through the sample loop and 23 % fewer samples per frame on speech at 48 kHz.
-constexpr int RF_NP = 7 * MAX_SLOTS;    // candidate positions of a frame
 constexpr int RF_GROUP = 3;             // passes whose start phases are staged together (see phase 1 above)
-template <bool TABLE>
+// RF_NP: candidate positions of a frame the LDS is sized for (7 S <= RF_NP; 112 covers the reference's default 15 slots, 7 MAX_SLOTS everything)
+template <bool TABLE, int RF_NP>
 __global__ __launch_bounds__(64, WC_REFINE_WAVES) void hv_refine_packed_kernel(RefArgs a) {
 	const int lane = threadIdx.x;
 	const int grp = lane >> 3, sub = lane & 7;
@@ -1056,11 +1056,11 @@ __global__ __launch_bounds__(64, WC_REFINE_WAVES) void hv_refine_packed_kernel(R
 	const double *__restrict__ y = a.y + u.y_off;
 	const double *__restrict__ crow = a.cand0 + (u.l1_off + i) * S;
 	__shared__ double it_f[RF_NP];              // live candidates, slot-major
-	__shared__ double row_f[RF_NP];             // the keys while duplicates are looked for, the refined F0 row afterwards
-	__shared__ double row_s[RF_NP];
+	__shared__ unsigned long long key[RF_NP];   // half window length and harmonic bins
+	__shared__ double row_f[RF_NP], row_s[RF_NP];
 	__shared__ double2 stage[RF_GROUP][64];     // start phases of a pass; the harmonics it found overwrite them
-	__shared__ unsigned char it_pos[RF_NP], it_u[RF_NP], it_rep[RF_NP], un_src[RF_NP], dup_of[RF_NP];
-	unsigned long long *const key = reinterpret_cast<unsigned long long *>(row_f);
+	__shared__ int it_basic[RF_NP];             // first sample of the window (reference :762-771)
+	__shared__ unsigned char it_pos[RF_NP], it_u[RF_NP], it_rep[RF_NP], un_src[RF_NP], dup_of[RF_NP], it_nh[RF_NP];
 	const unsigned long long below = (1ull << lane) - 1ull;
 
 	// 1. live candidates of the overlap (reference :987-1000), slot-major: position k = 7 j + block
@@ -1078,21 +1078,21 @@ __global__ __launch_bounds__(64, WC_REFINE_WAVES) void hv_refine_packed_kernel(R
 			const int hw = min((int)(1.5 * fs / f + 1.0), RF_MAXHW);
 			const int N = 1 << (2 + (31 - __clz(hw * 2 + 1)));
 			const double bin_unit = f * N / fs;
-			// key: half window length and the six bins (reference :853-861, :950-962).  Bin h is within 3.5 of (h + 1) times
-			// bin 0, so four bits each hold the differences; a first bin too large for its field makes the key one of a kind
+			// key: half window length (11 bits) and the six bins (reference :853-861, :950-962): bin 0 in the upper word, four
+			// bits each for what bin h adds to (h + 1) times bin 0 -- rounding keeps that within 3.5
 			const int b0 = mround(bin_unit);
-			unsigned long long kk = (unsigned long long)hw | ((unsigned long long)(unsigned)b0 << 11);
-			bool fits = b0 >= 0 && b0 < (1 << 20);
+			unsigned long long kk = (unsigned long long)hw | ((unsigned long long)(unsigned)b0 << 32);
 #pragma unroll
 			for (int h = 1; h < 6; ++h) {
 				const int dlt = mround(bin_unit * (h + 1)) - (h + 1) * b0 + 8;
-				fits = fits && dlt >= 0 && dlt < 16;
-				kk |= (unsigned long long)(dlt & 15) << (31 + 4 * (h - 1));
+				kk |= (unsigned long long)(dlt & 15) << (11 + 4 * (h - 1));
 			}
-			if (!fits) kk = (1ull << 63) | (unsigned long long)at;
 			it_f[at] = f;
 			it_pos[at] = (unsigned char)(j + S * blk);
 			key[at] = kk;
+			// what every lane of a pass needs of the candidate besides its key, worked out once here
+			it_basic[at] = mround((pos + (-hw) / fs) * fs + 0.001);
+			it_nh[at] = (unsigned char)min((int)(fs / 2.0 / f), 6);
 		}
 		n += __popcll(m);
 	}
@@ -1129,13 +1129,12 @@ __global__ __launch_bounds__(64, WC_REFINE_WAVES) void hv_refine_packed_kernel(R
 	}
 	__syncthreads();
 	for (int k = lane; k < nd; k += 64) { const int t = dup_of[k]; it_u[t] = it_u[it_rep[t]]; }
-	for (int k = lane; k < NC; k += 64) { row_f[k] = 0.0; row_s[k] = 0.0; }  // (the keys are done with)
+	for (int k = lane; k < NC; k += 64) { row_f[k] = 0.0; row_s[k] = 0.0; }
 	__syncthreads();
 
 	// the score of a candidate from the harmonics in lanes 0..5 of its group (fixF0, reference :880-893 and :964-979)
-	auto finish = [&](double inst, double amp, double fc, bool live, double &rf, double &rs) {
+	auto finish = [&](double inst, double amp, double fc, int nh, bool live, double &rf, double &rs) {
 		const int h = sub;
-		const int nh = min((int)(fs / 2.0 / fc), 6);
 		const double e_num = amp * inst, e_den = amp * (h + 1.0), e_sc = fabs((inst / (h + 1.0) - fc) / fc);
 		double num = 0.0, den = 0.0, sc = 0.0;
 #pragma unroll
@@ -1159,11 +1158,10 @@ __global__ __launch_bounds__(64, WC_REFINE_WAVES) void hv_refine_packed_kernel(R
 		// phase 1 (see the kernel above): window phases at every lane's first sample
 		for (int q = 0; q < cn; ++q) {
 			const int r = (c0 + q) * 8 + grp;
-			const double fc = r < nu ? it_f[un_src[r]] : 100.0;
-			const int hw = min((int)(1.5 * fs / fc + 1.0), RF_MAXHW);
+			const int t_own = r < nu ? un_src[r] : 0;  // (an idle group borrows candidate 0: any valid window will do)
+			const int hw = (int)(key[t_own] & 2047ull);
+			const int basic = it_basic[t_own];
 			const double wlt = (2.0 * hw + 1.0) / fs;
-			const double bt0 = (-hw) / fs;
-			const int basic = mround((pos + bt0) * fs + 0.001);
 			const double tmp = (basic + sub - 1.0) / fs - pos;
 			const double tmp2 = 2.0 * kPi * tmp / wlt;
 			double wc, ws;
@@ -1175,17 +1173,19 @@ __global__ __launch_bounds__(64, WC_REFINE_WAVES) void hv_refine_packed_kernel(R
 			const int r = (c0 + q) * 8 + grp;
 			const bool live = r < nu;
 			const int t_own = live ? un_src[r] : 0;
-			const double fc = live ? it_f[t_own] : 100.0;
-			const int hw = min((int)(1.5 * fs / fc + 1.0), RF_MAXHW);
+			const double fc = it_f[t_own];
+			const unsigned long long kk = key[t_own];
+			const int hw = (int)(kk & 2047ull);
 			const int bt = live ? 2 * hw + 1 : 0;
 			const double wlt = (2.0 * hw + 1.0) / fs;
 			const int fft_index = 2 + (31 - __clz(hw * 2 + 1));
 			const int N = 1 << fft_index;
 			const int tsh = kTwiddleN / N;
-			const double bt0 = (-hw) / fs;
-			const int basic = mround((pos + bt0) * fs + 0.001);
-			double bin_unit = fc * N / fs;
-			auto bin_of = [&](int h) { return mround(bin_unit * (h + 1)); };
+			const int basic = it_basic[t_own];
+			auto bin_of = [&](int h) -> int {  // harmonic bins (reference :853-861) out of the key
+				const int b0 = (int)(kk >> 32);
+				return h == 0 ? b0 : (h + 1) * b0 + (int)(((unsigned)kk >> (11 + 4 * (h - 1))) & 15u) - 8;
+			};
 			double wc = stage[q][lane].x, ws = stage[q][lane].y;
 			const double2 r1 = a.rot[2 * hw], r8 = a.rot[2 * hw + 1];
 			const double k1 = 0.5 * r1.y, k2 = 0.16 * (2.0 * r1.y * r1.x);
@@ -1260,7 +1260,6 @@ __global__ __launch_bounds__(64, WC_REFINE_WAVES) void hv_refine_packed_kernel(R
 				}
 				Q += 2;
 			}
-			asm volatile("" : "+v"(bin_unit));
 			int idx[6];
 #pragma unroll
 			for (int h = 0; h < 6; ++h) idx[h] = bin_of(h);
@@ -1314,7 +1313,7 @@ __global__ __launch_bounds__(64, WC_REFINE_WAVES) void hv_refine_packed_kernel(R
 			const double amp = sqrt(pw);
 			if (sub < 6) stage[q][grp * 6 + sub] = make_double2(inst, amp);  // (every lane took its start phase from here long ago)
 			double rf, rs;
-			finish(inst, amp, fc, live, rf, rs);
+			finish(inst, amp, fc, it_nh[t_own], live, rf, rs);
 			if (sub == 0 && live) {
 				row_f[it_pos[t_own]] = rf;
 				row_s[it_pos[t_own]] = rs;
@@ -1334,9 +1333,9 @@ __global__ __launch_bounds__(64, WC_REFINE_WAVES) void hv_refine_packed_kernel(R
 				inst = ia.x;
 				amp = ia.y;
 			}
-			const double fc = mine ? it_f[t] : 100.0;
+			const double fc = it_f[t];
 			double rf, rs;
-			finish(inst, amp, fc, mine, rf, rs);
+			finish(inst, amp, fc, it_nh[t], mine, rf, rs);
 			if (sub == 0 && mine) {
 				row_f[it_pos[t]] = rf;
 				row_s[it_pos[t]] = rs;
@@ -2182,8 +2181,14 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 		if (h->use_cos_table) hipLaunchKernelGGL(hv_refine_kernel<true>, dim3((unsigned)total_l1), dim3(256), 0, s, fa);
 		else hipLaunchKernelGGL(hv_refine_kernel<false>, dim3((unsigned)total_l1), dim3(256), 0, s, fa);
 	} else {
-		if (h->use_cos_table) hipLaunchKernelGGL(hv_refine_packed_kernel<true>, dim3((unsigned)total_l1), dim3(64), 0, s, fa);
-		else hipLaunchKernelGGL(hv_refine_packed_kernel<false>, dim3((unsigned)total_l1), dim3(64), 0, s, fa);
+		const bool small = 7 * S <= 112;
+		if (h->use_cos_table) {
+			if (small) hipLaunchKernelGGL((hv_refine_packed_kernel<true, 112>), dim3((unsigned)total_l1), dim3(64), 0, s, fa);
+			else hipLaunchKernelGGL((hv_refine_packed_kernel<true, 7 * MAX_SLOTS>), dim3((unsigned)total_l1), dim3(64), 0, s, fa);
+		} else {
+			if (small) hipLaunchKernelGGL((hv_refine_packed_kernel<false, 112>), dim3((unsigned)total_l1), dim3(64), 0, s, fa);
+			else hipLaunchKernelGGL((hv_refine_packed_kernel<false, 7 * MAX_SLOTS>), dim3((unsigned)total_l1), dim3(64), 0, s, fa);
+		}
 	}
 	WC_HIP(hipGetLastError());
 	if ((rc = dev->time_end("harvest_refine", s))) return rc;
