@@ -1024,6 +1024,31 @@ __global__ __launch_bounds__(256, WC_REFINE_WAVES) void hv_refine_kernel(RefArgs
 	}
 }
 
+// Exchanges inside a group of eight lanes as DPP moves (VALU, no trip through the LDS crossbar that __shfl_xor's ds_bpermute
+// takes): quad permutes for lane ^ 1 and lane ^ 2; lane ^ 4 as a row shift left by four into lanes 0-3 of each eight (banks
+// 0 and 2 of the row) and right by four into lanes 4-7 (banks 1 and 3).
+#ifndef WC_REFINE_DPP
+#define WC_REFINE_DPP 1
+#endif
+template <int X>
+__device__ __forceinline__ double group8_xor(double v) {
+#if WC_REFINE_DPP
+	int w[2] = {__double2loint(v), __double2hiint(v)};
+#pragma unroll
+	for (int k = 0; k < 2; ++k) {
+		if (X == 1) w[k] = __builtin_amdgcn_mov_dpp(w[k], 0xB1, 0xF, 0xF, true);       // quad_perm:[1,0,3,2]
+		else if (X == 2) w[k] = __builtin_amdgcn_mov_dpp(w[k], 0x4E, 0xF, 0xF, true);  // quad_perm:[2,3,0,1]
+		else {
+			int r = __builtin_amdgcn_update_dpp(w[k], w[k], 0x104, 0xF, 0x5, false);   // row_shl:4 -> lanes 0-3, 8-11
+			w[k] = __builtin_amdgcn_update_dpp(r, w[k], 0x114, 0xF, 0xA, false);       // row_shr:4 -> lanes 4-7, 12-15
+		}
+	}
+	return __hiloint2double(w[1], w[0]);
+#else
+	return __shfl_xor(v, X, 64);
+#endif
+}
+
 // The same refinement with the frame's work packed (default; the kernel above is WC_HARVEST_REFINE=slots).
 // What a candidate's spectral part -- instantaneous frequency and amplitude of the six harmonics -- depends on is the
 // frame, the half window length and the six harmonic bins, not the candidate frequency itself (reference :844-878: only the
@@ -1282,7 +1307,7 @@ __global__ __launch_bounds__(64, WC_REFINE_WAVES) void hv_refine_packed_kernel(R
 				for (int c = 0; c < 4; ++c) {
 					const double send = up ? lo[c] : hi[c];
 					const double keep = up ? hi[c] : lo[c];
-					v[4 * p + c] = keep + __shfl_xor(send, 4, 64);
+					v[4 * p + c] = keep + group8_xor<4>(send);
 				}
 #if WC_REFINE_FENCE
 				asm volatile("" ::: "memory");
@@ -1293,14 +1318,14 @@ __global__ __launch_bounds__(64, WC_REFINE_WAVES) void hv_refine_packed_kernel(R
 				const bool up = (sub & 2) != 0;
 				const double send = up ? v[k] : v[8 + k];
 				const double keep = up ? v[8 + k] : v[k];
-				v[k] = keep + __shfl_xor(send, 2, 64);
+				v[k] = keep + group8_xor<2>(send);
 			}
 #pragma unroll
 			for (int k = 0; k < 4; ++k) {
 				const bool up = (sub & 1) != 0;
 				const double send = up ? v[k] : v[4 + k];
 				const double keep = up ? v[4 + k] : v[k];
-				v[k] = keep + __shfl_xor(send, 1, 64);
+				v[k] = keep + group8_xor<1>(send);
 			}
 			const int h = sub;
 			int myidx = 0;
@@ -1309,7 +1334,7 @@ __global__ __launch_bounds__(64, WC_REFINE_WAVES) void hv_refine_packed_kernel(R
 			const double mr = v[0], mi = v[1], dr = v[2], di = v[3];
 			const double pw = mr * mr + mi * mi;
 			const double ni = mr * di - mi * dr;
-			const double inst = (pw == 0.0) ? 0.0 : (double)myidx * fs / N + ni / pw * fs / 2.0 / kPi;
+			const double inst = (pw == 0.0) ? 0.0 : (double)myidx * fs * (1.0 / N) + ni / pw * fs / 2.0 / kPi;  // (N is a power of two: the product is the quotient of :871)
 			const double amp = sqrt(pw);
 			if (sub < 6) stage[q][grp * 6 + sub] = make_double2(inst, amp);  // (every lane took its start phase from here long ago)
 			double rf, rs;
