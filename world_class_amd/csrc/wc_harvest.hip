@@ -1066,7 +1066,7 @@ __device__ __forceinline__ double group8_xor(double v) {
 constexpr int RF_GROUP = 3;             // passes whose start phases are staged together (see phase 1 above)
 // RF_NP: candidate positions of a frame the LDS is sized for (7 S <= RF_NP; 112 covers the reference's default 15 slots, 7 MAX_SLOTS everything)
 template <bool TABLE, int RF_NP>
-__global__ __launch_bounds__(64, WC_REFINE_WAVES) void hv_refine_packed_kernel(RefArgs a) {
+__global__ __launch_bounds__(64, RF_NP > 112 ? 2 : WC_REFINE_WAVES) void hv_refine_packed_kernel(RefArgs a) {  // (the LDS of the wide variant allows 11 wavefronts per CU anyway)
 	const int lane = threadIdx.x;
 	const int grp = lane >> 3, sub = lane & 7;
 	const long long g = blockIdx.x;
@@ -1082,10 +1082,10 @@ __global__ __launch_bounds__(64, WC_REFINE_WAVES) void hv_refine_packed_kernel(R
 	const double *__restrict__ crow = a.cand0 + (u.l1_off + i) * S;
 	__shared__ double it_f[RF_NP];              // live candidates, slot-major
 	__shared__ unsigned long long key[RF_NP];   // half window length and harmonic bins
-	__shared__ double row_f[RF_NP], row_s[RF_NP];
+	__shared__ double row_f[RF_NP], row_s[RF_NP], row_c[RF_NP];  // per position: the three sums over harmonics of :880-893
 	__shared__ double2 stage[RF_GROUP][64];     // start phases of a pass; the harmonics it found overwrite them
 	__shared__ int it_basic[RF_NP];             // first sample of the window (reference :762-771)
-	__shared__ unsigned char it_pos[RF_NP], it_u[RF_NP], it_rep[RF_NP], un_src[RF_NP], dup_of[RF_NP], it_nh[RF_NP];
+	__shared__ unsigned char it_pos[RF_NP], it_u[RF_NP], it_rep[RF_NP], un_src[RF_NP], dup_of[RF_NP], it_nh[RF_NP], pos_nh[RF_NP];
 	const unsigned long long below = (1ull << lane) - 1ull;
 
 	// 1. live candidates of the overlap (reference :987-1000), slot-major: position k = 7 j + block
@@ -1098,6 +1098,7 @@ __global__ __launch_bounds__(64, WC_REFINE_WAVES) void hv_refine_packed_kernel(R
 		if (k < NC && src >= 0 && src < u.L1) f = crow[(src - i) * S + j];
 		const bool live = f > 0.0;
 		const unsigned long long m = __ballot(live);
+		if (k < NC && !live) pos_nh[j + S * blk] = 0;  // an empty position
 		if (live) {
 			const int at = n + __popcll(m & below);
 			const int hw = min((int)(1.5 * fs / f + 1.0), RF_MAXHW);
@@ -1117,7 +1118,9 @@ __global__ __launch_bounds__(64, WC_REFINE_WAVES) void hv_refine_packed_kernel(R
 			key[at] = kk;
 			// what every lane of a pass needs of the candidate besides its key, worked out once here
 			it_basic[at] = mround((pos + (-hw) / fs) * fs + 0.001);
-			it_nh[at] = (unsigned char)min((int)(fs / 2.0 / f), 6);
+			const int nh = min((int)(fs / 2.0 / f), 6);  // >= 1 below the Nyquist frequency
+			it_nh[at] = (unsigned char)nh;
+			pos_nh[j + S * blk] = (unsigned char)nh;
 		}
 		n += __popcll(m);
 	}
@@ -1128,16 +1131,24 @@ __global__ __launch_bounds__(64, WC_REFINE_WAVES) void hv_refine_packed_kernel(R
 		}
 		return;
 	}
+	// 2. the first candidate of every key, found through a 256-entry table indexed by a hash of the key: the smallest candidate
+	//    index that hashes to an entry owns it.  A candidate whose entry belongs to a different key counts as one of a kind and
+	//    has its harmonics computed again -- to the same bits; what the table decides is work, never results.
+	unsigned int *const tab = reinterpret_cast<unsigned int *>(&stage[0][0]);
+	auto slot_of = [](unsigned long long kk) { return (((unsigned)kk * 2654435761u) ^ ((unsigned)(kk >> 32) * 40503u * 65537u)) >> 24; };
+	for (int k = lane; k < 256; k += 64) tab[k] = 0xFFFFFFFFu;
 	__syncthreads();
-	// 2. the first candidate of every key
+	for (int t = lane; t < n; t += 64) atomicMin(&tab[slot_of(key[t])], (unsigned)t);
+	__syncthreads();
 	int nu = 0, nd = 0;
 	for (int t0 = 0; t0 < n; t0 += 64) {
 		const int t = t0 + lane;
-		const unsigned long long mine = t < n ? key[t] : 0ull;
 		int rep = t;
-		const int stop = min(n, t0 + 64);
-		for (int s = 0; s < stop; ++s)
-			if (s < t && rep == t && key[s] == mine) rep = s;
+		if (t < n) {
+			const unsigned long long mine = key[t];
+			const int r = (int)tab[slot_of(mine)];
+			if (r != t && key[r] == mine) rep = r;
+		}
 		const bool uniq = t < n && rep == t, dup = t < n && rep != t;
 		const unsigned long long mu = __ballot(uniq), md = __ballot(dup);
 		if (uniq) {
@@ -1154,26 +1165,20 @@ __global__ __launch_bounds__(64, WC_REFINE_WAVES) void hv_refine_packed_kernel(R
 	}
 	__syncthreads();
 	for (int k = lane; k < nd; k += 64) { const int t = dup_of[k]; it_u[t] = it_u[it_rep[t]]; }
-	for (int k = lane; k < NC; k += 64) { row_f[k] = 0.0; row_s[k] = 0.0; }
 	__syncthreads();
 
-	// the score of a candidate from the harmonics in lanes 0..5 of its group (fixF0, reference :880-893 and :964-979)
-	auto finish = [&](double inst, double amp, double fc, int nh, bool live, double &rf, double &rs) {
+	// the sums over harmonics behind a candidate's refined F0 and score, from the harmonics in lanes 0..5 of its group (fixF0,
+	// reference :880-893); the quotients of :964-979 wait for the sweep over the row at the end
+	auto finish = [&](double inst, double amp, double fc, int nh, double &num, double &den, double &sc) {
 		const int h = sub;
 		const double e_num = amp * inst, e_den = amp * (h + 1.0), e_sc = fabs((inst / (h + 1.0) - fc) / fc);
-		double num = 0.0, den = 0.0, sc = 0.0;
+		num = 0.0; den = 0.0; sc = 0.0;
 #pragma unroll
 		for (int q = 0; q < 6; ++q) {  // the reference's summation order over harmonics
 			const double x1 = __shfl(e_num, (lane & 56) + q, 64);
 			const double x2 = __shfl(e_den, (lane & 56) + q, 64);
 			const double x3 = __shfl(e_sc, (lane & 56) + q, 64);
 			if (q < nh) { num += x1; den += x2; sc += x3; }
-		}
-		rf = 0.0; rs = 0.0;
-		if (live) {
-			rf = num / (den + kSafeH);
-			rs = 1.0 / (sc / nh + kSafeH);
-			if (rf < a.p.f0_floor || rf > a.p.f0_ceil || rs < 2.5) { rf = 0.0; rs = 0.0; }  // reference :974-979
 		}
 	};
 
@@ -1228,8 +1233,8 @@ __global__ __launch_bounds__(64, WC_REFINE_WAVES) void hv_refine_packed_kernel(R
 				const double dindex2 = fmod(dindex * 2, 8000.0);
 				return 0.42 + 0.5 * a.cos_table[(int)round(dindex)] + 0.08 * a.cos_table[(int)round(dindex2)];
 			};
-			auto sample = [&](int n_, double &xm, double &xd) {
-				const double yv = (n_ < bt) ? y[clampi(basic + n_ - 1, 0, u.y_len - 1)] : 0.0;
+			auto sample = [&](int n_, double yl, double &xm, double &xd) {
+				const double yv = (n_ < bt) ? yl : 0.0;
 				if (TABLE) {
 					double m = 0.0, d = 0.0;
 					if (n_ < bt) {
@@ -1254,8 +1259,7 @@ __global__ __launch_bounds__(64, WC_REFINE_WAVES) void hv_refine_packed_kernel(R
 				ws = fma(ws, r8.x, wc * r8.y);
 				wc = nc_;
 			};
-			auto interior = [&](int n_, double &xm, double &xd) {
-				const double yv = y[clampi(basic + n_ - 1, 0, u.y_len - 1)];
+			auto interior = [&](int n_, double yv, double &xm, double &xd) {
 				const double m = fma(wc, fma(0.16, wc, 0.5), 0.34);
 				const double d = ws * fma(k2, wc, k1);
 				xm = m * yv;
@@ -1264,26 +1268,32 @@ __global__ __launch_bounds__(64, WC_REFINE_WAVES) void hv_refine_packed_kernel(R
 				ws = fma(ws, r8.x, wc * r8.y);
 				wc = nc_;
 			};
+			// the two samples of a trip are loaded one trip ahead (the index is clamped: a load past the window is harmless and unused)
+			auto sample_at = [&](int n_) { return y[clampi(basic + n_ - 1, 0, u.y_len - 1)]; };
+			double y0 = sample_at(sub), y1 = sample_at(sub + 8);
 			int Q = 0;
 			for (int n_ = sub; n_ < bt; n_ += 16) {
+				const double ny0 = sample_at(n_ + 16), ny1 = sample_at(n_ + 24);
 				const bool ends = TABLE || n_ == sub || n_ + 9 >= bt;
 				const bool any_end = __ballot(ends) != 0ull;
 				double xm, xd;
-				if (any_end) sample(n_, xm, xd);
-				else interior(n_, xm, xd);
+				if (any_end) sample(n_, y0, xm, xd);
+				else interior(n_, y0, xm, xd);
 #pragma unroll
 				for (int h = 0; h < 6; ++h) {
 					sb[2 * h] = fma(c2[h], sa[2 * h], xm) - sb[2 * h];
 					sb[2 * h + 1] = fma(c2[h], sa[2 * h + 1], xd) - sb[2 * h + 1];
 				}
-				if (any_end) sample(n_ + 8, xm, xd);
-				else interior(n_ + 8, xm, xd);
+				if (any_end) sample(n_ + 8, y1, xm, xd);
+				else interior(n_ + 8, y1, xm, xd);
 #pragma unroll
 				for (int h = 0; h < 6; ++h) {
 					sa[2 * h] = fma(c2[h], sb[2 * h], xm) - sa[2 * h];
 					sa[2 * h + 1] = fma(c2[h], sb[2 * h + 1], xd) - sa[2 * h + 1];
 				}
 				Q += 2;
+				y0 = ny0;
+				y1 = ny1;
 			}
 			int idx[6];
 #pragma unroll
@@ -1337,11 +1347,13 @@ __global__ __launch_bounds__(64, WC_REFINE_WAVES) void hv_refine_packed_kernel(R
 			const double inst = (pw == 0.0) ? 0.0 : (double)myidx * fs * (1.0 / N) + ni / pw * fs / 2.0 / kPi;  // (N is a power of two: the product is the quotient of :871)
 			const double amp = sqrt(pw);
 			if (sub < 6) stage[q][grp * 6 + sub] = make_double2(inst, amp);  // (every lane took its start phase from here long ago)
-			double rf, rs;
-			finish(inst, amp, fc, it_nh[t_own], live, rf, rs);
+			double num, den, sc;
+			finish(inst, amp, fc, it_nh[t_own], num, den, sc);
 			if (sub == 0 && live) {
-				row_f[it_pos[t_own]] = rf;
-				row_s[it_pos[t_own]] = rs;
+				const int at = it_pos[t_own];
+				row_f[at] = num;
+				row_s[at] = den;
+				row_c[at] = sc;
 			}
 		}
 		__syncthreads();
@@ -1359,18 +1371,28 @@ __global__ __launch_bounds__(64, WC_REFINE_WAVES) void hv_refine_packed_kernel(R
 				amp = ia.y;
 			}
 			const double fc = it_f[t];
-			double rf, rs;
-			finish(inst, amp, fc, it_nh[t], mine, rf, rs);
+			double num, den, sc;
+			finish(inst, amp, fc, it_nh[t], num, den, sc);
 			if (sub == 0 && mine) {
-				row_f[it_pos[t]] = rf;
-				row_s[it_pos[t]] = rs;
+				const int at = it_pos[t];
+				row_f[at] = num;
+				row_s[at] = den;
+				row_c[at] = sc;
 			}
 		}
 		__syncthreads();
 	}
+	// refined F0 and score of every position (reference :964-979), one lane each; the rows leave contiguously
 	for (int k = lane; k < NC; k += 64) {
-		a.cand1[g * a.p.n_cand + k] = row_f[k];
-		a.score1[g * a.p.n_cand + k] = row_s[k];
+		const int nh = pos_nh[k];
+		double rf = 0.0, rs = 0.0;
+		if (nh > 0) {
+			rf = row_f[k] / (row_s[k] + kSafeH);
+			rs = 1.0 / (row_c[k] / nh + kSafeH);
+			if (rf < a.p.f0_floor || rf > a.p.f0_ceil || rs < 2.5) { rf = 0.0; rs = 0.0; }  // reference :974-979
+		}
+		a.cand1[g * a.p.n_cand + k] = rf;
+		a.score1[g * a.p.n_cand + k] = rs;
 	}
 }
 
