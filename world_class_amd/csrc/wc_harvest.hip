@@ -17,10 +17,13 @@
 //                        (utterance, band), register tiled from LDS), kept behind WC_HARVEST_BANDPASS=fir
 //   hv_raw_kernel        interp1 of the four interval series onto the 1 ms grid (:1098-1143)
 //   hv_detect_kernel     per-frame candidate detection over bands (:1005-1083)
-//   hv_refine_kernel     eight lanes per (frame, candidate): overlap (:987-1000) folded into the
+//   hv_refine_packed_kernel  eight lanes per (frame, candidate): overlap (:987-1000) folded into the
 //                        gather, Blackman / differentiated windows (<true>: from the reference's cosine
 //                        table, HarvestOption::use_cos_table), and -- instead of the reference's two
-//                        full FFTs -- Goertzel recurrences for the <= 6 harmonic bins fixF0 reads (:809-927)
+//                        full FFTs -- Goertzel recurrences for the <= 6 harmonic bins fixF0 reads (:809-927).
+//                        One wavefront per frame: live candidates packed eight to a pass, candidates that share
+//                        window length and bins computed once.  hv_refine_kernel is the plain layout (a wavefront
+//                        per candidate slot, the seven overlap blocks side by side), kept behind WC_HARVEST_REFINE=slots
 //   hv_unreliable_kernel (:708-744)
 //   hv_contour_kernel<0/1/2>  the sequential contour logic (:254-634: fixStep1..4, extend, merge): one
 //                        wavefront per utterance with the candidate searches spread over the lanes, except
@@ -1169,15 +1172,15 @@ __global__ __launch_bounds__(64, RF_NP > 112 ? 2 : WC_REFINE_WAVES) void hv_refi
 
 	// the sums over harmonics behind a candidate's refined F0 and score, from the harmonics in lanes 0..5 of its group (fixF0,
 	// reference :880-893); the quotients of :964-979 wait for the sweep over the row at the end
-	auto finish = [&](double inst, double amp, double fc, int nh, double &num, double &den, double &sc) {
-		const int h = sub;
+	auto finish = [&](int ln, double inst, double amp, double fc, int nh, double &num, double &den, double &sc) {
+		const int h = ln & 7;
 		const double e_num = amp * inst, e_den = amp * (h + 1.0), e_sc = fabs((inst / (h + 1.0) - fc) / fc);
 		num = 0.0; den = 0.0; sc = 0.0;
 #pragma unroll
 		for (int q = 0; q < 6; ++q) {  // the reference's summation order over harmonics
-			const double x1 = __shfl(e_num, (lane & 56) + q, 64);
-			const double x2 = __shfl(e_den, (lane & 56) + q, 64);
-			const double x3 = __shfl(e_sc, (lane & 56) + q, 64);
+			const double x1 = __shfl(e_num, (ln & 56) + q, 64);
+			const double x2 = __shfl(e_den, (ln & 56) + q, 64);
+			const double x3 = __shfl(e_sc, (ln & 56) + q, 64);
 			if (q < nh) { num += x1; den += x2; sc += x3; }
 		}
 	};
@@ -1203,7 +1206,6 @@ __global__ __launch_bounds__(64, RF_NP > 112 ? 2 : WC_REFINE_WAVES) void hv_refi
 			const int r = (c0 + q) * 8 + grp;
 			const bool live = r < nu;
 			const int t_own = live ? un_src[r] : 0;
-			const double fc = it_f[t_own];
 			const unsigned long long kk = key[t_own];
 			const int hw = (int)(kk & 2047ull);
 			const int bt = live ? 2 * hw + 1 : 0;
@@ -1295,13 +1297,28 @@ __global__ __launch_bounds__(64, RF_NP > 112 ? 2 : WC_REFINE_WAVES) void hv_refi
 				y0 = ny0;
 				y1 = ny1;
 			}
+			// Everything the closing arithmetic needs of the candidate is looked up again from an opaque copy of the lane index: the
+			// sample loop above holds 118 registers of recurrence state, and whatever stays live across it is spilled -- once per
+			// thread, which at 640 k wavefronts per batch is gigabytes of scratch writes.
+			int ln = lane;
+			asm volatile("" : "+v"(ln));
+			const int sub_c = ln & 7, grp_c = ln >> 3;
+			const int r_c = (c0 + q) * 8 + grp_c;
+			const bool live_c = r_c < nu;
+			const int t_c = live_c ? un_src[r_c] : 0;
+			const unsigned long long kk_c = key[t_c];
+			const int N_c = 1 << (2 + (31 - __clz((int)(kk_c & 2047ull) * 2 + 1)));
+			const int tsh_c = kTwiddleN / N_c;
 			int idx[6];
 #pragma unroll
-			for (int h = 0; h < 6; ++h) idx[h] = bin_of(h);
+			for (int h = 0; h < 6; ++h) {
+				const int b0 = (int)(kk_c >> 32);
+				idx[h] = h == 0 ? b0 : (h + 1) * b0 + (int)(((unsigned)kk_c >> (11 + 4 * (h - 1))) & 15u) - 8;
+			}
 			double v[16];
 			auto closing = [&](int h, double (&o)[4]) {
-				const double2 e1 = a.tw[((idx[h] * (sub + 8 * (Q - 1))) & (N - 1)) * tsh];
-				const double2 e2 = a.tw[((idx[h] * (sub + 8 * Q)) & (N - 1)) * tsh];
+				const double2 e1 = a.tw[((idx[h] * (sub_c + 8 * (Q - 1))) & (N_c - 1)) * tsh_c];
+				const double2 e2 = a.tw[((idx[h] * (sub_c + 8 * Q)) & (N_c - 1)) * tsh_c];
 				o[0] = sa[2 * h] * e1.x - sb[2 * h] * e2.x;
 				o[1] = sb[2 * h] * e2.y - sa[2 * h] * e1.y;
 				o[2] = sa[2 * h + 1] * e1.x - sb[2 * h + 1] * e2.x;
@@ -1312,7 +1329,7 @@ __global__ __launch_bounds__(64, RF_NP > 112 ? 2 : WC_REFINE_WAVES) void hv_refi
 				double lo[4], hi[4] = {0.0, 0.0, 0.0, 0.0};
 				closing(p, lo);
 				if (p < 2) closing(p + 4, hi);
-				const bool up = (sub & 4) != 0;
+				const bool up = (sub_c & 4) != 0;
 #pragma unroll
 				for (int c = 0; c < 4; ++c) {
 					const double send = up ? lo[c] : hi[c];
@@ -1325,32 +1342,32 @@ __global__ __launch_bounds__(64, RF_NP > 112 ? 2 : WC_REFINE_WAVES) void hv_refi
 			}
 #pragma unroll
 			for (int k = 0; k < 8; ++k) {
-				const bool up = (sub & 2) != 0;
+				const bool up = (sub_c & 2) != 0;
 				const double send = up ? v[k] : v[8 + k];
 				const double keep = up ? v[8 + k] : v[k];
 				v[k] = keep + group8_xor<2>(send);
 			}
 #pragma unroll
 			for (int k = 0; k < 4; ++k) {
-				const bool up = (sub & 1) != 0;
+				const bool up = (sub_c & 1) != 0;
 				const double send = up ? v[k] : v[4 + k];
 				const double keep = up ? v[4 + k] : v[k];
 				v[k] = keep + group8_xor<1>(send);
 			}
-			const int h = sub;
+			const int h = sub_c;
 			int myidx = 0;
 #pragma unroll
 			for (int q2 = 0; q2 < 6; ++q2) if (q2 == h) myidx = idx[q2];
 			const double mr = v[0], mi = v[1], dr = v[2], di = v[3];
 			const double pw = mr * mr + mi * mi;
 			const double ni = mr * di - mi * dr;
-			const double inst = (pw == 0.0) ? 0.0 : (double)myidx * fs * (1.0 / N) + ni / pw * fs / 2.0 / kPi;  // (N is a power of two: the product is the quotient of :871)
+			const double inst = (pw == 0.0) ? 0.0 : (double)myidx * fs * (1.0 / N_c) + ni / pw * fs / 2.0 / kPi;  // (N is a power of two: the product is the quotient of :871)
 			const double amp = sqrt(pw);
-			if (sub < 6) stage[q][grp * 6 + sub] = make_double2(inst, amp);  // (every lane took its start phase from here long ago)
+			if (sub_c < 6) stage[q][grp_c * 6 + sub_c] = make_double2(inst, amp);  // (every lane took its start phase from here long ago)
 			double num, den, sc;
-			finish(inst, amp, fc, it_nh[t_own], num, den, sc);
-			if (sub == 0 && live) {
-				const int at = it_pos[t_own];
+			finish(ln, inst, amp, it_f[t_c], it_nh[t_c], num, den, sc);
+			if (sub_c == 0 && live_c) {
+				const int at = it_pos[t_c];
 				row_f[at] = num;
 				row_s[at] = den;
 				row_c[at] = sc;
@@ -1372,7 +1389,7 @@ __global__ __launch_bounds__(64, RF_NP > 112 ? 2 : WC_REFINE_WAVES) void hv_refi
 			}
 			const double fc = it_f[t];
 			double num, den, sc;
-			finish(inst, amp, fc, it_nh[t], num, den, sc);
+			finish(lane, inst, amp, fc, it_nh[t], num, den, sc);
 			if (sub == 0 && mine) {
 				const int at = it_pos[t];
 				row_f[at] = num;
