@@ -1415,68 +1415,94 @@ __global__ __launch_bounds__(64, RF_NP > 112 ? 2 : WC_REFINE_WAVES) void hv_refi
 
 // reference :708-744.  One workgroup per UNR_F consecutive frames of an utterance: the rows of the UNR_F + 2 frames involved are
 // compacted into LDS once (non-zero candidates in slot order; a zero candidate yields the error 1.0, which selectBestF0's allowed
-// range of 1.0 already is), then a wavefront per frame lets every candidate scan the lists of the two neighbouring frames.
+// range of 1.0 already is), then every candidate scans the lists of the two neighbouring frames.
 // min_k fl(|ref - x_k| / ref) = fl((min_k |ref - x_k|) / ref) -- rounding is monotone -- so the scan takes differences only and
-// divides once.  searchF0Base (:254-272) on the surviving candidates is a wave reduction (highest score, first slot on ties).
-// (Round 1 ran one workgroup per frame: three row reads, four barriers and two LDS-atomic compactions per frame.)
+// divides once.  searchF0Base (:254-272) on the surviving candidates is a reduction (highest score, first slot on ties).
+// A frame's own candidates are compacted as well (most of its 7 S positions are empty) and half a wavefront takes a frame -- eight
+// frames at once per workgroup; the rows travel through LDS once: read coalesced, candidates struck out in place, written back
+// coalesced.  LDS is sized by the row width at launch: (UNR_F + 2) lists + 2 UNR_F rows of nc doubles, 22 KB at the default nc = 105.
+// (Round 1 ran one workgroup per frame: three row reads, four barriers and two LDS-atomic compactions per frame; until late in round 2
+// a wavefront took a frame with its lanes over all 7 S positions, a fifth of them live: 2.46 -> 2.13 ms for the tail of 64 utterances.)
 constexpr int UNR_F = 8;
+
 __global__ __launch_bounds__(256) void hv_unreliable_kernel(const HvUtt *__restrict__ utts, const double *__restrict__ c1,
 									 const double *__restrict__ s1, double *__restrict__ c2, double *__restrict__ s2,
 									 double *__restrict__ base, int nc) {
-	__shared__ double lst[UNR_F + 2][7 * MAX_SLOTS];
-	__shared__ int cnt[UNR_F + 2];
+	extern __shared__ double unr_lds[];
+	double *const lst = unr_lds;                        // [UNR_F + 2][nc] non-zero candidates of frames first - 1 .. first + UNR_F
+	double *const row_v = lst + (UNR_F + 2) * nc;       // [UNR_F][nc] the frames' own rows
+	double *const row_s = row_v + UNR_F * nc;
+	int *const cnt = reinterpret_cast<int *>(row_s + UNR_F * nc);  // [UNR_F + 2] list lengths
+	int *const own_n = cnt + UNR_F + 2;                 // [UNR_F] live positions of a frame's own row
+	unsigned char *const own_j = reinterpret_cast<unsigned char *>(own_n + UNR_F);  // [UNR_F][nc] ... and where they are
 	const HvUtt u = utts[blockIdx.y];
 	const int first = blockIdx.x * UNR_F;
 	if (first >= u.L1) return;
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const unsigned long long below = (1ull << lane) - 1ull;
 	for (int r = wv; r < UNR_F + 2; r += 4) {
 		const int i = first - 1 + r;
+		const bool exists = i >= 0 && i < u.L1;
 		// the reference's comparison copy holds frames 1 .. L-2 only (:714-715); its rows 0 and L-1 are never written
 		// (uninitialised there; zero here, as with a zero-filling allocator under the reference)
 		const bool held = i >= 1 && i <= u.L1 - 2;
+		const bool own = r >= 1 && r <= UNR_F;
 		int n = 0;
 		for (int j0 = 0; j0 < nc; j0 += 64) {
 			const int j = j0 + lane;
-			const double v = (held && j < nc) ? c1[(u.l1_off + i) * nc + j] : 0.0;
+			double v = 0.0, sc = 0.0;
+			if (exists && j < nc) {
+				v = c1[(u.l1_off + i) * nc + j];
+				if (own) sc = s1[(u.l1_off + i) * nc + j];
+			}
 			const unsigned long long m = __ballot(v != 0.0);
-			if (v != 0.0) lst[r][n + __popcll(m & ((1ull << lane) - 1ull))] = v;
+			const int at = n + __popcll(m & below);
+			if (v != 0.0) {
+				if (held) lst[r * nc + at] = v;
+				if (own) own_j[(r - 1) * nc + at] = (unsigned char)j;
+			}
+			if (own && j < nc) { row_v[(r - 1) * nc + j] = v; row_s[(r - 1) * nc + j] = sc; }
 			n += __popcll(m);
 		}
-		if (lane == 0) cnt[r] = n;
+		if (lane == 0) {
+			cnt[r] = held ? n : 0;
+			if (own) own_n[r - 1] = n;
+		}
 	}
 	__syncthreads();
-	for (int k = wv; k < UNR_F; k += 4) {
-		const int i = first + k;
-		if (i >= u.L1) break;
-		const bool interior = i >= 1 && i < u.L1 - 1;
-		const long long g = u.l1_off + i;
+	const int k = threadIdx.x >> 5, l32 = threadIdx.x & 31;  // half a wavefront per frame
+	const int i = first + k;
+	const bool interior = i >= 1 && i < u.L1 - 1;
+	if (interior) {
 		const int n_prev = cnt[k], n_next = cnt[k + 2];
-		const double *__restrict__ prv = lst[k], *__restrict__ nxt = lst[k + 2];
+		const double *__restrict__ prv = lst + k * nc, *__restrict__ nxt = lst + (k + 2) * nc;
+		for (int q0 = l32; q0 < own_n[k]; q0 += 32) {
+			const int j = own_j[k * nc + q0];
+			const double ref = row_v[k * nc + j];
+			double dmin = ref;  // |ref - 0| / ref = 1.0, the allowed range
+			for (int q = 0; q < n_next; ++q) dmin = fmin(dmin, fabs(ref - nxt[q]));
+			for (int q = 0; q < n_prev; ++q) dmin = fmin(dmin, fabs(ref - prv[q]));
+			if (fmin(1.0, dmin / ref) > 0.05) { row_v[k * nc + j] = 0.0; row_s[k * nc + j] = 0.0; }
+		}
+	}
+	__syncthreads();
+	if (i < u.L1) {
+		const long long g = u.l1_off + i;
 		double top_sc = 0.0, top_ref = 0.0;
 		int top_slot = 0x7fffffff;
-		for (int j0 = 0; j0 < nc; j0 += 64) {
-			const int j = j0 + lane;
-			double ref = 0.0, sc = 0.0;
-			if (j < nc) { ref = c1[g * nc + j]; sc = s1[g * nc + j]; }
-			if (ref != 0.0 && interior) {
-				double dmin = ref;  // |ref - 0| / ref = 1.0, the allowed range
-				for (int q = 0; q < n_next; ++q) dmin = fmin(dmin, fabs(ref - nxt[q]));
-				for (int q = 0; q < n_prev; ++q) dmin = fmin(dmin, fabs(ref - prv[q]));
-				if (fmin(1.0, dmin / ref) > 0.05) { ref = 0.0; sc = 0.0; }
-			}
-			if (j < nc) {
-				c2[g * nc + j] = ref;
-				s2[g * nc + j] = sc;
-				if (sc > top_sc) { top_sc = sc; top_ref = ref; top_slot = j; }  // (a lane's slots come in ascending order)
-			}
+		for (int j = l32; j < nc; j += 32) {
+			const double ref = row_v[k * nc + j], sc = row_s[k * nc + j];
+			c2[g * nc + j] = ref;
+			s2[g * nc + j] = sc;
+			if (sc > top_sc) { top_sc = sc; top_ref = ref; top_slot = j; }  // (a lane's slots come in ascending order)
 		}
 #pragma unroll
-		for (int o = 32; o > 0; o >>= 1) {
+		for (int o = 16; o > 0; o >>= 1) {  // searchF0Base (:254-272): highest score, first slot on ties, within the half wavefront
 			const double osc = __shfl_xor(top_sc, o, 64), oref = __shfl_xor(top_ref, o, 64);
 			const int oslot = __shfl_xor(top_slot, o, 64);
 			if (osc > top_sc || (osc == top_sc && oslot < top_slot)) { top_sc = osc; top_ref = oref; top_slot = oslot; }
 		}
-		if (lane == 0) base[g] = top_sc > 0.0 ? top_ref : 0.0;
+		if (l32 == 0) base[g] = top_sc > 0.0 ? top_ref : 0.0;
 	}
 }
 
@@ -2265,7 +2291,8 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 		return WC_OK;
 	}
 	if ((rc = dev->time_begin("harvest_contour", s))) return rc;  // the per-utterance tail: unreliable-candidate test, contour logic, smoothing
-	hipLaunchKernelGGL(hv_unreliable_kernel, dim3((unsigned)((max_L1 + UNR_F - 1) / UNR_F), n_utt), dim3(256), 0, s, du, h->cand1.as<double>(),
+	const size_t unr_lds = sizeof(double) * (size_t)(3 * UNR_F + 2) * nc + sizeof(int) * (2 * UNR_F + 2) + (size_t)UNR_F * nc;
+	hipLaunchKernelGGL(hv_unreliable_kernel, dim3((unsigned)((max_L1 + UNR_F - 1) / UNR_F), n_utt), dim3(256), unr_lds, s, du, h->cand1.as<double>(),
 					   h->score1.as<double>(), h->cand2.as<double>(), h->score2.as<double>(), h->base.as<double>(), nc);
 	CtrArgs ca;
 	ca.utts = du; ca.cand = h->cand2.as<double>(); ca.score = h->score2.as<double>(); ca.base = h->base.as<double>();
