@@ -231,3 +231,28 @@ def test_packed_refinement_is_bit_identical(wca):
             assert np.array_equal(got[k][1], b.debug_fetch("score1", k)), (opts, k)
             assert np.array_equal(ra[k][1], rb[k][1])
         assert sum(int((c != 0).sum()) for c, _ in got) > 500
+
+
+def test_packed_refinement_with_more_candidates_than_the_detector_finds(wca):
+    """Harvest's detector leaves at most six to nine candidates in a frame (a candidate needs ten neighbouring bands to itself), so a
+    frame collects fewer than 64 from its neighbours and a dozen or two distinct (window, bins) keys -- one round of the packed kernel's
+    gather and one group of passes.  The refinement alone, on rows written by the test (wc_harvest_debug_refine): every slot of every
+    frame filled, frequencies anywhere between floor and ceiling, whole stretches repeating a neighbour's value (equal keys), at 15
+    and at 30 slots -- up to 210 live candidates per frame.  Packed and slot layouts agree bit for bit."""
+    fs = 16000
+    x = make_utterance(fs, 1.0, 4242)
+    rng = np.random.default_rng(99)
+    for opts in ({}, dict(channels_in_octave=80.0), dict(use_cos_table=True)):
+        h = wca.Harvest(fs, **opts)
+        h.compute(x)
+        L1 = len(h.debug_fetch("f0_1ms", 0))
+        S = len(h.debug_fetch("cand0", 0)) // L1
+        for fill in (1.0, 0.6):
+            c0 = np.exp(rng.uniform(np.log(72.0), np.log(790.0), (L1, S)))
+            c0[1::3] = c0[0:-1:3][: len(c0[1::3])]             # every third frame repeats its neighbour: equal keys across the overlap
+            c0[:, 1::4] = c0[:, 0::4][:, : c0[:, 1::4].shape[1]] * (1 + 1e-9)  # and near-equal frequencies inside a frame
+            c0[rng.uniform(size=c0.shape) > fill] = 0.0
+            pa, sa = h.debug_refine(c0)
+            pb, sb = h.debug_refine(c0, by_slots=True)
+            assert np.array_equal(pa, pb) and np.array_equal(sa, sb), (opts, fill)
+            assert (pa != 0).sum(axis=1).max() > (64 if fill == 1.0 else 30)

@@ -55,6 +55,19 @@ class Harvest:
         _check(min(0, int(fn(self._h, name.encode(), utt, out.ctypes.data))))
         return out
 
+    def debug_refine(self, cand0, by_slots=False):
+        """Development hook: the refinement kernel alone on the candidate rows `cand0` ([1 ms frames of the most recent call][S],
+        0 = empty slot); returns (refined candidates, scores), each [frames][7 S].  by_slots: the slot layout instead of the packed one."""
+        fn = lib().wc_harvest_debug_refine
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        cand0 = np.ascontiguousarray(cand0, dtype=np.float64)
+        frames, S = cand0.shape
+        c1 = np.zeros((frames, 7 * S))
+        s1 = np.zeros((frames, 7 * S))
+        _check(fn(self._h, cand0.ctypes.data, 1 if by_slots else 0, c1.ctypes.data, s1.ctypes.data))
+        return c1, s1
+
     def __del__(self):
         try:
             if getattr(self, "_h", None):

@@ -2055,6 +2055,8 @@ struct wc_harvest {
 	DevBuf d_x, d_tpos, d_f0;
 	HostBuf h_stage;
 	std::vector<HvUtt> last_utts;
+	RefArgs last_refine;       // arguments of the most recent refinement launch (wc_harvest_debug_refine)
+	bool last_refine_valid = false;
 };
 
 static DecCoef dec_coef(int r) {
@@ -2094,6 +2096,23 @@ static inline int h_mround(double x) { return x > 0 ? static_cast<int>(x + 0.5) 
 // Enqueue-only (no host synchronisation), shared with the fused pipeline.  `full` selects the hard bound for the
 // zero-crossing buffers; with the rate bound an overflow is reported through h->overflow (device) and handled by
 // the caller (hv_overflowed) by re-running with full == true.
+static void launch_refine(const RefArgs &fa, hipStream_t s, bool by_slots, bool table) {
+	const unsigned frames = (unsigned)fa.total_frames;
+	if (by_slots) {
+		if (table) hipLaunchKernelGGL(hv_refine_kernel<true>, dim3(frames), dim3(256), 0, s, fa);
+		else hipLaunchKernelGGL(hv_refine_kernel<false>, dim3(frames), dim3(256), 0, s, fa);
+	} else {
+		const bool small = 7 * fa.p.S <= 112;
+		if (table) {
+			if (small) hipLaunchKernelGGL((hv_refine_packed_kernel<true, 112>), dim3(frames), dim3(64), 0, s, fa);
+			else hipLaunchKernelGGL((hv_refine_packed_kernel<true, 7 * MAX_SLOTS>), dim3(frames), dim3(64), 0, s, fa);
+		} else {
+			if (small) hipLaunchKernelGGL((hv_refine_packed_kernel<false, 112>), dim3(frames), dim3(64), 0, s, fa);
+			else hipLaunchKernelGGL((hv_refine_packed_kernel<false, 7 * MAX_SLOTS>), dim3(frames), dim3(64), 0, s, fa);
+		}
+	}
+}
+
 int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const int *x_length, double *d_tpos, double *d_f0,
 			   bool full, hipEvent_t mid_event, hipEvent_t start_after) {
 	Device *dev = h->dev;
@@ -2267,19 +2286,9 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 	fa.p.f0_floor = h->f0_floor; fa.p.f0_ceil = h->f0_ceil; fa.p.frame_period = h->frame_period;
 	if ((rc = dev->time_begin("harvest_refine", s))) return rc;
 	fa.cos_table = h->d_cos_table.as<double>();
-	if (h->refine_by_slots) {
-		if (h->use_cos_table) hipLaunchKernelGGL(hv_refine_kernel<true>, dim3((unsigned)total_l1), dim3(256), 0, s, fa);
-		else hipLaunchKernelGGL(hv_refine_kernel<false>, dim3((unsigned)total_l1), dim3(256), 0, s, fa);
-	} else {
-		const bool small = 7 * S <= 112;
-		if (h->use_cos_table) {
-			if (small) hipLaunchKernelGGL((hv_refine_packed_kernel<true, 112>), dim3((unsigned)total_l1), dim3(64), 0, s, fa);
-			else hipLaunchKernelGGL((hv_refine_packed_kernel<true, 7 * MAX_SLOTS>), dim3((unsigned)total_l1), dim3(64), 0, s, fa);
-		} else {
-			if (small) hipLaunchKernelGGL((hv_refine_packed_kernel<false, 112>), dim3((unsigned)total_l1), dim3(64), 0, s, fa);
-			else hipLaunchKernelGGL((hv_refine_packed_kernel<false, 7 * MAX_SLOTS>), dim3((unsigned)total_l1), dim3(64), 0, s, fa);
-		}
-	}
+	launch_refine(fa, s, h->refine_by_slots, h->use_cos_table);
+	h->last_refine = fa;
+	h->last_refine_valid = true;
 	WC_HIP(hipGetLastError());
 	if ((rc = dev->time_end("harvest_refine", s))) return rc;
 	}
@@ -2537,6 +2546,25 @@ long long wc_harvest_debug_fetch(wc_harvest *h, const char *name, int utt, doubl
 		WC_HIP(hipStreamSynchronize(h->dev->active()));
 	}
 	return n;
+}
+
+// Development hook: the refinement kernel alone, on candidate rows given by the caller, over the utterances of the most recent
+// call (their decimated signals are still in place).  cand0: [1 ms frames of the batch][S] candidate frequencies (0 = empty slot);
+// cand1 / score1: [frames][7 S] refined candidates and scores.  by_slots selects the slot layout (hv_refine_kernel) instead of
+// the packed one.  Lets the tests put more candidates into a frame than Harvest's detector ever finds.
+int wc_harvest_debug_refine(wc_harvest *h, const double *cand0, int by_slots, double *cand1, double *score1) {
+	if (!h || !cand0 || !cand1 || !score1 || !h->last_refine_valid) return fail(WC_ERR_INVALID, "harvest debug: no refinement to repeat");
+	DeviceLock lock(h->dev);
+	hipStream_t s = h->dev->active();
+	const RefArgs fa = h->last_refine;
+	const size_t n_in = (size_t)fa.total_frames * fa.p.S, n_out = (size_t)fa.total_frames * fa.p.n_cand;
+	WC_HIP(hipMemcpyAsync(const_cast<double *>(fa.cand0), cand0, sizeof(double) * n_in, hipMemcpyHostToDevice, s));
+	launch_refine(fa, s, by_slots != 0, h->use_cos_table);
+	WC_HIP(hipGetLastError());
+	WC_HIP(hipMemcpyAsync(cand1, fa.cand1, sizeof(double) * n_out, hipMemcpyDeviceToHost, s));
+	WC_HIP(hipMemcpyAsync(score1, fa.score1, sizeof(double) * n_out, hipMemcpyDeviceToHost, s));
+	WC_HIP(hipStreamSynchronize(s));
+	return WC_OK;
 }
 
 }  // extern "C"
