@@ -39,7 +39,16 @@ def main():
         if flt and flt not in name:
             continue
         dem = subprocess.run(["c++filt", name], stdout=subprocess.PIPE, text=True).stdout.strip()
-        dem = re.sub(r"\(.*", "", dem).replace("void wc::", "")
+        # "void (anonymous namespace)::k<...>(args)" / "wc::k(args)": drop the return type and the argument list, keep template arguments
+        dem = re.sub(r"^void ", "", dem).replace("(anonymous namespace)::", "").replace("wc::", "")
+        depth, cut = 0, len(dem)
+        for i, ch in enumerate(dem):
+            depth += ch == "<"
+            depth -= ch == ">"
+            if ch == "(" and depth == 0:
+                cut = i
+                break
+        dem = dem[:cut]
         rows.append((dem, g("vgpr_count"), g("sgpr_count"), g("private_segment_fixed_size"), g("group_segment_fixed_size")))
     print("%-60s %5s %5s %8s %8s" % ("kernel", "vgpr", "sgpr", "scratch", "lds"))
     for r in sorted(rows):
