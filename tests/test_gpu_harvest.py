@@ -256,3 +256,36 @@ def test_packed_refinement_with_more_candidates_than_the_detector_finds(wca):
             pb, sb = h.debug_refine(c0, by_slots=True)
             assert np.array_equal(pa, pb) and np.array_equal(sa, sb), (opts, fill)
             assert (pa != 0).sum(axis=1).max() > (64 if fill == 1.0 else 30)
+
+
+def test_raw_candidates_from_the_band_pass_slots_are_bit_identical(wca):
+    """getRawF0Candidates' interval series (reference src/harvest.cpp:1098-1143, :1179-1255) are read by hv_raw straight out of the
+    (band, chunk, type) slots the sliding band-pass wrote its zero-crossing edges to; WC_HARVEST_RAW=lists packs them into per-band
+    lists first (what the FIR formulation produces).  Same raw candidates bit for bit -- speech, a signal with long silences (chunks
+    without edges: the slice of a frame block reaches several chunks back), another internal rate (a frame block is not a chunk any
+    more), tiny slot capacities (overflow and retry), a ragged batch."""
+    import os
+    from world_class_amd.synth import make_signal
+    fs = 16000
+    gaps = make_utterance(fs, 4.0, 616)
+    gaps[fs // 2: 2 * fs] = 0.0            # 1.5 s of digital silence
+    gaps[int(2.6 * fs): int(3.5 * fs)] *= 1e-9
+    batch = [make_utterance(fs, 3.0, 515), gaps, make_utterance(fs, 0.2, 9), make_signal(fs, 1.5, 230002)]
+    for opts, env in (({}, {}), (dict(target_fs=4000.0), {}), (dict(target_fs=16000.0, f0_floor=60.0), {}), ({}, {"WC_DEBUG_SMALL_CAPS": "1"}),
+                      (dict(channels_in_octave=80.0), {})):
+        os.environ.update(env)
+        try:
+            a = wca.Harvest(fs, **opts)
+            os.environ["WC_HARVEST_RAW"] = "lists"
+            try:
+                b = wca.Harvest(fs, **opts)
+            finally:
+                del os.environ["WC_HARVEST_RAW"]
+        finally:
+            for k in env:
+                del os.environ[k]
+        ra, rb = a.compute_batch(batch), b.compute_batch(batch)
+        for k in range(len(batch)):
+            assert np.array_equal(a.debug_fetch("raw", k), b.debug_fetch("raw", k)), (opts, env, k)
+            assert np.array_equal(ra[k][1], rb[k][1])
+        assert sum(int((a.debug_fetch("raw", k) != 0).sum()) for k in range(len(batch))) > 10000

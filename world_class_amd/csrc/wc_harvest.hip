@@ -393,7 +393,7 @@ __global__ __launch_bounds__(BP_T, 3) void hv_bandpass_kernel(BpArgs a) {
 // zero over the first window (the same recurrence without the leaving sample), then slides, running the four
 // zero-crossing detectors of reference :1179-1255 on its outputs as they appear (rounding errors of the
 // rotations random-walk over one chunk only: ~1e-14 relative).  Edges go to per-(band, chunk, type) slots;
-// hv_compact_kernel packs them in time order into the event lists and fills tile_run.
+// hv_compact_kernel fills tile_run (edges before every chunk) and, for WC_HARVEST_RAW=lists only, packs the edges in time order into per-band lists.
 // ------------------------------------------------------------------------------------------------
 struct SdArgs {
 	const HvUtt *utts;
@@ -556,6 +556,7 @@ struct CpArgs {
 	int *overflow;
 	int *tile_run;  // [utt][band][n_chunks + 1][4]
 	int n_bands, n_chunks;
+	int copy;       // 0: the running counts only -- hv_raw reads the edges out of the slots itself
 };
 
 // One workgroup per (band, utterance), wave ty packs the slots of type ty chunk after chunk.
@@ -575,15 +576,17 @@ __global__ __launch_bounds__(256) void hv_compact_kernel(CpArgs a) {
 		const int n = sc[c * 4 + ty];
 		ovf = ovf || n > scap;
 		const int m = min(n, scap);
-		const double *__restrict__ src = slot + ((long long)c * 4 + ty) * scap;
-		for (int j = lane; j < m; j += 64)
-			if (run + j < cap) ev[run + j] = src[j];
+		if (a.copy) {
+			const double *__restrict__ src = slot + ((long long)c * 4 + ty) * scap;
+			for (int j = lane; j < m; j += 64)
+				if (run + j < cap) ev[run + j] = src[j];
+		}
 		run += n;
 	}
 	if (lane == 0) {
 		trun[a.n_chunks * 4 + ty] = run;
 		a.ev_count[((long long)blockIdx.y * a.n_bands + band) * 4 + ty] = run;
-		if (ovf || run > cap) atomicExch(a.overflow, 1);
+		if (ovf || (a.copy && run > cap)) atomicExch(a.overflow, 1);
 	}
 }
 
@@ -599,6 +602,12 @@ struct RawArgs {
 	const double *band_f0;
 	const int *tile_run;
 	int n_tiles, tile_adv;  // tile_run[q] = edges before sample q * tile_adv
+	// SLOTS: the edges still lie in the (band, chunk, type) slots the sliding band-pass wrote them to; edge q of a list is entry
+	// q - tile_run[c] of the chunk c with tile_run[c] <= q < tile_run[c + 1]
+	const double *slots;
+	const long long *slot_off;
+	const int *slot_cap;
+	long long slots_per_utt;
 	double *raw;  // [utt: l1_off * n_bands][band][L1]
 	int n_bands;
 	double fs_d, f0_floor, f0_ceil;
@@ -630,8 +639,15 @@ constexpr int RAW_LDS = 304;    // staged intervals per type: 256 ms of a 968 Hz
 // and stages its intervals in LDS as (midpoint time, interval frequency) pairs -- the divisions of reference
 // :1210-1213 done once per interval instead of once per frame and probe -- then every thread interpolates its
 // frame from LDS (falling back to the global lists if a slice does not fit).
+// SLOTS (default): the lists are never materialised.  Edge q of a list is entry q - tile_run[c] of the slot of the chunk c with
+// tile_run[c] <= q < tile_run[c + 1]; a block of 256 frames is 256 ms -- one chunk of the 8 kHz signal -- so its slice is its own
+// chunk's slot plus four edges from either side, and both edges of an interval are fetched straight from their slots (a slice that
+// reaches further than four chunks -- silence -- goes through a copy in LDS; single edges for the fallback are found by bisecting
+// tile_run).  hv_compact_kernel then only forms the running counts: 0.33 -> 0.02 ms per half batch and 1.6 GB less traffic per
+// step, for 0.13 ms more in this kernel.  <false>: per-band lists, as the FIR band-pass writes them and WC_HARVEST_RAW=lists packs them.
+template <bool SLOTS>
 __global__ __launch_bounds__(RAW_T) void hv_raw_kernel(RawArgs a) {
-	__shared__ double X[4][RAW_LDS], Y[4][RAW_LDS];
+	__shared__ double X[4][RAW_LDS], Y[4][RAW_LDS + 1];  // (Y holds the slice's edges first: interval j replaces edge j once both of its edges are read)
 	__shared__ int s_base[4], s_len[4];
 	const int tid = threadIdx.x, lane = tid & 63, ty_w = tid >> 6;
 	const int band = blockIdx.y;
@@ -641,14 +657,34 @@ __global__ __launch_bounds__(RAW_T) void hv_raw_kernel(RawArgs a) {
 	const int i = i0 + tid;
 	const int *cnt = a.ev_count + ((long long)blockIdx.z * a.n_bands + band) * 4;
 	const int cap = a.ev_cap[band];
-	const double *__restrict__ ev = a.events + u.ev_off + a.ev_band_off[band];
+	const double *__restrict__ ev = SLOTS ? nullptr : a.events + u.ev_off + a.ev_band_off[band];
+	const int scap = SLOTS ? a.slot_cap[band] : 0;
+	const double *__restrict__ slot = SLOTS ? a.slots + blockIdx.z * a.slots_per_utt + a.slot_off[band] : nullptr;
+	const int *__restrict__ trun_b = a.tile_run + ((long long)blockIdx.z * a.n_bands + band) * (a.n_tiles + 1) * 4;
+	// edge q of the list of type ty, wherever it lies
+	auto edge = [&](int ty, int q) -> double {
+		if (!SLOTS) return ev[(long long)ty * cap + q];
+		int lo = 0, hi = a.n_tiles;  // last chunk c with tile_run[c] <= q
+		while (hi - lo > 1) {
+			const int mid = (lo + hi) >> 1;
+			if (trun_b[mid * 4 + ty] <= q) lo = mid; else hi = mid;
+		}
+		return slot[((long long)lo * 4 + ty) * scap + min(q - trun_b[lo * 4 + ty], scap - 1)];
+	};
 	double *__restrict__ out = a.raw + u.l1_off * a.n_bands + (long long)band * u.L1;
+	// the band-pass kernel recorded how many edges precede every tile, so the slice is bounded without searching: the running
+	// counts of the chunks around the block in one load (lane l: chunk q0 - 2 + l), requested before anything depends on them
+	const int i1 = min(i0 + RAW_T - 1, u.L1 - 1);
+	const int q0 = min(a.n_tiles, max(0, (int)((i0 * 1 / 1000.0) * a.fs_d) / a.tile_adv));
+	const int q1 = min(a.n_tiles, (int)((i1 * 1 / 1000.0) * a.fs_d) / a.tile_adv + 1);
+	const int tr_first = q0 - 2;
+	const int tr_mine = trun_b[min(max(tr_first + (lane & 7), 0), a.n_tiles) * 4 + ty_w];
 	// number of intervals = edges - 1 (0 when fewer than 2 edges); all four need more than 2 (reference :1101-1107)
 	int n[4];
 	bool ok = true;
 #pragma unroll
 	for (int ty = 0; ty < 4; ++ty) {
-		const int ce = min(cnt[ty], cap);  // (an overflowed list is re-done by the caller; stay inside the buffer)
+		const int ce = SLOTS ? cnt[ty] : min(cnt[ty], cap);  // (an overflowed list is re-done by the caller; stay inside the buffer)
 		n[ty] = ce < 2 ? 0 : ce - 1;
 		ok = ok && n[ty] > 2;
 	}
@@ -658,24 +694,67 @@ __global__ __launch_bounds__(RAW_T) void hv_raw_kernel(RawArgs a) {
 	}
 	const double fs = a.fs_d;
 	{
-		// the band-pass kernel recorded how many edges precede every tile, so the slice is bounded without searching
 		const int ty = ty_w;
-		const double *__restrict__ e = ev + (long long)ty * cap;
-		const int *__restrict__ trun = a.tile_run + ((long long)blockIdx.z * a.n_bands + band) * (a.n_tiles + 1) * 4;
-		const int i1 = min(i0 + RAW_T - 1, u.L1 - 1);
-		const int q0 = min(a.n_tiles, max(0, (int)((i0 * 1 / 1000.0) * fs) / a.tile_adv));
-		const int q1 = min(a.n_tiles, (int)((i1 * 1 / 1000.0) * fs) / a.tile_adv + 1);
+		const int *__restrict__ trun = trun_b;
 		const int ce = n[ty] + 1;  // edges in the list
-		const int base = max(0, min(trun[q0 * 4 + ty], ce) - 4);
-		const int end = min(ce, min(trun[q1 * 4 + ty], ce) + 4);
+		auto T = [&](int c) -> int {  // tile_run[c] of this type (c wave-uniform)
+			const int l = c - tr_first;
+			return (l >= 0 && l < 8) ? __shfl(tr_mine, l, 64) : trun[c * 4 + ty];
+		};
+		const int base = max(0, min(T(q0), ce) - 4);
+		const int end = min(ce, min(T(q1), ce) + 4);
 		const int len = end - base - 1;  // staged intervals base .. base + len - 1
 		if (lane == 0) { s_base[ty] = (len <= RAW_LDS) ? base : -1; s_len[ty] = len; }
-		if (len <= RAW_LDS)
-			for (int j = lane; j < len; j += 64) {
-				const double ea = e[base + j], eb = e[base + j + 1];
-				X[ty][j] = (ea + eb) / 2.0 / fs;
-				Y[ty][j] = fs / (eb - ea);
+		if (len <= RAW_LDS) {
+			double *__restrict__ E = Y[ty];  // edges base .. end - 1 (general path)
+			bool done = false;
+			if (SLOTS) {
+				int c = q0;
+				while (c > 0 && T(c) > base) --c;  // first chunk that holds an edge of the slice
+				const int t0 = T(c), t1 = T(min(c + 1, a.n_tiles)), t2 = T(min(c + 2, a.n_tiles)), t3 = T(min(c + 3, a.n_tiles)),
+						  t4 = T(min(c + 4, a.n_tiles));
+				if (end <= t4 || c + 4 >= a.n_tiles) {
+					// the usual case, a slice within four chunks (the block's own chunk, a few edges either side): both edges of an
+					// interval straight from their slots
+					auto at = [&](int q) -> double {
+						const int k = (q >= t1 ? 1 : 0) + (q >= t2 ? 1 : 0) + (q >= t3 ? 1 : 0);
+						const int tk = k == 0 ? t0 : (k == 1 ? t1 : (k == 2 ? t2 : t3));
+						return slot[((long long)(c + k) * 4 + ty) * scap + min(q - tk, scap - 1)];
+					};
+					for (int j = lane; j < len; j += 64) {
+						const double ea = at(base + j), eb = at(base + j + 1);
+						X[ty][j] = (ea + eb) / 2.0 / fs;
+						Y[ty][j] = fs / (eb - ea);
+					}
+					done = true;
+				} else {
+					for (; c < a.n_tiles && T(c) < end; ++c) {
+						const int tc = T(c);
+						const int lo = max(base, tc), hi = min(end, T(c + 1));
+						const double *__restrict__ src = slot + ((long long)c * 4 + ty) * scap;
+						for (int q = lo + lane; q < hi; q += 64) E[q - base] = src[min(q - tc, scap - 1)];
+					}
+				}
+			} else {
+				const double *__restrict__ e = ev + (long long)ty * cap;
+				for (int j = lane; j < len; j += 64) {
+					const double ea = e[base + j], eb = e[base + j + 1];
+					X[ty][j] = (ea + eb) / 2.0 / fs;
+					Y[ty][j] = fs / (eb - ea);
+				}
+				done = true;
 			}
+			if (!done)
+				for (int j0 = 0; j0 < len; j0 += 64) {  // (one wavefront per type: the reads of a trip precede its writes)
+					const int j = j0 + lane;
+					double ea = 0.0, eb = 1.0;
+					if (j < len) { ea = E[j]; eb = E[j + 1]; }
+					if (j < len) {
+						X[ty][j] = (ea + eb) / 2.0 / fs;
+						Y[ty][j] = fs / (eb - ea);
+					}
+				}
+		}
 	}
 	__syncthreads();
 	if (i >= u.L1) return;
@@ -683,7 +762,6 @@ __global__ __launch_bounds__(RAW_T) void hv_raw_kernel(RawArgs a) {
 	double s = 0.0;
 #pragma unroll
 	for (int ty = 0; ty < 4; ++ty) {  // (a + b + c + d) in the reference's order: negative-going, positive-going, peaks, dips
-		const double *__restrict__ e = ev + (long long)ty * cap;
 		const int base = s_base[ty];
 		double x0, x1, y0, y1;
 		bool staged = false;
@@ -708,10 +786,10 @@ __global__ __launch_bounds__(RAW_T) void hv_raw_kernel(RawArgs a) {
 			}
 		}
 		if (!staged) {
-			auto eg = [&](int q) { return e[q]; };
+			auto eg = [&](int q) { return edge(ty, q); };
 			const int c = hv_count_le(eg, 0, n[ty], fs, t);
 			const int k = min(max(c, 1), n[ty] - 1);
-			const double e0 = e[k - 1], e1 = e[k], e2 = e[k + 1];
+			const double e0 = eg(k - 1), e1 = eg(k), e2 = eg(k + 1);
 			x0 = (e0 + e1) / 2.0 / fs; x1 = (e1 + e2) / 2.0 / fs;
 			y0 = fs / (e1 - e0); y1 = fs / (e2 - e1);
 		}
@@ -2047,6 +2125,8 @@ struct wc_harvest {
 	bool use_cos_table;  // HarvestOption::use_cos_table
 	DevBuf d_cos_table;
 	int phases = 3;  // hv_set_phases: 1 = front (decimation .. refinement), 2 = tail (unreliable-candidate test .. output), 3 = both
+	bool raw_from_lists;    // WC_HARVEST_RAW=lists: the edges packed into per-band lists before hv_raw reads them (A/B and the bit-identity test)
+	long long slots_per_utt = 0;
 	bool refine_by_slots;   // WC_HARVEST_REFINE=slots: one wavefront per candidate slot instead of the packed passes (A/B and the bit-identity test)
 	bool smooth_full_walk;  // WC_HARVEST_SMOOTH=full: the smoothing filter without the skipping of settled stretches (A/B and the bit-identity test)
 	bool direct_decimation;  // WC_HARVEST_DECIMATE=direct: every lane reads its own stream from memory (A/B and the bit-identity test)
@@ -2177,7 +2257,8 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 			per_utt += 4ll * ev_cap[b];
 		}
 		for (int u = 0; u < n_utt; ++u) utts[u].ev_off = per_utt * u;
-		if ((rc = h->events.reserve(sizeof(double) * per_utt * n_utt))) return rc;
+		// (per-band edge lists: only the FIR band-pass and WC_HARVEST_RAW=lists use them -- by default hv_raw reads the band-pass's slots)
+		if ((h->use_fir || h->raw_from_lists) && (rc = h->events.reserve(sizeof(double) * per_utt * n_utt))) return rc;
 		if ((rc = h->d_ev_band_off.reserve(sizeof(long long) * nb))) return rc;
 		if ((rc = h->d_ev_cap.reserve(sizeof(int) * nb))) return rc;
 		// sliding band-pass: one slot per (band, chunk, type); same rate bound / hard bound policy per chunk
@@ -2255,12 +2336,14 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 			sa.utts = du; sa.y = h->y.as<double>(); sa.rot = h->d_sd_rot.as<double2>(); sa.p0 = h->d_sd_p0.as<double2>();
 			sa.half_len = h->d_half_len.as<int>(); sa.slot_off = h->d_slot_off.as<long long>(); sa.slot_cap = h->d_slot_cap.as<int>();
 			sa.slots_per_utt = slots_per_utt; sa.slots = h->slots.as<double>(); sa.slot_count = h->slot_count.as<int>();
+			h->slots_per_utt = slots_per_utt;
 			sa.n_bands = nb; sa.n_chunks = n_tiles;
 			hipLaunchKernelGGL(hv_bandpass_sdft_kernel, dim3((nb * n_tiles + 63) / 64, n_utt), dim3(64), 0, s, sa);
 			CpArgs ca;
 			ca.utts = du; ca.slot_off = sa.slot_off; ca.slot_cap = sa.slot_cap; ca.slots_per_utt = slots_per_utt; ca.slots = sa.slots;
 			ca.slot_count = sa.slot_count; ca.ev_band_off = ba.ev_band_off; ca.ev_cap = ba.ev_cap; ca.events = ba.events;
 			ca.ev_count = ba.ev_count; ca.overflow = ba.overflow; ca.tile_run = ba.tile_run; ca.n_bands = nb; ca.n_chunks = n_tiles;
+			ca.copy = h->raw_from_lists ? 1 : 0;
 			hipLaunchKernelGGL(hv_compact_kernel, dim3(nb, n_utt), dim3(256), 0, s, ca);
 		}
 		WC_HIP(hipGetLastError());
@@ -2275,7 +2358,10 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 	ra.tile_run = h->tile_run.as<int>(); ra.n_tiles = n_tiles; ra.tile_adv = tile_adv;
 	ra.fs_d = h->fs_d; ra.f0_floor = h->f0_floor; ra.f0_ceil = h->f0_ceil;
 	if ((rc = dev->time_begin("harvest_raw", s))) return rc;
-	hipLaunchKernelGGL(hv_raw_kernel, dim3((max_L1 + 255) / 256, nb, n_utt), dim3(256), 0, s, ra);
+	ra.slots = h->slots.as<double>(); ra.slot_off = h->d_slot_off.as<long long>(); ra.slot_cap = h->d_slot_cap.as<int>();
+	ra.slots_per_utt = h->slots_per_utt;
+	if (h->use_fir || h->raw_from_lists) hipLaunchKernelGGL(hv_raw_kernel<false>, dim3((max_L1 + 255) / 256, nb, n_utt), dim3(256), 0, s, ra);
+	else hipLaunchKernelGGL(hv_raw_kernel<true>, dim3((max_L1 + 255) / 256, nb, n_utt), dim3(256), 0, s, ra);
 	hipLaunchKernelGGL(hv_detect_kernel, dim3((max_L1 + 255) / 256, n_utt), dim3(256), 0, s, du, h->raw.as<double>(), h->cand0.as<double>(), nb, S);
 	WC_HIP(hipGetLastError());
 	if ((rc = dev->time_end("harvest_raw", s))) return rc;
@@ -2450,6 +2536,8 @@ wc_harvest *wc_harvest_create(int fs, double f0_floor, double f0_ceil, double fr
 		h->smooth_full_walk = sm && std::strcmp(sm, "full") == 0;
 		const char *rfm = getenv("WC_HARVEST_REFINE");
 		h->refine_by_slots = rfm && std::strcmp(rfm, "slots") == 0;
+		const char *rw = getenv("WC_HARVEST_RAW");
+		h->raw_from_lists = rw && std::strcmp(rw, "lists") == 0;
 	}
 	{
 		std::vector<double2> rot(2 * (RF_MAXHW + 1));
