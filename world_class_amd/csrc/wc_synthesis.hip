@@ -582,6 +582,9 @@ __device__ __forceinline__ void minimum_phase_lds(double2 *A, const double (&ls)
 
 __device__ __forceinline__ double safe_ap(double v) { return fmax(0.001, fmin(0.999999999999, v)); }
 
+#ifndef WC_SYN_XCD
+#define WC_SYN_XCD 1
+#endif
 template <int N, int T>
 __global__ __launch_bounds__(T) void syn_pulse_kernel(SynArgs a) {
 	constexpr int M = N / 2;
@@ -591,8 +594,17 @@ __global__ __launch_bounds__(T) void syn_pulse_kernel(SynArgs a) {
 	__shared__ double red[2 * (T / 64) + 2];
 	double *Ar = reinterpret_cast<double *>(A);
 	int tid = threadIdx.x;
+#if WC_SYN_XCD
+	// consecutive pulses read the same two spectrogram / aperiodicity rows: blocks are dealt round-robin to the eight XCDs, so
+	// block b takes pulse (b mod 8) * ceil(total / 8) + b / 8 and an XCD's L2 sees a contiguous eighth of the pulses
+	const long long total_p = a.pulse_prefix[a.n_utt];
+	if ((long long)blockIdx.x >= 8 * ((total_p + 7) / 8)) return;
+	const long long gp = xcd_frame(blockIdx.x, total_p);
+	if (gp >= total_p) return;
+#else
 	const long long gp = blockIdx.x;
 	if (gp >= a.pulse_prefix[a.n_utt]) return;
+#endif
 	if (a.only_pulse >= 0 && gp != a.only_pulse) return;
 	// utterance of this pulse
 	int lo = 0, hi = a.n_utt - 1;
