@@ -1111,6 +1111,9 @@ __global__ __launch_bounds__(256, WC_REFINE_WAVES) void hv_refine_kernel(RefArgs
 #ifndef WC_REFINE_DPP
 #define WC_REFINE_DPP 1
 #endif
+#ifndef WC_REFINE_XCD
+#define WC_REFINE_XCD 1
+#endif
 template <int X>
 __device__ __forceinline__ double group8_xor(double v) {
 #if WC_REFINE_DPP
@@ -1150,7 +1153,12 @@ template <bool TABLE, int RF_NP>
 __global__ __launch_bounds__(64, RF_NP > 112 ? 2 : WC_REFINE_WAVES) void hv_refine_packed_kernel(RefArgs a) {  // (the LDS of the wide variant allows 11 wavefronts per CU anyway)
 	const int lane = threadIdx.x;
 	const int grp = lane >> 3, sub = lane & 7;
+#if WC_REFINE_XCD
+	// frames XCD by XCD: a frame's windows overlap its neighbours', and an eighth of a batch's decimated signals fits one XCD's L2
+	const long long g = xcd_frame(blockIdx.x, a.total_frames);
+#else
 	const long long g = blockIdx.x;
+#endif
 	if (g >= a.total_frames) return;
 	const int ui = hv_find(a.utts, a.n_utt, g, &HvUtt::l1_off);
 	const HvUtt u = a.utts[ui];
@@ -2177,7 +2185,7 @@ static inline int h_mround(double x) { return x > 0 ? static_cast<int>(x + 0.5) 
 // zero-crossing buffers; with the rate bound an overflow is reported through h->overflow (device) and handled by
 // the caller (hv_overflowed) by re-running with full == true.
 static void launch_refine(const RefArgs &fa, hipStream_t s, bool by_slots, bool table) {
-	const unsigned frames = (unsigned)fa.total_frames;
+	const unsigned frames = (unsigned)(8 * ((fa.total_frames + 7) / 8));  // (the packed kernel deals frames to the XCDs in eighths)
 	if (by_slots) {
 		if (table) hipLaunchKernelGGL(hv_refine_kernel<true>, dim3(frames), dim3(256), 0, s, fa);
 		else hipLaunchKernelGGL(hv_refine_kernel<false>, dim3(frames), dim3(256), 0, s, fa);
