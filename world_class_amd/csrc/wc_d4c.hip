@@ -530,8 +530,11 @@ __global__ __launch_bounds__(T, T >= 1024 ? 8 : (4 * T) / 256) void d4c_band_ker
 	double *Ar = reinterpret_cast<double *>(A);
 	int tid = threadIdx.x;
 	const int n_ap = a.n_ap;
-	const long long blk = blockIdx.x;
-	const long long g = xcd_frame(blk / n_ap, a.total_frames);
+	// (frame, band) pairs XCD by XCD -- the XCD of a block is its index mod 8, so the pair is chosen from the block index itself:
+	// the bands of a frame, whose slices of the group delay overlap by half, then meet in one L2 (no measurable difference to
+	// dealing the frames alone, 6.9 ms either way)
+	const long long blk = xcd_frame(blockIdx.x, (long long)gridDim.x);
+	const long long g = blk / n_ap;
 	const int bnd = (int)(blk % n_ap);
 	if (g >= a.total_frames) return;
 	const double f0v = a.f0[g];
