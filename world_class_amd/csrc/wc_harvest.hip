@@ -83,7 +83,10 @@ __device__ __forceinline__ int hv_find(const HvUtt *__restrict__ u, int n, long 
 // decimation
 // ------------------------------------------------------------------------------------------------
 struct DecCoef { double a0, a1, a2, b0, b1; };
-constexpr int DEC_CHUNK = 1024, DEC_WARM = 768;
+#ifndef WC_DEC_CHUNK
+#define WC_DEC_CHUNK 512
+#endif
+constexpr int DEC_CHUNK = WC_DEC_CHUNK, DEC_WARM = 768;
 
 // pass 0: forward over the edge-padded input; pass 1: forward over the reversed pass-0 output, storing
 // only the samples the decimated signal keeps.  Index algebra of reference
