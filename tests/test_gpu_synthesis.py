@@ -98,21 +98,25 @@ def test_exact_parallel_phase_accumulation_matches_the_serial_chain(wca, port, f
     contours = [np.zeros(n_frames), np.full(n_frames, 100.0), np.full(n_frames, 125.0), np.full(n_frames, 250.0),
                 np.where(rng.random(n_frames) > 0.4, rng.uniform(60, 700, n_frames), 0.0)]
     ys = {}
-    for mode in ("parallel", "serial"):
+    for mode in ("parallel", "serial", "utterance"):
         if mode == "serial":
             os.environ["WC_SYN_TIMEBASE"] = "serial"
+        if mode == "utterance":  # the pulses picked out of the finished phase by one workgroup per utterance instead of one per tile
+            os.environ["WC_SYN_PULSES"] = "utterance"
         try:
             s = wca.Synthesis(fs, fft, 5.0)
         finally:
             os.environ.pop("WC_SYN_TIMEBASE", None)
+            os.environ.pop("WC_SYN_PULSES", None)
         out = []
         for f0 in contours:
             wca.rng_set_position(0)
             out.append(s.compute(f0, sp, ap))
         ys[mode] = out
     wca.rng_set_position(0)
-    for a, b in zip(ys["parallel"], ys["serial"]):
+    for a, b, c in zip(ys["parallel"], ys["serial"], ys["utterance"]):
         assert np.abs(a - b).max() < 1e-9    # a pulse moved by one sample shows up as ~1e-2
+        assert np.abs(a - c).max() < 1e-9
     port.rng_reset()
     assert np.abs(ys["parallel"][4] - port.synthesis(contours[4], sp, ap, fs, 5.0)).max() < 1e-8
     port.rng_reset()
