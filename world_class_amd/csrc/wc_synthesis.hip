@@ -259,7 +259,13 @@ __global__ __launch_bounds__(64) void syn_timebase_kernel(TbArgs a, const double
 // a run of consecutive exceptions (the first few dozen samples, where the sum doubles every few steps, or a constant
 // increment that happens to tie throughout a binade) is walked serially.  One workgroup per utterance.
 // ------------------------------------------------------------------------------------------------
-constexpr int TB_T = 256, TB_K = 16, TB_W = TB_T * TB_K;  // threads, samples per thread, samples per window
+#ifndef WC_TB_K
+#define WC_TB_K 16
+#endif
+#ifndef WC_TB_T
+#define WC_TB_T 512
+#endif
+constexpr int TB_T = WC_TB_T, TB_K = WC_TB_K, TB_W = TB_T * TB_K;  // threads, samples per thread, samples per window
 constexpr int TB_SERIAL = 64;                             // serial stretch at the start and after back-to-back exceptions
 
 __global__ __launch_bounds__(TB_T) void syn_phase_kernel(TbArgs a, const double *__restrict__ inc_all, double *__restrict__ phase_all) {
