@@ -226,7 +226,16 @@ __global__ void hv_dc_kernel(const HvUtt *__restrict__ utts, double *__restrict_
 	if (threadIdx.x == 0) flag = 0;
 	__syncthreads();
 	int f = 0;
-	for (int i = threadIdx.x; i < u.y_len; i += blockDim.x) if (fabs(yy[i]) >= 1.0) f = 1;
+	for (int i0 = threadIdx.x; i0 < u.y_len; i0 += 8 * blockDim.x) {  // eight loads in flight per thread: this scan heads every batch
+		double v[8];
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			const int i = i0 + k * blockDim.x;
+			v[k] = i < u.y_len ? yy[i] : 0.0;
+		}
+#pragma unroll
+		for (int k = 0; k < 8; ++k) if (fabs(v[k]) >= 1.0) f = 1;
+	}
 	if (f) flag = 1;
 	__syncthreads();
 	if (!flag) return;
@@ -2326,7 +2335,7 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 					hipLaunchKernelGGL(hv_decimate_lds_kernel<1>, grid, dim3(64), 0, s, du, d_x, h->dec.as<double>(), h->y.as<double>(), c, r, lag);
 				}
 			}
-			hipLaunchKernelGGL(hv_dc_kernel, dim3(n_utt), dim3(256), 0, s, du, h->y.as<double>());
+			hipLaunchKernelGGL(hv_dc_kernel, dim3(n_utt), dim3(1024), 0, s, du, h->y.as<double>());
 			WC_HIP(hipGetLastError());
 			if ((rc = dev->time_end("harvest_decimate", s))) return rc;
 		}
