@@ -8,12 +8,14 @@
 // FFT, and device libm; the noise draws come from the exact stream positions the reference's serial
 // order would use (see wc_core.hip).
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
 #include "wc_device.hpp"
 #include "wc_internal.hpp"
 #include "wc_frames.hpp"
+#include "wc_wavefft.hpp"
 
 namespace wc {
 
@@ -30,6 +32,7 @@ struct CtArgs {
 	long long total_frames;
 	int fs;
 	double q1, f0_floor;  // f0_floor = 3 fs / (N - 3)
+	int rare_only;        // the block kernel behind the wavefront kernel: only the frames that one leaves out (ct_wave_can)
 };
 
 // per-frame number of draws: window (2 hw + 1) then one per bin (reference :153, :227)
@@ -42,22 +45,24 @@ __global__ void ct_count_kernel(const double *__restrict__ f0, long long total, 
 	cnt[g] = (uint32_t)(2 * mround(1.5 * fs / f0c) + 1 + bins);
 }
 
+// Which frames the one-wavefront kernel (ct_wave_kernel, N = 2048) takes: its 9 KB of LDS hold the mirrored segment of the
+// smoothing (1025 + 2 b + 1 terms, b = half width in bins) and the low bins of the DC correction only for F0 below ~2 kHz at
+// 48 kHz -- every contour Harvest can produce (ceiling 800 Hz) and anything a caller could mean by a pitch.  Frames above
+// that go to the block kernel, launched behind it on a small grid that looks for them.
+template <int N>
+__device__ __forceinline__ bool ct_wave_can(double f0c, int fs) {
+	const int b = (int)(f0c * 2.0 / 3.0 * N / fs) + 1;
+	const int upper = 2 + (int)(f0c * N / fs);
+	return b <= 60 && upper <= 120;
+}
+
 template <int N, int T>
-__global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
+__device__ __forceinline__ void ct_frame_block(const CtArgs &a, long long g, double2 *A, double *scr, double *red) {
 	constexpr int M = N / 2;
 	constexpr int EPT = (N + T - 1) / T;       // window elements per thread
 	constexpr int BPT = (M + 1 + T - 1) / T;   // bins per thread
-	__shared__ double2 A[fft_lds_size(M)];
-	// LDS: the FFT workspace and the scratch of the cumulative sum only (18.3 KB at N = 2048: eight workgroups per CU).  The power
-	// spectrum has no array of its own: it lives in the workspace until it has been DC-corrected, goes through registers and
-	// comes back as the mirrored terms of the cumulative sum.
-	__shared__ double scr[T + 2 * (T / 64)];
-	__shared__ double red[2 * (T / 64) + 2];
 	double *Ar = reinterpret_cast<double *>(A);
-
 	int tid = threadIdx.x;
-	long long g = xcd_frame(blockIdx.x, a.total_frames);
-	if (g >= a.total_frames) return;
 	const int u = find_utt(a.utts, a.n_utt, g);
 	const UttDesc ud = a.utts[u];
 	const double *__restrict__ x = a.x + ud.x_off;
@@ -272,12 +277,293 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 	for (int k = tid; k <= M; k += T) out[k] = exp(Ar[k]);
 }
 
+template <int N, int T, bool RARE = false>
+__global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
+	constexpr int M = N / 2;
+	// LDS: the FFT workspace and the scratch of the cumulative sum only (18.3 KB at N = 2048: eight workgroups per CU).  The power
+	// spectrum has no array of its own: it lives in the workspace until it has been DC-corrected, goes through registers and
+	// comes back as the mirrored terms of the cumulative sum.
+	__shared__ double2 A[fft_lds_size(M)];
+	__shared__ double scr[T + 2 * (T / 64)];
+	__shared__ double red[2 * (T / 64) + 2];
+	if constexpr (RARE) {
+		for (long long g = blockIdx.x; g < a.total_frames; g += gridDim.x) {
+			const double f0v = a.f0[g];
+			if (ct_wave_can<N>((f0v <= a.f0_floor) ? 500.0 : f0v, a.fs)) continue;
+			ct_frame_block<N, T>(a, g, A, scr, red);
+			__syncthreads();
+		}
+	} else {
+		const long long g = xcd_frame(blockIdx.x, a.total_frames);
+		if (g >= a.total_frames) return;
+		ct_frame_block<N, T>(a, g, A, scr, red);
+	}
+}
+
+
+// ---- one wavefront per frame (N = 2048: 48 kHz) ------------------------------------------------------------------------
+// The same arithmetic as ct_frame_block with the frame in the registers of ONE wavefront from the windowed gather to the
+// final exp(): 16 complex points per lane, the three transforms by wc_wavefft.hpp (two LDS exchanges each, no barrier), the
+// spectrum in the "paired" layout so that the real-transform unpacking, the power spectrum, the lifters and everything else
+// per bin stay in the lane.  LDS: 9.6 KB (exchange buffer = mirrored segment of the smoothing, scratch of the cumulative
+// sum), 16 wavefronts per CU.  What is done differently from the block kernel, none of it above 1e-15 relative:
+//   * the halving of the real-transform unpacking is folded into the window norm / the lifter scale (exact);
+//   * LinearSmoothing's two interpolation abscissae are k + c_lo, k + c_hi with one (c_lo, c_hi) per frame instead of a
+//     quotient per bin (the reference's per-bin rounding of them moves the interpolant by < 1e-13 of one term);
+//   * (hi - lo) * (1 / width), sin / (alpha k) as a product with tabulated 1 / k, the lean log / exp of wc_wavefft.hpp.
+// The FFT of the log spectrum is real, so only real parts are unpacked (wf_r2c_unpack_re) and the liftered spectrum goes
+// back through the real-spectrum packing (wf_c2r_pack_re).
+#ifndef WC_CT_WAVE_OCC
+#define WC_CT_WAVE_OCC 3
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_CT_WAVE_OCC, WC_CT_WAVE_OCC))) void ct_wave_kernel(CtArgs a) {
+	constexpr int N = 2048, M = 1024;
+	__shared__ __attribute__((aligned(16))) double L[kWfLds];
+	__shared__ double scr[64 + 2];
+	__shared__ double red[2];
+	const int lane = threadIdx.x;
+	const long long g = xcd_frame(blockIdx.x, a.total_frames);
+	if (g >= a.total_frames) return;
+	const int fs = a.fs;
+	const double f0v = a.f0[g];
+	const double f0c = uniform_d((f0v <= a.f0_floor) ? 500.0 : f0v);  // reference :77
+	if (!ct_wave_can<N>(f0c, fs)) return;
+	const int u = find_utt(a.utts, a.n_utt, g);
+	const UttDesc ud = a.utts[u];
+	const double *__restrict__ x = a.x + ud.x_off;
+	const int x_last = ud.x_len - 1;
+	const double pos = a.tpos[g];
+	const uint32_t *__restrict__ rng = a.rng_table + (a.rng_off[g] - a.rng_base);
+
+	// ---- F0-adaptive window (reference :137-196): window sample i of slot q is 2 lane + 128 q (+ 1) ----
+	const int hw = __builtin_amdgcn_readfirstlane(mround(1.5 * fs / f0c));
+	const int wl = 2 * hw + 1;
+	const int base = __builtin_amdgcn_readfirstlane(mround(pos * fs + 0.001)) - hw;  // signal index of window sample 0
+	double ce0, se0, co0, so0, cd, sd;
+	{
+		const double kappa = f0c / 1.5 / fs;  // angle per sample in units of pi
+		sincospi(kappa * (2 * lane - hw), &se0, &ce0);
+		sincospi(kappa * (2 * lane + 1 - hw), &so0, &co0);
+		sincospi(kappa * 128.0, &sd, &cd);
+		sd = uniform_d(sd);
+		cd = uniform_d(cd);
+	}
+	// walks the live slots (whole groups of four slots beyond the window are skipped: uniform branches) with the raw window
+	// values of the slot's two samples, advanced by a rotation recurrence from the exact start phases
+	auto walk = [&](auto &&body) {
+		double ce = ce0, se = se0, co = co0, so = so0;
+#pragma unroll
+		for (int q = 0; q < 16; ++q) {
+			if ((q & 3) == 0 && q * 128 >= wl) break;
+			const int i0 = 2 * lane + 128 * q;
+			const double We = (i0 < wl) ? fma(0.5, ce, 0.5) : 0.0;
+			const double Wo = (i0 + 1 < wl) ? fma(0.5, co, 0.5) : 0.0;
+			body(q, i0, We, Wo);
+			const double cen = fma(ce, cd, -(se * sd)), con = fma(co, cd, -(so * sd));
+			se = fma(se, cd, ce * sd);
+			so = fma(so, cd, co * sd);
+			ce = cen;
+			co = con;
+		}
+	};
+	double re[16], im[16];
+#pragma unroll
+	for (int q = 0; q < 16; ++q) re[q] = im[q] = 0.0;
+	double ssq = 0.0;
+	walk([&](int, int, double We, double Wo) { ssq = fma(Wo, Wo, fma(We, We, ssq)); });
+	ssq = wave_sum_all(ssq);
+	const double hr = 0.5 * (1.0 / sqrt(ssq));  // half the window norm: the transform below then yields X, not 2 X
+	double s1 = 0.0, s2 = 0.0;
+	walk([&](int q, int i0, double We, double Wo) {
+		const bool le = i0 < wl, lo = i0 + 1 < wl;
+		const double we = We * hr, wo = Wo * hr;
+		const double xe = x[clampi(base + i0, 0, x_last)], xo = x[clampi(base + i0 + 1, 0, x_last)];
+		const double ne = randn_at(rng, le ? i0 : 0) * (0.5 * 0.000000000000001);
+		const double no = randn_at(rng, lo ? i0 + 1 : 0) * (0.5 * 0.000000000000001);
+		re[q] = le ? fma(xe, we, ne) : 0.0;
+		im[q] = lo ? fma(xo, wo, no) : 0.0;
+		s1 += re[q] + im[q];
+		s2 += we + wo;
+	});
+	s1 = wave_sum_all(s1);
+	s2 = wave_sum_all(s2);
+	const double wc = s1 / s2;
+	walk([&](int q, int, double We, double Wo) {
+		re[q] = fma(-(We * hr), wc, re[q]);
+		im[q] = fma(-(Wo * hr), wc, im[q]);
+	});
+
+	// ---- power spectrum (reference :198-218) ----
+	if (wl <= 512) wdft16<+1, 1>(re, im);
+	else if (wl <= 1024) wdft16<+1, 2>(re, im);
+	else wdft16<+1, 4>(re, im);
+	wf_fft1024_dit_rest<+1>(re, im, L, a.tw, lane);
+	double pw[16], pwM;
+	{
+		double nyq;
+		wf_r2c_unpack(re, im, nyq, a.tw, lane);
+#pragma unroll
+		for (int s = 0; s < 16; ++s) pw[s] = fma(re[s], re[s], im[s] * im[s]);
+		pwM = nyq * nyq;
+	}
+	// DC correction (reference src/world_common.cpp:61-80): bins below upper - 1 <= 119, i.e. slots A_0 (bin lane) and C_0
+	// (bin 64 + lane), from bins <= upper + 1
+	{
+		const int upper = __builtin_amdgcn_readfirstlane(2 + (int)(f0c * N / fs));
+		const double dx = -(double)fs / N, rdx = 1.0 / dx;
+		L[lane] = pw[0];
+		L[64 + lane] = pw[8];
+		wf_fence();
+		auto rep = [&](int i) {
+			const double axis = (double)i * fs / N;
+			return interp1q_rcp(f0c, dx, rdx, [&](int b) { return L[min(max(b, 0), 127)]; }, upper + 1, axis);
+		};
+		if (lane < upper - 1) pw[0] += rep(lane);
+		if (upper - 1 > 64) {
+			if (64 + lane < upper - 1) pw[8] += rep(64 + lane);
+		}
+		wf_fence();
+	}
+
+	// ---- linear smoothing, width 2 f0 / 3 (reference src/world_common.cpp:27-52, :82-116), infinitesimal noise, log ----
+	int jg[4];
+#pragma unroll
+	for (int gq = 0; gq < 4; ++gq) jg[gq] = wf_bin(lane, gq, 0);
+	double lp[16], lpM;
+	{
+		const double width = f0c * 2.0 / 3.0;
+		const int b = __builtin_amdgcn_readfirstlane((int)(width * N / fs) + 1);  // <= 60 (ct_wave_can)
+		const int len = M + 2 * b + 1;
+		// mirrored segment (reference src/world_common.cpp:33-44): position i holds bin b - i (i < b), bin i - b (b <= i < M + b),
+		// bin 2 M + b - i (M + b <= i <= M + 2 b).  The low mirror comes from slot A_0 (bins 1 .. b of lanes 1 .. b), the high one
+		// from slot B_3 (bins 1024 - lane); bin 1024 itself sits at M + b.
+#pragma unroll
+		for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+			for (int q = 0; q < 4; ++q) L[jg[gq] + 256 * q + b] = pw[4 * gq + q] * fs * (1.0 / N);
+		if (lane == 0) L[M + b] = pwM * fs * (1.0 / N);
+		if (lane >= 1 && lane <= b) {
+			L[b - lane] = pw[0] * fs * (1.0 / N);
+			L[M + b + lane] = pw[7] * fs * (1.0 / N);
+		}
+		__syncthreads();
+		seq_cumsum_nonneg<64>(L, len, scr, red, lane);
+		const double step = (double)fs / N;
+		const double origin_axis = -(b - 0.5) * fs / N;
+		const double c_lo = (-width / 2.0 - origin_axis) / step, c_hi = ((-width / 2.0 + width) - origin_axis) / step;
+		const int i_lo = __builtin_amdgcn_readfirstlane((int)c_lo), i_hi = __builtin_amdgcn_readfirstlane((int)c_hi);
+		const double f_lo = c_lo - i_lo, f_hi = c_hi - i_hi;
+		const double rwidth = 1.0 / width;
+		const uint32_t *__restrict__ rngb = rng + wl;
+		bool odd = false;  // a smoothed value that is not a positive finite number (the reference then takes log of it all the same)
+		auto smooth = [&](int k, bool slow) {
+			const double l0 = L[k + i_lo], l1 = L[k + i_lo + 1], h0 = L[k + i_hi], h1 = L[k + i_hi + 1];
+			const double lo_v = fma(l1 - l0, f_lo, l0), hi_v = fma(h1 - h0, f_hi, h0);
+			double sm = (hi_v - lo_v) * rwidth;
+			// infinitesimal noise (reference :220-228) then log (reference :251-252)
+			sm = fma(fabs(randn_at(rngb, k)), 0.00000000000000022204460492503131, sm);
+			if (slow) return wf_log_libm(sm);
+			odd = odd || !wf_log_ok(sm);
+			return wf_log_fast(sm, a.tw);
+		};
+#pragma unroll
+		for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+			for (int q = 0; q < 4; ++q) lp[4 * gq + q] = smooth(jg[gq] + 256 * q, false);
+		lpM = smooth(M, false);
+		if (__any(odd)) {  // (never on signals with a noise floor)
+#pragma unroll
+			for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+				for (int q = 0; q < 4; ++q) lp[4 * gq + q] = smooth(jg[gq] + 256 * q, true);
+			lpM = smooth(M, true);
+		}
+		wf_fence();
+	}
+	// the mirrored log spectrum as the packed input of the second transform: sample n of slot q is 2 lane + 128 q (+ 1),
+	// samples beyond 1024 are the mirror images 2048 - n
+#pragma unroll
+	for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+		for (int q = 0; q < 4; ++q) L[jg[gq] + 256 * q] = lp[4 * gq + q];
+	if (lane == 0) L[M] = lpM;
+	wf_fence();
+#pragma unroll
+	for (int q = 0; q < 8; ++q) {
+		const double2 v = *reinterpret_cast<const double2 *>(&L[2 * lane + 128 * q]);
+		re[q] = v.x;
+		im[q] = v.y;
+	}
+#pragma unroll
+	for (int q = 8; q < 16; ++q) {
+		re[q] = L[2048 - 2 * lane - 128 * q];
+		im[q] = L[2047 - 2 * lane - 128 * q];
+	}
+	wf_fence();
+
+	// ---- smoothing + recovery lifters in the cepstral domain (reference :230-276) ----
+	wf_fft1024_dit<+1>(re, im, L, a.tw, lane);
+	double yM;
+	{
+		double nyq;
+		wf_r2c_unpack_re(re, im, nyq, a.tw, lane);  // 2 X, real
+		// lifters at quefrency k / fs: sinc(f0 q) and 1 - 2 q1 + 2 q1 cos(2 pi q f0); with theta = pi f0 k / fs the cosine is
+		// 1 - 2 sin^2 theta.  (cos, sin) of every slot's bin by rotations from three exact sincos: E_t (the lane), E_64, and
+		// E_256 = E_64^4; slot A_q = E_t E_256^q, C_q = E_64 A_q, B_q = E_256^{q+1} conj(E_t) (lane 0: E_128 E_256^q),
+		// D_q = E_256^{q+1} conj(E_64 E_t)
+		const double q1 = a.q1;
+		const double ralpha = 1.0 / (kPi * f0c / fs);
+		const double scale = 0.5 / N;  // the halving left over from the unpacking and the reference's / fft_size
+		double ct, st, c64, s64;
+		sincospi(f0c / fs * lane, &st, &ct);
+		sincospi(f0c / fs * 64.0, &s64, &c64);
+		const double c128 = fma(-2.0 * s64, s64, 1.0), s128 = 2.0 * s64 * c64;
+		const double c256 = uniform_d(fma(-2.0 * s128, s128, 1.0)), s256 = uniform_d(2.0 * s128 * c128);
+		double ec[4], es[4];  // the four butterflies' running (cos, sin)
+		ec[0] = ct; es[0] = st;
+		ec[2] = fma(ct, c64, -(st * s64)); es[2] = fma(st, c64, ct * s64);
+		ec[1] = lane ? fma(c256, ct, s256 * st) : c128; es[1] = lane ? fma(s256, ct, -(c256 * st)) : s128;
+		ec[3] = fma(c256, ec[2], s256 * es[2]); es[3] = fma(s256, ec[2], -(c256 * es[2]));
+		const double cl0 = 1.0 - 2.0 * q1, cl1 = 2.0 * q1;
+		auto lift = [&](double v, double sn, int k) {
+			const double sl = sn * (ralpha * tw_load_d(a.tw + kTwInvK, k));
+			const double cl = fma(cl1, fma(-2.0 * sn, sn, 1.0), cl0);
+			return v * sl * cl * scale;
+		};
+#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+#pragma unroll
+			for (int gq = 0; gq < 4; ++gq) {
+				const int k = jg[gq] + 256 * q;
+				double v = lift(re[4 * gq + q], es[gq], k);
+				if (gq == 0 && q == 0) v = (lane == 0) ? re[0] * (cl0 + cl1) * scale : v;  // k = 0: sinc = 1
+				re[4 * gq + q] = v;
+				const double cn = fma(ec[gq], c256, -(es[gq] * s256));
+				es[gq] = fma(es[gq], c256, ec[gq] * s256);
+				ec[gq] = cn;
+			}
+		}
+		yM = lift(nyq, es[0], M);  // lane 0: A_3 advanced once more is bin 1024
+	}
+	wf_c2r_pack_re(re, im, yM, a.tw, lane);
+	wf_fft1024_dif<-1>(re, im, L, a.tw, lane);
+	double *__restrict__ out = a.sp + g * (long long)(M + 1);
+#pragma unroll
+	for (int q = 0; q < 8; ++q) {
+		out[2 * lane + 128 * q] = wf_exp(re[q], a.tw);
+		out[2 * lane + 128 * q + 1] = wf_exp(im[q], a.tw);
+	}
+	const double last = wf_exp(re[8], a.tw);
+	if (lane == 0) out[M] = last;
+}
+
 }  // namespace wc
 
 using namespace wc;
 
 struct wc_cheaptrick {
 	int fs, fft_size;
+	bool wave;  // N = 2048: one wavefront per frame (default; WC_CT_IMPL=block: the workgroup-per-frame kernel for every frame)
 	double q1, f0_floor_opt, f0_floor;
 	Device *dev;
 	DevBuf utts, cnt, off, endpos, d_x, d_tpos, d_f0, d_sp;
@@ -354,10 +640,21 @@ int ct_frames(wc_cheaptrick *c, hipStream_t s, int n_utt, const double *d_x, con
 	a.rng_base = dev->rng_base; a.tw = dev->twiddle; a.sp = d_sp; a.total_frames = total; a.fs = c->fs;
 	a.q1 = c->q1; a.f0_floor = c->f0_floor;
 	if ((rc = dev->time_begin("cheaptrick_frames", s))) return rc;
+	a.rare_only = 0;
 	switch (c->fft_size) {
 		case 512: launch_ct<512>(a, s); break;
 		case 1024: launch_ct<1024>(a, s); break;
-		case 2048: launch_ct<2048>(a, s); break;
+		case 2048:
+			if (c->wave) {
+				// one wavefront per frame; the frames it leaves out (F0 above ~2 kHz, ct_wave_can) are found and done by a
+				// small grid of the block kernel behind it
+				hipLaunchKernelGGL(ct_wave_kernel, dim3((unsigned)(((total + 7) / 8) * 8)), dim3(64), 0, s, a);
+				a.rare_only = 1;
+				hipLaunchKernelGGL((ct_frames_kernel<2048, WC_CT_THREADS, true>), dim3(256), dim3(WC_CT_THREADS), 0, s, a);
+			} else {
+				launch_ct<2048>(a, s);
+			}
+			break;
 		case 4096: launch_ct<4096>(a, s); break;
 		default: return fail(WC_ERR_UNSUPPORTED, "cheaptrick: fft_size must be 512, 1024, 2048 or 4096");
 	}
@@ -415,6 +712,10 @@ wc_cheaptrick *wc_cheaptrick_create(int fs, double q1, double f0_floor, int fft_
 	c->fft_size = fft_size ? fft_size : wc_cheaptrick_fft_size(fs, f0_floor);  // reference :36-41
 	c->f0_floor = wc_cheaptrick_f0_floor(fs, c->fft_size);                      // reference :44
 	c->dev = dev;
+	{
+		const char *impl = getenv("WC_CT_IMPL");
+		c->wave = !(impl && std::strcmp(impl, "block") == 0);
+	}
 	if (c->fft_size != 512 && c->fft_size != 1024 && c->fft_size != 2048 && c->fft_size != 4096) {
 		set_error("cheaptrick: fft_size must be 512, 1024, 2048 or 4096 (fs between 8 kHz and 96 kHz)");
 		delete c;

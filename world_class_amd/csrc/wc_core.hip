@@ -8,6 +8,7 @@
 
 #include "wc_device.hpp"
 #include "wc_internal.hpp"
+#include "wc_wavefft.hpp"
 
 namespace wc {
 
@@ -242,7 +243,7 @@ Device *current_device() {
 			set_error("hipStreamCreate failed");
 			return nullptr;
 		}
-		std::vector<double2> tw(kTwiddleN);
+		std::vector<double2> tw(kTwTotal, make_double2(0.0, 0.0));
 		for (int k = 0; k < kTwiddleN; ++k) {
 			double a = 2.0 * 3.14159265358979323846 * k / kTwiddleN;
 			tw[k] = make_double2(std::cos(a), std::sin(a));
@@ -252,8 +253,22 @@ Device *current_device() {
 		tw[kTwiddleN / 4] = make_double2(0.0, 1.0);
 		tw[kTwiddleN / 2] = make_double2(-1.0, 0.0);
 		tw[3 * kTwiddleN / 4] = make_double2(0.0, -1.0);
-		if (hipMalloc(&d->twiddle, sizeof(double2) * kTwiddleN) != hipSuccess ||
-			hipMemcpy(d->twiddle, tw.data(), sizeof(double2) * kTwiddleN, hipMemcpyHostToDevice) != hipSuccess) {
+		// tables of the wavefront transforms behind the main one (wc_wavefft.hpp): the second stage's twiddles row by row,
+		// and the arguments of the lean log / exp
+		for (int k = 0; k < 16; ++k)
+			for (int r = 0; r < 16; ++r) tw[kTwT2 + 16 * k + r] = tw[(16 * r * k) % kTwiddleN];
+		for (int i = 0; i < 128; ++i) {
+			const double c = 0.5 + (i + 0.5) / 256.0, invc = 1.0 / c;
+			tw[kTwLog + i] = make_double2(invc, (double)-logl((long double)invc));
+		}
+		{
+			double *ex = reinterpret_cast<double *>(&tw[kTwExp]);
+			for (int j = 0; j < 64; ++j) ex[j] = (double)exp2l((long double)j / 64.0L);
+			double *ik = reinterpret_cast<double *>(&tw[kTwInvK]);
+			for (int k = 1; k < 1040; ++k) ik[k] = 1.0 / k;
+		}
+		if (hipMalloc(&d->twiddle, sizeof(double2) * kTwTotal) != hipSuccess ||
+			hipMemcpy(d->twiddle, tw.data(), sizeof(double2) * kTwTotal, hipMemcpyHostToDevice) != hipSuccess) {
 			set_error("twiddle table upload failed");
 			return nullptr;
 		}

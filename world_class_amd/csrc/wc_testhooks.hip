@@ -6,6 +6,7 @@
 
 #include "wc_device.hpp"
 #include "wc_internal.hpp"
+#include "wc_wavefft.hpp"
 
 namespace wc {
 
@@ -64,6 +65,61 @@ __global__ __launch_bounds__(T) void hook_cumsum_kernel(const double *__restrict
 	__syncthreads();
 	seq_cumsum_nonneg<T>(S, n, scr, red, tid);
 	for (int i = tid; i < n; i += T) out[(size_t)blockIdx.x * n + i] = S[i];
+}
+
+// The one-wavefront transforms of wc_wavefft.hpp: a 2048-point real transform per 64-thread workgroup.
+// KIND 0: r2c (in 2048 doubles, out 1025 complex); 1: c2r (in 1025 complex, out 2048 doubles, unnormalised);
+// 2: r2c with the input zero beyond its first quarter, through the pruned leading stage
+template <int KIND>
+__global__ __launch_bounds__(64) void hook_wave_fft_kernel(const double *__restrict__ in, double *__restrict__ out,
+															const double2 *__restrict__ tw) {
+	__shared__ __attribute__((aligned(16))) double L[kWfLds];
+	const int lane = threadIdx.x;
+	double re[16], im[16];
+	if constexpr (KIND != 1) {
+		const double *x = in + (size_t)blockIdx.x * 2048;
+		double2 *X = reinterpret_cast<double2 *>(out) + (size_t)blockIdx.x * 1025;
+#pragma unroll
+		for (int q = 0; q < 16; ++q) {
+			re[q] = x[2 * (lane + 64 * q)];
+			im[q] = x[2 * (lane + 64 * q) + 1];
+		}
+		if constexpr (KIND == 2) wdft16<+1, 1>(re, im);
+		else wdft16<+1>(re, im);
+		wf_fft1024_dit_rest<+1>(re, im, L, tw, lane);
+		double nyq;
+		wf_r2c_unpack(re, im, nyq, tw, lane);
+#pragma unroll
+		for (int g = 0; g < 4; ++g)
+#pragma unroll
+			for (int q = 0; q < 4; ++q) X[wf_bin(lane, g, q)] = make_double2(0.5 * re[4 * g + q], 0.5 * im[4 * g + q]);
+		if (lane == 0) X[1024] = make_double2(0.5 * nyq, 0.0);
+	} else {
+		const double2 *Y = reinterpret_cast<const double2 *>(in) + (size_t)blockIdx.x * 1025;
+		double *y = out + (size_t)blockIdx.x * 2048;
+#pragma unroll
+		for (int g = 0; g < 4; ++g)
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				const double2 v = Y[wf_bin(lane, g, q)];
+				re[4 * g + q] = v.x;
+				im[4 * g + q] = v.y;
+			}
+		const double nyq = Y[1024].x;
+		wf_c2r_pack(re, im, nyq, tw, lane);
+		wf_fft1024_dif<-1>(re, im, L, tw, lane);
+#pragma unroll
+		for (int q = 0; q < 16; ++q) {
+			y[2 * (lane + 64 * q)] = re[q];
+			y[2 * (lane + 64 * q) + 1] = im[q];
+		}
+	}
+}
+// kind 0: wf_log, 1: wf_exp
+__global__ void hook_logexp_kernel(int kind, const double *__restrict__ in, double *__restrict__ out, long long n,
+								   const double2 *__restrict__ tw) {
+	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) out[i] = kind == 0 ? wf_log(in[i], tw) : wf_exp(in[i], tw);
 }
 
 }  // namespace wc
@@ -154,6 +210,48 @@ int wc_debug_seq_cumsum(const double *v, int n, int batch, int threads, double *
 	else hipLaunchKernelGGL(hook_cumsum_kernel<512>, dim3(batch), dim3(512), 0, s, static_cast<const double *>(d_in.p), n, static_cast<double *>(d_out.p));
 	WC_HIP(hipGetLastError());
 	WC_HIP(hipMemcpyAsync(out, d_out.p, sizeof(double) * total, hipMemcpyDeviceToHost, s));
+	WC_HIP(hipStreamSynchronize(s));
+	return WC_OK;
+}
+
+// 2048-point real transforms by one wavefront each (wc_wavefft.hpp).  kind 0 r2c, 1 c2r, 2 r2c of an input whose last
+// three quarters are zero (pruned leading stage); host pointers; doubles in 2048 / 2050 / 2048, out 2050 / 2048 / 2050.
+int wc_debug_wave_fft(int kind, int batch, const double *in, double *out) {
+	if (kind < 0 || kind > 2 || batch <= 0 || !in || !out) return fail(WC_ERR_INVALID, "debug wave fft: bad argument");
+	Device *dev = current_device();
+	if (!dev) return WC_ERR_DEVICE;
+	DeviceLock lock(dev);
+	hipStream_t s = dev->active();
+	const size_t n_in = (kind == 1 ? 2050 : 2048) * (size_t)batch, n_out = (kind == 1 ? 2048 : 2050) * (size_t)batch;
+	Scoped d_in, d_out;
+	WC_HIP(hipMalloc(&d_in.p, sizeof(double) * n_in));
+	WC_HIP(hipMalloc(&d_out.p, sizeof(double) * n_out));
+	WC_HIP(hipMemcpyAsync(d_in.p, in, sizeof(double) * n_in, hipMemcpyHostToDevice, s));
+	const double *di = static_cast<const double *>(d_in.p);
+	double *dout = static_cast<double *>(d_out.p);
+	if (kind == 0) hipLaunchKernelGGL(hook_wave_fft_kernel<0>, dim3(batch), dim3(64), 0, s, di, dout, dev->twiddle);
+	else if (kind == 1) hipLaunchKernelGGL(hook_wave_fft_kernel<1>, dim3(batch), dim3(64), 0, s, di, dout, dev->twiddle);
+	else hipLaunchKernelGGL(hook_wave_fft_kernel<2>, dim3(batch), dim3(64), 0, s, di, dout, dev->twiddle);
+	WC_HIP(hipGetLastError());
+	WC_HIP(hipMemcpyAsync(out, d_out.p, sizeof(double) * n_out, hipMemcpyDeviceToHost, s));
+	WC_HIP(hipStreamSynchronize(s));
+	return WC_OK;
+}
+// the lean logarithm / exponential of wc_wavefft.hpp on n host values (kind 0 log, 1 exp)
+int wc_debug_logexp(int kind, long long n, const double *in, double *out) {
+	if (kind < 0 || kind > 1 || n <= 0 || !in || !out) return fail(WC_ERR_INVALID, "debug logexp: bad argument");
+	Device *dev = current_device();
+	if (!dev) return WC_ERR_DEVICE;
+	DeviceLock lock(dev);
+	hipStream_t s = dev->active();
+	Scoped d_in, d_out;
+	WC_HIP(hipMalloc(&d_in.p, sizeof(double) * n));
+	WC_HIP(hipMalloc(&d_out.p, sizeof(double) * n));
+	WC_HIP(hipMemcpyAsync(d_in.p, in, sizeof(double) * n, hipMemcpyHostToDevice, s));
+	hipLaunchKernelGGL(hook_logexp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, kind, static_cast<const double *>(d_in.p),
+					   static_cast<double *>(d_out.p), n, dev->twiddle);
+	WC_HIP(hipGetLastError());
+	WC_HIP(hipMemcpyAsync(out, d_out.p, sizeof(double) * n, hipMemcpyDeviceToHost, s));
 	WC_HIP(hipStreamSynchronize(s));
 	return WC_OK;
 }

@@ -1,0 +1,443 @@
+// Register-resident FFT for ONE wavefront (gfx950, wave64, FP64): a 1024-point complex transform whose 16 points
+// per lane live in VGPRs from the first butterfly to the last.  The data cross the lanes twice through a 9 KB
+// exchange buffer in LDS (real and imaginary parts one after the other, so the buffer is half the transform) and
+// never meet a workgroup barrier: a wavefront's LDS instructions execute in issue order, so a read that follows
+// the writes of all 64 lanes sees them.  Three radix stages (16 x 16 x 4) instead of five radix-4 round trips
+// through LDS; all index arithmetic is folded into immediate offsets.
+//
+// Conventions are the reference's (reference src/world_fft.cpp:31-77): sign S = +1 is its "forward" e^{+i}.
+//
+// Layouts (t = lane):
+//   strided   slot q (0..15) holds element t + 64 q
+//   paired    slot 4 g + q (g = 0..3: A, B, C, D; q = 0..3) holds element j_g + 256 q with
+//                 j_A = t,  j_B = 256 - t (lane 0: 128),  j_C = 64 + t,  j_D = 192 - t
+//             so that element k and element 1024 - k always sit in the same lane (A_q with B_{3-q}, C_q with D_{3-q};
+//             lane 0 pairs A_1 with A_3, B_0 with B_3, B_1 with B_2 and keeps the self-paired 0 and 512 in A_0, A_2):
+//             the unpacking passes of the real transforms need no further exchange.
+//   wf_fft1024_dit  strided -> paired  (decimation in time)
+//   wf_fft1024_dif  paired -> strided  (the transposed factorisation)
+#pragma once
+#include "wc_device.hpp"
+
+namespace wc {
+
+constexpr int kWfLds = 1152;  // doubles of LDS per wavefront: 1024 + one pad per 16, rounded up (also holds 1025 + 2 * 63 terms)
+constexpr double kC8 = 0.92387953251128675613;  // cos(pi/8)
+constexpr double kS8 = 0.38268343236508977173;  // sin(pi/8)
+constexpr double kH = 0.70710678118654752440;   // sqrt(1/2)
+
+// Orders this lane's LDS accesses for the compiler.  The hardware needs nothing: the wavefront's DS instructions
+// execute in order, and a workgroup is one wavefront.
+#ifndef WC_WF_SYNC
+#define WC_WF_SYNC 0  // 1: __syncthreads() instead (a wait for all outstanding LDS traffic; debugging aid)
+#endif
+__device__ __forceinline__ void wf_fence() {
+#if WC_WF_SYNC
+	__syncthreads();
+#else
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
+// ---- 4- and 16-point DFTs on split real / imaginary registers ------------------------------------------------------
+// y[q] = sum_r x[r] e^{S 2 pi i r q / 4}, in place
+template <int S>
+__device__ __forceinline__ void wdft4(double &ar, double &ai, double &br, double &bi, double &cr, double &ci, double &dr,
+									  double &di) {
+	const double s02r = ar + cr, s02i = ai + ci, d02r = ar - cr, d02i = ai - ci;
+	const double s13r = br + dr, s13i = bi + di, e13r = br - dr, e13i = bi - di;
+	ar = s02r + s13r; ai = s02i + s13i;
+	cr = s02r - s13r; ci = s02i - s13i;
+	if (S > 0) { br = d02r - e13i; bi = d02i + e13r; dr = d02r + e13i; di = d02i - e13r; }
+	else       { br = d02r + e13i; bi = d02i - e13r; dr = d02r - e13i; di = d02i + e13r; }
+}
+// the same with x[2] = x[3] = 0 / x[1] = x[2] = x[3] = 0 (leading stage of a transform whose tail is zero padding)
+template <int S>
+__device__ __forceinline__ void wdft4_2(double &ar, double &ai, double &br, double &bi, double &cr, double &ci, double &dr,
+										double &di) {
+	const double xr = ar, xi = ai, yr = br, yi = bi;
+	ar = xr + yr; ai = xi + yi;
+	cr = xr - yr; ci = xi - yi;
+	if (S > 0) { br = xr - yi; bi = xi + yr; dr = xr + yi; di = xi - yr; }
+	else       { br = xr + yi; bi = xi - yr; dr = xr - yi; di = xi + yr; }
+}
+// (x + i y) (cr + i ci)
+__device__ __forceinline__ void wrot(double &x, double &y, double cr, double ci) {
+	const double nx = fma(x, cr, -(y * ci));
+	y = fma(x, ci, y * cr);
+	x = nx;
+}
+// 16-point DFT, sign S, natural order in and out.  NG: only the first 4 NG inputs are non-zero (NG = 4: all).
+//   r = 4 a + b, q = c + 4 d:  y[c + 4 d] = sum_b (S i)^{b d} w16^{b c} sum_a (S i)^{a c} x[4 a + b],  w16 = e^{S 2 pi i / 16}
+template <int S, int NG = 4>
+__device__ __forceinline__ void wdft16(double (&xr)[16], double (&xi)[16]) {
+	// over a, for each b: slot 4 c + b <- u_b[c]
+#pragma unroll
+	for (int b = 0; b < 4; ++b) {
+		if constexpr (NG >= 3) {
+			wdft4<S>(xr[b], xi[b], xr[4 + b], xi[4 + b], xr[8 + b], xi[8 + b], xr[12 + b], xi[12 + b]);
+		} else if constexpr (NG == 2) {
+			wdft4_2<S>(xr[b], xi[b], xr[4 + b], xi[4 + b], xr[8 + b], xi[8 + b], xr[12 + b], xi[12 + b]);
+		} else {
+			xr[4 + b] = xr[8 + b] = xr[12 + b] = xr[b];
+			xi[4 + b] = xi[8 + b] = xi[12 + b] = xi[b];
+		}
+	}
+	// slot 4 c + b *= w16^{b c}
+	constexpr double s = S > 0 ? 1.0 : -1.0;
+	// c = 1: w^1, w^2, w^3
+	wrot(xr[5], xi[5], kC8, s * kS8);
+	{ const double x = xr[6], y = xi[6]; xr[6] = kH * (S > 0 ? x - y : x + y); xi[6] = kH * (S > 0 ? x + y : y - x); }
+	wrot(xr[7], xi[7], kS8, s * kC8);
+	// c = 2: w^2, w^4, w^6
+	{ const double x = xr[9], y = xi[9]; xr[9] = kH * (S > 0 ? x - y : x + y); xi[9] = kH * (S > 0 ? x + y : y - x); }
+	{ const double x = xr[10], y = xi[10]; xr[10] = S > 0 ? -y : y; xi[10] = S > 0 ? x : -x; }
+	{ const double x = xr[11], y = xi[11]; xr[11] = S > 0 ? -kH * (x + y) : kH * (y - x); xi[11] = S > 0 ? kH * (x - y) : -kH * (x + y); }
+	// c = 3: w^3, w^6, w^9
+	wrot(xr[13], xi[13], kS8, s * kC8);
+	{ const double x = xr[14], y = xi[14]; xr[14] = S > 0 ? -kH * (x + y) : kH * (y - x); xi[14] = S > 0 ? kH * (x - y) : -kH * (x + y); }
+	wrot(xr[15], xi[15], -kC8, -s * kS8);
+	// over b, for each c: slot 4 c + d <- y[c + 4 d]
+#pragma unroll
+	for (int c = 0; c < 4; ++c)
+		wdft4<S>(xr[4 * c], xi[4 * c], xr[4 * c + 1], xi[4 * c + 1], xr[4 * c + 2], xi[4 * c + 2], xr[4 * c + 3], xi[4 * c + 3]);
+	// natural order (register renaming only)
+	double tr[16], ti[16];
+#pragma unroll
+	for (int c = 0; c < 4; ++c)
+#pragma unroll
+		for (int d = 0; d < 4; ++d) { tr[c + 4 * d] = xr[4 * c + d]; ti[c + 4 * d] = xi[4 * c + d]; }
+#pragma unroll
+	for (int q = 0; q < 16; ++q) { xr[q] = tr[q]; xi[q] = ti[q]; }
+}
+
+// ---- the exchanges ---------------------------------------------------------------------------------------------------
+// 16 values per lane out to LDS at wbase + q * WS, back from rbase + r * RS (element indices carry one pad per 16)
+template <int WS, int RS>
+__device__ __forceinline__ void wf_xchg(double (&v)[16], double *lds, int wbase, int rbase) {
+#pragma unroll
+	for (int q = 0; q < 16; ++q) lds[wbase + q * WS] = v[q];
+	wf_fence();
+#pragma unroll
+	for (int r = 0; r < 16; ++r) v[r] = lds[rbase + r * RS];
+	wf_fence();
+}
+// pass 3 side: four butterflies of four values each, slot 4 g + r at jbase[g] + 272 r
+__device__ __forceinline__ void wf_xchg_in3(double (&v)[16], double *lds, int wbase, const int (&jb)[4]) {
+#pragma unroll
+	for (int q = 0; q < 16; ++q) lds[wbase + q * 17] = v[q];
+	wf_fence();
+#pragma unroll
+	for (int g = 0; g < 4; ++g)
+#pragma unroll
+		for (int r = 0; r < 4; ++r) v[4 * g + r] = lds[jb[g] + 272 * r];
+	wf_fence();
+}
+__device__ __forceinline__ void wf_xchg_out3(double (&v)[16], double *lds, const int (&jb)[4], int rbase) {
+#pragma unroll
+	for (int g = 0; g < 4; ++g)
+#pragma unroll
+		for (int r = 0; r < 4; ++r) lds[jb[g] + 272 * r] = v[4 * g + r];
+	wf_fence();
+#pragma unroll
+	for (int q = 0; q < 16; ++q) v[q] = lds[rbase + q * 17];
+	wf_fence();
+}
+
+constexpr int kTwT2 = kTwiddleN;          // 256 entries behind the main table: W_256^{r k} at [16 k + r]
+constexpr int kTwLog = kTwT2 + 256;       // 128 entries (1 / c_i, log c_i), c_i = 1/2 + (i + 1/2) / 256
+constexpr int kTwExp = kTwLog + 128;      // 32 entries = 64 doubles 2^{j/64}
+constexpr int kTwInvK = kTwExp + 32;      // 1040 doubles 1 / k (k = 0: 0)
+constexpr int kTwTotal = kTwInvK + 520;   // double2 entries of the whole table
+
+struct WfIdx {
+	int jb[4];       // padded element index of butterfly g's first input: j + (j >> 4)
+	int x1w, x1r;    // exchange 1: write 17 t (+ q), read t + (t >> 4) (+ 68 r)
+	int x2;          // exchange 2, 16-point side: 272 (t >> 4) + (t & 15) (+ 17 q)
+	int jB;          // j_B
+};
+__device__ __forceinline__ WfIdx wf_idx(int lane) {
+	WfIdx x;
+	const int jA = lane, jB = lane ? 256 - lane : 128, jC = 64 + lane, jD = 192 - lane;
+	x.jb[0] = jA + (jA >> 4); x.jb[1] = jB + (jB >> 4); x.jb[2] = jC + (jC >> 4); x.jb[3] = jD + (jD >> 4);
+	x.x1w = 17 * lane;
+	x.x1r = lane + (lane >> 4);
+	x.x2 = 272 * (lane >> 4) + (lane & 15);
+	x.jB = jB;
+	return x;
+}
+
+// the twiddles W_1024^{r j}, r = 1..3, of the four butterflies of the radix-4 stage (sign S), from two table rows
+template <int S>
+__device__ __forceinline__ void wf_tw3(const double2 *__restrict__ tw, int lane, double (&wr)[4][3], double (&wi)[4][3]) {
+	constexpr double s = S > 0 ? 1.0 : -1.0;
+#pragma unroll
+	for (int r = 1; r <= 3; ++r) {
+		const double2 a = tw_load(tw, 4 * r * lane), c = tw_load(tw + 256 * r, 4 * r * lane);  // j = t and j = 64 + t
+		wr[0][r - 1] = a.x; wi[0][r - 1] = s * a.y;
+		wr[2][r - 1] = c.x; wi[2][r - 1] = s * c.y;
+	}
+	// j' = 256 - j:  W^{r j'} = (S i)^r conj(W^{r j})
+#pragma unroll
+	for (int g = 0; g < 4; g += 2) {
+		wr[g + 1][0] = s * wi[g][0];  wi[g + 1][0] = s * wr[g][0];
+		wr[g + 1][1] = -wr[g][1];     wi[g + 1][1] = wi[g][1];
+		wr[g + 1][2] = -s * wi[g][2]; wi[g + 1][2] = -s * wr[g][2];
+	}
+	if (lane == 0) {  // j_B = 128: e^{S i pi r / 4}
+		wr[1][0] = kH;  wi[1][0] = s * kH;
+		wr[1][1] = 0.0; wi[1][1] = s;
+		wr[1][2] = -kH; wi[1][2] = s * kH;
+	}
+}
+
+// ---- the transforms ----------------------------------------------------------------------------------------------------
+// strided -> paired; the caller has already run the leading 16-point stage (wdft16<S, NG>: pruned where the input's tail is
+// zero padding) on the strided data
+template <int S>
+__device__ __forceinline__ void wf_fft1024_dit_rest(double (&re)[16], double (&im)[16], double *lds, const double2 *__restrict__ tw_,
+													 int lane) {
+	const double2 *__restrict__ tw = tw_fresh(tw_);
+	const WfIdx ix = wf_idx(lane);
+	wf_xchg<1, 68>(re, lds, ix.x1w, ix.x1r);
+	wf_xchg<1, 68>(im, lds, ix.x1w, ix.x1r);
+	{
+		const double2 *__restrict__ t2 = tw + kTwT2 + 16 * (lane & 15);
+#pragma unroll
+		for (int r = 1; r < 16; ++r) {
+			const double2 w = tw_load(t2, r);
+			wrot(re[r], im[r], w.x, S > 0 ? w.y : -w.y);
+		}
+	}
+	wdft16<S>(re, im);
+	wf_xchg_in3(re, lds, ix.x2, ix.jb);
+	wf_xchg_in3(im, lds, ix.x2, ix.jb);
+	double wr[4][3], wi[4][3];
+	wf_tw3<S>(tw, lane, wr, wi);
+#pragma unroll
+	for (int g = 0; g < 4; ++g) {
+#pragma unroll
+		for (int r = 1; r <= 3; ++r) wrot(re[4 * g + r], im[4 * g + r], wr[g][r - 1], wi[g][r - 1]);
+		wdft4<S>(re[4 * g], im[4 * g], re[4 * g + 1], im[4 * g + 1], re[4 * g + 2], im[4 * g + 2], re[4 * g + 3], im[4 * g + 3]);
+	}
+}
+// strided -> paired
+template <int S>
+__device__ __forceinline__ void wf_fft1024_dit(double (&re)[16], double (&im)[16], double *lds, const double2 *__restrict__ tw,
+												int lane) {
+	wdft16<S>(re, im);
+	wf_fft1024_dit_rest<S>(re, im, lds, tw, lane);
+}
+// paired -> strided
+template <int S>
+__device__ __forceinline__ void wf_fft1024_dif(double (&re)[16], double (&im)[16], double *lds, const double2 *__restrict__ tw_,
+												int lane) {
+	const double2 *__restrict__ tw = tw_fresh(tw_);
+	const WfIdx ix = wf_idx(lane);
+	{
+		double wr[4][3], wi[4][3];
+		wf_tw3<S>(tw, lane, wr, wi);
+#pragma unroll
+		for (int g = 0; g < 4; ++g) {
+			wdft4<S>(re[4 * g], im[4 * g], re[4 * g + 1], im[4 * g + 1], re[4 * g + 2], im[4 * g + 2], re[4 * g + 3], im[4 * g + 3]);
+#pragma unroll
+			for (int r = 1; r <= 3; ++r) wrot(re[4 * g + r], im[4 * g + r], wr[g][r - 1], wi[g][r - 1]);
+		}
+	}
+	wf_xchg_out3(re, lds, ix.jb, ix.x2);
+	wf_xchg_out3(im, lds, ix.jb, ix.x2);
+	wdft16<S>(re, im);
+	{
+		const double2 *__restrict__ t2 = tw + kTwT2 + 16 * (lane & 15);
+#pragma unroll
+		for (int r = 1; r < 16; ++r) {
+			const double2 w = tw_load(t2, r);
+			wrot(re[r], im[r], w.x, S > 0 ? w.y : -w.y);
+		}
+	}
+	wf_xchg<68, 1>(re, lds, ix.x1r, ix.x1w);
+	wf_xchg<68, 1>(im, lds, ix.x1r, ix.x1w);
+	wdft16<S>(re, im);
+}
+
+// ---- real transforms of 2048 points on top of them -------------------------------------------------------------------------
+// Unpacking of one pair of bins (k, 1024 - k) of the real transform from the half-size complex one, reference convention
+// (r2c: X[k] = sum x[n] e^{+2 pi i k n / N}); w = e^{+2 pi i k / 2048}.  Yields TWICE the spectrum (the halving of the
+// even / odd split is left to the caller, who folds it into a scale factor he applies anyway).
+__device__ __forceinline__ void wf_r2c_pair(double &kr, double &ki, double &mr, double &mi, double wr, double wi) {
+	const double sx = kr + mr, sy = ki - mi, dx = kr - mr, dy = ki + mi;
+	const double ox = fma(wr, dy, wi * dx), oy = fma(wi, dy, -(wr * dx));
+	kr = sx + ox; ki = sy + oy;
+	mr = sx - ox; mi = oy - sy;
+}
+// the twiddles e^{+2 pi i k / 2048} of the bins of slots A_q and C_q
+__device__ __forceinline__ void wf_tw_real(const double2 *__restrict__ tw, int lane, double (&wr)[8], double (&wi)[8]) {
+#pragma unroll
+	for (int q = 0; q < 4; ++q) {
+		const double2 a = tw_load(tw + 512 * q, 2 * lane), c = tw_load(tw + 512 * q + 128, 2 * lane);
+		wr[q] = a.x; wi[q] = a.y;
+		wr[4 + q] = c.x; wi[4 + q] = c.y;
+	}
+}
+// In: the paired output of wf_fft1024_dit<+1> on the packed signal z[m] = x[2 m] + i x[2 m + 1].  Out: slot (g, q) holds
+// 2 X[j_g + 256 q]; lane 0's A_0 holds (2 X[0], 0) and nyq = 2 X[1024] (valid on lane 0).
+__device__ __forceinline__ void wf_r2c_unpack(double (&re)[16], double (&im)[16], double &nyq, const double2 *__restrict__ tw_,
+											   int lane) {
+	const double2 *__restrict__ tw = tw_fresh(tw_);
+	double wr[8], wi[8];
+	wf_tw_real(tw, lane, wr, wi);
+	nyq = 0.0;
+	if (lane == 0) {
+		const double a = re[0], b = im[0];
+		re[0] = 2.0 * (a + b); im[0] = 0.0;
+		nyq = 2.0 * (a - b);
+		re[2] = 2.0 * re[2]; im[2] = 2.0 * im[2];                     // bin 512: X = Z
+		wf_r2c_pair(re[1], im[1], re[3], im[3], kH, kH);              // 256 | 768
+		wf_r2c_pair(re[4], im[4], re[7], im[7], kC8, kS8);            // 128 | 896
+		wf_r2c_pair(re[5], im[5], re[6], im[6], kS8, kC8);            // 384 | 640
+	} else {
+#pragma unroll
+		for (int q = 0; q < 4; ++q) wf_r2c_pair(re[q], im[q], re[7 - q], im[7 - q], wr[q], wi[q]);
+	}
+#pragma unroll
+	for (int q = 0; q < 4; ++q) wf_r2c_pair(re[8 + q], im[8 + q], re[15 - q], im[15 - q], wr[4 + q], wi[4 + q]);
+}
+// Inverse: in: the Hermitian spectrum Y in the paired layout (lane 0: A_0 = (Y[0], .), nyq = Y[1024], imaginary parts of
+// both ignored).  Out: Z such that wf_fft1024_dif<-1> yields the real signal y[n] = sum_k Yh[k] e^{-2 pi i k n / N}
+// (reference c2r, unnormalised) as strided packed pairs (y[2 m], y[2 m + 1]).
+__device__ __forceinline__ void wf_c2r_pair(double &kr, double &ki, double &mr, double &mi, double wr, double wi) {
+	const double ex = kr + mr, ey = ki - mi, dx = kr - mr, dy = ki + mi;
+	const double ox = fma(dx, wr, dy * wi), oy = fma(dy, wr, -(dx * wi));  // (dx + i dy) conj(w)
+	kr = ex - oy; ki = ey + ox;
+	mr = ex + oy; mi = ox - ey;
+}
+__device__ __forceinline__ void wf_c2r_pack(double (&re)[16], double (&im)[16], double nyq, const double2 *__restrict__ tw_,
+											 int lane) {
+	const double2 *__restrict__ tw = tw_fresh(tw_);
+	double wr[8], wi[8];
+	wf_tw_real(tw, lane, wr, wi);
+	if (lane == 0) {
+		const double y0 = re[0];
+		re[0] = y0 + nyq; im[0] = y0 - nyq;
+		re[2] = 2.0 * re[2]; im[2] = 2.0 * im[2];
+		wf_c2r_pair(re[1], im[1], re[3], im[3], kH, kH);
+		wf_c2r_pair(re[4], im[4], re[7], im[7], kC8, kS8);
+		wf_c2r_pair(re[5], im[5], re[6], im[6], kS8, kC8);
+	} else {
+#pragma unroll
+		for (int q = 0; q < 4; ++q) wf_c2r_pair(re[q], im[q], re[7 - q], im[7 - q], wr[q], wi[q]);
+	}
+#pragma unroll
+	for (int q = 0; q < 4; ++q) wf_c2r_pair(re[8 + q], im[8 + q], re[15 - q], im[15 - q], wr[4 + q], wi[4 + q]);
+}
+// The same for a transform whose result is known to be real (the input is real and even): real parts only, 7 instead
+// of 12 instructions per pair.  The imaginary parts are left unspecified.
+__device__ __forceinline__ void wf_r2c_pair_re(double &kr, double ki, double &mr, double mi, double wr, double wi) {
+	const double sx = kr + mr, dx = kr - mr, dy = ki + mi;
+	const double ox = fma(wr, dy, wi * dx);
+	kr = sx + ox;
+	mr = sx - ox;
+}
+__device__ __forceinline__ void wf_r2c_unpack_re(double (&re)[16], const double (&im)[16], double &nyq,
+												  const double2 *__restrict__ tw_, int lane) {
+	const double2 *__restrict__ tw = tw_fresh(tw_);
+	double wr[8], wi[8];
+	wf_tw_real(tw, lane, wr, wi);
+	nyq = 0.0;
+	if (lane == 0) {
+		const double a = re[0], b = im[0];
+		re[0] = 2.0 * (a + b);
+		nyq = 2.0 * (a - b);
+		re[2] = 2.0 * re[2];
+		wf_r2c_pair_re(re[1], im[1], re[3], im[3], kH, kH);
+		wf_r2c_pair_re(re[4], im[4], re[7], im[7], kC8, kS8);
+		wf_r2c_pair_re(re[5], im[5], re[6], im[6], kS8, kC8);
+	} else {
+#pragma unroll
+		for (int q = 0; q < 4; ++q) wf_r2c_pair_re(re[q], im[q], re[7 - q], im[7 - q], wr[q], wi[q]);
+	}
+#pragma unroll
+	for (int q = 0; q < 4; ++q) wf_r2c_pair_re(re[8 + q], im[8 + q], re[15 - q], im[15 - q], wr[4 + q], wi[4 + q]);
+}
+// wf_c2r_pack for a REAL spectrum (re[] in, nyq = Y[1024]; im[] is written)
+__device__ __forceinline__ void wf_c2r_pair_re(double &kr, double &ki, double &mr, double &mi, double wr, double wi) {
+	const double ex = kr + mr, dx = kr - mr;
+	const double o = dx * wr;
+	kr = fma(dx, wi, ex); ki = o;
+	mr = fma(-dx, wi, ex); mi = o;
+}
+__device__ __forceinline__ void wf_c2r_pack_re(double (&re)[16], double (&im)[16], double nyq, const double2 *__restrict__ tw_,
+												int lane) {
+	const double2 *__restrict__ tw = tw_fresh(tw_);
+	double wr[8], wi[8];
+	wf_tw_real(tw, lane, wr, wi);
+	if (lane == 0) {
+		const double y0 = re[0];
+		re[0] = y0 + nyq; im[0] = y0 - nyq;
+		re[2] = 2.0 * re[2]; im[2] = 0.0;
+		wf_c2r_pair_re(re[1], im[1], re[3], im[3], kH, kH);
+		wf_c2r_pair_re(re[4], im[4], re[7], im[7], kC8, kS8);
+		wf_c2r_pair_re(re[5], im[5], re[6], im[6], kS8, kC8);
+	} else {
+#pragma unroll
+		for (int q = 0; q < 4; ++q) wf_c2r_pair_re(re[q], im[q], re[7 - q], im[7 - q], wr[q], wi[q]);
+	}
+#pragma unroll
+	for (int q = 0; q < 4; ++q) wf_c2r_pair_re(re[8 + q], im[8 + q], re[15 - q], im[15 - q], wr[4 + q], wi[4 + q]);
+}
+// sum over the wavefront, in every lane (and in scalar registers)
+__device__ __forceinline__ double wave_sum_all(double v) { return uniform_d(wave_sum(v)); }
+
+// bin held by slot 4 g + q of the paired layout
+__device__ __forceinline__ int wf_bin(int lane, int g, int q) {
+	const int j = g == 0 ? lane : g == 1 ? (lane ? 256 - lane : 128) : g == 2 ? 64 + lane : 192 - lane;
+	return j + 256 * q;
+}
+
+// ---- lean log / exp ------------------------------------------------------------------------------------------------------
+// log(x) for finite x > 0 to ~3e-16 absolute (relative for |log x| > 1): x = 2^e m, m in [1/2, 1); the top seven mantissa
+// bits pick c_i with (1 / c_i, log c_i) tabulated; log m = log c_i + log1p(r), r = m / c_i - 1, |r| < 2^-8, degree-6 series.
+// 14 vector instructions and one 16-byte load against ocml's 98 (double-double arithmetic for the last bit, which nothing
+// here needs: the values are envelope logarithms compared at 1e-7).  Anything else (0, negative, inf, NaN) goes to libm.
+// wf_log_fast: the arithmetic alone (garbage outside finite x > 0); wf_log_ok: whether x is inside.
+__device__ __forceinline__ double wf_log_fast(double x, const double2 *__restrict__ tw) {
+	const int e = __builtin_amdgcn_frexp_exp(x);
+	const double m = __builtin_amdgcn_frexp_mant(x);
+	const int i = (__double2hiint(m) >> 13) & 127;
+	const double2 c = tw_load(tw + kTwLog, i);
+	const double r = fma(m, c.x, -1.0);
+	double q = fma(r, -1.0 / 6.0, 0.2);
+	q = fma(r, q, -0.25);
+	q = fma(r, q, 1.0 / 3.0);
+	q = fma(r, q, -0.5);
+	const double p = fma(r * r, q, r);
+	return fma((double)e, 0.69314718055994530942, c.y) + p;
+}
+__device__ __forceinline__ bool wf_log_ok(double x) { return x > 0.0 && x < __builtin_huge_val(); }
+__device__ __noinline__ double wf_log_libm(double x) { return log(x); }
+__device__ __forceinline__ double wf_log(double x, const double2 *__restrict__ tw) {
+	double res = wf_log_fast(x, tw);
+	if (!wf_log_ok(x)) res = wf_log_libm(x);
+	return res;
+}
+// exp(x) to ~2e-16 relative: x = (64 k + j) ln2 / 64 + r, |r| <= ln2 / 128; 2^{j/64} tabulated, degree-5 series.
+__device__ __forceinline__ double tw_load_d(const double2 *tw, int idx) {
+	typedef const double __attribute__((address_space(1))) *gptr;
+	return ((gptr)tw)[idx];
+}
+__device__ __forceinline__ double wf_exp(double x, const double2 *__restrict__ tw) {
+	const double n = rint(x * 0x1.71547652b82fep+6);  // 64 / ln 2
+	double r = fma(n, -0x1.62e42feep-7, x);            // ln2 / 64: leading 32 bits (n times it is exact)
+	r = fma(n, -0x1.a39ef35793c76p-39, r);             // the rest
+	const int ni = (int)n;
+	const double t = tw_load_d(tw + kTwExp, ni & 63);
+	double q = fma(r, 1.0 / 120.0, 1.0 / 24.0);
+	q = fma(r, q, 1.0 / 6.0);
+	q = fma(r, q, 0.5);
+	const double p = fma(r * r, q, r);
+	return ldexp(fma(t, p, t), ni >> 6);
+}
+
+}  // namespace wc
