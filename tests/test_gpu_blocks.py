@@ -122,7 +122,8 @@ def cumsum_cases(n, rng):
 
 
 @pytest.mark.parametrize("threads,n", [(256, 1035), (256, 527), (256, 2048), (256, 4096), (256, 7), (256, 256), (256, 257),
-                                       (512, 2100), (512, 4096), (512, 300)])
+                                       (512, 2100), (512, 4096), (512, 300),
+                                       (64, 1035), (64, 1150), (64, 2291), (64, 2304), (64, 7), (64, 64), (64, 65), (64, 1153)])
 def test_cumulative_sum_is_the_sequential_one_bit_for_bit(hooks, threads, n):
     v = cumsum_cases(n, np.random.default_rng(threads + n))
     got = hooks.cumsum(v, threads)
@@ -136,6 +137,7 @@ def test_cumulative_sum_of_many_random_spectra(hooks):
     v = np.exp(rng.normal(size=(400, 1100)) * rng.uniform(0.1, 8.0, (400, 1))) * 10.0 ** rng.uniform(-20, 10, (400, 1))
     got = hooks.cumsum(v, 256)
     assert np.array_equal(got, sequential(v))
+    assert np.array_equal(hooks.cumsum(v, 64), sequential(v))  # the one-wavefront form (seq_cumsum_nonneg_wave)
     # a tree-ordered sum is NOT what the reference computes: the test above would not pass with one
     tree = np.cumsum(v.astype(np.longdouble), axis=1).astype(np.float64)
     assert not np.array_equal(tree, sequential(v))

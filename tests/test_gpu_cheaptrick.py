@@ -118,3 +118,26 @@ def test_cheaptrick_options_golden(wca):
         sp = wca.CheapTrick(fs, **kw).compute(x, tpos, f0)
         assert sp.shape[1] == rows.shape[1], name
         assert rel(sp[::stride], rows) < SP_REL and rel(sp.sum(1), rowsum) < SP_REL, name
+
+
+def test_cheaptrick_one_wavefront_kernel_against_the_block_kernel_and_frames_it_leaves_out(wca, port, monkeypatch):
+    """48 kHz default: one wavefront per frame (ct_wave_kernel).  Against the workgroup-per-frame kernel on the same input, and
+    on a contour with F0 above what its LDS holds (~2 kHz), which the block kernel picks up behind it."""
+    fs = 48000
+    x = make_utterance(fs, 0.5, 98)
+    tpos, f0 = port.harvest(x, fs)
+    f0 = f0.copy()
+    f0[10:20] = 2500.0
+    f0[30:34] = 1900.0
+    wca.rng_set_position(777)
+    a = wca.CheapTrick(fs).compute(x, tpos, f0)
+    end = wca.rng_get_position()
+    monkeypatch.setenv("WC_CT_IMPL", "block")
+    wca.rng_set_position(777)
+    b = wca.CheapTrick(fs).compute(x, tpos, f0)
+    assert wca.rng_get_position() == end
+    port.rng_seek(777)
+    ref = port.cheaptrick(x, fs, tpos, f0)
+    port.rng_reset()
+    assert rel(a, b) < SP_REL
+    assert rel(a, ref) < SP_REL

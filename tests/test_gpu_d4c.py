@@ -93,20 +93,19 @@ def test_d4c_edges(wca, port):
 
 
 @pytest.mark.parametrize("fs", [16000, 48000])
-def test_d4c_fused_and_split_schedules_agree(wca, port, fs):
-    """default: frames / band / rows kernels; WC_D4C_SPLIT=0: one fused kernel.  Same arithmetic, so identical rows
-    (the pruned band FFT of the split kernel at 48 kHz is bit-identical to running all passes)."""
-    import os
+def test_d4c_fused_and_split_schedules_agree(wca, port, fs, monkeypatch):
+    """workgroup-per-frame kernels (WC_D4C_IMPL=block): frames / band / rows kernels against WC_D4C_SPLIT=0, one fused kernel.
+    Same arithmetic, so identical rows (the pruned band FFT of the split kernel at 48 kHz is bit-identical to running all
+    passes)."""
+    monkeypatch.setenv("WC_D4C_IMPL", "block")
     x = make_utterance(fs, 0.6, 4321)
     tpos, f0 = port.harvest(x, fs)
     fft = wca.cheaptrick_fft_size(fs)
     wca.rng_set_position(0)
     a = wca.D4C(fs).compute(x, tpos, f0, fft)
-    os.environ["WC_D4C_SPLIT"] = "0"
-    try:
-        d = wca.D4C(fs)
-    finally:
-        del os.environ["WC_D4C_SPLIT"]
+    monkeypatch.setenv("WC_D4C_SPLIT", "0")
+    d = wca.D4C(fs)
+    monkeypatch.delenv("WC_D4C_SPLIT")
     wca.rng_set_position(0)
     b = d.compute(x, tpos, f0, fft)
     wca.rng_set_position(0)
@@ -124,3 +123,25 @@ def test_d4c_threshold_golden(wca):
         wca.rng_set_position(0)
         ap = wca.D4C(fs, threshold=thr).compute(x, tpos, f0, 1024)
         assert np.abs(ap[::stride] - rows).max() < AP_ABS and np.abs(ap.sum(1) - rowsum).max() < AP_ABS * 1024, name
+
+
+def test_d4c_two_wavefront_kernels_against_the_block_kernels_and_frames_they_leave_out(wca, port, monkeypatch):
+    """48 kHz default: two wavefronts per frame (d4c2_*).  Against the workgroup-per-frame kernels on the same input, and on a
+    contour with F0 above what their LDS holds (~1.4 kHz), which the block kernel picks up behind them."""
+    fs = 48000
+    x = make_utterance(fs, 0.5, 99)
+    tpos, f0 = port.harvest(x, fs)
+    f0 = f0.copy()
+    f0[10:20] = 1800.0   # frames the two-wavefront kernel leaves out
+    f0[30:34] = 1300.0   # just inside
+    fft = wca.cheaptrick_fft_size(fs)
+    wca.rng_set_position(0)
+    a = wca.D4C(fs).compute(x, tpos, f0, fft)
+    monkeypatch.setenv("WC_D4C_IMPL", "block")
+    wca.rng_set_position(0)
+    b = wca.D4C(fs).compute(x, tpos, f0, fft)
+    port.rng_reset()
+    ref = port.d4c(x, fs, tpos, f0, fft)
+    port.rng_reset()
+    assert np.abs(a - b).max() < AP_ABS
+    assert np.abs(a - ref).max() < AP_ABS

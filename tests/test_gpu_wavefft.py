@@ -23,7 +23,7 @@ def hooks():
         @staticmethod
         def fft(kind, x):
             x = np.ascontiguousarray(x, dtype=np.float64)
-            n_in, n_out = (2050, 2048) if kind == 1 else (2048, 2050)
+            n_in, n_out = {0: (2048, 2050), 1: (2050, 2048), 2: (2048, 2050), 3: (4096, 4098)}[kind]
             batch = x.size // n_in
             out = np.empty(batch * n_out)
             rc = L.wc_debug_wave_fft(kind, batch, x.ctypes.data_as(dp), out.ctypes.data_as(dp))
@@ -74,6 +74,17 @@ def test_wave_transforms_batched_against_numpy(hooks):
     got = hooks.fft(2, xz).reshape(batch, n // 2 + 1, 2)
     want = np.conj(np.fft.rfft(xz, axis=1))
     assert np.abs(got[..., 0] + 1j * got[..., 1] - want).max() < 1e-12
+
+
+def test_two_wavefront_transform_of_4096_points(golden, hooks):
+    n = 4096
+    got = hooks.fft(3, golden[f"fft/r2c_in_{n}"]).reshape(n // 2 + 1, 2)
+    want = golden[f"fft/r2c_out_{n}"]
+    assert np.abs(got - want).max() < 1e-13 * np.abs(want).max()
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((19, n))
+    got = hooks.fft(3, x).reshape(19, n // 2 + 1, 2)
+    assert np.abs(got[..., 0] + 1j * got[..., 1] - np.conj(np.fft.rfft(x, axis=1))).max() < 2e-12
 
 
 def test_lean_log_and_exp(hooks):

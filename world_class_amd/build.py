@@ -21,8 +21,11 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libworldclass_hip.so")
 OBJ = os.path.join(HERE, "_obj")
 EXTRA = os.environ.get("WC_EXTRA_FLAGS", "").split()
+# -simplifycfg-sink-common=false: where a wavefront's lane 0 takes a branch of its own on the register-resident transforms
+# (wc_wavefft.hpp), sinking the branches' common tail turns static register-array indices into dynamic ones and the arrays
+# into scratch memory
 FLAGS = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics", "-Wall",
-         "-Wno-unused-function", "-Wno-unused-result"]
+         "-Wno-unused-function", "-Wno-unused-result", "-mllvm", "-simplifycfg-sink-common=false"]
 HASH_MARKER = b"WC_SOURCE_HASH="
 
 

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "wc_device.hpp"
@@ -319,8 +320,6 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_CT_WAVE_OCC, WC_CT_WAVE_OCC))) void ct_wave_kernel(CtArgs a) {
 	constexpr int N = 2048, M = 1024;
 	__shared__ __attribute__((aligned(16))) double L[kWfLds];
-	__shared__ double scr[64 + 2];
-	__shared__ double red[2];
 	const int lane = threadIdx.x;
 	const long long g = xcd_frame(blockIdx.x, a.total_frames);
 	if (g >= a.total_frames) return;
@@ -349,37 +348,53 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_CT_WAVE_O
 		cd = uniform_d(cd);
 	}
 	// walks the live slots (whole groups of four slots beyond the window are skipped: uniform branches) with the raw window
-	// values of the slot's two samples, advanced by a rotation recurrence from the exact start phases
-	auto walk = [&](auto &&body) {
+	// values of the slot's two samples, advanced by a rotation recurrence from the exact start phases.  LOADS = 1: the group's
+	// sixteen loads (signal and draws) are issued together and fenced off from their uses, so that they are in flight at once
+	// (left alone, the scheduler waits for every one of them in turn).
+	auto walk = [&](auto loads_c, auto &&body) {
+		constexpr int LOADS = decltype(loads_c)::value;
 		double ce = ce0, se = se0, co = co0, so = so0;
 #pragma unroll
-		for (int q = 0; q < 16; ++q) {
-			if ((q & 3) == 0 && q * 128 >= wl) break;
-			const int i0 = 2 * lane + 128 * q;
-			const double We = (i0 < wl) ? fma(0.5, ce, 0.5) : 0.0;
-			const double Wo = (i0 + 1 < wl) ? fma(0.5, co, 0.5) : 0.0;
-			body(q, i0, We, Wo);
-			const double cen = fma(ce, cd, -(se * sd)), con = fma(co, cd, -(so * sd));
-			se = fma(se, cd, ce * sd);
-			so = fma(so, cd, co * sd);
-			ce = cen;
-			co = con;
+		for (int qg = 0; qg < 16; qg += 4) {
+			if (qg * 128 >= wl) break;
+			double xs[8];
+			uint32_t ns[8];
+			if (LOADS) {
+#pragma unroll
+				for (int k = 0; k < 8; ++k) {
+					const int i = 2 * lane + 128 * (qg + (k >> 1)) + (k & 1);
+					xs[k] = x[clampi(base + i, 0, x_last)];
+					ns[k] = rng[i < wl ? i : 0];
+				}
+				WF_SCHED_FENCE();
+			}
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const int q = qg + k, i0 = 2 * lane + 128 * q;
+				const double We = (i0 < wl) ? fma(0.5, ce, 0.5) : 0.0;
+				const double Wo = (i0 + 1 < wl) ? fma(0.5, co, 0.5) : 0.0;
+				body(q, i0, We, Wo, LOADS ? xs[2 * k] : 0.0, LOADS ? xs[2 * k + 1] : 0.0, LOADS ? ns[2 * k] : 0u, LOADS ? ns[2 * k + 1] : 0u);
+				const double cen = fma(ce, cd, -(se * sd)), con = fma(co, cd, -(so * sd));
+				se = fma(se, cd, ce * sd);
+				so = fma(so, cd, co * sd);
+				ce = cen;
+				co = con;
+			}
 		}
 	};
 	double re[16], im[16];
 #pragma unroll
 	for (int q = 0; q < 16; ++q) re[q] = im[q] = 0.0;
 	double ssq = 0.0;
-	walk([&](int, int, double We, double Wo) { ssq = fma(Wo, Wo, fma(We, We, ssq)); });
+	walk(std::integral_constant<int, 0>(), [&](int, int, double We, double Wo, double, double, uint32_t, uint32_t) { ssq = fma(Wo, Wo, fma(We, We, ssq)); });
 	ssq = wave_sum_all(ssq);
 	const double hr = 0.5 * (1.0 / sqrt(ssq));  // half the window norm: the transform below then yields X, not 2 X
 	double s1 = 0.0, s2 = 0.0;
-	walk([&](int q, int i0, double We, double Wo) {
+	walk(std::integral_constant<int, 1>(), [&](int q, int i0, double We, double Wo, double xe, double xo, uint32_t re_, uint32_t ro_) {
 		const bool le = i0 < wl, lo = i0 + 1 < wl;
 		const double we = We * hr, wo = Wo * hr;
-		const double xe = x[clampi(base + i0, 0, x_last)], xo = x[clampi(base + i0 + 1, 0, x_last)];
-		const double ne = randn_at(rng, le ? i0 : 0) * (0.5 * 0.000000000000001);
-		const double no = randn_at(rng, lo ? i0 + 1 : 0) * (0.5 * 0.000000000000001);
+		const double ne = (re_ / 268435456.0 - 6.0) * (0.5 * 0.000000000000001);
+		const double no = (ro_ / 268435456.0 - 6.0) * (0.5 * 0.000000000000001);
 		re[q] = le ? fma(xe, we, ne) : 0.0;
 		im[q] = lo ? fma(xo, wo, no) : 0.0;
 		s1 += re[q] + im[q];
@@ -388,7 +403,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_CT_WAVE_O
 	s1 = wave_sum_all(s1);
 	s2 = wave_sum_all(s2);
 	const double wc = s1 / s2;
-	walk([&](int q, int, double We, double Wo) {
+	walk(std::integral_constant<int, 0>(), [&](int q, int, double We, double Wo, double, double, uint32_t, uint32_t) {
 		re[q] = fma(-(We * hr), wc, re[q]);
 		im[q] = fma(-(Wo * hr), wc, im[q]);
 	});
@@ -446,8 +461,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_CT_WAVE_O
 			L[b - lane] = pw[0] * fs * (1.0 / N);
 			L[M + b + lane] = pw[7] * fs * (1.0 / N);
 		}
-		__syncthreads();
-		seq_cumsum_nonneg<64>(L, len, scr, red, lane);
+		wf_fence();
+		seq_cumsum_nonneg_wave<18>(L, len, lane);
 		const double step = (double)fs / N;
 		const double origin_axis = -(b - 0.5) * fs / N;
 		const double c_lo = (-width / 2.0 - origin_axis) / step, c_hi = ((-width / 2.0 + width) - origin_axis) / step;

@@ -256,7 +256,11 @@ Device *current_device() {
 		// tables of the wavefront transforms behind the main one (wc_wavefft.hpp): the second stage's twiddles row by row,
 		// and the arguments of the lean log / exp
 		for (int k = 0; k < 16; ++k)
-			for (int r = 0; r < 16; ++r) tw[kTwT2 + 16 * k + r] = tw[(16 * r * k) % kTwiddleN];
+			for (int r = 0; r < 16; ++r) tw[kTwT2 + 16 * r + k] = tw[(16 * r * k) % kTwiddleN];
+		for (int r = 1; r <= 3; ++r)
+			for (int j = 0; j < 256; ++j) tw[kTwP3 + 256 * (r - 1) + j] = tw[(4 * r * j) % kTwiddleN];
+		for (int n = 0; n <= 1024; ++n) tw[kTwU + n] = tw[2 * n];
+		for (int j = 0; j < 1024; ++j) tw[kTwUo + j] = tw[2 * j + 1];
 		for (int i = 0; i < 128; ++i) {
 			const double c = 0.5 + (i + 0.5) / 256.0, invc = 1.0 / c;
 			tw[kTwLog + i] = make_double2(invc, (double)-logl((long double)invc));

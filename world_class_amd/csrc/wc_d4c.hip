@@ -14,12 +14,16 @@
 // The noise draws come from the exact stream positions of the reference's serial order: all
 // LoveTrain frames first, then the gated frames (RNG draw-count contract).
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "wc_device.hpp"
 #include "wc_internal.hpp"
 #include "wc_frames.hpp"
+#include "wc_wavefft.hpp"
 
 namespace wc {
 
@@ -44,6 +48,8 @@ struct D4cArgs {
 	long long total_frames;
 	int fs, fft_size_out, n_ap, window_length;
 	double threshold;
+	long long sgd_stride;  // doubles per frame in sgd
+	int rare_only;  // d4c_frames_kernel behind d4c2_frames_kernel: only the frames that one leaves out (d4c2_can)
 };
 
 // F0-adaptive window of reference src/d4c.cpp:246-303 for the calling block; each thread keeps its
@@ -181,6 +187,14 @@ __device__ __forceinline__ void linear_smoothing_lds(const double *P, double *S,
 	__syncthreads();
 }
 
+// Which gated frames the two-wavefront kernels (d4c2_*, N = 4096) take: their 18 KB of LDS hold the mirrored segment of the
+// widest smoothing (2049 + 2 b + 1 terms, b = f0 N / fs + 1) and the low bins of the DC correction for F0 below ~1.4 kHz at
+// 48 kHz (Harvest's ceiling is 800 Hz).  Frames above that go through d4c_frames_kernel, launched behind with rare_only.
+__device__ __forceinline__ bool d4c2_can(double f0, int fs) {
+	const int v = (int)(f0 * 4096 / fs);
+	return v + 1 <= 120 && v + 2 <= 122;
+}
+
 // number of draws of one frame's LoveTrain window / of its three D4C windows
 __global__ void d4c_lt_count_kernel(const double *__restrict__ f0, long long total, int fs, uint32_t *__restrict__ cnt) {
 	long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -269,6 +283,7 @@ __global__ __launch_bounds__(T, T >= 1024 ? 4 : (2 * T) / 256) void d4c_frames_k
 	if (g >= a.total_frames) return;
 	const double f0v = a.f0[g];
 	if (f0v == 0.0 || a.ap0[g] <= a.threshold) return;  // reference :147
+	if (a.rare_only && d4c2_can(fmax(47.0, f0v), a.fs)) return;
 	const int u = find_utt(a.utts, a.n_utt, g);
 	const UttDesc ud = a.utts[u];
 	const double *__restrict__ x = a.x + ud.x_off;
@@ -374,7 +389,7 @@ __global__ __launch_bounds__(T, T >= 1024 ? 4 : (2 * T) / 256) void d4c_frames_k
 	return;
 #endif
 	if (SPLIT) {  // the band loop runs as its own kernel (one band per workgroup, leaner and with more waves in flight)
-		double *__restrict__ dst = a.sgd + g * (long long)(M + 1);
+		double *__restrict__ dst = a.sgd + g * a.sgd_stride;
 		for (int k = tid; k <= M; k += T) dst[k] = Cc[k];
 		return;
 	}
@@ -545,7 +560,7 @@ __global__ __launch_bounds__(T, T >= 1024 ? 8 : (4 * T) / 256) void d4c_band_ker
 	const int boundary = mround(N * 8.0 / wln);
 	const int bins = M + 1;
 	const unsigned int K = (unsigned int)(bins - boundary - 1);
-	const double *__restrict__ sgd = a.sgd + g * (long long)(M + 1);
+	const double *__restrict__ sgd = a.sgd + g * a.sgd_stride;
 	const int center = (int)(3000.0 * (bnd + 1) * N / fs);
 	for (int i = tid; i < 4 * 256; i += T) (&hist[0][0])[i] = 0u;
 	if constexpr (M == 2048 && WC_D4C_PRUNE) {
@@ -692,6 +707,515 @@ __global__ __launch_bounds__(256) void d4c_rows_kernel(D4cArgs a) {
 	}
 }
 
+
+// ==== N = 4096 (sampling rates above 24 kHz): one wavefront per frame, no barrier ==========================================
+// The same arithmetic as the kernels above on the register-resident transforms of wc_wavefft.hpp.  A 4096-point real
+// transform is two independent 1024-point complex ones (even and odd bins, wc_wavefft.hpp "even / odd split"), which the
+// wavefront runs one after the other: 16 complex points per lane, two LDS exchanges per half, nothing shared with another
+// wavefront, so no workgroup barrier anywhere (a first version with two cooperating wavefronts per frame spent more than
+// half its time in the barriers around the exchanges: 7.9 ms against 3.7 ms without them for d4c_frames per 64
+// utterances).  Bins stay in the lane that computed them: slot 4 g + q of parity p holds bin 2 (j_g + 256 q) + p.
+// LDS: 18.5 KB per frame wavefront (exchange buffer = mirrored segment of the smoothings), 9.8 KB per band wavefront,
+// instead of 64 KB / 36 KB per 8-wavefront workgroup.  Deviations from the kernels above, all at the 1e-15 level: the
+// halving of the real-transform unpacking is folded into scale factors; the smoothings' two interpolation abscissae are
+// k + c_lo, k + c_hi with one pair per frame; (hi - lo) * (1 / width).  The window is generated once per half (the
+// wavefront cannot hold a frame's 4096 samples next to a transform in flight): 6 instead of 3 window generations per frame.
+constexpr long long kD4Row = 4160;  // doubles per frame of the group-delay array when d4c2_frames_kernel parks its halves in it
+constexpr int kD4Lds = 2304;  // doubles: the smoothings' 2049 + 2 b + 1 terms, b <= 120 (d4c2_can); the exchange buffer is its head
+
+// F0-adaptive window of reference src/d4c.cpp:246-303 as the strided packed input of one half of the transform: slot q
+// holds z[n] +- z[n + 1024] for n = lane + 64 q, z[m] = (sample 2 m, sample 2 m + 1) of the mean-removed windowed signal
+// (minus for the odd half; windows longer than 2048 samples -- F0 below 94 Hz at 48 kHz -- reach the second term).
+// type 1 = Hanning, 2 = Blackman.  rng: the frame's draws for this window.  weighted: sample i times (i + 1) (the second
+// transform of the centroid).  Returns the window length; sumsq = sum of squares of the (unweighted) samples.
+__device__ __forceinline__ int d4c2_windowed(int type, const double *__restrict__ x, int x_last, int fs, double f0, double pos, double ratio,
+											 const uint32_t *__restrict__ rng, int odd, bool weighted, double (&re)[16],
+											 double (&im)[16], double &sumsq, int lane) {
+	WC_FRESH(lane);
+	const int hw = __builtin_amdgcn_readfirstlane(mround(ratio * fs / f0 / 2.0));
+	const int wl = 2 * hw + 1;
+	const int base = __builtin_amdgcn_readfirstlane(mround(pos * fs + 0.001)) - hw;
+	const double c1 = 2.0 / ratio / fs;
+	double ce0, se0, co0, so0, cd, sd;  // angles in units of pi
+	sincospi(f0 * (c1 * (2 * lane - hw)), &se0, &ce0);
+	sincospi(f0 * (c1 * (2 * lane + 1 - hw)), &so0, &co0);
+	sincospi(f0 * (c1 * 128.0), &sd, &cd);
+	sd = uniform_d(sd);
+	cd = uniform_d(cd);
+	// Hanning 0.5 c + 0.5; Blackman 0.42 + 0.5 c + 0.08 cos 2theta = 0.34 + c (0.5 + 0.16 c): a0 + c (0.5 + a2 c) for both
+	const double a0 = type == 1 ? 0.5 : 0.34, a2 = type == 1 ? 0.0 : 0.16;
+	auto win = [&](double c) { return fma(c, fma(a2, c, 0.5), a0); };
+	// Walks window samples 2 lane + 128 q (+ 1), q = 0 .. 31 at most, in whole groups of four slots while they are live.  A
+	// group's sixteen loads (signal and draws) are issued together and fenced off from their uses, so that they are in flight
+	// at once (left alone, the scheduler waits for every one of them in turn).  LOADS: 0 none, 1 all groups, 2 second half only.
+	auto walk = [&](auto loads_c, auto &&body) {
+		constexpr int LOADS = decltype(loads_c)::value;
+		double ce = ce0, se = se0, co = co0, so = so0;
+#pragma unroll
+		for (int qg = 0; qg < 32; qg += 4) {
+			if (qg * 128 >= wl) break;
+			double xs[8];
+			uint32_t ns[8];
+			const bool ld = LOADS == 1 || (LOADS == 2 && qg >= 16);
+			if (ld) {
+#pragma unroll
+				for (int k = 0; k < 8; ++k) {
+					const int i = 2 * lane + 128 * (qg + (k >> 1)) + (k & 1);
+					xs[k] = x[clampi(base + i, 0, x_last)];
+					ns[k] = rng[i < wl ? i : 0];
+				}
+				WF_SCHED_FENCE();
+			}
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const int q = qg + k, i0 = 2 * lane + 128 * q;
+				const double We = (i0 < wl) ? win(ce) : 0.0, Wo = (i0 + 1 < wl) ? win(co) : 0.0;
+				// the windowed samples with their noise floor (reference :287-291)
+				const double ve = (ld && i0 < wl) ? fma(xs[2 * k], We, (ns[2 * k] / 268435456.0 - 6.0) * kSafe) : 0.0;
+				const double vo = (ld && i0 + 1 < wl) ? fma(xs[2 * k + 1], Wo, (ns[2 * k + 1] / 268435456.0 - 6.0) * kSafe) : 0.0;
+				body(q, i0, We, Wo, ve, vo);
+				const double cen = fma(ce, cd, -(se * sd)), con = fma(co, cd, -(so * sd));
+				se = fma(se, cd, ce * sd);
+				so = fma(so, cd, co * sd);
+				ce = cen;
+				co = con;
+			}
+		}
+	};
+#pragma unroll
+	for (int q = 0; q < 16; ++q) re[q] = im[q] = 0.0;
+	double s1 = 0.0, s2 = 0.0;
+	walk(std::integral_constant<int, 1>(), [&](int q, int, double We, double Wo, double ve, double vo) {
+		if (q < 16) { re[q] = ve; im[q] = vo; }  // (the second half is formed again below: no room to keep it)
+		s1 += ve + vo;
+		s2 += We + Wo;
+	});
+	s1 = wave_sum_all(s1);
+	s2 = wave_sum_all(s2);
+	const double wc = s1 / s2;
+	sumsq = 0.0;
+	walk(std::integral_constant<int, 2>(), [&](int q, int i0, double We, double Wo, double ve, double vo) {
+		if (q < 16) { ve = re[q]; vo = im[q]; }
+		ve = fma(-We, wc, ve);
+		vo = fma(-Wo, wc, vo);
+		sumsq = fma(vo, vo, fma(ve, ve, sumsq));
+		if (weighted) { ve *= i0 + 1.0; vo *= i0 + 2.0; }
+		if (q < 16) { re[q] = ve; im[q] = vo; }
+		else if (odd) { re[q & 15] -= ve; im[q & 15] -= vo; }
+		else { re[q & 15] += ve; im[q & 15] += vo; }
+	});
+	sumsq = wave_sum_all(sumsq);
+	return wl;
+}
+// number of leading four-slot groups of a half's input that are not all zero
+__device__ __forceinline__ int d4c2_groups(int wl) { return wl > 2048 ? 4 : (wl + 511) >> 9; }
+
+#ifndef WC_D4C2_LT_OCC
+#define WC_D4C2_LT_OCC 2
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_D4C2_LT_OCC, WC_D4C2_LT_OCC))) void d4c2_lovetrain_kernel(D4cArgs a) {
+	constexpr int N = 4096, M = 2048;
+	__shared__ __attribute__((aligned(16))) double L[kWfLds];
+	const int lane = threadIdx.x;
+	const long long g = xcd_frame(blockIdx.x, a.total_frames);
+	if (g >= a.total_frames) return;
+	const int bins_out = a.fft_size_out / 2 + 1;
+	double *__restrict__ row = a.ap + g * (long long)bins_out;
+	const double f0v = a.f0[g];
+	double ap0 = 0.0;
+	if (f0v != 0.0) {
+		const int u = find_utt(a.utts, a.n_utt, g);
+		const UttDesc ud = a.utts[u];
+		const int fs = a.fs;
+		const double f0c = uniform_d(fmax(f0v, 40.0));
+		// cumulative powers above 100 Hz up to 4000 Hz and 7900 Hz (reference :184-186, :226-235); a common factor (the
+		// unpacking's 2) does not matter to their ratio
+		const int b0 = (int)ceil(100.0 * N / fs);
+		const int b1 = (int)ceil(4000.0 * N / fs);
+		const int b2 = min((int)ceil(7900.0 * N / fs), M);
+		double p1 = 0.0, p2 = 0.0;
+#pragma unroll 1
+		for (int odd = 0; odd < 2; ++odd) {
+			double re[16], im[16], nyq, unused;
+			const int wl = d4c2_windowed(2, a.x + ud.x_off, ud.x_len - 1, fs, f0c, a.tpos[g], 3.0,
+											a.rng_table + (a.rng_off[g] - a.rng_base), odd, false, re, im, unused, lane);
+			wf_r2c4096_half(re, im, nyq, d4c2_groups(wl), L, a.tw, lane, odd);
+#pragma unroll
+			for (int gq = 0; gq < 4; ++gq) {
+				const int j = wf_j(lane, odd, gq);
+#pragma unroll
+				for (int q = 0; q < 4; ++q) {
+					const int k = 2 * (j + 256 * q) + odd;
+					const double p = fma(re[4 * gq + q], re[4 * gq + q], im[4 * gq + q] * im[4 * gq + q]);
+					p2 += (k > b0 && k <= b2) ? p : 0.0;
+					p1 += (k > b0 && k <= min(b1, b2)) ? p : 0.0;
+				}
+			}
+			if (odd == 0 && lane == 0 && b2 == M) {
+				p2 += nyq * nyq;
+				if (b1 >= M) p1 += nyq * nyq;
+			}
+		}
+		p1 = wave_sum_all(p1);
+		p2 = wave_sum_all(p2);
+		ap0 = p1 / p2;
+	}
+	const bool gate = !(f0v == 0.0 || ap0 <= a.threshold);  // reference :147
+	if (lane == 0) {
+		a.ap0[g] = ap0;
+		a.cnt[g] = gate ? (uint32_t)(3 * (2 * mround(4.0 * a.fs / fmax(47.0, f0v) / 2.0) + 1)) : 0u;
+	}
+	if (!gate) {
+		const double init_val = 1.0 - kSafe;
+		for (int k = lane; k < bins_out; k += 64) row[k] = init_val;
+	}
+}
+
+// A frame's per-bin values: v[p][4 g + q] = bin 2 (j_g + 256 q) + p, vM = bin 2048 (lane 0).
+struct D4Bins {
+	double v[2][16];
+	double vM;
+};
+// DCCorrection (reference src/world_common.cpp:61-80): only bins below upper - 1 <= 121 change, all in slot A_0 of either
+// parity (bins 2 lane, 2 lane + 1), from bins <= upper + 1 <= 123
+__device__ __forceinline__ void d4c2_dc_correction(D4Bins &s, double f0, int fs, double *L, int lane) {
+	constexpr int N = 4096;
+	WC_FRESH(lane);
+	const int upper = __builtin_amdgcn_readfirstlane(2 + (int)(f0 * N / fs));
+	const double dx = -(double)fs / N, rdx = 1.0 / dx;
+	L[2 * lane] = s.v[0][0];
+	L[2 * lane + 1] = s.v[1][0];
+	wf_fence();
+	auto rep = [&](int i) {
+		const double axis = (double)i * fs / N;
+		return interp1q_rcp(f0, dx, rdx, [&](int b) { return L[min(max(b, 0), 127)]; }, upper + 1, axis);
+	};
+	if (2 * lane < upper - 1) s.v[0][0] += rep(2 * lane);
+	if (2 * lane + 1 < upper - 1) s.v[1][0] += rep(2 * lane + 1);
+	wf_fence();
+}
+// LinearSmoothing (reference src/world_common.cpp:27-52, :82-116), in place.  NONNEG: the cumulative sum in the reference's
+// own sequential rounding (seq_cumsum_nonneg); otherwise scanned over the lanes.
+template <bool NONNEG>
+__device__ __forceinline__ void d4c2_smooth(D4Bins &s, double width, int fs, double *L, int lane) {
+	constexpr int N = 4096, M = 2048;
+	WC_FRESH(lane);
+	const int b = __builtin_amdgcn_readfirstlane((int)(width * N / fs) + 1);  // <= 120 (d4c2_can)
+	const int len = M + 2 * b + 1;
+	int jg[2][4];
+#pragma unroll
+	for (int p = 0; p < 2; ++p)
+#pragma unroll
+		for (int gq = 0; gq < 4; ++gq) jg[p][gq] = 2 * wf_j(lane, p, gq) + p;
+	// mirrored segment: position i holds bin b - i (i < b), bin i - b (b <= i < M + b), bin 2 M + b - i (M + b <= i <= M + 2 b).
+	// The low mirror comes from slot A_0 (bins 2 lane, 2 lane + 1), the high one from slot B_3 (bins 2048 - 2 lane, 2047 - 2 lane).
+#pragma unroll
+	for (int p = 0; p < 2; ++p)
+#pragma unroll
+		for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+			for (int q = 0; q < 4; ++q) L[jg[p][gq] + 512 * q + b] = s.v[p][4 * gq + q] * fs / N;
+	if (lane == 0) L[M + b] = s.vM * fs / N;
+	{
+		const int ke = 2 * lane, ko = 2 * lane + 1;
+		if (ke >= 1 && ke <= b) {
+			L[b - ke] = s.v[0][0] * fs / N;
+			L[M + b + ke] = s.v[0][7] * fs / N;  // bin 2048 - 2 lane
+		}
+		if (ko <= b) {
+			L[b - ko] = s.v[1][0] * fs / N;
+			L[M + b + ko] = s.v[1][7] * fs / N;  // bin 2047 - 2 lane
+		}
+	}
+	wf_fence();
+	if (NONNEG) {
+		seq_cumsum_nonneg_wave<36>(L, len, lane);
+	} else {
+		// every lane's chunk of <= 36 terms through registers: read at once, summed, scanned over the lanes, written at once
+		const int ch = (len + 63) / 64;
+		const int lo = min(lane * ch, len), n = min(len, lo + ch) - lo;
+		double c[36];
+#pragma unroll
+		for (int k = 0; k < 36; ++k) c[k] = L[min(lo + k, len - 1)];
+		wf_fence();
+		double loc = 0.0;
+#pragma unroll
+		for (int k = 0; k < 36; ++k) {
+			c[k] = (k < n) ? c[k] : 0.0;
+			loc += c[k];
+		}
+		double run = wave_incl_scan(loc, lane) - loc;
+#pragma unroll
+		for (int k = 0; k < 36; ++k) {
+			run = c[k] + run;
+			if (k < n) L[lo + k] = run;
+		}
+		wf_fence();
+	}
+	const double step = (double)fs / N;
+	const double origin_axis = -(b - 0.5) * fs / N;
+	const double c_lo = (-width / 2.0 - origin_axis) / step, c_hi = ((-width / 2.0 + width) - origin_axis) / step;
+	const int i_lo = __builtin_amdgcn_readfirstlane((int)c_lo), i_hi = __builtin_amdgcn_readfirstlane((int)c_hi);
+	const double f_lo = uniform_d(c_lo - i_lo), f_hi = uniform_d(c_hi - i_hi);
+	const double rwidth = uniform_d(1.0 / width);
+	auto at = [&](int k) {
+		const double l0 = L[k + i_lo], l1 = L[k + i_lo + 1], h0 = L[k + i_hi], h1 = L[k + i_hi + 1];
+		return (fma(h1 - h0, f_hi, h0) - fma(l1 - l0, f_lo, l0)) * rwidth;
+	};
+#pragma unroll
+	for (int p = 0; p < 2; ++p)
+#pragma unroll
+		for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+			for (int q = 0; q < 4; ++q) s.v[p][4 * gq + q] = at(jg[p][gq] + 512 * q);
+	s.vM = at(M);
+	wf_fence();
+}
+
+#ifndef WC_D4C2_OCC
+#define WC_D4C2_OCC 2
+#endif
+// WC_D4C2_TRACE (development builds only): lane 0 stamps the shader clock at the phase boundaries of every gated frame into
+// the tail of the frame's row (doubles 4128 .. 4143), which WC_D4C_TRACE=<file> dumps after the call (tools/d4c_trace.py)
+#ifndef WC_D4C2_TRACE
+#define WC_D4C2_TRACE 0
+#endif
+#if WC_D4C2_TRACE
+#define D4_STAMP(i) do { if (lane == 0) reinterpret_cast<unsigned long long *>(park + 4128)[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define D4_STAMP(i) do { } while (0)
+#endif
+// gated frames up to the static group delay (reference :308-460), which the band kernel reads back
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_D4C2_OCC, WC_D4C2_OCC))) void d4c2_frames_kernel(D4cArgs a) {
+	constexpr int M = 2048;
+	__shared__ __attribute__((aligned(16))) double L[kD4Lds];
+	const int lane = threadIdx.x;
+	const long long g = xcd_frame(blockIdx.x, a.total_frames);
+	if (g >= a.total_frames) return;
+	const double f0v = a.f0[g];
+	if (f0v == 0.0 || a.ap0[g] <= a.threshold) return;  // reference :147
+	const int fs = a.fs;
+	const double f0 = uniform_d(fmax(47.0, f0v));
+	if (!d4c2_can(f0, fs)) return;
+	const int u = find_utt(a.utts, a.n_utt, g);
+	const UttDesc ud = a.utts[u];
+	const double *__restrict__ x = a.x + ud.x_off;
+	const int x_last = ud.x_len - 1;
+	const double pos = uniform_d(a.tpos[g]);
+	const uint32_t *__restrict__ rng = a.rng_table + (a.rng_off[g] - a.rng_base);
+	// Each half's results (centroid, power spectrum) wait in the frame's own row of the group-delay array (kD4Row doubles: four
+	// blocks of 1024) until both halves are through: nothing but the running products stays in registers across the
+	// transforms.  Every lane reads back what it wrote itself; the row's head is written for good at the end.
+	double *park = a.sgd + g * a.sgd_stride;
+	D4_STAMP(0);
+
+	// ---- static centroid (reference :339-405): at t -+ T0/4, Re S1 Re S2 + Im S1 Im S2 of the unit-energy windowed signal and
+	// of the same signal times (n + 1), and the power spectrum of the Hanning-windowed frame (reference :411-434); bin by
+	// bin, so half by half.  Jobs 0, 1: the centroid's two positions, job 2: the power spectrum, through one copy of the code.
+	const int wl = __builtin_amdgcn_readfirstlane(2 * mround(4.0 * fs / f0 / 2.0) + 1);
+	const int ng = d4c2_groups(wl);
+	double cenM = 0.0, spsM = 0.0;  // bin 2048 (lane 0, even half)
+#pragma unroll 1
+	for (int odd = 0; odd < 2; ++odd) {
+		double acc[16], accM = 0.0;
+#pragma unroll
+		for (int s = 0; s < 16; ++s) acc[s] = 0.0;
+#pragma unroll 1
+		for (int job = 0; job < 3; ++job) {
+			int ln = lane;
+			WC_FRESH(ln);  // (what derives from the lane index must not be hoisted out of the loops and spilled)
+			double ar[16], ai[16], re[16], im[16], sumsq, nyq1;
+			const double p = (job == 0) ? pos - 0.25 / f0 : (job == 1) ? pos + 0.25 / f0 : pos;
+			d4c2_windowed(job == 2 ? 1 : 2, x, x_last, fs, f0, p, 4.0, rng + (long long)job * wl, odd, false, ar, ai, sumsq, ln);
+			if (odd == 0 && job == 0) D4_STAMP(1);
+			// (the reference divides every sample by the norm: an ulp apart); half of it: the transforms below then yield X, not 2 X.
+			// The power spectrum's window is not normalised: its 2 X is put right by the 0.25 below.
+			const double pw = (job == 2) ? 1.0 : 0.5 * (1.0 / sqrt(sumsq));
+#pragma unroll
+			for (int q = 0; q < 16; ++q) {
+				re[q] = ar[q] * pw;
+				im[q] = ai[q] * pw;
+			}
+			wf_r2c4096_half(re, im, nyq1, ng, L, a.tw, lane, odd);
+			if (odd == 0 && job == 0) D4_STAMP(2);
+			if (job == 2) {
+#pragma unroll
+				for (int s = 0; s < 16; ++s) park[2048 + 1024 * odd + 64 * s + ln] = 0.25 * fma(re[s], re[s], im[s] * im[s]);
+				if (odd == 0) spsM = 0.25 * (nyq1 * nyq1);
+			} else {
+				double nyq2;
+				if (wl > 2048) {  // the weights (i + 1) differ between the two samples folded into a slot: form them again
+					d4c2_windowed(2, x, x_last, fs, f0, p, 4.0, rng + (long long)job * wl, odd, true, ar, ai, sumsq, ln);
+#pragma unroll
+					for (int q = 0; q < 16; ++q) { ar[q] *= pw; ai[q] *= pw; }
+				} else {
+#pragma unroll
+					for (int q = 0; q < 16; ++q) {
+						const int i0 = 2 * ln + 128 * q;
+						ar[q] *= pw * (i0 + 1.0);
+						ai[q] *= pw * (i0 + 2.0);
+					}
+				}
+				wf_r2c4096_half(ar, ai, nyq2, ng, L, a.tw, lane, odd);
+#pragma unroll
+				for (int s = 0; s < 16; ++s) acc[s] += fma(re[s], ar[s], im[s] * ai[s]);
+				accM += nyq1 * nyq2;
+				if (odd == 0 && job == 0) D4_STAMP(3);
+			}
+		}
+#pragma unroll
+		for (int s = 0; s < 16; ++s) park[1024 * odd + 64 * s + lane] = acc[s];
+		if (odd == 0) cenM = accM;
+		if (odd == 0) D4_STAMP(4);
+	}
+	D4_STAMP(5);
+	D4Bins cen, sps;
+#pragma unroll
+	for (int p = 0; p < 2; ++p)
+#pragma unroll
+		for (int s = 0; s < 16; ++s) {
+			cen.v[p][s] = park[1024 * p + 64 * s + lane];
+			sps.v[p][s] = park[2048 + 1024 * p + 64 * s + lane];
+		}
+	cen.vM = cenM;
+	sps.vM = spsM;
+	D4_STAMP(6);
+	d4c2_dc_correction(cen, f0, fs, L, lane);
+	d4c2_dc_correction(sps, f0, fs, L, lane);
+	D4_STAMP(7);
+	d4c2_smooth<true>(sps, f0, fs, L, lane);
+	D4_STAMP(8);
+	// ---- static group delay (reference :440-460) ----
+#pragma unroll
+	for (int p = 0; p < 2; ++p)
+#pragma unroll
+		for (int s = 0; s < 16; ++s) cen.v[p][s] = cen.v[p][s] / sps.v[p][s];
+	cen.vM = cen.vM / sps.vM;
+	// smoothed over f0 / 2, minus that smoothed once more over f0 (one copy of the code, run twice)
+#pragma unroll 1
+	for (int it = 0; it < 2; ++it) {
+		d4c2_smooth<false>(cen, it ? f0 : f0 / 2.0, fs, L, lane);
+		if (it == 0) sps = cen;
+	}
+	// (sps: once smoothed; cen: twice)
+	D4_STAMP(9);
+	double *dst = park;
+#pragma unroll
+	for (int p = 0; p < 2; ++p)
+#pragma unroll
+		for (int gq = 0; gq < 4; ++gq) {
+			const int j = 2 * wf_j(lane, p, gq) + p;
+#pragma unroll
+			for (int q = 0; q < 4; ++q) dst[j + 512 * q] = sps.v[p][4 * gq + q] - cen.v[p][4 * gq + q];
+		}
+	if (lane == 0) dst[M] = sps.vM - cen.vM;
+	D4_STAMP(10);
+}
+
+#ifndef WC_D4C2_BAND_OCC
+#define WC_D4C2_BAND_OCC 2
+#endif
+// one wavefront per (gated frame, band) (reference :466-503): Nuttall-windowed group delay (<= 1023 samples) -> the two
+// halves of the 4096-point transform with pruned leading stages -> power spectrum in registers (33 keys per lane) -> the sum
+// of the K = bins - boundary - 1 smallest powers by bisecting the bit patterns (non-negative doubles order like integers):
+// per step one 64-bit compare per key and the count from ballots in scalar registers; it stops as soon as a threshold has
+// exactly K keys below it (after ~log2(2^62 / gap between the K-th and the next key) steps), or with the K-th key itself.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_D4C2_BAND_OCC, WC_D4C2_BAND_OCC))) void d4c2_band_kernel(D4cArgs a) {
+	constexpr int N = 4096, M = 2048;
+	__shared__ __attribute__((aligned(16))) double L[kWfLds];
+	const int lane = threadIdx.x;
+	const int n_ap = a.n_ap;
+	const long long blk = xcd_frame(blockIdx.x, (long long)gridDim.x);
+	const long long g = blk / n_ap;
+	const int bnd = (int)(blk % n_ap);
+	if (g >= a.total_frames) return;
+	const double f0v = a.f0[g];
+	if (f0v == 0.0 || a.ap0[g] <= a.threshold) return;
+	const double f0 = fmax(47.0, f0v);
+	const int fs = a.fs;
+	const int wln = a.window_length, hwl = wln / 2;  // <= 1023 samples = 512 packed points: slots 0 .. 7
+	const int boundary = mround(N * 8.0 / wln);
+	const unsigned int K = (unsigned int)(M + 1 - boundary - 1);
+	const int center = (int)(3000.0 * (bnd + 1) * N / fs);
+	const double *__restrict__ src = a.sgd + g * a.sgd_stride + (center - hwl);
+	const int ng = wln > 512 ? 2 : 1;
+	double key[2][16], keyM = 0.0;
+#pragma unroll
+	for (int odd = 0; odd < 2; ++odd) {
+		// the packed windowed group delay, elements lane + 64 q (read again for the second half rather than held across the first)
+		double re[16], im[16], nyq;
+		{
+			double sv[16], nv[16];
+#pragma unroll
+			for (int k = 0; k < 16; ++k) {
+				const int i = min(2 * lane + 128 * (k >> 1) + (k & 1), wln - 1);
+				sv[k] = src[i];
+				nv[k] = a.nuttall[i];
+			}
+			WF_SCHED_FENCE();
+#pragma unroll
+			for (int q = 0; q < 16; ++q) {
+				re[q] = im[q] = 0.0;
+				if (q < 8) {
+					const int i0 = 2 * lane + 128 * q;
+					re[q] = (i0 < wln) ? sv[2 * q] * nv[2 * q] : 0.0;
+					im[q] = (i0 + 1 < wln) ? sv[2 * q + 1] * nv[2 * q + 1] : 0.0;
+				}
+			}
+		}
+		if (odd) wf_odd_twist(re, im, a.tw, lane, 8);
+		if (ng == 1) wdft16<+1, 1>(re, im);
+		else wdft16<+1, 2>(re, im);
+		wf_fft1024_dit_rest_p<+1>(re, im, L, a.tw, lane, odd);
+		if (odd) wf_r2c_unpack_odd(re, im, a.tw, lane);
+		else wf_r2c_unpack(re, im, nyq, a.tw, lane);  // 2 X: a common factor of all powers
+#pragma unroll
+		for (int s = 0; s < 16; ++s) key[odd][s] = fma(re[s], re[s], im[s] * im[s]);
+		if (!odd) keyM = nyq * nyq;  // lane 0
+	}
+	// largest key
+	double mx = (lane == 0) ? keyM : 0.0;
+#pragma unroll
+	for (int s = 0; s < 16; ++s) mx = fmax(mx, fmax(key[0][s], key[1][s]));
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_down(mx, o, 64));
+	mx = uniform_d(mx);
+	long long lo = -1, hi = __double_as_longlong(mx);
+	unsigned int c_lo = 0;
+	for (int it = 0; it < 64 && hi - lo > 1; ++it) {
+		const long long mid = lo + ((hi - lo) >> 1);
+		unsigned int c = (unsigned int)__popcll(__ballot(lane == 0 && __double_as_longlong(keyM) <= mid));
+#pragma unroll
+		for (int s = 0; s < 16; ++s) {
+			c += (unsigned int)__popcll(__ballot(__double_as_longlong(key[0][s]) <= mid));
+			c += (unsigned int)__popcll(__ballot(__double_as_longlong(key[1][s]) <= mid));
+		}
+		if (c >= K) hi = mid;
+		if (c <= K) { lo = mid; c_lo = c; }
+		if (c == K) break;
+	}
+	// sum of the K smallest = sum(keys <= lo) + (K - #{keys <= lo}) * (the key at hi), and the total
+	double low = 0.0, tot = 0.0;
+#pragma unroll
+	for (int p = 0; p < 2; ++p)
+#pragma unroll
+		for (int s = 0; s < 16; ++s) {
+			tot += key[p][s];
+			low += (__double_as_longlong(key[p][s]) <= lo) ? key[p][s] : 0.0;
+		}
+	if (lane == 0) {
+		tot += keyM;
+		low += (__double_as_longlong(keyM) <= lo) ? keyM : 0.0;
+	}
+	low = wave_sum_all(low);
+	tot = wave_sum_all(tot);
+	if (lane == 0) {
+		const double part = low + (double)(K - c_lo) * __longlong_as_double(hi);
+		const double cv = 10 * log10(part / tot);
+		a.coarse[g * kMaxBands + bnd] = fmin(0.0, cv + (f0 - 100) / 50.0);  // reference :326-328
+	}
+}
+
 }  // namespace wc
 
 using namespace wc;
@@ -700,6 +1224,7 @@ struct wc_d4c {
 	int fs, fft_size_d4c, fft_size_lt, n_ap, window_length;
 	double threshold;
 	bool split;  // band loop and row output as separate kernels (default; WC_D4C_SPLIT=0: one fused kernel)
+	bool wave2;  // 4096-point transforms by two wavefronts per frame (d4c2_*; default where they apply, WC_D4C_IMPL=block: never)
 	Device *dev;
 	DevBuf nuttall, utts, cnt, off, endpos, endpos2, ap0, sgd, coarse, d_x, d_tpos, d_f0, d_ap;
 	HostBuf h_stage;
@@ -761,7 +1286,8 @@ int d4c_enqueue(wc_d4c *d, hipStream_t s, int n_utt, const double *d_x, const in
 	if ((rc = d->ap0.reserve(sizeof(double) * total))) return rc;
 	const bool split = d->split;
 	if (split) {
-		if ((rc = d->sgd.reserve(sizeof(double) * (size_t)total * (d->fft_size_d4c / 2 + 1)))) return rc;
+		const bool rows2 = d->wave2 && d->fft_size_d4c == 4096 && d->window_length <= 1023;
+		if ((rc = d->sgd.reserve(sizeof(double) * (size_t)total * (rows2 ? (size_t)kD4Row : (size_t)(d->fft_size_d4c / 2 + 1))))) return rc;
 		if ((rc = d->coarse.reserve(sizeof(double) * (size_t)total * kMaxBands))) return rc;
 	}
 	if ((rc = d->endpos.reserve(sizeof(uint64_t) * n_utt))) return rc;
@@ -781,8 +1307,14 @@ int d4c_enqueue(wc_d4c *d, hipStream_t s, int n_utt, const double *d_x, const in
 	a.sgd = d->sgd.as<double>(); a.coarse = d->coarse.as<double>();
 	a.nuttall = d->nuttall.as<double>(); a.total_frames = total; a.fs = d->fs; a.fft_size_out = fft_size;
 	a.n_ap = d->n_ap; a.window_length = d->window_length; a.threshold = d->threshold;
+	a.rare_only = 0;
+	a.sgd_stride = (d->wave2 && split && d->fft_size_d4c == 4096 && d->window_length <= 1023) ? kD4Row : (long long)(d->fft_size_d4c / 2 + 1);
+	const long long blocks8 = ((total + 7) / 8) * 8;
+	const bool lt2 = d->wave2 && d->fft_size_lt == 4096;
+	const bool main2 = d->wave2 && split && d->fft_size_d4c == 4096 && d->window_length <= 1023;
 	if ((rc = dev->time_begin("d4c_lovetrain", s))) return rc;
-	switch (d->fft_size_lt) {
+	if (lt2) hipLaunchKernelGGL(d4c2_lovetrain_kernel, dim3((unsigned)blocks8), dim3(64), 0, s, a);
+	else switch (d->fft_size_lt) {
 		case 1024: launch_lt<1024>(a, s); break;
 		case 2048: launch_lt<2048>(a, s); break;
 		case 4096: launch_lt<4096>(a, s); break;
@@ -797,6 +1329,16 @@ int d4c_enqueue(wc_d4c *d, hipStream_t s, int n_utt, const double *d_x, const in
 	for (int part = 0; part < (split ? 2 : 1); ++part) {
 		const char *name = part == 0 ? "d4c_frames" : "d4c_bands";
 		if ((rc = dev->time_begin(name, s))) return rc;
+		if (main2 && part == 0) {
+			// one wavefront per frame; the frames it leaves out (F0 above ~1.4 kHz, d4c2_can) by the block kernel behind them
+			hipLaunchKernelGGL(d4c2_frames_kernel, dim3((unsigned)blocks8), dim3(64), 0, s, a);
+			a.rare_only = 1;
+			hipLaunchKernelGGL((d4c_frames_kernel<4096, 512, true>), dim3((unsigned)blocks8), dim3(512), 0, s, a);
+			a.rare_only = 0;
+		} else if (main2 && part == 1) {
+			if (a.n_ap > 0) hipLaunchKernelGGL(d4c2_band_kernel, dim3((unsigned)(blocks8 * a.n_ap)), dim3(64), 0, s, a);
+			hipLaunchKernelGGL(d4c_rows_kernel, dim3((unsigned)a.total_frames), dim3(256), 0, s, a);
+		} else
 		switch (d->fft_size_d4c) {
 			case 1024: launch_main<1024>(a, s, split, part); break;
 			case 2048: launch_main<2048>(a, s, split, part); break;
@@ -807,6 +1349,19 @@ int d4c_enqueue(wc_d4c *d, hipStream_t s, int n_utt, const double *d_x, const in
 		WC_HIP(hipGetLastError());
 		if ((rc = dev->time_end(name, s))) return rc;
 	}
+#if WC_D4C2_TRACE
+	if (const char *path = getenv("WC_D4C_TRACE")) {
+		std::vector<double> row((size_t)kD4Row);
+		std::vector<unsigned long long> out;
+		WC_HIP(hipStreamSynchronize(s));
+		for (long long g = 0; g < total; g += 7) {
+			WC_HIP(hipMemcpy(row.data(), d->sgd.as<double>() + g * kD4Row, sizeof(double) * kD4Row, hipMemcpyDeviceToHost));
+			const unsigned long long *st = reinterpret_cast<const unsigned long long *>(row.data() + 4128);
+			out.insert(out.end(), st, st + 16);
+		}
+		if (FILE *f = fopen(path, "wb")) { fwrite(out.data(), 8, out.size(), f); fclose(f); }
+	}
+#endif
 	return WC_OK;
 }
 
@@ -857,6 +1412,8 @@ wc_d4c *wc_d4c_create(int fs, double threshold) {
 	{
 		const char *sp = getenv("WC_D4C_SPLIT");  // default: split schedule; WC_D4C_SPLIT=0 runs the single fused kernel
 		d->split = !(sp && sp[0] == '0');
+		const char *impl = getenv("WC_D4C_IMPL");
+		d->wave2 = !(impl && std::strcmp(impl, "block") == 0);
 	}
 	// reference src/d4c.cpp:60-111
 	d->fft_size_d4c = static_cast<int>(std::pow(2.0, 1.0 + static_cast<int>(std::log(4.0 * fs / 47.0 + 1) / 0.69314718055994529)));

@@ -288,7 +288,13 @@ __device__ __forceinline__ double2 cmul_i(double2 a) {
 // Load from the (global) twiddle table through an explicit global-address-space pointer: a pointer that went
 // through tw_fresh() is opaque to the compiler, which would otherwise emit FLAT loads -- those count against
 // lgkmcnt as well, so every LDS wait would also wait for the outstanding twiddle loads.
+#ifndef WC_TW_ABLATE
+#define WC_TW_ABLATE 0  // 1: timing ablation (wrong results): twiddles made up from the index instead of loaded
+#endif
 __device__ __forceinline__ double2 tw_load(const double2 *tw, int idx) {
+#if WC_TW_ABLATE
+	return make_double2(1.0 - idx * 1e-9, idx * 1e-9);
+#endif
 	typedef double v2d __attribute__((ext_vector_type(2)));
 	typedef const v2d __attribute__((address_space(1))) *gptr;
 	const v2d v = ((gptr)tw)[idx];

@@ -67,6 +67,18 @@ __global__ __launch_bounds__(T) void hook_cumsum_kernel(const double *__restrict
 	for (int i = tid; i < n; i += T) out[(size_t)blockIdx.x * n + i] = S[i];
 }
 
+// seq_cumsum_nonneg_wave: one wavefront per sequence of n <= 2304 terms
+__global__ __launch_bounds__(64) void hook_cumsum_wave_kernel(const double *__restrict__ v, int n, double *__restrict__ out) {
+	__shared__ double S[2304];
+	const int lane = threadIdx.x;
+	const double *src = v + (size_t)blockIdx.x * n;
+	for (int i = lane; i < n; i += 64) S[i] = src[i];
+	__syncthreads();
+	if (n <= 1152) seq_cumsum_nonneg_wave<18>(S, n, lane);
+	else seq_cumsum_nonneg_wave<36>(S, n, lane);
+	for (int i = lane; i < n; i += 64) out[(size_t)blockIdx.x * n + i] = S[i];
+}
+
 // The one-wavefront transforms of wc_wavefft.hpp: a 2048-point real transform per 64-thread workgroup.
 // KIND 0: r2c (in 2048 doubles, out 1025 complex); 1: c2r (in 1025 complex, out 2048 doubles, unnormalised);
 // 2: r2c with the input zero beyond its first quarter, through the pruned leading stage
@@ -114,6 +126,27 @@ __global__ __launch_bounds__(64) void hook_wave_fft_kernel(const double *__restr
 			y[2 * (lane + 64 * q) + 1] = im[q];
 		}
 	}
+}
+// 4096-point real transform by two wavefronts (one 128-thread workgroup): in 4096 doubles, out 2049 complex
+__global__ __launch_bounds__(128) void hook_wave2_r2c_kernel(const double *__restrict__ in, double *__restrict__ out,
+															 const double2 *__restrict__ tw) {
+	__shared__ double L[kWf2Lds];
+	const int t = threadIdx.x;
+	const double *x = in + (size_t)blockIdx.x * 4096;
+	double2 *X = reinterpret_cast<double2 *>(out) + (size_t)blockIdx.x * 2049;
+	double re[16], im[16], nyq;
+#pragma unroll
+	for (int q = 0; q < 16; ++q) {
+		re[q] = x[2 * (t + 128 * q)];
+		im[q] = x[2 * (t + 128 * q) + 1];
+	}
+	wf2_fft2048_dit<+1>(re, im, L, tw, t);
+	wf2_r2c_unpack(re, im, nyq, tw, t);
+#pragma unroll
+	for (int g = 0; g < 2; ++g)
+#pragma unroll
+		for (int q = 0; q < 8; ++q) X[wf2_bin(t, g, q)] = make_double2(0.5 * re[8 * g + q], 0.5 * im[8 * g + q]);
+	if (t == 0) X[2048] = make_double2(0.5 * nyq, 0.0);
 }
 // kind 0: wf_log, 1: wf_exp
 __global__ void hook_logexp_kernel(int kind, const double *__restrict__ in, double *__restrict__ out, long long n,
@@ -196,7 +229,7 @@ int wc_debug_fft(int kind, int n, int batch, const double *in, double *out) {
 // `batch` sequences of n (<= 4096) non-negative terms each: out = their cumulative sums as seq_cumsum_nonneg forms them
 // (threads: 256 or 512, the two block sizes the stages use)
 int wc_debug_seq_cumsum(const double *v, int n, int batch, int threads, double *out) {
-	if (!v || !out || n <= 0 || n > 4096 || batch <= 0 || (threads != 256 && threads != 512)) return fail(WC_ERR_INVALID, "debug cumsum: bad argument");
+	if (!v || !out || n <= 0 || n > 4096 || batch <= 0 || (threads != 64 && threads != 256 && threads != 512) || (threads == 64 && n > 2304)) return fail(WC_ERR_INVALID, "debug cumsum: bad argument");
 	Device *dev = current_device();
 	if (!dev) return WC_ERR_DEVICE;
 	DeviceLock lock(dev);
@@ -206,7 +239,8 @@ int wc_debug_seq_cumsum(const double *v, int n, int batch, int threads, double *
 	WC_HIP(hipMalloc(&d_in.p, sizeof(double) * total));
 	WC_HIP(hipMalloc(&d_out.p, sizeof(double) * total));
 	WC_HIP(hipMemcpyAsync(d_in.p, v, sizeof(double) * total, hipMemcpyHostToDevice, s));
-	if (threads == 256) hipLaunchKernelGGL(hook_cumsum_kernel<256>, dim3(batch), dim3(256), 0, s, static_cast<const double *>(d_in.p), n, static_cast<double *>(d_out.p));
+	if (threads == 64) hipLaunchKernelGGL(hook_cumsum_wave_kernel, dim3(batch), dim3(64), 0, s, static_cast<const double *>(d_in.p), n, static_cast<double *>(d_out.p));
+	else if (threads == 256) hipLaunchKernelGGL(hook_cumsum_kernel<256>, dim3(batch), dim3(256), 0, s, static_cast<const double *>(d_in.p), n, static_cast<double *>(d_out.p));
 	else hipLaunchKernelGGL(hook_cumsum_kernel<512>, dim3(batch), dim3(512), 0, s, static_cast<const double *>(d_in.p), n, static_cast<double *>(d_out.p));
 	WC_HIP(hipGetLastError());
 	WC_HIP(hipMemcpyAsync(out, d_out.p, sizeof(double) * total, hipMemcpyDeviceToHost, s));
@@ -217,12 +251,13 @@ int wc_debug_seq_cumsum(const double *v, int n, int batch, int threads, double *
 // 2048-point real transforms by one wavefront each (wc_wavefft.hpp).  kind 0 r2c, 1 c2r, 2 r2c of an input whose last
 // three quarters are zero (pruned leading stage); host pointers; doubles in 2048 / 2050 / 2048, out 2050 / 2048 / 2050.
 int wc_debug_wave_fft(int kind, int batch, const double *in, double *out) {
-	if (kind < 0 || kind > 2 || batch <= 0 || !in || !out) return fail(WC_ERR_INVALID, "debug wave fft: bad argument");
+	if (kind < 0 || kind > 3 || batch <= 0 || !in || !out) return fail(WC_ERR_INVALID, "debug wave fft: bad argument");
 	Device *dev = current_device();
 	if (!dev) return WC_ERR_DEVICE;
 	DeviceLock lock(dev);
 	hipStream_t s = dev->active();
-	const size_t n_in = (kind == 1 ? 2050 : 2048) * (size_t)batch, n_out = (kind == 1 ? 2048 : 2050) * (size_t)batch;
+	// (kind 3: the 4096-point r2c by two wavefronts, 4096 doubles in, 4098 out)
+	const size_t n_in = (kind == 3 ? 4096 : kind == 1 ? 2050 : 2048) * (size_t)batch, n_out = (kind == 3 ? 4098 : kind == 1 ? 2048 : 2050) * (size_t)batch;
 	Scoped d_in, d_out;
 	WC_HIP(hipMalloc(&d_in.p, sizeof(double) * n_in));
 	WC_HIP(hipMalloc(&d_out.p, sizeof(double) * n_out));
@@ -231,7 +266,8 @@ int wc_debug_wave_fft(int kind, int batch, const double *in, double *out) {
 	double *dout = static_cast<double *>(d_out.p);
 	if (kind == 0) hipLaunchKernelGGL(hook_wave_fft_kernel<0>, dim3(batch), dim3(64), 0, s, di, dout, dev->twiddle);
 	else if (kind == 1) hipLaunchKernelGGL(hook_wave_fft_kernel<1>, dim3(batch), dim3(64), 0, s, di, dout, dev->twiddle);
-	else hipLaunchKernelGGL(hook_wave_fft_kernel<2>, dim3(batch), dim3(64), 0, s, di, dout, dev->twiddle);
+	else if (kind == 2) hipLaunchKernelGGL(hook_wave_fft_kernel<2>, dim3(batch), dim3(64), 0, s, di, dout, dev->twiddle);
+	else hipLaunchKernelGGL(hook_wave2_r2c_kernel, dim3(batch), dim3(128), 0, s, di, dout, dev->twiddle);
 	WC_HIP(hipGetLastError());
 	WC_HIP(hipMemcpyAsync(out, d_out.p, sizeof(double) * n_out, hipMemcpyDeviceToHost, s));
 	WC_HIP(hipStreamSynchronize(s));

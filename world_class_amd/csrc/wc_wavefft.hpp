@@ -146,11 +146,33 @@ __device__ __forceinline__ void wf_xchg_out3(double (&v)[16], double *lds, const
 	wf_fence();
 }
 
-constexpr int kTwT2 = kTwiddleN;          // 256 entries behind the main table: W_256^{r k} at [16 k + r]
+// Tables of the wavefront transforms, behind the main twiddle table.  Every one is laid out so that the 64 lanes of a load
+// read CONSECUTIVE entries: the main table indexed with a stride (W_1024^{r j} = tw[4 r j], ...) makes one load instruction
+// touch up to 96 cache lines for 1 KB of twiddles, and the L1 of a CU (32 KB) then turns over with every transform.
+constexpr int kTwT2 = kTwiddleN;          // 256 entries: W_256^{r k} at [16 r + k], r, k < 16 (second stage)
 constexpr int kTwLog = kTwT2 + 256;       // 128 entries (1 / c_i, log c_i), c_i = 1/2 + (i + 1/2) / 256
 constexpr int kTwExp = kTwLog + 128;      // 32 entries = 64 doubles 2^{j/64}
 constexpr int kTwInvK = kTwExp + 32;      // 1040 doubles 1 / k (k = 0: 0)
-constexpr int kTwTotal = kTwInvK + 520;   // double2 entries of the whole table
+constexpr int kTwP3 = kTwInvK + 520;      // 3 x 256 entries: W_1024^{r j} at [256 (r - 1) + j], j < 256 (radix-4 stage)
+constexpr int kTwU = kTwP3 + 768;         // 1040 entries: W_2048^n, n <= 1024 (real-transform unpacking; the odd half's twist)
+constexpr int kTwUo = kTwU + 1040;        // 1024 entries: W_4096^{2 j + 1} (unpacking of the odd half of a 4096-point transform)
+constexpr int kTwTotal = kTwUo + 1024;    // double2 entries of the whole table
+
+// Left alone, the scheduler puts every twiddle load right in front of its use (load, wait ~500 cycles, use, 15 times per
+// stage: measured, the transforms ran five times slower than their arithmetic).  The loads of a stage are therefore issued
+// together, ahead of the LDS exchange in front of the stage, and fenced off: nothing is scheduled across the fence, so they
+// are all in flight while the exchange runs and the wait stands once, in front of the first use.
+#define WF_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+__device__ __forceinline__ void wf_t2_load(double2 (&w)[16], const double2 *__restrict__ tw, int lane) {
+#pragma unroll
+	for (int r = 1; r < 16; ++r) w[r] = tw_load(tw + kTwT2 + 16 * r, lane & 15);
+	WF_SCHED_FENCE();
+}
+template <int S>
+__device__ __forceinline__ void wf_t2_apply(double (&re)[16], double (&im)[16], const double2 (&w)[16]) {
+#pragma unroll
+	for (int r = 1; r < 16; ++r) wrot(re[r], im[r], w[r].x, S > 0 ? w[r].y : -w[r].y);
+}
 
 struct WfIdx {
 	int jb[4];       // padded element index of butterfly g's first input: j + (j >> 4)
@@ -173,11 +195,17 @@ __device__ __forceinline__ WfIdx wf_idx(int lane) {
 template <int S>
 __device__ __forceinline__ void wf_tw3(const double2 *__restrict__ tw, int lane, double (&wr)[4][3], double (&wi)[4][3]) {
 	constexpr double s = S > 0 ? 1.0 : -1.0;
+	double2 a[3], c[3];
 #pragma unroll
 	for (int r = 1; r <= 3; ++r) {
-		const double2 a = tw_load(tw, 4 * r * lane), c = tw_load(tw + 256 * r, 4 * r * lane);  // j = t and j = 64 + t
-		wr[0][r - 1] = a.x; wi[0][r - 1] = s * a.y;
-		wr[2][r - 1] = c.x; wi[2][r - 1] = s * c.y;
+		a[r - 1] = tw_load(tw + kTwP3 + 256 * (r - 1), lane);       // j = t
+		c[r - 1] = tw_load(tw + kTwP3 + 256 * (r - 1) + 64, lane);  // j = 64 + t
+	}
+	WF_SCHED_FENCE();
+#pragma unroll
+	for (int r = 0; r < 3; ++r) {
+		wr[0][r] = a[r].x; wi[0][r] = s * a[r].y;
+		wr[2][r] = c[r].x; wi[2][r] = s * c[r].y;
 	}
 	// j' = 256 - j:  W^{r j'} = (S i)^r conj(W^{r j})
 #pragma unroll
@@ -201,21 +229,18 @@ __device__ __forceinline__ void wf_fft1024_dit_rest(double (&re)[16], double (&i
 													 int lane) {
 	const double2 *__restrict__ tw = tw_fresh(tw_);
 	const WfIdx ix = wf_idx(lane);
-	wf_xchg<1, 68>(re, lds, ix.x1w, ix.x1r);
-	wf_xchg<1, 68>(im, lds, ix.x1w, ix.x1r);
 	{
-		const double2 *__restrict__ t2 = tw + kTwT2 + 16 * (lane & 15);
-#pragma unroll
-		for (int r = 1; r < 16; ++r) {
-			const double2 w = tw_load(t2, r);
-			wrot(re[r], im[r], w.x, S > 0 ? w.y : -w.y);
-		}
+		double2 w2[16];
+		wf_t2_load(w2, tw, lane);
+		wf_xchg<1, 68>(re, lds, ix.x1w, ix.x1r);
+		wf_xchg<1, 68>(im, lds, ix.x1w, ix.x1r);
+		wf_t2_apply<S>(re, im, w2);
 	}
 	wdft16<S>(re, im);
-	wf_xchg_in3(re, lds, ix.x2, ix.jb);
-	wf_xchg_in3(im, lds, ix.x2, ix.jb);
 	double wr[4][3], wi[4][3];
 	wf_tw3<S>(tw, lane, wr, wi);
+	wf_xchg_in3(re, lds, ix.x2, ix.jb);
+	wf_xchg_in3(im, lds, ix.x2, ix.jb);
 #pragma unroll
 	for (int g = 0; g < 4; ++g) {
 #pragma unroll
@@ -246,16 +271,13 @@ __device__ __forceinline__ void wf_fft1024_dif(double (&re)[16], double (&im)[16
 			for (int r = 1; r <= 3; ++r) wrot(re[4 * g + r], im[4 * g + r], wr[g][r - 1], wi[g][r - 1]);
 		}
 	}
-	wf_xchg_out3(re, lds, ix.jb, ix.x2);
-	wf_xchg_out3(im, lds, ix.jb, ix.x2);
-	wdft16<S>(re, im);
 	{
-		const double2 *__restrict__ t2 = tw + kTwT2 + 16 * (lane & 15);
-#pragma unroll
-		for (int r = 1; r < 16; ++r) {
-			const double2 w = tw_load(t2, r);
-			wrot(re[r], im[r], w.x, S > 0 ? w.y : -w.y);
-		}
+		double2 w2[16];
+		wf_t2_load(w2, tw, lane);
+		wf_xchg_out3(re, lds, ix.jb, ix.x2);
+		wf_xchg_out3(im, lds, ix.jb, ix.x2);
+		wdft16<S>(re, im);
+		wf_t2_apply<S>(re, im, w2);
 	}
 	wf_xchg<68, 1>(re, lds, ix.x1r, ix.x1w);
 	wf_xchg<68, 1>(im, lds, ix.x1r, ix.x1w);
@@ -276,10 +298,11 @@ __device__ __forceinline__ void wf_r2c_pair(double &kr, double &ki, double &mr, 
 __device__ __forceinline__ void wf_tw_real(const double2 *__restrict__ tw, int lane, double (&wr)[8], double (&wi)[8]) {
 #pragma unroll
 	for (int q = 0; q < 4; ++q) {
-		const double2 a = tw_load(tw + 512 * q, 2 * lane), c = tw_load(tw + 512 * q + 128, 2 * lane);
+		const double2 a = tw_load(tw + kTwU + 256 * q, lane), c = tw_load(tw + kTwU + 256 * q + 64, lane);
 		wr[q] = a.x; wi[q] = a.y;
 		wr[4 + q] = c.x; wi[4 + q] = c.y;
 	}
+	WF_SCHED_FENCE();
 }
 // In: the paired output of wf_fft1024_dit<+1> on the packed signal z[m] = x[2 m] + i x[2 m + 1].  Out: slot (g, q) holds
 // 2 X[j_g + 256 q]; lane 0's A_0 holds (2 X[0], 0) and nyq = 2 X[1024] (valid on lane 0).
@@ -394,6 +417,389 @@ __device__ __forceinline__ double wave_sum_all(double v) { return uniform_d(wave
 __device__ __forceinline__ int wf_bin(int lane, int g, int q) {
 	const int j = g == 0 ? lane : g == 1 ? (lane ? 256 - lane : 128) : g == 2 ? 64 + lane : 192 - lane;
 	return j + 256 * q;
+}
+
+// ---- either half of a 2048-point transform by the same wavefront ("even / odd split") --------------------------------------
+// A 4096-point real transform (D4C) packs into 2048 complex points z[m]; one decimation-in-frequency step splits their
+// transform Z into two independent 1024-point ones:  Z[2 j] = FFT(z[n] + z[n + 1024]),  Z[2 j + 1] = FFT((z[n] - z[n + 1024]) W_2048^n).
+// The real-transform unpacking pairs Z[k] with Z[2048 - k] -- both even or both odd -- so each half is unpacked on its own:
+//   even  pairs (E[j], E[1024 - j]), twiddle W_4096^{2 j}: exactly the 2048-point real unpacking (wf_r2c_unpack)
+//   odd   pairs (O[j], O[1023 - j]), twiddle W_4096^{2 j + 1}: the paired layout with j_B = 255 - t, j_D = 191 - t
+//         (no self-paired element, no special lane)
+// One wavefront runs the two halves one after the other with the same code: the parity is a run-time value that only moves
+// a few indices.  Slot 4 g + q of parity p then holds bin 2 (j_g + 256 q) + p of the 4096-point real transform.
+__device__ __forceinline__ int wf_j(int lane, int odd, int g) {
+	return g == 0 ? lane : g == 1 ? (odd ? 255 - lane : (lane ? 256 - lane : 128)) : g == 2 ? 64 + lane : (odd ? 191 - lane : 192 - lane);
+}
+__device__ __forceinline__ WfIdx wf_idx_p(int lane, int odd) {
+	WfIdx x;
+#pragma unroll
+	for (int g = 0; g < 4; ++g) {
+		const int j = wf_j(lane, odd, g);
+		x.jb[g] = j + (j >> 4);
+	}
+	x.x1w = 17 * lane;
+	x.x1r = lane + (lane >> 4);
+	x.x2 = 272 * (lane >> 4) + (lane & 15);
+	x.jB = wf_j(lane, odd, 1);
+	return x;
+}
+// strided -> paired layout of parity `odd`; the caller has run the leading wdft16<S, NG>
+template <int S>
+__device__ __forceinline__ void wf_fft1024_dit_rest_p(double (&re)[16], double (&im)[16], double *lds, const double2 *__restrict__ tw_,
+													   int lane, int odd) {
+	const double2 *__restrict__ tw = tw_fresh(tw_);
+	const WfIdx ix = wf_idx_p(lane, odd);
+	{
+		double2 w2[16];
+		wf_t2_load(w2, tw, lane);
+		wf_xchg<1, 68>(re, lds, ix.x1w, ix.x1r);
+		wf_xchg<1, 68>(im, lds, ix.x1w, ix.x1r);
+		wf_t2_apply<S>(re, im, w2);
+	}
+	wdft16<S>(re, im);
+	double2 w3[4][3];
+#pragma unroll
+	for (int g = 0; g < 4; ++g) {
+		const int j = wf_j(lane, odd, g);
+#pragma unroll
+		for (int r = 1; r <= 3; ++r) w3[g][r - 1] = tw_load(tw + kTwP3 + 256 * (r - 1), j);
+	}
+	WF_SCHED_FENCE();
+	wf_xchg_in3(re, lds, ix.x2, ix.jb);
+	wf_xchg_in3(im, lds, ix.x2, ix.jb);
+#pragma unroll
+	for (int g = 0; g < 4; ++g) {
+#pragma unroll
+		for (int r = 1; r <= 3; ++r) wrot(re[4 * g + r], im[4 * g + r], w3[g][r - 1].x, S > 0 ? w3[g][r - 1].y : -w3[g][r - 1].y);
+		wdft4<S>(re[4 * g], im[4 * g], re[4 * g + 1], im[4 * g + 1], re[4 * g + 2], im[4 * g + 2], re[4 * g + 3], im[4 * g + 3]);
+	}
+}
+// the odd half's input: element n = lane + 64 q times W_2048^n
+__device__ __forceinline__ void wf_odd_twist(double (&re)[16], double (&im)[16], const double2 *__restrict__ tw_, int lane, int nslots) {
+	const double2 *__restrict__ tw = tw_fresh(tw_);
+	double2 w[16];
+#pragma unroll
+	for (int q = 0; q < 16; ++q)
+		if (q < nslots) w[q] = tw_load(tw + kTwU + 64 * q, lane);
+	WF_SCHED_FENCE();
+#pragma unroll
+	for (int q = 0; q < 16; ++q)
+		if (q < nslots) wrot(re[q], im[q], w[q].x, w[q].y);
+}
+// unpacking of the odd half: slot (g, q) <- 2 X[2 (j_g + 256 q) + 1]
+__device__ __forceinline__ void wf_r2c_unpack_odd(double (&re)[16], double (&im)[16], const double2 *__restrict__ tw_, int lane) {
+	const double2 *__restrict__ tw = tw_fresh(tw_);
+	double2 a[4], c[4];
+#pragma unroll
+	for (int q = 0; q < 4; ++q) {
+		a[q] = tw_load(tw + kTwUo + 256 * q, lane);
+		c[q] = tw_load(tw + kTwUo + 256 * q + 64, lane);
+	}
+	WF_SCHED_FENCE();
+#pragma unroll
+	for (int q = 0; q < 4; ++q) {
+		wf_r2c_pair(re[q], im[q], re[7 - q], im[7 - q], a[q].x, a[q].y);
+		wf_r2c_pair(re[8 + q], im[8 + q], re[15 - q], im[15 - q], c[q].x, c[q].y);
+	}
+}
+// the 4096-point real transform's half of parity `odd`, from the strided packed input of that half (the even half's input is
+// z[n] + z[n + 1024], the odd half's (z[n] - z[n + 1024]) before the twist, which is applied here).  ng: the input's slots
+// 4 ng .. 15 are zero.  Out: slot (g, q) = 2 X[2 (j_g + 256 q) + odd]; even half: lane 0's A_0 = (2 X[0], 0), nyq = 2 X[2048].
+__device__ __forceinline__ void wf_r2c4096_half(double (&re)[16], double (&im)[16], double &nyq, int ng, double *lds,
+												const double2 *__restrict__ tw, int lane, int odd) {
+	WC_FRESH(lane);  // (lane-derived addresses must not be hoisted out of the caller's loops and spilled)
+	if (odd) {
+		if (ng <= 1) wf_odd_twist(re, im, tw, lane, 4);
+		else if (ng == 2) wf_odd_twist(re, im, tw, lane, 8);
+		else wf_odd_twist(re, im, tw, lane, 16);
+	}
+	if (ng <= 1) wdft16<+1, 1>(re, im);
+	else if (ng == 2) wdft16<+1, 2>(re, im);
+	else wdft16<+1, 4>(re, im);
+	wf_fft1024_dit_rest_p<+1>(re, im, lds, tw, lane, odd);
+	nyq = 0.0;
+	if (odd) wf_r2c_unpack_odd(re, im, tw, lane);
+	else wf_r2c_unpack(re, im, nyq, tw, lane);
+}
+
+// ======== 2048-point complex transform by TWO wavefronts (one 128-thread workgroup), 16 points per lane ================
+// The same construction one size up (16 x 16 x 8), for the 4096-point real transforms of D4C: the lanes of both
+// wavefronts meet in one 17 KB exchange buffer, so every exchange is bracketed by workgroup barriers (two wavefronts:
+// cheap).  t = thread 0..127.
+//   strided   slot q (0..15) holds element t + 128 q
+//   paired    slot 8 g + q (g = 0: A, 1: B; q = 0..7) holds element j_g + 256 q, j_A = t, j_B = 256 - t (thread 0: 128):
+//             element k and element 2048 - k share a lane (A_q with B_{7-q}; thread 0 pairs A_q with A_{8-q}, B_q with
+//             B_{7-q} and keeps the self-paired 0 and 1024 in A_0, A_4)
+constexpr int kWf2Lds = 2304;  // doubles: 2048 + one pad per 16, and room for D4C's 2049 + 2 * 127 smoothing terms
+
+// 8-point DFT, sign S, natural order in and out
+template <int S>
+__device__ __forceinline__ void wdft8(double (&xr)[8], double (&xi)[8]) {
+	// r = 2 a + b (a = 0..3, b = 0..1), q = c + 4 d:  y[c + 4 d] = sum_b (-1)^{b d} w8^{b c} sum_a (S i)^{a c} x[2 a + b]
+	wdft4<S>(xr[0], xi[0], xr[2], xi[2], xr[4], xi[4], xr[6], xi[6]);  // slot 2 c     <- u_0[c]
+	wdft4<S>(xr[1], xi[1], xr[3], xi[3], xr[5], xi[5], xr[7], xi[7]);  // slot 2 c + 1 <- u_1[c]
+	// u_1[c] *= w8^c
+	{ const double x = xr[3], y = xi[3]; xr[3] = kH * (S > 0 ? x - y : x + y); xi[3] = kH * (S > 0 ? x + y : y - x); }
+	{ const double x = xr[5], y = xi[5]; xr[5] = S > 0 ? -y : y; xi[5] = S > 0 ? x : -x; }
+	{ const double x = xr[7], y = xi[7]; xr[7] = S > 0 ? -kH * (x + y) : kH * (y - x); xi[7] = S > 0 ? kH * (x - y) : -kH * (x + y); }
+	double tr[8], ti[8];
+#pragma unroll
+	for (int c = 0; c < 4; ++c) {
+		tr[c] = xr[2 * c] + xr[2 * c + 1]; ti[c] = xi[2 * c] + xi[2 * c + 1];
+		tr[c + 4] = xr[2 * c] - xr[2 * c + 1]; ti[c + 4] = xi[2 * c] - xi[2 * c + 1];
+	}
+#pragma unroll
+	for (int q = 0; q < 8; ++q) { xr[q] = tr[q]; xi[q] = ti[q]; }
+}
+
+struct Wf2Idx {
+	int jb[2];     // padded element index of butterfly g's first input
+	int x1w, x1r;  // exchange 1: write 17 t (+ q), read t + (t >> 4) (+ 136 r)
+	int x2;        // exchange 2, 16-point side: 272 (t >> 4) + (t & 15) (+ 17 q)
+	int jB;
+};
+__device__ __forceinline__ Wf2Idx wf2_idx(int t) {
+	Wf2Idx x;
+	const int jB = t ? 256 - t : 128;
+	x.jb[0] = t + (t >> 4);
+	x.jb[1] = jB + (jB >> 4);
+	x.x1w = 17 * t;
+	x.x1r = t + (t >> 4);
+	x.x2 = 272 * (t >> 4) + (t & 15);
+	x.jB = jB;
+	return x;
+}
+#ifndef WC_WF2_NOBAR
+#define WC_WF2_NOBAR 0  // 1: timing ablation (wrong results): the exchanges of the two-wavefront transform without barriers
+#endif
+#if WC_WF2_NOBAR
+#define WF2_SYNC() wf_fence()
+#else
+#define WF2_SYNC() __syncthreads()
+#endif
+template <int WS, int RS>
+__device__ __forceinline__ void wf2_xchg(double (&v)[16], double *lds, int wbase, int rbase) {
+#pragma unroll
+	for (int q = 0; q < 16; ++q) lds[wbase + q * WS] = v[q];
+	WF2_SYNC();
+#pragma unroll
+	for (int r = 0; r < 16; ++r) v[r] = lds[rbase + r * RS];
+	WF2_SYNC();
+}
+__device__ __forceinline__ void wf2_xchg_in3(double (&v)[16], double *lds, int wbase, const int (&jb)[2]) {
+#pragma unroll
+	for (int q = 0; q < 16; ++q) lds[wbase + q * 17] = v[q];
+	WF2_SYNC();
+#pragma unroll
+	for (int g = 0; g < 2; ++g)
+#pragma unroll
+		for (int r = 0; r < 8; ++r) v[8 * g + r] = lds[jb[g] + 272 * r];
+	WF2_SYNC();
+}
+__device__ __forceinline__ void wf2_xchg_out3(double (&v)[16], double *lds, const int (&jb)[2], int rbase) {
+#pragma unroll
+	for (int g = 0; g < 2; ++g)
+#pragma unroll
+		for (int r = 0; r < 8; ++r) lds[jb[g] + 272 * r] = v[8 * g + r];
+	WF2_SYNC();
+#pragma unroll
+	for (int q = 0; q < 16; ++q) v[q] = lds[rbase + q * 17];
+	WF2_SYNC();
+}
+// radix-8 stage of one butterfly group: twiddles W_2048^{r j} (sign S) before (DIT) or after (DIF) the 8-point DFT
+template <int S, bool DIT>
+__device__ __forceinline__ void wf2_stage8(double (&re)[16], double (&im)[16], const double2 *__restrict__ tw, int g, int j) {
+	double xr[8], xi[8];
+#pragma unroll
+	for (int r = 0; r < 8; ++r) { xr[r] = re[8 * g + r]; xi[r] = im[8 * g + r]; }
+	if (!DIT) wdft8<S>(xr, xi);
+#pragma unroll
+	for (int r = 1; r < 8; ++r) {
+		const double2 w = tw_load(tw, 2 * r * j);
+		wrot(xr[r], xi[r], w.x, S > 0 ? w.y : -w.y);
+	}
+	if (DIT) wdft8<S>(xr, xi);
+#pragma unroll
+	for (int r = 0; r < 8; ++r) { re[8 * g + r] = xr[r]; im[8 * g + r] = xi[r]; }
+}
+// strided -> paired; the caller has run the leading wdft16<S, NG> on the strided data
+template <int S>
+__device__ __forceinline__ void wf2_fft2048_dit_rest(double (&re)[16], double (&im)[16], double *lds, const double2 *__restrict__ tw_,
+													  int t) {
+	const double2 *__restrict__ tw = tw_fresh(tw_);
+	const Wf2Idx ix = wf2_idx(t);
+	wf2_xchg<1, 136>(re, lds, ix.x1w, ix.x1r);
+	wf2_xchg<1, 136>(im, lds, ix.x1w, ix.x1r);
+	{
+		const double2 *__restrict__ t2 = tw + kTwT2;
+#pragma unroll
+		for (int r = 1; r < 16; ++r) {
+			const double2 w = tw_load(t2 + 16 * r, t & 15);
+			wrot(re[r], im[r], w.x, S > 0 ? w.y : -w.y);
+		}
+	}
+	wdft16<S>(re, im);
+	wf2_xchg_in3(re, lds, ix.x2, ix.jb);
+	wf2_xchg_in3(im, lds, ix.x2, ix.jb);
+	wf2_stage8<S, true>(re, im, tw, 0, t);
+	wf2_stage8<S, true>(re, im, tw, 1, ix.jB);
+}
+template <int S>
+__device__ __forceinline__ void wf2_fft2048_dit(double (&re)[16], double (&im)[16], double *lds, const double2 *__restrict__ tw,
+												 int t) {
+	wdft16<S>(re, im);
+	wf2_fft2048_dit_rest<S>(re, im, lds, tw, t);
+}
+// paired -> strided
+template <int S>
+__device__ __forceinline__ void wf2_fft2048_dif(double (&re)[16], double (&im)[16], double *lds, const double2 *__restrict__ tw_,
+												 int t) {
+	const double2 *__restrict__ tw = tw_fresh(tw_);
+	const Wf2Idx ix = wf2_idx(t);
+	wf2_stage8<S, false>(re, im, tw, 0, t);
+	wf2_stage8<S, false>(re, im, tw, 1, ix.jB);
+	wf2_xchg_out3(re, lds, ix.jb, ix.x2);
+	wf2_xchg_out3(im, lds, ix.jb, ix.x2);
+	wdft16<S>(re, im);
+	{
+		const double2 *__restrict__ t2 = tw + kTwT2;
+#pragma unroll
+		for (int r = 1; r < 16; ++r) {
+			const double2 w = tw_load(t2 + 16 * r, t & 15);
+			wrot(re[r], im[r], w.x, S > 0 ? w.y : -w.y);
+		}
+	}
+	wf2_xchg<136, 1>(re, lds, ix.x1r, ix.x1w);
+	wf2_xchg<136, 1>(im, lds, ix.x1r, ix.x1w);
+	wdft16<S>(re, im);
+}
+// bin held by slot 8 g + q
+__device__ __forceinline__ int wf2_bin(int t, int g, int q) { return (g == 0 ? t : (t ? 256 - t : 128)) + 256 * q; }
+// 4096-point real transform, unpacking (see wf_r2c_unpack): slot (g, q) <- 2 X[j_g + 256 q]; thread 0: A_0 = (2 X[0], 0),
+// nyq = 2 X[2048]
+__device__ __forceinline__ void wf2_r2c_unpack(double (&re)[16], double (&im)[16], double &nyq, const double2 *__restrict__ tw_,
+												int t) {
+	const double2 *__restrict__ tw = tw_fresh(tw_);
+	nyq = 0.0;
+	if (t == 0) {
+		const double a = re[0], b = im[0];
+		re[0] = 2.0 * (a + b); im[0] = 0.0;
+		nyq = 2.0 * (a - b);
+		re[4] = 2.0 * re[4]; im[4] = 2.0 * im[4];  // bin 1024: X = Z
+#pragma unroll
+		for (int q = 1; q < 4; ++q) {  // 256 q | 2048 - 256 q
+			const double2 w = tw_load(tw, 256 * q);
+			wf_r2c_pair(re[q], im[q], re[8 - q], im[8 - q], w.x, w.y);
+		}
+#pragma unroll
+		for (int q = 0; q < 4; ++q) {  // 128 + 256 q | 1920 - 256 q
+			const double2 w = tw_load(tw, 128 + 256 * q);
+			wf_r2c_pair(re[8 + q], im[8 + q], re[15 - q], im[15 - q], w.x, w.y);
+		}
+	} else {
+#pragma unroll
+		for (int q = 0; q < 8; ++q) {
+			const double2 w = tw_load(tw + 256 * q, t);
+			wf_r2c_pair(re[q], im[q], re[15 - q], im[15 - q], w.x, w.y);
+		}
+	}
+}
+
+// ---- the reference's sequential cumulative sum, bit for bit, by one wavefront ---------------------------------------------
+// seq_cumsum_nonneg (wc_device.hpp) for a single wavefront with every lane's chunk (<= CHMAX consecutive terms) held in
+// registers: the block version walks its chunks through LDS one dependent read at a time, which a lone wavefront cannot hide
+// (measured: 30 k cycles per 2291-term sum).  Same construction, same results: clean lanes (no binade crossing, no tie) get
+// their exact increment by adding their terms to 2^e and a segmented scan; the other ("dirty") lanes are visited in order,
+// each adding its own terms to the running sum in the reference's order while the rest of the wavefront waits; every clean
+// lane then re-adds its terms from its exact start value.  In: S[0 .. len) terms (non-negative), out: their running sums.
+template <int CHMAX>
+__device__ __forceinline__ void seq_cumsum_nonneg_wave(double *S, int len, int lane) {
+	const int ch = (len + 63) / 64;  // <= CHMAX
+	const int lo = min(lane * ch, len), hi = min(len, lo + ch), n = hi - lo;
+	double v[CHMAX];
+#pragma unroll
+	for (int k = 0; k < CHMAX; ++k) v[k] = S[min(lo + k, len - 1)];
+	wf_fence();
+	double loc = 0.0;
+	bool bad = false;
+#pragma unroll
+	for (int k = 0; k < CHMAX; ++k) {
+		v[k] = (k < n) ? v[k] : 0.0;
+		loc += v[k];
+		bad = bad || !(v[k] >= 0.0);
+	}
+	const double base_a = wave_incl_scan(loc, lane) - loc;
+	const double lower = base_a * (1.0 - 0x1p-30), upper = (base_a + loc) * (1.0 + 0x1p-30);
+	const int E = (__double2hiint(lower) >> 20) & 0x7ff;
+	bool dirty = lane == 0 || bad || !(lower > 0.0) || E != ((__double2hiint(upper) >> 20) & 0x7ff) || E < 64 || E > 1984;
+	double d = 0.0;
+	if (n <= 0) {
+		dirty = lane == 0;
+	} else if (!dirty) {
+		const double C = __hiloint2double(E << 20, 0);               // 2^e, the start of the binade
+		const double rulp = __hiloint2double((2098 - E) << 20, 0);   // 2^(52 - e) = 1 / ulp
+		double r = C;
+#pragma unroll
+		for (int k = 0; k < CHMAX; ++k) {
+			const double t = v[k] * rulp;
+			dirty = dirty || (t - floor(t)) == 0.5;
+			r = v[k] + r;
+		}
+		d = dirty ? 0.0 : r - C;
+	}
+	// inclusive segmented scan of d over the lanes, restarting behind every dirty lane
+	double x = d;
+	int f = dirty ? 1 : 0;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const double xo = __shfl_up(x, o, 64);
+		const int fo = __shfl_up(f, o, 64);
+		if (lane >= o) {
+			if (!f) x += xo;
+			f |= fo;
+		}
+	}
+	unsigned long long mk = __ballot(dirty);
+	const unsigned long long m = mk;
+	// the walk over the dirty lanes, in order; endv: the running sum behind a dirty lane's terms (kept in that lane)
+	double so = 0.0, endv = 0.0;
+	int prev = -1;
+	while (mk) {
+		const int t = __ffsll((long long)mk) - 1;
+		mk &= mk - 1;
+		const double xp = __shfl(x, max(t - 1, 0), 64);
+		const double si = prev < 0 ? 0.0 : (t == prev + 1 ? so : so + xp);
+		if (lane == t) {
+			double run = si;
+#pragma unroll
+			for (int k = 0; k < CHMAX; ++k) {
+				run = v[k] + run;  // (terms beyond the chunk are zero: the sum does not move)
+				v[k] = run;
+			}
+			endv = run;
+		}
+		so = __shfl(endv, t, 64);
+		prev = t;
+	}
+	{
+		// (the cross-lane read stands outside the branch: a lane switched off there would hand over nothing)
+		const unsigned long long below = m & ((1ull << lane) - 1ull);  // lane 0 is always dirty, so never empty for a clean lane
+		const int j = below ? 63 - __clzll((long long)below) : 0;
+		const double start = __shfl(endv, j, 64) + (x - d);
+		if (!dirty) {
+			double run = start;
+#pragma unroll
+			for (int k = 0; k < CHMAX; ++k) {
+				run = v[k] + run;
+				v[k] = run;
+			}
+		}
+	}
+#pragma unroll
+	for (int k = 0; k < CHMAX; ++k)
+		if (k < n) S[lo + k] = v[k];
+	wf_fence();
 }
 
 // ---- lean log / exp ------------------------------------------------------------------------------------------------------
