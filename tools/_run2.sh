@@ -1,3 +1,3 @@
 mkdir -p gpurun_out; rm -f gpurun_out/*.log
-timeout 900 python bench.py --steps 10 --warmup 3 > gpurun_out/bench.log 2>gpurun_out/bench.err
-tail -3 gpurun_out/bench.err; cat gpurun_out/bench.log
+WC_LIB_PATH=world_class_amd/_variants/synnoat.so python tools/microbench.py --stages cds --utts 64 --iters 3 > gpurun_out/tr.log 2>&1
+tail -8 gpurun_out/tr.log

@@ -320,6 +320,7 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_CT_WAVE_OCC, WC_CT_WAVE_OCC))) void ct_wave_kernel(CtArgs a) {
 	constexpr int N = 2048, M = 1024;
 	__shared__ __attribute__((aligned(16))) double L[kWfLds];
+	__shared__ __attribute__((aligned(16))) double T[kWfTabLds];  // the tables of the lean log / exp
 	const int lane = threadIdx.x;
 	const long long g = xcd_frame(blockIdx.x, a.total_frames);
 	if (g >= a.total_frames) return;
@@ -333,6 +334,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_CT_WAVE_O
 	const int x_last = ud.x_len - 1;
 	const double pos = a.tpos[g];
 	const uint32_t *__restrict__ rng = a.rng_table + (a.rng_off[g] - a.rng_base);
+	wf_tables_to_lds(T, a.tw, lane);
 
 	// ---- F0-adaptive window (reference :137-196): window sample i of slot q is 2 lane + 128 q (+ 1) ----
 	const int hw = __builtin_amdgcn_readfirstlane(mround(1.5 * fs / f0c));
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_CT_WAVE_O
 			sm = fma(fabs(randn_at(rngb, k)), 0.00000000000000022204460492503131, sm);
 			if (slow) return wf_log_libm(sm);
 			odd = odd || !wf_log_ok(sm);
-			return wf_log_fast(sm, a.tw);
+			return wf_log_fast_l(sm, T);
 		};
 #pragma unroll
 		for (int gq = 0; gq < 4; ++gq)
@@ -565,10 +567,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_CT_WAVE_O
 	double *__restrict__ out = a.sp + g * (long long)(M + 1);
 #pragma unroll
 	for (int q = 0; q < 8; ++q) {
-		out[2 * lane + 128 * q] = wf_exp(re[q], a.tw);
-		out[2 * lane + 128 * q + 1] = wf_exp(im[q], a.tw);
+		out[2 * lane + 128 * q] = wf_exp_l(re[q], T);
+		out[2 * lane + 128 * q + 1] = wf_exp_l(im[q], T);
 	}
-	const double last = wf_exp(re[8], a.tw);
+	const double last = wf_exp_l(re[8], T);
 	if (lane == 0) out[M] = last;
 }
 

@@ -21,6 +21,7 @@
 #include "wc_device.hpp"
 #include "wc_internal.hpp"
 #include "wc_frames.hpp"
+#include "wc_wavefft.hpp"
 
 namespace wc {
 
@@ -576,6 +577,7 @@ struct SynArgs {
 	double *out;
 	long long total_pulses;  // launch size (capacity); the real count is pulse_prefix[n_utt]
 	const unsigned long long *rng_start;  // per-utterance stream position (device), NULL = utts[u].rng_pos
+	unsigned long long *trace;  // WC_SYN_TRACE builds: 16 shader-clock stamps per pulse
 	long long only_pulse;  // debugging aid (builds with -DWC_DEBUG_HOOKS, env WC_DEBUG_ONLY_PULSE): synthesise only this pulse, -1 = all
 	int fs;
 	double frame_period;
@@ -889,6 +891,313 @@ __global__ __launch_bounds__(T) void syn_pulse_kernel(SynArgs a) {
 	}
 }
 
+
+// ==== N = 2048 (48 kHz): one wavefront per pulse ==========================================================================
+// The same arithmetic as syn_pulse_kernel on the register-resident transforms of wc_wavefft.hpp: the pulse's spectra live in
+// the registers of ONE wavefront (16 complex points per lane, bins in the "paired" layout), seven transforms with two LDS
+// exchanges each and no workgroup barrier; lean log / exp (wf_log, wf_exp).  Only the first half of the periodic response
+// survives the reference's DC removal (:459-474: the shifted first half is overwritten with -dc * remover), so 16 values per
+// lane are all that is kept of it while the aperiodic response is formed.  LDS: 9.2 KB per pulse.
+//
+// MinimumPhaseAnalysis::compute (reference src/world_common.cpp:196-233): in: the log spectrum ls[4 g + q] of bin
+// j_g + 256 q and lsM of bin 1024 (lane 0); out: the minimum-phase spectrum (mr, mi) in the same layout, (mMr, 0) for bin 1024.
+__device__ __forceinline__ void minimum_phase_wave(const double (&ls)[16], double lsM, double (&mr)[16], double (&mi)[16], double &mMr,
+												   double *L, const double *T, const double2 *__restrict__ tw, int lane) {
+	constexpr int N = 2048, M = 1024;
+	WC_FRESH(lane);
+	int jg[4];
+#pragma unroll
+	for (int g = 0; g < 4; ++g) jg[g] = wf_bin(lane, g, 0);
+	// the mirrored log spectrum (reference :199-200) as the packed input of the first transform
+#pragma unroll
+	for (int g = 0; g < 4; ++g)
+#pragma unroll
+		for (int q = 0; q < 4; ++q) L[jg[g] + 256 * q] = ls[4 * g + q];
+	if (lane == 0) L[M] = lsM;
+	wf_fence();
+#pragma unroll
+	for (int q = 0; q < 8; ++q) {
+		const double2 v = *reinterpret_cast<const double2 *>(&L[2 * lane + 128 * q]);
+		mr[q] = v.x;
+		mi[q] = v.y;
+	}
+#pragma unroll
+	for (int q = 8; q < 16; ++q) {
+		mr[q] = L[2048 - 2 * lane - 128 * q];
+		mi[q] = L[2047 - 2 * lane - 128 * q];
+	}
+	wf_fence();
+	wf_fft1024_dit<+1>(mr, mi, L, tw, lane);
+	double nyq;
+	wf_r2c_unpack_re(mr, mi, nyq, tw, lane);  // twice the (real) cepstrum
+	// folding (reference :207-217): bins 1 .. M-1 doubled, 0 and M kept, the upper half zero; the cepstrum of a real even log
+	// spectrum is real, so the second transform is a real one too (see minimum_phase_lds)
+#pragma unroll
+	for (int g = 0; g < 4; ++g)
+#pragma unroll
+		for (int q = 0; q < 4; ++q) L[jg[g] + 256 * q] = (g == 0 && q == 0 && lane == 0) ? 0.5 * mr[0] : mr[4 * g + q];
+	if (lane == 0) L[M] = 0.5 * nyq;
+	wf_fence();
+#pragma unroll
+	for (int q = 0; q < 8; ++q) {
+		const double2 v = *reinterpret_cast<const double2 *>(&L[2 * lane + 128 * q]);
+		mr[q] = v.x;
+		mi[q] = v.y;
+	}
+	mr[8] = lane == 0 ? L[M] : 0.0;
+	mi[8] = 0.0;
+#pragma unroll
+	for (int q = 9; q < 16; ++q) mr[q] = mi[q] = 0.0;
+	wf_fence();
+	wf_fft1024_dit<+1>(mr, mi, L, tw, lane);
+	wf_r2c_unpack(mr, mi, nyq, tw, lane);  // twice the spectrum of the folded cepstrum
+#pragma unroll
+	for (int s = 0; s < 16; ++s) {
+		const double t = wf_exp_l(mr[s] * (0.5 / N), T);
+		double sn, cs;
+		wf_sincos(mi[s] * (0.5 / N), sn, cs);
+		mr[s] = t * cs;
+		mi[s] = t * sn;
+	}
+	mMr = wf_exp_l(nyq * (0.5 / N), T);
+}
+
+#ifndef WC_SYN_WAVE_OCC
+#define WC_SYN_WAVE_OCC 2
+#endif
+// WC_SYN_TRACE (development builds only): lane 0 stamps the shader clock at the phase boundaries of every pulse;
+// WC_SYN_TRACE_FILE=<file> dumps them after the call (tools/syn_trace.py)
+#ifndef WC_SYN_TRACE
+#define WC_SYN_TRACE 0
+#endif
+#ifndef WC_SYN_NOATOMIC
+#define WC_SYN_NOATOMIC 0  // 1: timing ablation (wrong results): plain stores instead of the atomic overlap-add
+#endif
+#if WC_SYN_NOATOMIC
+#define SYN_ADD(p, v) (*(p) = (v))
+#else
+#define SYN_ADD(p, v) atomicAdd((p), (v))
+#endif
+#if WC_SYN_TRACE
+#define SYN_STAMP(i) do { if (lane == 0) a.trace[gp * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SYN_STAMP(i) do { } while (0)
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_SYN_WAVE_OCC, WC_SYN_WAVE_OCC))) void syn_pulse_wave_kernel(SynArgs a) {
+	constexpr int N = 2048, M = 1024;
+	__shared__ __attribute__((aligned(16))) double L[kWfLds];
+	__shared__ __attribute__((aligned(16))) double T[kWfTabLds];
+	const int lane = threadIdx.x;
+	const long long total_p = a.pulse_prefix[a.n_utt];
+	if ((long long)blockIdx.x >= 8 * ((total_p + 7) / 8)) return;
+	const long long gp = xcd_frame(blockIdx.x, total_p);
+	if (gp >= total_p) return;
+	if (a.only_pulse >= 0 && gp != a.only_pulse) return;
+	int lo = 0, hi = a.n_utt - 1;
+	while (lo < hi) {
+		int mid = (lo + hi + 1) >> 1;
+		if (a.pulse_prefix[mid] <= gp) lo = mid; else hi = mid - 1;
+	}
+	const int u = lo;
+	const UttDesc ud = a.utts[u];
+	const long long slot = a.cap_off[u] + (gp - a.pulse_prefix[u]);
+	const int pidx = a.p.index[slot];
+	const double shift = a.p.shift[slot];
+	const int noise_size = a.p.noise_size[slot];
+	const double vuv = (double)a.p.vuv[slot];
+	const int fs = a.fs, Lf = ud.f_len;
+	const double fp = a.frame_period;
+	const double t = pidx / (double)fs;  // time_axis[ii] (reference :227)
+
+	// ---- spectral envelope / aperiodic ratio at the pulse (reference :346-393), then the two log spectra ----
+	const int fl = min(Lf - 1, (int)floor(t / fp));
+	const int ce = min(Lf - 1, (int)ceil(t / fp));
+	const double ipol = uniform_d(t / fp - fl);
+	const double *__restrict__ sf = a.sp + (ud.f_off + fl) * (long long)(M + 1);
+	const double *__restrict__ sc = a.sp + (ud.f_off + ce) * (long long)(M + 1);
+	const double *__restrict__ af = a.ap + (ud.f_off + fl) * (long long)(M + 1);
+	const double *__restrict__ ac = a.ap + (ud.f_off + ce) * (long long)(M + 1);
+	const bool same = fl == ce;
+	auto blend = [&](double s0, double s1, double a0, double a1, double &env, double &ar) {
+		if (same) {
+			env = fabs(s0);
+			const double s = safe_ap(a0);
+			ar = s * s;
+		} else {
+			env = fma(1.0 - ipol, fabs(s0), ipol * fabs(s1));
+			// both products rounded as in the reference (:388-390), no fused multiply-add (see syn_pulse_kernel)
+			const double s = (1.0 - ipol) * safe_ap(a0) + ipol * safe_ap(a1);
+			ar = s * s;
+		}
+	};
+	double ar0;  // aperiodic_ratio[0] decides whether there is a periodic response (reference :410)
+	{
+		double env;
+		blend(sf[0], sc[0], af[0], ac[0], env, ar0);
+		ar0 = uniform_d(ar0);
+	}
+	SYN_STAMP(0);
+	wf_tables_to_lds(T, a.tw, lane);
+	SYN_STAMP(1);
+
+	// ---- periodic response (reference :403-474; what survives of it is wave[n] - dc remover[n], n < M), then the aperiodic
+	// response (reference :479-530), through one copy of the code: minimum phase of the part's log spectrum, times the
+	// fractional delay / the noise spectrum, back to the time domain ----
+	double dc = 0.0;
+	const double sq = sqrt((double)noise_size);
+	double *__restrict__ out = a.out + ud.y_off;
+	const int index = pidx - M;
+	const bool has_periodic = !(vuv <= 0.5 || ar0 > 0.999);
+#pragma unroll 1
+	for (int part = has_periodic ? 0 : 1; part < 2; ++part) {
+		int ln = lane;
+		WC_FRESH(ln);
+		double wr[16], wi[16];
+		double nr[16], ni[16], nsM = 0.0;
+		if (part == 1) {
+			// the noise (reference :514-530): noise_size draws from the pulse's place in the stream, mean removed
+			const unsigned long long rstart = a.rng_start ? a.rng_start[u] : ud.rng_pos;
+			const uint32_t *__restrict__ rng = a.rng_table + (rstart + (unsigned long long)(pidx - a.first_index[u]) - a.rng_base);
+			double s = 0.0;
+			{
+				uint32_t raw[32];
+#pragma unroll
+				for (int q = 0; q < 16; ++q) {
+					if ((q & 3) == 0 && q * 128 >= noise_size) break;
+					const int i0 = 2 * ln + 128 * q;
+					raw[2 * q] = rng[i0 < noise_size ? i0 : 0];
+					raw[2 * q + 1] = rng[i0 + 1 < noise_size ? i0 + 1 : 0];
+				}
+				WF_SCHED_FENCE();
+#pragma unroll
+				for (int q = 0; q < 16; ++q) {
+					nr[q] = ni[q] = 0.0;
+					if (q * 128 < ((noise_size + 511) & ~511)) {
+						const int i0 = 2 * ln + 128 * q;
+						if (i0 < noise_size) nr[q] = raw[2 * q] / 268435456.0 - 6.0;
+						if (i0 + 1 < noise_size) ni[q] = raw[2 * q + 1] / 268435456.0 - 6.0;
+						s += nr[q] + ni[q];
+					}
+				}
+			}
+			s = wave_sum_all(s);
+			const double avg = s / noise_size;
+#pragma unroll
+			for (int q = 0; q < 16; ++q) {
+				const int i0 = 2 * ln + 128 * q;
+				nr[q] = (i0 < noise_size) ? nr[q] - avg : 0.0;
+				ni[q] = (i0 + 1 < noise_size) ? ni[q] - avg : 0.0;
+			}
+			if (noise_size <= 512) wdft16<+1, 1>(nr, ni);
+			else if (noise_size <= 1024) wdft16<+1, 2>(nr, ni);
+			else wdft16<+1, 4>(nr, ni);
+			wf_fft1024_dit_rest<+1>(nr, ni, L, a.tw, ln);
+			wf_r2c_unpack(nr, ni, nsM, a.tw, ln);  // twice the noise spectrum
+			SYN_STAMP(6);
+		}
+		// the part's log spectrum from the two rows around the pulse: log(env (1 - ar) + safeguard) / 2 for the periodic part
+		// (reference :416-417), log(env ar) / 2 or, unvoiced, log(env) / 2 for the aperiodic one (:490-497)
+		double ls[16], lsM, mM;
+		{
+			auto logspec = [&](double env, double ar) {
+				return wf_log_l(part == 0 ? env * (1.0 - ar) + kSafe : (vuv != 0.0 ? env * ar : env), T) / 2.0;
+			};
+#pragma unroll
+			for (int g = 0; g < 4; ++g) {
+				double v[4][4];
+#pragma unroll
+				for (int q = 0; q < 4; ++q) {
+					const int k = wf_bin(ln, g, q);
+					v[q][0] = sf[k]; v[q][1] = sc[k]; v[q][2] = af[k]; v[q][3] = ac[k];
+				}
+				WF_SCHED_FENCE();
+#pragma unroll
+				for (int q = 0; q < 4; ++q) {
+					double env, ar;
+					blend(v[q][0], v[q][1], v[q][2], v[q][3], env, ar);
+					ls[4 * g + q] = logspec(env, ar);
+				}
+			}
+			double env, ar;
+			blend(sf[M], sc[M], af[M], ac[M], env, ar);
+			lsM = logspec(env, ar);
+		}
+		SYN_STAMP(part ? 7 : 2);
+		minimum_phase_wave(ls, lsM, wr, wi, mM, L, T, a.tw, ln);
+		SYN_STAMP(part ? 8 : 3);
+		double yM;
+		if (part == 0) {
+			// fractional time shift (reference :443-457)
+			const double coef = 2.0 * kPi * shift * fs / N;
+#pragma unroll
+			for (int g = 0; g < 4; ++g)
+#pragma unroll
+				for (int q = 0; q < 4; ++q) {
+					const int k = wf_bin(ln, g, q);
+					double sn_, re2;
+					wf_sincos(coef * k, sn_, re2);
+					const double im2 = sqrt(1.0 - re2 * re2);
+					const double x = wr[4 * g + q], y = wi[4 * g + q];
+					wr[4 * g + q] = fma(x, re2, -(y * im2));
+					wi[4 * g + q] = fma(x, im2, y * re2);
+				}
+			double sn_, reM;
+			wf_sincos(coef * M, sn_, reM);
+			yM = mM * reM;
+		} else {
+#pragma unroll
+			for (int sI = 0; sI < 16; ++sI) {
+				const double x = wr[sI], y = wi[sI], nx = 0.5 * nr[sI], ny = 0.5 * ni[sI];
+				wr[sI] = fma(x, nx, -(y * ny));
+				wi[sI] = fma(x, ny, y * nx);
+			}
+			yM = mM * (0.5 * nsM);
+		}
+		wf_c2r_pack(wr, wi, yM, a.tw, ln);
+		wf_fft1024_dif<-1>(wr, wi, L, a.tw, ln);
+		SYN_STAMP(part ? 9 : 4);
+		if (part == 0) {
+			// DC removal (reference :459-474): dc = sum of the shifted second half = sum wave[0 .. M); the shifted first half is
+			// overwritten with -dc * remover, so wave[0 .. M) (shifted samples M + n) is all that is left of the response itself.
+			// It goes to the output now (times sqrt(noise_size) / fft_size, reference :339-343) rather than being held across the
+			// aperiodic part; the -dc * remover term joins the aperiodic response below.
+#pragma unroll
+			for (int q = 0; q < 8; ++q) {
+				dc += wr[q] + wi[q];
+#pragma unroll
+				for (int h = 0; h < 2; ++h) {
+					const int o = index + 1 + M + 2 * ln + 128 * q + h;
+					if (o >= 0 && o < ud.y_len) SYN_ADD(&out[o], (h ? wi[q] : wr[q]) * sq / N);
+				}
+			}
+			dc = wave_sum_all(dc);
+			SYN_STAMP(5);
+		} else {
+			// ---- mix + overlap-add (reference :339-343, :118-139): shifted sample j is unshifted sample j - M (j >= M) / j + M ----
+			double dr[16];
+#pragma unroll
+			for (int q = 0; q < 8; ++q) {
+				dr[2 * q] = a.dc_remover[2 * ln + 128 * q];
+				dr[2 * q + 1] = a.dc_remover[2 * ln + 128 * q + 1];
+			}
+			WF_SCHED_FENCE();
+			const double dcs = has_periodic ? -dc * sq : 0.0;
+#pragma unroll
+			for (int q = 0; q < 16; ++q) {
+#pragma unroll
+				for (int h = 0; h < 2; ++h) {
+					const int n = 2 * ln + 128 * q + h;  // unshifted sample
+					const double r = fma(dcs, dr[2 * (q & 7) + h], h ? wi[q] : wr[q]) / N;
+					const int o = index + 1 + (q < 8 ? n + M : n - M);
+					if (o >= 0 && o < ud.y_len) SYN_ADD(&out[o], r);
+				}
+			}
+			SYN_STAMP(10);
+		}
+	}
+
+}
+
 }  // namespace wc
 
 using namespace wc;
@@ -899,6 +1208,7 @@ struct wc_synthesis {
 	Device *dev;
 	DevBuf dc_remover, utts, meta, pulses, incs, phase, tile_cnt, d_f0, d_sp, d_ap, d_out;
 	bool pulses_by_utterance;  // WC_SYN_PULSES=utterance: one workgroup walks an utterance's tiles (A/B and the bit-identity test)
+	bool wave;  // N = 2048: one wavefront per pulse (default; WC_SYN_IMPL=block: the workgroup-per-pulse kernel)
 	bool serial_timebase;  // WC_SYN_TIMEBASE=serial: the one-wavefront sequential accumulation instead of the exact parallel one
 	HostBuf h_stage;
 	long long total_out = 0, cap_total = 0;  // of the most recent syn_prepare
@@ -911,7 +1221,8 @@ static void launch_pulses(const SynArgs &a, hipStream_t s) {
 	// every FFT pass: 3.53 -> 3.35 ms per 64 x 10 s at 16 kHz, 2.08 -> 1.53 ms at 8 kHz); 512 threads per 2048-point pulse measured
 	// slower (13.2 vs 10.0 ms per 64 x 10 s batch)
 	constexpr int TP = (N >= 2048) ? 256 : (N / 8 < 64 ? 64 : N / 8);
-	hipLaunchKernelGGL((syn_pulse_kernel<N, TP>), dim3((unsigned)a.total_pulses), dim3(TP), 0, s, a);
+	// (the pulses are dealt to the XCDs in eighths: the grid is a multiple of eight, the kernel drops what lies beyond the count)
+	hipLaunchKernelGGL((syn_pulse_kernel<N, TP>), dim3((unsigned)(8 * ((a.total_pulses + 7) / 8))), dim3(TP), 0, s, a);
 }
 
 // per-utterance pulse prefix, overflow flag and end-of-stage stream positions (one small workgroup)
@@ -1074,15 +1385,33 @@ int syn_pulses(wc_synthesis *sy, hipStream_t s, const double *d_f0, const double
 #else
 	a.only_pulse = -1;
 #endif
+	a.trace = nullptr;
+#if WC_SYN_TRACE
+	static DevBuf tracebuf;
+	if (tracebuf.reserve(sizeof(unsigned long long) * 16 * (size_t)co)) return WC_ERR_DEVICE;
+	(void)hipMemsetAsync(tracebuf.p, 0, sizeof(unsigned long long) * 16 * (size_t)co, s);
+	a.trace = tracebuf.as<unsigned long long>();
+#endif
 	if ((rc = dev->time_begin("synthesis_pulses", s))) return rc;
 	switch (sy->fft_size) {
 		case 512: launch_pulses<512>(a, s); break;
 		case 1024: launch_pulses<1024>(a, s); break;
-		case 2048: launch_pulses<2048>(a, s); break;
+		case 2048:
+			if (sy->wave) hipLaunchKernelGGL(syn_pulse_wave_kernel, dim3((unsigned)(8 * ((a.total_pulses + 7) / 8))), dim3(64), 0, s, a);
+			else launch_pulses<2048>(a, s);
+			break;
 		case 4096: launch_pulses<4096>(a, s); break;
 		default: return fail(WC_ERR_UNSUPPORTED, "synthesis: fft_size must be 512, 1024, 2048 or 4096");
 	}
 	WC_HIP(hipGetLastError());
+#if WC_SYN_TRACE
+	if (const char *path = getenv("WC_SYN_TRACE_FILE")) {
+		std::vector<unsigned long long> h((size_t)16 * co);
+		WC_HIP(hipStreamSynchronize(s));
+		WC_HIP(hipMemcpy(h.data(), a.trace, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+		if (FILE *f = fopen(path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+	}
+#endif
 	return dev->time_end("synthesis_pulses", s);
 }
 
@@ -1147,6 +1476,8 @@ wc_synthesis *wc_synthesis_create(int fs, int fft_size, double frame_period_ms) 
 		s->serial_timebase = tb && std::string(tb) == "serial";
 		const char *pu = getenv("WC_SYN_PULSES");
 		s->pulses_by_utterance = pu && std::string(pu) == "utterance";
+		const char *impl = getenv("WC_SYN_IMPL");
+		s->wave = !(impl && std::string(impl) == "block");
 	}
 	s->dev = dev;
 	// getDCRemover, reference :290-303

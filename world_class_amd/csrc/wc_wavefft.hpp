@@ -846,4 +846,75 @@ __device__ __forceinline__ double wf_exp(double x, const double2 *__restrict__ t
 	return ldexp(fma(t, p, t), ni >> 6);
 }
 
+// The tables of wf_log / wf_exp in LDS (kWfTabLds doubles: 128 x (1 / c, log c), then 64 x 2^{j/64}), copied once per
+// wavefront by wf_tables_to_lds: a look-up is then an LDS read (~100 cycles) instead of a gather from L2 (~500), which a
+// lone wavefront meets 34 times per frame or pulse.
+constexpr int kWfTabLds = 320;
+__device__ __forceinline__ void wf_tables_to_lds(double *T, const double2 *__restrict__ tw, int lane) {
+	double2 v[3];
+#pragma unroll
+	for (int i = 0; i < 3; ++i) v[i] = tw_load(tw + kTwLog, min(lane + 64 * i, 159));  // 128 + 32 entries, contiguous
+	WF_SCHED_FENCE();
+#pragma unroll
+	for (int i = 0; i < 3; ++i)
+		if (lane + 64 * i < 160) reinterpret_cast<double2 *>(T)[lane + 64 * i] = v[i];
+	wf_fence();
+}
+__device__ __forceinline__ double wf_log_fast_l(double x, const double *T) {
+	const int e = __builtin_amdgcn_frexp_exp(x);
+	const double m = __builtin_amdgcn_frexp_mant(x);
+	const int i = (__double2hiint(m) >> 13) & 127;
+	const double2 c = reinterpret_cast<const double2 *>(T)[i];
+	const double r = fma(m, c.x, -1.0);
+	double q = fma(r, -1.0 / 6.0, 0.2);
+	q = fma(r, q, -0.25);
+	q = fma(r, q, 1.0 / 3.0);
+	q = fma(r, q, -0.5);
+	const double p = fma(r * r, q, r);
+	return fma((double)e, 0.69314718055994530942, c.y) + p;
+}
+__device__ __forceinline__ double wf_log_l(double x, const double *T) {
+	double res = wf_log_fast_l(x, T);
+	if (!wf_log_ok(x)) res = wf_log_libm(x);
+	return res;
+}
+__device__ __forceinline__ double wf_exp_l(double x, const double *T) {
+	const double n = rint(x * 0x1.71547652b82fep+6);  // 64 / ln 2
+	double r = fma(n, -0x1.62e42feep-7, x);
+	r = fma(n, -0x1.a39ef35793c76p-39, r);
+	const int ni = (int)n;
+	const double t = T[256 + (ni & 63)];
+	double q = fma(r, 1.0 / 120.0, 1.0 / 24.0);
+	q = fma(r, q, 1.0 / 6.0);
+	q = fma(r, q, 0.5);
+	const double p = fma(r * r, q, r);
+	return ldexp(fma(t, p, t), ni >> 6);
+}
+
+// sin and cos of x to ~1 ulp for |x| up to ~1e5 (the phases here are a few radians): x = n pi/2 + r, |r| <= pi/4, by
+// two fused steps; the kernels are fdlibm's polynomials.  ~35 vector instructions against ~120 of ocml's sincos with
+// its large-argument path, 17 times per minimum-phase spectrum.
+__device__ __forceinline__ void wf_sincos(double x, double &sn, double &cs) {
+	const double n = rint(x * 0.63661977236758134308);
+	double r = fma(n, -1.57079632679489655800e+00, x);
+	r = fma(n, -6.12323399573676603587e-17, r);
+	const int q = (int)n;
+	const double z = r * r;
+	double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+	ps = fma(z, ps, 2.75573137070700676789e-06);
+	ps = fma(z, ps, -1.98412698298579493134e-04);
+	ps = fma(z, ps, 8.33333333332248946124e-03);
+	ps = fma(z, ps, -1.66666666666666324348e-01);
+	const double s = fma(z * r, ps, r);
+	double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+	pc = fma(z, pc, -2.75573143513906633035e-07);
+	pc = fma(z, pc, 2.48015872894767294178e-05);
+	pc = fma(z, pc, -1.38888888888741095749e-03);
+	pc = fma(z, pc, 4.16666666666666019037e-02);
+	const double c = fma(z * z, pc, fma(z, -0.5, 1.0));
+	const double a = (q & 1) ? c : s, b = (q & 1) ? s : c;
+	sn = (q & 2) ? -a : a;
+	cs = ((q + 1) & 2) ? -b : b;
+}
+
 }  // namespace wc
