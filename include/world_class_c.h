@@ -148,6 +148,13 @@ int wc_pipeline_run_device(wc_pipeline *p, int n_utt, const double *d_x, const i
 int wc_pipeline_run_batch_host(wc_pipeline *p, int n_utt, const void *const *x, int x_is_pcm16, const int *x_length, double *const *tpos,
                                double *const *f0, double *const *sp, double *const *ap, void *const *y, int y_is_pcm16,
                                uint64_t *rng_pos);
+/* The same with the reference's feature codec (include/codec.hpp, src/codec.cpp:211-325; world_class_codec.h) as the epilogue of
+ * CheapTrick / D4C: coded_sp[u] receives frames x number_of_dimensions mel-cepstral coefficients, coded_ap[u] frames x
+ * GetNumberOfAperiodicities(fs) band aperiodicities -- 65 instead of 2050 doubles per 48 kHz frame cross PCIe.  Any table may
+ * be NULL.  (wc_pipeline_run_batch_host: destination rows in page-locked memory are written by the copy engine directly.) */
+int wc_pipeline_run_batch_host_coded(wc_pipeline *p, int n_utt, const void *const *x, int x_is_pcm16, const int *x_length, double *const *tpos,
+                                     double *const *f0, double *const *coded_sp, int number_of_dimensions, double *const *coded_ap,
+                                     void *const *y, int y_is_pcm16, uint64_t *rng_pos);
 
 /* ---- device memory plumbing for callers without their own HIP allocator (tests, C++ demo) ------ */
 void *wc_device_malloc(uint64_t bytes);

@@ -154,6 +154,34 @@ def test_host_batch_front_end_pcm16_and_double(wca):
         assert np.abs(g["y"] - r["y"]).max() < 1e-10
 
 
+def test_host_batch_front_end_pinned_rows_and_coded_outputs(wca):
+    """wc_pipeline_run_batch_host with the caller's rows in page-locked memory (written by the copy engine directly, no staging)
+    gives the same rows; wc_pipeline_run_batch_host_coded returns what the reference's codec (src/codec.cpp:211-325) makes of
+    those rows: mel-cepstral coefficients and band aperiodicities, checked against the CPU restatement of the codec."""
+    from oracle import port_codec as pc
+    fs = 48000
+    xs = [make_utterance(fs, sec, seed) for sec, seed in ((0.4, 41), (0.7, 42), (0.3, 43), (0.55, 44))]
+    p = wca.Pipeline(fs)
+    ref = p.run_batch(xs)
+    pinned = p.host_buffers([len(x) for x in xs], pinned=True)
+    for g in pinned:
+        for v in g.values():
+            v.fill(-1.0)
+    got = p.run_batch_host(xs, out=pinned)
+    for r, g, h in zip(ref, pinned, got):
+        assert all(g[k] is h[k] for k in g)
+        assert np.array_equal(g["tpos"], r["tpos"]) and np.array_equal(g["f0"], r["f0"])
+        assert np.array_equal(g["sp"], r["sp"]) and np.array_equal(g["ap"], r["ap"])
+        assert np.abs(g["y"] - r["y"]).max() < 1e-10
+    nd = 60
+    coded = p.run_batch_host_coded(xs, number_of_dimensions=nd)
+    for r, c in zip(ref, coded):
+        assert np.array_equal(c["f0"], r["f0"]) and np.abs(c["y"] - r["y"]).max() < 1e-10
+        assert c["csp"].shape == (len(r["f0"]), nd)
+        assert np.abs(c["csp"] - pc.code_spectral_envelope(r["sp"], fs, p.fft_size, nd)).max() < 1e-10
+        assert np.abs(c["cap"] - pc.code_aperiodicity(r["ap"], fs, p.fft_size)).max() < 1e-10
+
+
 def test_pipeline_at_96_khz_golden(wca):
     """96 kHz: decimation ratio 12, 4096-point CheapTrick / Synthesis, 8192-point D4C and LoveTrain (the unpacking twiddles of
     the 8192-point real transforms lie between the entries of the 4096-entry table and are computed) against the real

@@ -1,3 +1,4 @@
 mkdir -p gpurun_out; rm -f gpurun_out/*.log
-WC_LIB_PATH=world_class_amd/_variants/synnoat.so python tools/microbench.py --stages cds --utts 64 --iters 3 > gpurun_out/tr.log 2>&1
-tail -8 gpurun_out/tr.log
+timeout 900 python -m pytest tests/test_gpu_pipeline.py tests/test_gpu_stream.py tests/test_gpu_cheaptrick.py -x -q 2>&1 | tail -12 > gpurun_out/t2.log
+timeout 300 python tools/microbench.py --stages c --utts 256 --iters 3 >> gpurun_out/d4.log 2>&1
+cat gpurun_out/t2.log gpurun_out/d4.log

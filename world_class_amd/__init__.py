@@ -59,6 +59,8 @@ _SIGNATURES = {
     "wc_pipeline_run_device": (C.c_int, [_vp, C.c_int, _vp, _ip, _vp, _vp, _vp, _vp, _vp, _u64p]),
     "wc_pipeline_run_batch_host": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.c_int, _ip, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp),
                                              C.POINTER(_vp), C.POINTER(_vp), C.c_int, _u64p]),
+    "wc_pipeline_run_batch_host_coded": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.c_int, _ip, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp),
+                                                   C.c_int, C.POINTER(_vp), C.POINTER(_vp), C.c_int, _u64p]),
     "wc_device_malloc": (_vp, [C.c_uint64]),
     "wc_device_free": (None, [_vp]),
     "wc_memcpy_h2d": (C.c_int, [_vp, _vp, C.c_uint64]),

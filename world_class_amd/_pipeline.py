@@ -77,6 +77,53 @@ class Pipeline:
         res = [{k: outs[k][u] for k in outs if outs[k] is not None} for u in range(n)]
         return (res, list(arr)) if rng_pos is not None else res
 
+    def host_buffers(self, x_lengths, want=("tpos", "f0", "sp", "ap", "y"), y_pcm16=False, pinned=True):
+        """Result buffers for run_batch_host(..., out=...), one dict per utterance.  pinned: page-locked (torch pinned
+        tensors seen as numpy arrays) -- the spectrogram / aperiodicity rows are then written by the copy engine directly,
+        without the staging copy and the host-side scatter."""
+        import torch
+        fl, yl = self.lengths(list(x_lengths))
+
+        def arr(shape, dtype):
+            if pinned:
+                return torch.empty(shape, dtype={np.float64: torch.float64, np.int16: torch.int16}[dtype], pin_memory=True).numpy()
+            return np.empty(shape, dtype=dtype)
+        res = []
+        for f, m in zip(fl, yl):
+            r = {}
+            for k in want:
+                r[k] = arr(f, np.float64) if k in ("tpos", "f0") else arr((f, self.bins), np.float64) if k in ("sp", "ap") else \
+                    arr(m, np.int16 if y_pcm16 else np.float64)
+            res.append(r)
+        return res
+
+    def run_batch_host_coded(self, xs, number_of_dimensions=60, want=("f0", "csp", "cap", "y"), y_pcm16=False, rng_pos=None):
+        """wc_pipeline_run_batch_host_coded: the host front-end with the reference's feature codec as the epilogue -- per frame
+        `number_of_dimensions` mel-cepstral coefficients ("csp") and the band aperiodicities ("cap") instead of the rows."""
+        import ctypes as C
+        from .codec import number_of_aperiodicities
+        fmt = {np.dtype(np.int16): 1, np.dtype(np.float32): 2}.get(xs[0].dtype, 0)
+        xs = [np.ascontiguousarray(v, dtype=(np.float64, np.int16, np.float32)[fmt]) for v in xs]
+        n = len(xs)
+        xl = [len(v) for v in xs]
+        fl, yl = self.lengths(xl)
+        n_ap = number_of_aperiodicities(self.fs)
+        VP = C.c_void_p * n
+        shapes = {"tpos": lambda f, m: (f,), "f0": lambda f, m: (f,), "csp": lambda f, m: (f, number_of_dimensions),
+                  "cap": lambda f, m: (f, n_ap), "y": lambda f, m: (m,)}
+        outs, tabs = {}, {}
+        for k in shapes:
+            if k in want:
+                outs[k] = [np.empty(shapes[k](f, m), dtype=np.int16 if (k == "y" and y_pcm16) else np.float64) for f, m in zip(fl, yl)]
+                tabs[k] = VP(*[a.ctypes.data for a in outs[k]])
+            else:
+                tabs[k] = None
+        arr, arg = _rng_arg(rng_pos, n)
+        _check(lib().wc_pipeline_run_batch_host_coded(self._h, n, VP(*[v.ctypes.data for v in xs]), fmt, _ints(xl), tabs["tpos"], tabs["f0"],
+                                                      tabs["csp"], number_of_dimensions, tabs["cap"], tabs["y"], 1 if y_pcm16 else 0, arg))
+        res = [{k: outs[k][u] for k in outs} for u in range(n)]
+        return (res, list(arr)) if rng_pos is not None else res
+
     def __del__(self):
         try:
             if getattr(self, "_h", None):

@@ -33,14 +33,16 @@ struct CtArgs {
 	long long total_frames;
 	int fs;
 	double q1, f0_floor;  // f0_floor = 3 fs / (N - 3)
+	const int *uidx;      // utterance of every frame (ct_count_kernel)
 	int rare_only;        // the block kernel behind the wavefront kernel: only the frames that one leaves out (ct_wave_can)
 };
 
 // per-frame number of draws: window (2 hw + 1) then one per bin (reference :153, :227)
 __global__ void ct_count_kernel(const double *__restrict__ f0, long long total, int fs, double f0_floor,
-								int bins, uint32_t *__restrict__ cnt) {
+								int bins, uint32_t *__restrict__ cnt, const UttDesc *__restrict__ utts, int n_utt, int *__restrict__ uidx) {
 	long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 	if (g >= total) return;
+	uidx[g] = find_utt(utts, n_utt, g);  // (looked up once here rather than by every frame's wavefront, eight dependent loads each)
 	double f = f0[g];
 	double f0c = (f <= f0_floor) ? 500.0 : f;
 	cnt[g] = (uint32_t)(2 * mround(1.5 * fs / f0c) + 1 + bins);
@@ -288,10 +290,25 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 	__shared__ double scr[T + 2 * (T / 64)];
 	__shared__ double red[2 * (T / 64) + 2];
 	if constexpr (RARE) {
-		for (long long g = blockIdx.x; g < a.total_frames; g += gridDim.x) {
-			const double f0v = a.f0[g];
-			if (ct_wave_can<N>((f0v <= a.f0_floor) ? 500.0 : f0v, a.fs)) continue;
-			ct_frame_block<N, T>(a, g, A, scr, red);
+		// every thread looks at a frame of its own; the (rare) hits of a sweep are then done one after the other by the block
+		__shared__ int hits[T];
+		__shared__ int nhit;
+		for (long long base = (long long)blockIdx.x * T; base < a.total_frames; base += (long long)gridDim.x * T) {
+			const long long g = base + threadIdx.x;
+			bool hit = false;
+			if (g < a.total_frames) {
+				const double f0v = a.f0[g];
+				hit = !ct_wave_can<N>((f0v <= a.f0_floor) ? 500.0 : f0v, a.fs);
+			}
+			if (threadIdx.x == 0) nhit = 0;
+			__syncthreads();
+			if (hit) hits[atomicAdd(&nhit, 1)] = threadIdx.x;
+			__syncthreads();
+			const int n = nhit;
+			for (int i = 0; i < n; ++i) {
+				ct_frame_block<N, T>(a, base + hits[i], A, scr, red);
+				__syncthreads();
+			}
 			__syncthreads();
 		}
 	} else {
@@ -309,13 +326,11 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 // per bin stay in the lane.  LDS: 9.6 KB (exchange buffer = mirrored segment of the smoothing, scratch of the cumulative
 // sum), 16 wavefronts per CU.  What is done differently from the block kernel, none of it above 1e-15 relative:
 //   * the halving of the real-transform unpacking is folded into the window norm / the lifter scale (exact);
-//   * LinearSmoothing's two interpolation abscissae are k + c_lo, k + c_hi with one (c_lo, c_hi) per frame instead of a
-//     quotient per bin (the reference's per-bin rounding of them moves the interpolant by < 1e-13 of one term);
 //   * (hi - lo) * (1 / width), sin / (alpha k) as a product with tabulated 1 / k, the lean log / exp of wc_wavefft.hpp.
 // The FFT of the log spectrum is real, so only real parts are unpacked (wf_r2c_unpack_re) and the liftered spectrum goes
 // back through the real-spectrum packing (wf_c2r_pack_re).
 #ifndef WC_CT_WAVE_OCC
-#define WC_CT_WAVE_OCC 3
+#define WC_CT_WAVE_OCC 2
 #endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_CT_WAVE_OCC, WC_CT_WAVE_OCC))) void ct_wave_kernel(CtArgs a) {
 	constexpr int N = 2048, M = 1024;
@@ -328,8 +343,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_CT_WAVE_O
 	const double f0v = a.f0[g];
 	const double f0c = uniform_d((f0v <= a.f0_floor) ? 500.0 : f0v);  // reference :77
 	if (!ct_wave_can<N>(f0c, fs)) return;
-	const int u = find_utt(a.utts, a.n_utt, g);
-	const UttDesc ud = a.utts[u];
+	const UttDesc ud = a.utts[a.uidx[g]];
 	const double *__restrict__ x = a.x + ud.x_off;
 	const int x_last = ud.x_len - 1;
 	const double pos = a.tpos[g];
@@ -343,9 +357,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_CT_WAVE_O
 	double ce0, se0, co0, so0, cd, sd;
 	{
 		const double kappa = f0c / 1.5 / fs;  // angle per sample in units of pi
-		sincospi(kappa * (2 * lane - hw), &se0, &ce0);
-		sincospi(kappa * (2 * lane + 1 - hw), &so0, &co0);
-		sincospi(kappa * 128.0, &sd, &cd);
+		wf_sincospi(kappa * (2 * lane - hw), se0, ce0);
+		wf_sincospi(kappa * (2 * lane + 1 - hw), so0, co0);
+		wf_sincospi(kappa * 128.0, sd, cd);
 		sd = uniform_d(sd);
 		cd = uniform_d(cd);
 	}
@@ -467,15 +481,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_CT_WAVE_O
 		seq_cumsum_nonneg_wave<18>(L, len, lane);
 		const double step = (double)fs / N;
 		const double origin_axis = -(b - 0.5) * fs / N;
-		const double c_lo = (-width / 2.0 - origin_axis) / step, c_hi = ((-width / 2.0 + width) - origin_axis) / step;
-		const int i_lo = __builtin_amdgcn_readfirstlane((int)c_lo), i_hi = __builtin_amdgcn_readfirstlane((int)c_hi);
-		const double f_lo = c_lo - i_lo, f_hi = c_hi - i_hi;
+		const double rstep = 1.0 / step;
 		const double rwidth = 1.0 / width;
 		const uint32_t *__restrict__ rngb = rng + wl;
 		bool odd = false;  // a smoothed value that is not a positive finite number (the reference then takes log of it all the same)
 		auto smooth = [&](int k, bool slow) {
-			const double l0 = L[k + i_lo], l1 = L[k + i_lo + 1], h0 = L[k + i_hi], h1 = L[k + i_hi + 1];
-			const double lo_v = fma(l1 - l0, f_lo, l0), hi_v = fma(h1 - h0, f_hi, h0);
+			// the two abscissae in the reference's own per-bin arithmetic (interp1Q, reference src/world_matlabfunctions.cpp:220-241):
+			// where the terms are small against the running sum the result hangs on the last bits of these fractions (a chirp
+			// without dither: 5e-3 on the envelope with one fraction per frame instead)
+			const double lo_axis = (double)k / N * fs - width / 2.0, hi_axis = lo_axis + width;
+			const double lo_v = wf_interp1q(origin_axis, step, rstep, L, len, lo_axis);
+			const double hi_v = wf_interp1q(origin_axis, step, rstep, L, len, hi_axis);
 			double sm = (hi_v - lo_v) * rwidth;
 			// infinitesimal noise (reference :220-228) then log (reference :251-252)
 			sm = fma(fabs(randn_at(rngb, k)), 0.00000000000000022204460492503131, sm);
@@ -484,9 +500,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_CT_WAVE_O
 			return wf_log_fast_l(sm, T);
 		};
 #pragma unroll
-		for (int gq = 0; gq < 4; ++gq)
+		for (int gq = 0; gq < 4; ++gq) {
 #pragma unroll
 			for (int q = 0; q < 4; ++q) lp[4 * gq + q] = smooth(jg[gq] + 256 * q, false);
+			WF_SCHED_FENCE();  // (four bins at a time: interleaving all seventeen overflows the registers)
+		}
 		lpM = smooth(M, false);
 		if (__any(odd)) {  // (never on signals with a noise floor)
 #pragma unroll
@@ -532,8 +550,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_CT_WAVE_O
 		const double ralpha = 1.0 / (kPi * f0c / fs);
 		const double scale = 0.5 / N;  // the halving left over from the unpacking and the reference's / fft_size
 		double ct, st, c64, s64;
-		sincospi(f0c / fs * lane, &st, &ct);
-		sincospi(f0c / fs * 64.0, &s64, &c64);
+		wf_sincospi(f0c / fs * lane, st, ct);
+		wf_sincospi(f0c / fs * 64.0, s64, c64);
 		const double c128 = fma(-2.0 * s64, s64, 1.0), s128 = 2.0 * s64 * c64;
 		const double c256 = uniform_d(fma(-2.0 * s128, s128, 1.0)), s256 = uniform_d(2.0 * s128 * c128);
 		double ec[4], es[4];  // the four butterflies' running (cos, sin)
@@ -583,7 +601,7 @@ struct wc_cheaptrick {
 	bool wave;  // N = 2048: one wavefront per frame (default; WC_CT_IMPL=block: the workgroup-per-frame kernel for every frame)
 	double q1, f0_floor_opt, f0_floor;
 	Device *dev;
-	DevBuf utts, cnt, off, endpos, d_x, d_tpos, d_f0, d_sp;
+	DevBuf utts, cnt, uidx, off, endpos, d_x, d_tpos, d_f0, d_sp;
 	HostBuf h_stage;
 };
 
@@ -632,6 +650,7 @@ int ct_prepare(wc_cheaptrick *c, hipStream_t s, int n_utt, const int *x_length, 
 	int rc;
 	if ((rc = c->utts.reserve(sizeof(UttDesc) * n_utt))) return rc;
 	if ((rc = c->cnt.reserve(sizeof(uint32_t) * total))) return rc;
+	if ((rc = c->uidx.reserve(sizeof(int) * total))) return rc;
 	if ((rc = c->off.reserve(sizeof(uint64_t) * total))) return rc;
 	if ((rc = c->endpos.reserve(sizeof(uint64_t) * n_utt))) return rc;
 	if ((rc = c->h_stage.reserve(sizeof(UttDesc) * n_utt + sizeof(uint64_t) * n_utt))) return rc;
@@ -639,7 +658,7 @@ int ct_prepare(wc_cheaptrick *c, hipStream_t s, int n_utt, const int *x_length, 
 	WC_HIP(hipMemcpyAsync(c->utts.p, c->h_stage.p, sizeof(UttDesc) * n_utt, hipMemcpyHostToDevice, s));
 	if ((rc = c->h_stage.mark(s))) return rc;
 	hipLaunchKernelGGL(ct_count_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_f0, total, c->fs,
-					   c->f0_floor, bins, c->cnt.as<uint32_t>());
+					   c->f0_floor, bins, c->cnt.as<uint32_t>(), c->utts.as<UttDesc>(), n_utt, c->uidx.as<int>());
 	hipLaunchKernelGGL(utt_scan_kernel, dim3(n_utt), dim3(256), 0, s, c->cnt.as<uint32_t>(), c->utts.as<UttDesc>(),
 					   (const unsigned long long *)nullptr, c->off.as<unsigned long long>(), c->endpos.as<unsigned long long>());
 	WC_HIP(hipGetLastError());
@@ -655,7 +674,7 @@ int ct_frames(wc_cheaptrick *c, hipStream_t s, int n_utt, const double *d_x, con
 	a.x = d_x; a.utts = c->utts.as<UttDesc>(); a.n_utt = n_utt; a.tpos = d_tpos; a.f0 = d_f0;
 	a.rng_off = c->off.as<unsigned long long>(); a.rng_table = dev->rng_table.as<uint32_t>();
 	a.rng_base = dev->rng_base; a.tw = dev->twiddle; a.sp = d_sp; a.total_frames = total; a.fs = c->fs;
-	a.q1 = c->q1; a.f0_floor = c->f0_floor;
+	a.q1 = c->q1; a.f0_floor = c->f0_floor; a.uidx = c->uidx.as<int>();
 	if ((rc = dev->time_begin("cheaptrick_frames", s))) return rc;
 	a.rare_only = 0;
 	switch (c->fft_size) {
@@ -694,12 +713,13 @@ static int ct_run_device(wc_cheaptrick *c, int n_utt, const double *d_x, const i
 		const uint64_t per_frame_max = (uint64_t)(2 * (c->fft_size / 2) + 1 + bins);
 		uint64_t lo = ~0ull, hi = 0;
 		for (int u = 0; u < n_utt; ++u) {
+			if (f0_length[u] <= 0) continue;  // (no frames, no draws: its position -- a stream reset hours after the others -- must not stretch the table)
 			uint64_t p0 = rng_pos ? rng_pos[u] : 0ull;
 			lo = p0 < lo ? p0 : lo;
-			uint64_t e = p0 + per_frame_max * (uint64_t)(f0_length[u] > 0 ? f0_length[u] : 0);
+			uint64_t e = p0 + per_frame_max * (uint64_t)f0_length[u];
 			hi = e > hi ? e : hi;
 		}
-		if ((rc = dev->ensure_rng(lo, hi))) return rc;
+		if (hi > lo && (rc = dev->ensure_rng(lo, hi))) return rc;
 	}
 	if ((rc = ct_prepare(c, s, n_utt, x_length, d_f0, f0_length, rng_pos, &total, &min_pos, &max_end))) return rc;
 	if (total == 0) return WC_OK;
@@ -743,7 +763,7 @@ wc_cheaptrick *wc_cheaptrick_create(int fs, double q1, double f0_floor, int fft_
 void wc_cheaptrick_destroy(wc_cheaptrick *c) {
 	if (!c) return;
 	c->dev->quiesce();
-	c->utts.release(); c->cnt.release(); c->off.release(); c->endpos.release();
+	c->utts.release(); c->cnt.release(); c->uidx.release(); c->off.release(); c->endpos.release();
 	c->d_x.release(); c->d_tpos.release(); c->d_f0.release(); c->d_sp.release();
 	c->h_stage.release();
 	delete c;

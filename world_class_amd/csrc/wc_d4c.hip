@@ -737,9 +737,9 @@ __device__ __forceinline__ int d4c2_windowed(int type, const double *__restrict_
 	const int base = __builtin_amdgcn_readfirstlane(mround(pos * fs + 0.001)) - hw;
 	const double c1 = 2.0 / ratio / fs;
 	double ce0, se0, co0, so0, cd, sd;  // angles in units of pi
-	sincospi(f0 * (c1 * (2 * lane - hw)), &se0, &ce0);
-	sincospi(f0 * (c1 * (2 * lane + 1 - hw)), &so0, &co0);
-	sincospi(f0 * (c1 * 128.0), &sd, &cd);
+	wf_sincospi(f0 * (c1 * (2 * lane - hw)), se0, ce0);
+	wf_sincospi(f0 * (c1 * (2 * lane + 1 - hw)), so0, co0);
+	wf_sincospi(f0 * (c1 * 128.0), sd, cd);
 	sd = uniform_d(sd);
 	cd = uniform_d(cd);
 	// Hanning 0.5 c + 0.5; Blackman 0.42 + 0.5 c + 0.08 cos 2theta = 0.34 + c (0.5 + 0.16 c): a0 + c (0.5 + a2 c) for both
@@ -954,20 +954,21 @@ __device__ __forceinline__ void d4c2_smooth(D4Bins &s, double width, int fs, dou
 	}
 	const double step = (double)fs / N;
 	const double origin_axis = -(b - 0.5) * fs / N;
-	const double c_lo = (-width / 2.0 - origin_axis) / step, c_hi = ((-width / 2.0 + width) - origin_axis) / step;
-	const int i_lo = __builtin_amdgcn_readfirstlane((int)c_lo), i_hi = __builtin_amdgcn_readfirstlane((int)c_hi);
-	const double f_lo = uniform_d(c_lo - i_lo), f_hi = uniform_d(c_hi - i_hi);
+	const double rstep = 1.0 / step;
 	const double rwidth = uniform_d(1.0 / width);
+	// (the abscissae in the reference's own per-bin arithmetic, see ct_wave_kernel)
 	auto at = [&](int k) {
-		const double l0 = L[k + i_lo], l1 = L[k + i_lo + 1], h0 = L[k + i_hi], h1 = L[k + i_hi + 1];
-		return (fma(h1 - h0, f_hi, h0) - fma(l1 - l0, f_lo, l0)) * rwidth;
+		const double lo_axis = (double)k / N * fs - width / 2.0, hi_axis = lo_axis + width;
+		return (wf_interp1q(origin_axis, step, rstep, L, len, hi_axis) - wf_interp1q(origin_axis, step, rstep, L, len, lo_axis)) * rwidth;
 	};
 #pragma unroll
 	for (int p = 0; p < 2; ++p)
 #pragma unroll
-		for (int gq = 0; gq < 4; ++gq)
+		for (int gq = 0; gq < 4; ++gq) {
 #pragma unroll
 			for (int q = 0; q < 4; ++q) s.v[p][4 * gq + q] = at(jg[p][gq] + 512 * q);
+			WF_SCHED_FENCE();  // (four bins at a time: interleaving all of them overflows the registers)
+		}
 	s.vM = at(M);
 	wf_fence();
 }

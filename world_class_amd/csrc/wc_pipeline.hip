@@ -28,6 +28,7 @@
 
 #include "wc_stages.hpp"
 #include "../../include/world_class_io.h"
+#include "../../include/world_class_codec.h"
 
 using namespace wc;
 
@@ -75,7 +76,18 @@ struct HostSink {
 	const int *f_len = nullptr;
 	int bins = 0;
 	bool overlapped[2] = {false, false};  // group g was copied and scattered during the run (first attempt only)
+	bool direct = false;  // every destination row lies in pinned host memory: the copy engine writes the rows where they belong
 };
+
+// true when p lies in page-locked host memory (hipHostMalloc / hipHostRegister; e.g. a pinned torch tensor)
+static bool is_pinned(const void *p) {
+	hipPointerAttribute_t at;
+	if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+		(void)hipGetLastError();
+		return false;
+	}
+	return at.type == hipMemoryTypeHost;
+}
 
 struct wc_pipeline {
 	int mode;  // 0: shared stages, Harvest split over streams; 1: independent staggered chains per utterance group
@@ -93,7 +105,7 @@ struct wc_pipeline {
 	hipStream_t s1, s2, s_copy;
 	hipEvent_t e0, e1, e2, e_copy[2];
 	// host batch front-end (wc_pipeline_run_batch_host): device-resident batch + pinned staging, grow-only
-	DevBuf b_x, b_pcm, b_t, b_f, b_sp, b_ap, b_y, b_ypcm;
+	DevBuf b_x, b_pcm, b_t, b_f, b_sp, b_ap, b_y, b_ypcm, b_coded;
 	HostBuf st_in, st_out;
 };
 
@@ -168,7 +180,7 @@ wc_pipeline *wc_pipeline_create(int fs, double frame_period, double harvest_f0_f
 void wc_pipeline_destroy(wc_pipeline *p) {
 	if (!p) return;
 	if (p->dev) p->dev->quiesce();
-	for (DevBuf *b : {&p->b_x, &p->b_pcm, &p->b_t, &p->b_f, &p->b_sp, &p->b_ap, &p->b_y, &p->b_ypcm}) b->release();
+	for (DevBuf *b : {&p->b_x, &p->b_pcm, &p->b_t, &p->b_f, &p->b_sp, &p->b_ap, &p->b_y, &p->b_ypcm, &p->b_coded}) b->release();
 	p->st_in.release();
 	p->st_out.release();
 	if (p->s1) { (void)hipStreamSynchronize(p->s1); (void)hipStreamDestroy(p->s1); }
@@ -286,8 +298,18 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 				if (sink && attempt == 0 && (sink->stage_sp || sink->stage_ap)) {
 					const size_t off = sizeof(double) * (size_t)sl[g].fo * bins_, len = sizeof(double) * (size_t)(fo_end[g] - sl[g].fo) * bins_;
 					WC_HIP(hipStreamWaitEvent(p->s_copy, G.e_aux, 0));
-					if (sink->stage_sp) WC_HIP(hipMemcpyAsync(sink->stage_sp + off, gsp, len, hipMemcpyDeviceToHost, p->s_copy));
-					if (sink->stage_ap) WC_HIP(hipMemcpyAsync(sink->stage_ap + off, gap, len, hipMemcpyDeviceToHost, p->s_copy));
+					if (sink->direct) {
+						long long fo2 = 0;
+						for (int u = u0; u < u0 + nu; ++u) {
+							const size_t ulen = sizeof(double) * (size_t)f_len[u] * bins_;
+							if (sink->stage_sp && sink->sp[u]) WC_HIP(hipMemcpyAsync(sink->sp[u], gsp + fo2 * bins_, ulen, hipMemcpyDeviceToHost, p->s_copy));
+							if (sink->stage_ap && sink->ap[u]) WC_HIP(hipMemcpyAsync(sink->ap[u], gap + fo2 * bins_, ulen, hipMemcpyDeviceToHost, p->s_copy));
+							fo2 += f_len[u];
+						}
+					} else {
+						if (sink->stage_sp) WC_HIP(hipMemcpyAsync(sink->stage_sp + off, gsp, len, hipMemcpyDeviceToHost, p->s_copy));
+						if (sink->stage_ap) WC_HIP(hipMemcpyAsync(sink->stage_ap + off, gap, len, hipMemcpyDeviceToHost, p->s_copy));
+					}
 					WC_HIP(hipEventRecord(p->e_copy[g], p->s_copy));
 				}
 				if ((rc = syn_prepare(G.sy, G.main, nu, gf, f_len.data() + u0, y_len.data() + u0, gy, nullptr, full[g][1]))) return rc;
@@ -299,6 +321,7 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 				// the rows of each half batch go to the caller's buffers as soon as their copy has landed: half A's while B computes
 				for (int g = 0; g < 2; ++g) {
 					WC_HIP(hipEventSynchronize(p->e_copy[g]));
+					if (sink->direct) { sink->overlapped[g] = true; continue; }
 					std::vector<CopyJob> jobs;
 					long long fo = sl[g].fo;
 					for (int u = sl[g].u0; u < sl[g].u0 + sl[g].nu; ++u) {
@@ -444,6 +467,11 @@ int wc_pipeline_run_batch_host(wc_pipeline *p, int n_utt, const void *const *x, 
 	sink.stage_sp = sp ? out + off_sp : nullptr;
 	sink.stage_ap = ap ? out + off_ap : nullptr;
 	sink.sp = sp; sink.ap = ap; sink.f_len = f_len.data(); sink.bins = bins;
+	// a caller who hands over page-locked rows (hipHostMalloc / hipHostRegister, a pinned torch tensor) gets them written by the
+	// copy engine directly: no staging copy, no host-side scatter of the 2 GB
+	sink.direct = (sp || ap);
+	for (int u = 0; u < n_utt && sink.direct; ++u)
+		sink.direct = (!sp || !sp[u] || is_pinned(sp[u])) && (!ap || !ap[u] || is_pinned(ap[u]));
 	if ((rc = pipeline_run(p, n_utt, p->b_x.as<double>(), x_length, p->b_t.as<double>(), p->b_f.as<double>(),
 						   p->b_sp.as<double>(), p->b_ap.as<double>(), p->b_y.as<double>(), rng_pos, &sink)))
 		return rc;
@@ -479,5 +507,47 @@ int wc_pipeline_run_batch_host(wc_pipeline *p, int n_utt, const void *const *x, 
 	parallel_copy(jobs);
 	return WC_OK;
 }
+
+// The same front-end with the reference's feature codec as the epilogue (reference src/codec.cpp:211-325, world_class_codec.h):
+// the spectral envelope leaves as number_of_dimensions mel-cepstral coefficients per frame, the aperiodicity as its
+// GetNumberOfAperiodicities(fs) band values -- 65 instead of 2050 doubles per 48 kHz frame cross PCIe.  coded_sp[u]: f_len[u] x
+// number_of_dimensions doubles, coded_ap[u]: f_len[u] x GetNumberOfAperiodicities(fs) doubles; f0 / tpos / y as above; any table
+// may be NULL.
+int wc_pipeline_run_batch_host_coded(wc_pipeline *p, int n_utt, const void *const *x, int x_is_pcm16, const int *x_length, double *const *tpos,
+									 double *const *f0, double *const *coded_sp, int number_of_dimensions, double *const *coded_ap,
+									 void *const *y, int y_is_pcm16, uint64_t *rng_pos) {
+	if (!p || n_utt <= 0 || !x || !x_length) return fail(WC_ERR_INVALID, "pipeline batch: null argument");
+	if (coded_sp && number_of_dimensions <= 0) return fail(WC_ERR_INVALID, "pipeline batch: number_of_dimensions must be positive");
+	// everything but the big rows through the plain front-end (which keeps the batch resident in p->b_*)
+	int rc = wc_pipeline_run_batch_host(p, n_utt, x, x_is_pcm16, x_length, tpos, f0, nullptr, nullptr, y, y_is_pcm16, rng_pos);
+	if (rc) return rc;
+	if (!coded_sp && !coded_ap) return WC_OK;
+	WC_HIP(hipSetDevice(p->dev->id));
+	DeviceLock lock(p->dev);
+	hipStream_t s = p->dev->active();
+	const int n_apc = GetNumberOfAperiodicities(p->fs);
+	std::vector<int> f_len(n_utt);
+	long long nf = 0;
+	for (int u = 0; u < n_utt; ++u) { f_len[u] = wc_get_samples(p->fs, x_length[u], p->frame_period); nf += f_len[u]; }
+	const size_t b_sp = coded_sp ? sizeof(double) * (size_t)nf * number_of_dimensions : 0, b_ap = coded_ap ? sizeof(double) * (size_t)nf * n_apc : 0;
+	if ((rc = p->b_coded.reserve(b_sp + b_ap + 16))) return rc;
+	if ((rc = p->st_out.reserve(b_sp + b_ap + 16))) return rc;
+	double *d_csp = p->b_coded.as<double>(), *d_cap = d_csp + (b_sp / sizeof(double));
+	if (coded_sp && (rc = wc_code_spectral_envelope_device(p->fs, p->fft_size, nf, number_of_dimensions, p->b_sp.as<double>(), d_csp))) return rc;
+	if (coded_ap && (rc = wc_code_aperiodicity_device(p->fs, p->fft_size, nf, p->b_ap.as<double>(), d_cap))) return rc;
+	char *out = static_cast<char *>(p->st_out.p);
+	if (b_sp + b_ap) WC_HIP(hipMemcpyAsync(out, d_csp, b_sp + b_ap, hipMemcpyDeviceToHost, s));
+	WC_HIP(hipStreamSynchronize(s));
+	std::vector<CopyJob> jobs;
+	long long fo = 0;
+	for (int u = 0; u < n_utt; ++u) {
+		if (coded_sp && coded_sp[u]) jobs.push_back({coded_sp[u], out + sizeof(double) * (size_t)fo * number_of_dimensions, sizeof(double) * (size_t)f_len[u] * number_of_dimensions});
+		if (coded_ap && coded_ap[u]) jobs.push_back({coded_ap[u], out + b_sp + sizeof(double) * (size_t)fo * n_apc, sizeof(double) * (size_t)f_len[u] * n_apc});
+		fo += f_len[u];
+	}
+	parallel_copy(jobs);
+	return WC_OK;
+}
+
 
 }  // extern "C"

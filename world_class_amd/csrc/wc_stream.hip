@@ -235,7 +235,13 @@ int wc_stream_set_incremental(wc_stream *s, int context_ms) {
 	if (!s->hv_front) {
 		s->hv_front = wc_harvest_create(s->fs, s->hv_floor, s->hv_ceil, s->frame_period, 8000.0, 40.0, 0);
 		s->hv_tail = s->hv_front ? wc_harvest_create(s->fs, s->hv_floor, s->hv_ceil, s->frame_period, 8000.0, 40.0, 0) : nullptr;
-		if (!s->hv_tail) return WC_ERR_DEVICE;
+		if (!s->hv_tail) {  // (both or neither: a later call must not find a front without its tail)
+			if (s->hv_front) wc_harvest_destroy(s->hv_front);
+			s->hv_front = nullptr;
+			return fail(WC_ERR_DEVICE, "stream: the incremental mode's Harvest handles could not be created");
+		}
+	}
+	{
 		hv_set_phases(s->hv_front, 1);
 		hv_set_phases(s->hv_tail, 2);
 	}

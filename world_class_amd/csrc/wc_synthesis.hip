@@ -1336,6 +1336,8 @@ int syn_prepare(wc_synthesis *sy, hipStream_t s, int n_utt, const double *d_f0, 
 		} else {
 			const int max_tiles = (max_out + TB_T * PT_K - 1) / (TB_T * PT_K);
 			if ((rc = sy->tile_cnt.reserve(sizeof(int) * (size_t)max_tiles * n_utt))) return rc;
+			// (an utterance without output samples has no tile that writes its count: it must not keep a stale one)
+			WC_HIP(hipMemsetAsync(d_count, 0, sizeof(int) * n_utt, s));
 			hipLaunchKernelGGL(syn_pulse_tiles_kernel<0>, dim3(max_tiles, n_utt), dim3(TB_T), 0, s, ta, (const double *)sy->incs.as<double>(),
 							   (const double *)sy->phase.as<double>(), sy->tile_cnt.as<int>(), max_tiles);
 			hipLaunchKernelGGL(syn_pulse_tiles_kernel<1>, dim3(max_tiles, n_utt), dim3(TB_T), 0, s, ta, (const double *)sy->incs.as<double>(),

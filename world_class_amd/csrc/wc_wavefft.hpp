@@ -706,6 +706,18 @@ __device__ __forceinline__ void wf2_r2c_unpack(double (&re)[16], double (&im)[16
 	}
 }
 
+// interp1Q (reference src/world_matlabfunctions.cpp:220-241) on a table in LDS, in interp1q_rcp's arithmetic (wc_device.hpp)
+// without its branch: the difference beyond the last entry is zero because the index is clamped, not because it is tested.
+__device__ __forceinline__ double wf_interp1q(double x0, double dx, double rdx, const double *S, int n, double xi) {
+	const double t = xi - x0;
+	double q = t * rdx;
+	q = fma(fma(-dx, q, t), rdx, q);
+	const int b = (int)q;
+	const double frac = q - b;
+	const double y0 = S[b], y1 = S[min(b + 1, n - 1)];
+	return fma(y1 - y0, frac, y0);
+}
+
 // ---- the reference's sequential cumulative sum, bit for bit, by one wavefront ---------------------------------------------
 // seq_cumsum_nonneg (wc_device.hpp) for a single wavefront with every lane's chunk (<= CHMAX consecutive terms) held in
 // registers: the block version walks its chunks through LDS one dependent read at a time, which a lone wavefront cannot hide
@@ -898,6 +910,31 @@ __device__ __forceinline__ void wf_sincos(double x, double &sn, double &cs) {
 	const double n = rint(x * 0.63661977236758134308);
 	double r = fma(n, -1.57079632679489655800e+00, x);
 	r = fma(n, -6.12323399573676603587e-17, r);
+	const int q = (int)n;
+	const double z = r * r;
+	double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+	ps = fma(z, ps, 2.75573137070700676789e-06);
+	ps = fma(z, ps, -1.98412698298579493134e-04);
+	ps = fma(z, ps, 8.33333333332248946124e-03);
+	ps = fma(z, ps, -1.66666666666666324348e-01);
+	const double s = fma(z * r, ps, r);
+	double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+	pc = fma(z, pc, -2.75573143513906633035e-07);
+	pc = fma(z, pc, 2.48015872894767294178e-05);
+	pc = fma(z, pc, -1.38888888888741095749e-03);
+	pc = fma(z, pc, 4.16666666666666019037e-02);
+	const double c = fma(z * z, pc, fma(z, -0.5, 1.0));
+	const double a = (q & 1) ? c : s, b = (q & 1) ? s : c;
+	sn = (q & 2) ? -a : a;
+	cs = ((q + 1) & 2) ? -b : b;
+}
+
+// sin(pi x), cos(pi x) for the window phases (|x| of a few units): the reduction x = n / 2 + r, |r| <= 1/4, is exact, so
+// the results keep sincospi's symmetries (sin(pi) = 0 exactly, ...); then wf_sincos' kernels on pi r.  ~35 vector
+// instructions against ocml's 70.
+__device__ __forceinline__ void wf_sincospi(double x, double &sn, double &cs) {
+	const double n = rint(x + x);
+	const double r = fma(n, -0.5, x) * 3.14159265358979311600e+00;  // (n / 2 and the difference are exact)
 	const int q = (int)n;
 	const double z = r * r;
 	double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
