@@ -17,9 +17,15 @@ the measured region and reported separately as `gather_ms`.  `value` = frames of
 wall time.
 
 At N = 1 rank 0 adds, outside the timed region:
-  stages          BASELINE config 3: 256 x 48 kHz 10 s, CheapTrick only, against the HBM roofline on B_ct
+  stages          the other BASELINE configs on this GPU: config 3 (256 x 48 kHz 10 s, CheapTrick only, against the HBM
+                  roofline on B_ct), config 2 (64 x 16 kHz 10 s, full pipeline), config 4 (one GPU's share of 1024
+                  utterances, Synthesis only), config 5 (one GPU's share of 4096 streams, 1 ms hop, chunked Harvest +
+                  CheapTrick: push time and algorithmic latency, whole windows and incremental), and
+                  dropin_single_utterance: what an unchanged caller of the four classes sees (host pointers, one
+                  48 kHz 10 s utterance, constructor / compute() split like reference test/test.cpp:76-264)
   with_transfers  the same batch through the host front-end (wc_pipeline_run_batch_host): H2D of x and D2H of
-                  the outputs inside the clock; never reported as `value`
+                  the outputs inside the clock; reported as `value_with_transfers`, never
+                  as `value`
   cpu_baseline    the real reference's OpenMP build (oracle/_ref, kind "reference") on a bounded sample of the
                   same workload, as many concurrent processes as the host's cores allow; our CPU restatement
                   (kind "port") when the reference build is absent
@@ -195,9 +201,130 @@ def stage_cheaptrick(w, L, torch, dev, d_x64, x_len64, d_t64, d_f64, f_len64, re
     t, k = float(np.median(wall)), float(np.mean(kern))
     b_ct = STAGE_BYTES["cheaptrick"]
     return {"workload": f"{len(xl)} x 48 kHz 10 s, CheapTrick only (2048-point FFT), contour given, resident in HBM (BASELINE config 3)",
-            "frames": frames, "ms": t * 1e3, "frames_per_s": frames / t, "kernel": "ct_frames_kernel<2048, 256>",
+            "frames": frames, "ms": t * 1e3, "frames_per_s": frames / t, "kernel": "ct_wave_kernel",
             "kernel_ms": k * 1e3, "bytes_per_frame": b_ct, "achieved_GBps": frames * b_ct / k / 1e9,
-            "hbm_frac": frames * b_ct / k / (HBM_PEAK_GBS * 1e9)}
+            "hbm_frac": frames * b_ct / k / (HBM_PEAK_GBS * 1e9), "_k": k}
+
+
+def _timed(fn, L, iters=3):
+    fn()
+    L.wc_synchronize()
+    ts = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        fn()
+        L.wc_synchronize()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts))
+
+
+def stage_config2(w, L, torch, dev):
+    """BASELINE config 2: 64 x 16 kHz x 10 s, 5 ms hop, full pipeline on one GPU, resident in HBM"""
+    from world_class_amd.synth import make_utterance
+    fs, n = 16000, 64
+    base = [make_utterance(fs, SECONDS, 2000 + u) for u in range(8)]
+    xs = [base[i % 8] for i in range(n)]
+    p = w.Pipeline(fs)
+    xl = [len(x) for x in xs]
+    fl, yl = p.lengths(xl)
+    d_x = torch.from_numpy(np.concatenate(xs)).to(dev)
+    d_t = torch.empty(sum(fl), dtype=torch.float64, device=dev)
+    d_f = torch.empty_like(d_t)
+    d_sp = torch.empty(sum(fl) * p.bins, dtype=torch.float64, device=dev)
+    d_ap = torch.empty_like(d_sp)
+    d_y = torch.empty(sum(yl), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    t = _timed(lambda: p.run_device(d_x, xl, d_t, d_f, d_sp, d_ap, d_y), L)
+    return {"workload": f"{n} x 16 kHz 10 s, 5 ms hop, full pipeline, resident in HBM (BASELINE config 2)", "frames": sum(fl),
+            "ms": t * 1e3, "frames_per_s": sum(fl) / t}
+
+
+def stage_config4(w, L, torch, dev, pipe):
+    """BASELINE config 4, one GPU's share: Synthesis only from precomputed {f0, sp, ap} of 128 x 48 kHz x 10 s (1024 / 8)"""
+    from world_class_amd.synth import make_utterance
+    n = 128
+    base = pipe.run_batch([make_utterance(FS, SECONDS, 4000 + u) for u in range(4)])
+    sy = w.Synthesis(FS, pipe.fft_size, FRAME_PERIOD)
+    fl = [len(base[i % 4]["f0"]) for i in range(n)]
+    yl = [sy.out_length(v) for v in fl]
+    d_f = torch.from_numpy(np.concatenate([base[i % 4]["f0"] for i in range(n)])).to(dev)
+    sp4 = [torch.from_numpy(b["sp"].ravel()).to(dev) for b in base]
+    ap4 = [torch.from_numpy(b["ap"].ravel()).to(dev) for b in base]
+    d_sp = torch.cat([sp4[i % 4] for i in range(n)])
+    d_ap = torch.cat([ap4[i % 4] for i in range(n)])
+    d_y = torch.empty(sum(yl), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    t = _timed(lambda: sy.compute_device(d_f, fl, d_sp, d_ap, yl, d_y), L)
+    return {"workload": f"{n} x 48 kHz 10 s (one GPU's share of 1024), Synthesis only from {(d_sp.numel() + d_ap.numel()) * 8 / 1e9:.1f} GB of "
+                        "resident f0 / sp / ap (BASELINE config 4)", "frames": sum(fl), "ms": t * 1e3, "frames_per_s": sum(fl) / t,
+            "bytes_per_frame": STAGE_BYTES["synthesis"], "hbm_frac": sum(fl) * STAGE_BYTES["synthesis"] / t / (HBM_PEAK_GBS * 1e9)}
+
+
+def stage_config5(w, L, torch, dev):
+    """BASELINE config 5, one GPU's share: 512 concurrent 24 kHz streams, 1 ms frames, chunked Harvest + CheapTrick
+    (include/world_class_stream.h), 200 ms chunks: whole windows and the incremental mode"""
+    from world_class_amd.stream import StreamAnalyzer
+    from world_class_amd.synth import make_utterance
+    fs, n = 24000, 512
+    sig = [make_utterance(fs, 4.0, 5000 + u) for u in range(8)]
+    out = {"workload": f"{n} concurrent 24 kHz streams (one GPU's share of 4096), 1 ms frames, chunked Harvest + CheapTrick, 200 ms per push "
+                       "(BASELINE config 5; the reference has no streaming mode: semantics in DESIGN.md section 10)"}
+    for key, chunk_ms, back_ms, ahead_ms, ctx_ms in (("whole_windows", 200, 400, 400, 0), ("incremental", 200, 400, 560, 160)):
+        sa = StreamAnalyzer(fs, n, frame_period=1.0, chunk_ms=chunk_ms, lookback_ms=back_ms, lookahead_ms=ahead_ms, context_ms=ctx_ms)
+        cs = sa.chunk_samples
+        cap = n * sa.max_frames
+        d_t = torch.empty(cap, dtype=torch.float64, device=dev)
+        d_f = torch.empty(cap, dtype=torch.float64, device=dev)
+        d_sp = torch.empty(cap * sa.bins, dtype=torch.float64, device=dev)
+        n_push = len(sig[0]) // cs
+        chunks = [torch.from_numpy(np.concatenate([sig[u % 8][k * cs:(k + 1) * cs] for u in range(n)])).to(dev) for k in range(n_push)]
+        torch.cuda.synchronize()
+        times, frames = [], []
+        for k in range(n_push):
+            t0 = time.perf_counter()
+            counts = sa.push_device(chunks[k], None, None, d_t, d_f, d_sp)
+            L.wc_synchronize()
+            times.append(time.perf_counter() - t0)
+            frames.append(sum(counts))
+        full = (back_ms + chunk_ms + ahead_ms) // chunk_ms + 1  # pushes until the history window is full
+        t = float(np.median(times[full:]))
+        out[key] = {"lookback_ms": back_ms, "lookahead_ms": ahead_ms, "context_ms": ctx_ms, "frames_per_push": frames[-1], "push_ms": t * 1e3,
+                    "frames_per_s": frames[-1] / t, "algorithmic_latency_ms": ahead_ms + chunk_ms,
+                    "latency_ms_incl_compute": ahead_ms + chunk_ms + t * 1e3, "real_time_factor": chunk_ms / (t * 1e3)}
+        del sa, chunks, d_t, d_f, d_sp
+    return out
+
+
+def stage_dropin(w, L, x):
+    """What an unchanged caller of the reference's four classes sees: host pointers, one 48 kHz 10 s utterance, constructor and
+    compute() timed apart like the demo (reference test/test.cpp:76-264: Harvest floor 40 Hz, CheapTrick floor 71 Hz, D4C
+    threshold 0.85).  `first`: fresh objects (workspaces and the noise table are created); `steady`: the same objects again."""
+    def once(objs):
+        ms = {}
+        t0 = time.perf_counter(); hv = objs.get("hv") or w.Harvest(FS, f0_floor=40.0, frame_period=FRAME_PERIOD); t1 = time.perf_counter()
+        tpos, f0 = hv.compute(x); t2 = time.perf_counter()
+        ms["harvest"] = {"ctor_ms": (t1 - t0) * 1e3, "compute_ms": (t2 - t1) * 1e3}
+        t0 = time.perf_counter(); ct = objs.get("ct") or w.CheapTrick(FS); t1 = time.perf_counter()
+        sp = ct.compute(x, tpos, f0); t2 = time.perf_counter()
+        ms["cheaptrick"] = {"ctor_ms": (t1 - t0) * 1e3, "compute_ms": (t2 - t1) * 1e3}
+        t0 = time.perf_counter(); d4 = objs.get("d4") or w.D4C(FS); t1 = time.perf_counter()
+        ap = d4.compute(x, tpos, f0, ct.fft_size); t2 = time.perf_counter()
+        ms["d4c"] = {"ctor_ms": (t1 - t0) * 1e3, "compute_ms": (t2 - t1) * 1e3}
+        t0 = time.perf_counter(); sy = objs.get("sy") or w.Synthesis(FS, ct.fft_size, FRAME_PERIOD); t1 = time.perf_counter()
+        y = sy.compute(f0, sp, ap); t2 = time.perf_counter()
+        ms["synthesis"] = {"ctor_ms": (t1 - t0) * 1e3, "compute_ms": (t2 - t1) * 1e3}
+        ms["total_compute_ms"] = sum(v["compute_ms"] for v in ms.values())
+        return ms, dict(hv=hv, ct=ct, d4=d4, sy=sy), len(f0), len(y)
+    w.rng_set_position(0)
+    first, objs, frames, _ = once({})
+    runs = []
+    for _ in range(3):
+        w.rng_set_position(0)
+        runs.append(once(objs)[0])
+    steady = min(runs, key=lambda r: r["total_compute_ms"])
+    return {"workload": "one 48 kHz 10 s utterance through Harvest::compute ... Synthesis::compute with host pointers (the reference demo's calls, "
+                        "reference test/test.cpp:76-264; H2D / D2H of every stage's arguments included)", "frames": frames,
+            "first": first, "steady": steady, "frames_per_s_steady": frames / (steady["total_compute_ms"] * 1e-3)}
 
 
 def with_transfers(w, pipe, xs, frames, iters=3):
@@ -205,12 +332,15 @@ def with_transfers(w, pipe, xs, frames, iters=3):
     out = {}
     pcm = [np.clip(np.round(x * 32768.0), -32768, 32767).astype(np.int16) for x in xs[:8]]
     pcm = [pcm[i % len(pcm)] for i in range(len(xs))]
+    xl = [len(x) for x in xs]
     for key, inp, want, ypcm, label in (
             ("f64_in_all_five_out", xs, ("tpos", "f0", "sp", "ap", "y"), False,
-             "x as float64 from host memory, tpos + f0 + spectrogram + aperiodicity + waveform back as float64 (section 8(d) to the letter)"),
+             "x as float64 from host memory, tpos + f0 + spectrogram + aperiodicity + waveform back as float64 into the caller's page-locked "
+             "rows (section 8(d) to the letter)"),
             ("pcm16_in_f0_pcm16_out", pcm, ("f0", "y"), True,
              "x as the int16 PCM of a WAV file, F0 + int16 waveform back; spectrogram and aperiodicity stay in HBM")):
-        res = pipe.run_batch_host(inp, want=want, y_pcm16=ypcm)  # warm-up: pinned staging, device buffers, result arrays
+        res = pipe.host_buffers(xl, want=want, y_pcm16=ypcm, pinned=True)  # the caller's result buffers, page-locked, reused
+        pipe.run_batch_host(inp, want=want, y_pcm16=ypcm, out=res)  # warm-up: pinned staging, device buffers
         ts = []
         for _ in range(iters):
             t0 = time.perf_counter()
@@ -221,6 +351,18 @@ def with_transfers(w, pipe, xs, frames, iters=3):
                     "host_bytes_in": int(sum(v.nbytes for v in inp)),
                     "host_bytes_out": int(sum(a.nbytes for r in res for a in r.values()))}
         del res
+    # the feature codec as the epilogue: F0 + 60 mel-cepstral coefficients + band aperiodicities + waveform back
+    res = pipe.run_batch_host_coded(xs, number_of_dimensions=60)
+    ts = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        pipe.run_batch_host_coded(xs, number_of_dimensions=60, out=res)
+        ts.append(time.perf_counter() - t0)
+    t = float(np.median(ts))
+    out["coded_out"] = {"what": "x as float64 in; F0, 60 mel-cepstral coefficients and the band aperiodicities per frame (the reference's codec, "
+                                "src/codec.cpp:211-325, as the epilogue of CheapTrick / D4C) and the float64 waveform back",
+                        "ms": t * 1e3, "frames_per_s": frames / t, "host_bytes_in": int(sum(v.nbytes for v in xs)),
+                        "host_bytes_out": int(sum(a.nbytes for r in res for a in r.values()))}
     return out
 
 
@@ -316,13 +458,15 @@ def main():
         if world > 1:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
+            # F0 contours: all-gather (every rank gets the 2001-frame contours: 16 KB per utterance); waveforms (--gather y,
+            # BASELINE config 4's gather): to rank 0 only, each peer over its own xGMI link (shard.gather_ragged_to_root)
             f0_all = lay.gather_frames(d_f)
-            y_all = lay.gather_samples(d_y) if a.gather == "y" else None
+            y_all = lay.gather_samples_to_root(d_y, root=0) if a.gather == "y" else None
             sums = [torch.empty_like(summary) for _ in range(world)]
             dist.all_gather(sums, summary)
             torch.cuda.synchronize()
             gather_s[0] = time.perf_counter() - t0
-            assert len(f0_all) == n_total and (y_all is None or len(y_all) == n_total)
+            assert len(f0_all) == n_total and (y_all is None or rank != 0 or len(y_all) == n_total)
         return summary
 
     for _ in range(a.warmup):
@@ -361,14 +505,23 @@ def main():
         full_grid = {k: v for k, v in kern.items() if k not in SEQUENTIAL_SCANS}
         dom = max(full_grid, key=full_grid.get) if full_grid else None
         roofline = None
+        pmc_all = None
         if dom:
             stage = KERNEL_STAGE[dom]
             achieved = frames * STAGE_BYTES[stage] / (kern[dom] * 1e-3) / 1e9
             traffic, fp64 = None, None
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            pmc = {}
             if os.path.exists(tpath):
                 with open(tpath) as f:
                     pmc = json.load(f)
+                # counters of another build say nothing about this one: the file carries the source hash of the library it was
+                # measured on (tools/profile_round.sh), and a stale one is refused
+                if pmc.get("_build_hash") != L.wc_build_hash().decode():
+                    sys.stderr.write("bench.py: profiles/pmc_traffic.json was measured on another build; traffic / FLOP figures left out\n")
+                    pmc = {}
+            pmc_all = pmc
+            if pmc:
                 traffic = pmc.get(dom)  # HBM bytes per step (PMC, see the file's _note)
                 flops = pmc.get("_fp64_flops_per_step", {}).get(dom)
                 if flops:  # FP64 FLOP/s from SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 x 64 lanes (FMA counted twice)
@@ -386,23 +539,40 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{n_utt} synthetic 48 kHz 10 s utterances per GPU ({distinct // world} distinct, tiled), 5 ms hop, "
-                                   "Harvest->CheapTrick->D4C->Synthesis, inputs resident in HBM",
+                                   "Harvest->CheapTrick->D4C->Synthesis, inputs resident in HBM when the clock starts (`value`; SURVEY.md section 8(d)'s "
+                                   "headline with H2D of x and D2H of all outputs inside the clock is `value_with_transfers`)",
                        "utterances_per_gpu": n_utt, "frames_per_gpu": frames, "fs": FS, "frame_period_ms": FRAME_PERIOD,
                        "fft_size": pipe.fft_size,
                        "parallelism": f"utterance-sharded x{world} (shard.partition), final RCCL all-gather of "
-                                      + ("F0 + waveforms + checksums" if a.gather == "y" else "F0 + checksums")},
+                                      + ("F0 + checksums, waveforms gathered to rank 0" if a.gather == "y" else "F0 + checksums")},
             "roofline": roofline,
         }
         if world > 1:
             out["gather_ms"] = gather_s[0] * 1e3
             out["gather"] = a.gather
         if world == 1 and not a.no_extras:
-            try:
-                out["stages"] = {"cheaptrick_config3": stage_cheaptrick(w, L, torch, dev, d_x, x_len, d_t, d_f, f_len)}
-            except Exception as e:
-                out["stages"] = {"error": str(e)}
+            st = {}
+            for key, fn in (("cheaptrick_config3", lambda: stage_cheaptrick(w, L, torch, dev, d_x, x_len, d_t, d_f, f_len)),
+                            ("config2_16k_full_pipeline", lambda: stage_config2(w, L, torch, dev)),
+                            ("config4_synthesis_only_share", lambda: stage_config4(w, L, torch, dev, pipe)),
+                            ("config5_streams_share", lambda: stage_config5(w, L, torch, dev)),
+                            ("dropin_single_utterance", lambda: stage_dropin(w, L, xs[0]))):
+                try:
+                    st[key] = fn()
+                except Exception as e:
+                    st[key] = {"error": str(e)}
+                torch.cuda.empty_cache()
+            c3 = st.get("cheaptrick_config3", {})
+            if "_k" in c3:
+                k = c3.pop("_k")
+                fl3 = (pmc_all or {}).get("_config3_fp64_flops")  # FP64 operations of the config-3 launch (counter pass of this build)
+                if fl3:
+                    c3["fp64_tflops"] = fl3 / k / 1e12
+                    c3["fp64_frac"] = fl3 / k / 1e12 / FP64_VECTOR_PEAK_TFLOPS
+            out["stages"] = st
             try:
                 out["with_transfers"] = with_transfers(w, pipe, xs, frames)
+                out["value_with_transfers"] = out["with_transfers"]["f64_in_all_five_out"]["frames_per_s"]
             except Exception as e:
                 out["with_transfers"] = {"error": str(e)}
         if world == 1 and not a.no_cpu_baseline:

@@ -27,6 +27,13 @@ int wc_shard_partition(const int *lengths, int n, int world, int *rank_of);
  * already in the process, e.g. PyTorch's, is preferred), so hosts that never gather do not need it. */
 int wc_gather_device(void *nccl_comm, int world, int rank, const double *d_local, const long long *counts, double *d_all);
 
+/* Gather to ONE rank (what a node that hands its results to one consumer needs): rank r sends its
+ * counts[r] doubles to `root` with one ncclSend; the root posts the world - 1 ncclRecv in one group -- xGMI is point to point,
+ * every peer has its own link to the root, so the blocks travel concurrently (BASELINE config 4: 0.49 GB per peer, ~3 ms at
+ * 153 GB/s per link) -- and copies its own block on the device.  Only the root allocates the total: d_all (sum(counts)
+ * doubles, rank order) is used on the root alone and may be NULL elsewhere.  Enqueue-only, like wc_gather_device. */
+int wc_gather_to_root_device(void *nccl_comm, int world, int rank, int root, const double *d_local, const long long *counts, double *d_all);
+
 #ifdef __cplusplus
 }
 #endif

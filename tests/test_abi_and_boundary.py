@@ -51,7 +51,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert {"wc_stream_create", "wc_stream_push_device", "wc_stream_reset"} <= set(stream_declared)
     assert not [s for s in stream_declared if s not in exported_all]
     shard_declared = [n for n in io_header_symbols("world_class_shard.h") if n.startswith("wc_")]
-    assert set(shard_declared) == {"wc_shard_partition", "wc_gather_device"}
+    assert set(shard_declared) == {"wc_shard_partition", "wc_gather_device", "wc_gather_to_root_device"}
     assert not [s for s in shard_declared if s not in exported_all]
     codec_declared = io_header_symbols("world_class_codec.h")
     assert {"CodeSpectralEnvelope", "DecodeAperiodicity", "GetNumberOfAperiodicities"} <= set(codec_declared)

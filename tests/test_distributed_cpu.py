@@ -98,6 +98,16 @@ def _layout_worker(rank, world, port, x_lengths, width, ret):
     f0_all = lay.gather_frames(cat(0, 0))
     rows_all = lay.gather_frames(cat(1, 0), width=width)
     y_all = lay.gather_samples(cat(2, 0))
+    # gather to ONE rank: ragged sends to the root, which alone holds the total; root 1 as well as root 0
+    for root in (0, world - 1):
+        f0_root = lay.gather_frames_to_root(cat(0, 0), root=root)
+        rows_root = lay.gather_frames_to_root(cat(1, 0), width=width, root=root)
+        y_root = lay.gather_samples_to_root(cat(2, 0), root=root)
+        if rank == root:
+            assert all(torch.equal(a, b) for a, b in zip(f0_root, f0_all)) and all(torch.equal(a, b) for a, b in zip(y_root, y_all))
+            assert all(torch.equal(a, b) for a, b in zip(rows_root, rows_all))
+        else:
+            assert f0_root is None and rows_root is None and y_root is None
     if rank == 0:
         ret.put(([t.numpy().copy() for t in f0_all], [t.numpy().copy() for t in rows_all], [t.numpy().copy() for t in y_all],
                  lay.parts, lay.all_f_len, lay.all_y_len))

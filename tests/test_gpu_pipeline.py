@@ -312,5 +312,12 @@ def test_c_abi_gather_over_rccl(wca):
         torch.cuda.synchronize()
         assert torch.equal(d_all, out[4]) and float(d_all.abs().sum()) > 0
         assert wca.lib().wc_gather_device(comm, 1, 3, out[4].data_ptr(), counts, d_all.data_ptr()) != 0  # rank outside the group
+        # gather to one rank (grouped ncclSend / ncclRecv; a one-rank group: the root's own block, copied on the device)
+        d_root = torch.zeros(y_len[0], dtype=torch.float64, device=dev)
+        assert wca.lib().wc_gather_to_root_device(comm, 1, 0, 0, out[4].data_ptr(), counts, d_root.data_ptr()) == 0, wca.last_error()
+        assert wca.lib().wc_synchronize() == 0
+        torch.cuda.synchronize()
+        assert torch.equal(d_root, out[4])
+        assert wca.lib().wc_gather_to_root_device(comm, 1, 0, 2, out[4].data_ptr(), counts, d_root.data_ptr()) != 0  # root outside the group
     finally:
         rccl.ncclCommDestroy(comm)

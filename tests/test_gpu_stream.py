@@ -31,6 +31,27 @@ def whole(wca, x, fs, fp):
     return tpos, f0, sp
 
 
+def oracle_whole(port, x, fs, fp):
+    """the same whole-utterance call by the CPU oracle (oracle/port.py, pinned to the real reference by tests/test_oracle_golden.py):
+    Harvest on the signal up to the last multiple of the decimation ratio, CheapTrick on all of it, noise stream from position 0"""
+    r = max(1, min(12, int(fs / 8000.0 + 0.5)))
+    tpos, f0 = port.harvest(x[:len(x) - len(x) % r], fs, frame_period=fp)
+    port.rng_reset()
+    sp = port.cheaptrick(x, fs, tpos, f0)
+    port.rng_reset()
+    return tpos, f0, sp
+
+
+def compare_oracle(got, want, what):
+    """every committed frame against the oracle, at the tolerances of SURVEY.md section 8(c): identical voicing, F0 1e-6 Hz, sp 1e-7"""
+    tpos, f0, sp = want
+    assert len(got["f0"]) == len(f0), what
+    assert np.abs(got["tpos"] - tpos).max() < 1e-12, what
+    assert np.array_equal(got["f0"] == 0, f0 == 0), what + ": voicing"
+    assert np.abs(got["f0"] - f0).max() < 1e-6, what
+    assert (np.abs(got["sp"] - sp) / sp).max() < 1e-7, what
+
+
 def compare(got, want, what):
     tpos, f0, sp = want
     assert len(got["f0"]) == len(f0), what
@@ -46,7 +67,7 @@ MODES = [dict(lookahead_ms=400, context_ms=0), dict(lookahead_ms=560, context_ms
 
 
 @pytest.mark.parametrize("mode", MODES, ids=["whole_windows", "incremental"])
-def test_streams_equal_whole_utterances_24k_1ms(wca, mode):
+def test_streams_equal_whole_utterances_24k_1ms(wca, port, mode):
     """BASELINE config 5's shape: 24 kHz, 1 ms frames; ragged lengths, one of them not a whole number of chunks or ms"""
     from world_class_amd.stream import StreamAnalyzer
     fs = 24000
@@ -55,6 +76,8 @@ def test_streams_equal_whole_utterances_24k_1ms(wca, mode):
     sa = StreamAnalyzer(fs, len(xs), frame_period=1.0, chunk_ms=200, lookback_ms=400, **mode)
     assert sa.latency_ms == 200 + mode["lookahead_ms"] and sa.chunk_samples == 4800
     res = sa.run_whole(xs)
+    for u, (x, r) in enumerate(zip(xs, res)):  # first of all: against the oracle's whole-utterance result
+        compare_oracle(r, oracle_whole(port, x, fs, 1.0), "stream %d vs oracle" % u)
     stats = [compare(r, whole(wca, x, fs, 1.0), "stream %d" % u) for u, (x, r) in enumerate(zip(xs, res))]
     # 40-100 % of the frames are bit-equal; the rest differ in the last bits only (1e-14 relative: the smoothing filter's backward
     # pass starts where the window ends and runs into its last-bit limit cycle with another phase)
@@ -67,13 +90,14 @@ def test_streams_equal_whole_utterances_24k_1ms(wca, mode):
 
 
 @pytest.mark.parametrize("mode", MODES, ids=["whole_windows", "incremental"])
-def test_streams_equal_whole_utterances_48k_5ms(wca, mode):
+def test_streams_equal_whole_utterances_48k_5ms(wca, port, mode):
     from world_class_amd.stream import StreamAnalyzer
     fs = 48000
     xs = [make_utterance(fs, sec, 5100 + i) for i, sec in enumerate((2.5, 1.7))]
     sa = StreamAnalyzer(fs, len(xs), frame_period=5.0, chunk_ms=200, lookback_ms=400, **mode)
     res = sa.run_whole(xs)
     for u, (x, r) in enumerate(zip(xs, res)):
+        compare_oracle(r, oracle_whole(port, x, fs, 5.0), "stream %d vs oracle" % u)
         compare(r, whole(wca, x, fs, 5.0), "stream %d" % u)
 
 
@@ -202,3 +226,23 @@ def test_chunks_as_int16_pcm_and_float32(wca):
     for src in (pcm, x.astype(np.float32)):
         got = StreamAnalyzer(fs, 1, frame_period=5.0).run_whole([src])[0]
         assert np.array_equal(got["f0"], want["f0"]) and np.array_equal(got["sp"], want["sp"])
+
+
+def test_config5_shape_512_streams_frame_accounting_and_identical_streams(wca, port):
+    """BASELINE config 5 at one GPU's size: 512 concurrent 24 kHz streams, 1 ms frames, 200 ms chunks (incremental mode).  Every
+    absolute frame is committed exactly once; everything is finite; streams fed the same signal return the same bits whatever
+    their slot; and one stream of each distinct signal is checked against the oracle's whole-utterance result."""
+    from world_class_amd.stream import StreamAnalyzer
+    fs, n = 24000, 512
+    sig = [make_utterance(fs, 0.9, 5300 + i) for i in range(4)]
+    xs = [sig[u % 4] for u in range(n)]
+    sa = StreamAnalyzer(fs, n, frame_period=1.0, chunk_ms=200, lookback_ms=400, lookahead_ms=560, context_ms=160)
+    res = sa.run_whole(xs)
+    for u in range(n):
+        want = wca.get_samples(fs, len(xs[u]) - len(xs[u]) % 3, 1.0)
+        assert sa.frames_committed(u) == want and len(res[u]["f0"]) == want
+        assert np.isfinite(res[u]["f0"]).all() and np.isfinite(res[u]["sp"]).all()
+    for u in range(4, n):
+        assert np.array_equal(res[u]["f0"], res[u % 4]["f0"]) and np.array_equal(res[u]["sp"], res[u % 4]["sp"]), u
+    for u in range(4):
+        compare_oracle(res[u], oracle_whole(port, xs[u], fs, 1.0), "stream %d vs oracle" % u)

@@ -97,7 +97,7 @@ class Pipeline:
             res.append(r)
         return res
 
-    def run_batch_host_coded(self, xs, number_of_dimensions=60, want=("f0", "csp", "cap", "y"), y_pcm16=False, rng_pos=None):
+    def run_batch_host_coded(self, xs, number_of_dimensions=60, want=("f0", "csp", "cap", "y"), y_pcm16=False, rng_pos=None, out=None):
         """wc_pipeline_run_batch_host_coded: the host front-end with the reference's feature codec as the epilogue -- per frame
         `number_of_dimensions` mel-cepstral coefficients ("csp") and the band aperiodicities ("cap") instead of the rows."""
         import ctypes as C
@@ -114,7 +114,10 @@ class Pipeline:
         outs, tabs = {}, {}
         for k in shapes:
             if k in want:
-                outs[k] = [np.empty(shapes[k](f, m), dtype=np.int16 if (k == "y" and y_pcm16) else np.float64) for f, m in zip(fl, yl)]
+                if out is not None:  # the caller's buffers of an earlier call, written again
+                    outs[k] = [o[k] for o in out]
+                else:
+                    outs[k] = [np.empty(shapes[k](f, m), dtype=np.int16 if (k == "y" and y_pcm16) else np.float64) for f, m in zip(fl, yl)]
                 tabs[k] = VP(*[a.ctypes.data for a in outs[k]])
             else:
                 tabs[k] = None

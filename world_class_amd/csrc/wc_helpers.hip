@@ -167,19 +167,15 @@ void fftshift(const double *x, int x_length, double *y) {
 	}
 }
 
+// MATLAB's histc as the reference uses it (interp1's segment search, reference src/world_matlabfunctions.cpp:136-155), from its
+// closed form for non-decreasing edges: index[i] = #{j : x[j] <= edges[i]}, kept inside [1, x_length - 1] (SURVEY.md,
+// appendix A) -- one merge walk over the two sorted sequences.
 void histc(const double *x, int x_length, const double *edges, int edges_length, int *index) {
-	int count = 1, i = 0;
-	for (; i < edges_length; ++i) {
-		index[i] = 1;
-		if (edges[i] >= x[0]) break;
+	int below = 0;  // how many grid points lie at or below the current edge
+	for (int e = 0; e < edges_length; ++e) {
+		while (below < x_length && x[below] <= edges[e]) ++below;
+		index[e] = std::min(std::max(below, 1), x_length - 1);
 	}
-	for (; i < edges_length; ++i) {
-		if (edges[i] < x[count]) index[i] = count;
-		else index[i--] = count++;
-		if (count == x_length) break;
-	}
-	count--;
-	for (i++; i < edges_length; ++i) index[i] = count;
 }
 
 void interp1(const double *x, const double *y, int x_length, const double *xi, int xi_length, double *yi) {
@@ -192,21 +188,25 @@ void interp1(const double *x, const double *y, int x_length, const double *xi, i
 	}
 }
 
+// MATLAB's decimate as the reference uses it (reference src/world_matlabfunctions.cpp:184-210): the signal, extended by nine
+// samples mirrored through each end point, goes through the order-3 low-pass forwards and then backwards (zero phase); every
+// r-th sample of the result is kept, the grid being anchored so that it ends on the last input sample's side -- output m is
+// the filtered sample at signal index (x_length mod r) - 1 + m r, for as long as that stays inside the extension.
 void decimate(const double *x, int x_length, int r, double *y) {
-	const int kNFact = 9;
-	const int len = x_length + 2 * kNFact;
-	std::vector<double> t1(len), t2(len);
-	for (int i = 0; i < kNFact; ++i) t1[i] = 2 * x[0] - x[kNFact - i];
-	for (int i = 0; i < x_length; ++i) t1[kNFact + i] = x[i];
-	for (int i = 0; i < kNFact; ++i) t1[kNFact + x_length + i] = 2 * x[x_length - 1] - x[x_length - 2 - i];
-	iir3(t1.data(), len, r, t2.data());
-	std::reverse_copy(t2.begin(), t2.end(), t1.begin());
-	iir3(t1.data(), len, r, t2.data());
-	std::reverse_copy(t2.begin(), t2.end(), t1.begin());
-	const int nout = x_length / r + 1;
-	const int nbeg = r - r * nout + x_length;
-	int count = 0;
-	for (int i = nbeg; i < x_length + kNFact; i += r) y[count++] = t1[i + kNFact - 1];
+	constexpr int kPad = 9;
+	const int total = x_length + 2 * kPad;
+	std::vector<double> fwd(total), tmp(total);
+	for (int k = 1; k <= kPad; ++k) {
+		fwd[kPad - k] = 2 * x[0] - x[k];                                          // left mirror through x[0]
+		fwd[kPad + x_length - 1 + k] = 2 * x[x_length - 1] - x[x_length - 1 - k];  // right mirror through x[n - 1]
+	}
+	std::copy(x, x + x_length, fwd.begin() + kPad);
+	iir3(fwd.data(), total, r, tmp.data());
+	std::reverse(tmp.begin(), tmp.end());
+	iir3(tmp.data(), total, r, fwd.data());
+	std::reverse(fwd.begin(), fwd.end());
+	int m = 0;
+	for (int pos = kPad - 1 + x_length % r; pos < total - 1; pos += r) y[m++] = fwd[pos];
 }
 
 int matlab_round(double x) { return x > 0 ? static_cast<int>(x + 0.5) : static_cast<int>(x - 0.5); }

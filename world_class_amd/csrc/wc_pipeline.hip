@@ -20,6 +20,8 @@
 // the CUs -- while the tails and time bases (64 wavefronts each) disappear behind the heavy kernels.
 // WC_PIPELINE_MODE=shared selects the older schedule: one set of stages, Harvest split over two streams.
 #include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -39,11 +41,17 @@ struct PipeGroup {
 	wc_d4c *d4 = nullptr;
 	wc_synthesis *sy = nullptr;
 	hipStream_t main = nullptr, aux = nullptr;
-	hipEvent_t e0 = nullptr, e_aux = nullptr, e_mid = nullptr;
+	hipEvent_t e0 = nullptr, e_aux = nullptr, e_mid = nullptr, e_ct = nullptr;
 };
 
 // Host-side copies of the batch front-end, spread over a few threads: one thread moves 5-10 GB/s, the 2.1 GB of
 // spectrogram + aperiodicity rows of a 64 x 10 s batch would take a quarter of a second on one.
+// WC_PIPELINE_TIMING=1: wall-clock marks of the host front-end's phases on stderr (development aid)
+static std::chrono::steady_clock::time_point g_mark0;
+static void pmark(const char *what) {
+	static const bool on = getenv("WC_PIPELINE_TIMING") != nullptr;
+	if (on) std::fprintf(stderr, "  [pipeline] %-30s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g_mark0).count());
+}
 struct CopyJob { void *dst; const void *src; size_t bytes; };
 static void parallel_copy(const std::vector<CopyJob> &jobs) {
 	constexpr size_t kPiece = 2u << 20;
@@ -165,6 +173,7 @@ wc_pipeline *wc_pipeline_create(int fs, double frame_period, double harvest_f0_f
 			ok = ok && hipEventCreateWithFlags(&G.e0, hipEventDisableTiming) == hipSuccess;
 			ok = ok && hipEventCreateWithFlags(&G.e_aux, hipEventDisableTiming) == hipSuccess;
 			ok = ok && hipEventCreateWithFlags(&G.e_mid, hipEventDisableTiming) == hipSuccess;
+			ok = ok && hipEventCreateWithFlags(&G.e_ct, hipEventDisableTiming) == hipSuccess;
 		}
 	}
 	if (!ok) {
@@ -195,6 +204,7 @@ void wc_pipeline_destroy(wc_pipeline *p) {
 		if (G.e0) (void)hipEventDestroy(G.e0);
 		if (G.e_aux) (void)hipEventDestroy(G.e_aux);
 		if (G.e_mid) (void)hipEventDestroy(G.e_mid);
+			if (G.e_ct) (void)hipEventDestroy(G.e_ct);
 		wc_synthesis_destroy(G.sy);
 		wc_d4c_destroy(G.d4);
 		wc_cheaptrick_destroy(G.ct);
@@ -291,24 +301,31 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 				WC_HIP(hipStreamWaitEvent(G.aux, G.e0, 0));
 				if (g == 0) WC_HIP(hipStreamWaitEvent(G.aux, p->grp[1].e_mid, 0));
 				if ((rc = ct_frames(G.ct, G.aux, nu, gx, gt, gf, gsp, total))) return rc;
+				WC_HIP(hipEventRecord(G.e_ct, G.aux));
 				if ((rc = d4c_enqueue(G.d4, G.aux, nu, gx, x_length + u0, gt, gf, f_len.data() + u0, p->fft_size, gap, nullptr,
 									  ct_end_positions(G.ct))))
 					return rc;
 				WC_HIP(hipEventRecord(G.e_aux, G.aux));
 				if (sink && attempt == 0 && (sink->stage_sp || sink->stage_ap)) {
 					const size_t off = sizeof(double) * (size_t)sl[g].fo * bins_, len = sizeof(double) * (size_t)(fo_end[g] - sl[g].fo) * bins_;
-					WC_HIP(hipStreamWaitEvent(p->s_copy, G.e_aux, 0));
-					if (sink->direct) {
-						long long fo2 = 0;
-						for (int u = u0; u < u0 + nu; ++u) {
-							const size_t ulen = sizeof(double) * (size_t)f_len[u] * bins_;
-							if (sink->stage_sp && sink->sp[u]) WC_HIP(hipMemcpyAsync(sink->sp[u], gsp + fo2 * bins_, ulen, hipMemcpyDeviceToHost, p->s_copy));
-							if (sink->stage_ap && sink->ap[u]) WC_HIP(hipMemcpyAsync(sink->ap[u], gap + fo2 * bins_, ulen, hipMemcpyDeviceToHost, p->s_copy));
-							fo2 += f_len[u];
+					// the spectrogram rows leave as soon as CheapTrick is through, the aperiodicity rows behind D4C: PCIe is the longest
+					// stretch of a run with all outputs (2.1 GB at ~50 GB/s), so it starts as early as it can
+					for (int which = 0; which < 2; ++which) {
+						WC_HIP(hipStreamWaitEvent(p->s_copy, which == 0 ? G.e_ct : G.e_aux, 0));
+						char *stage = which == 0 ? sink->stage_sp : sink->stage_ap;
+						double *const *rows = which == 0 ? sink->sp : sink->ap;
+						const double *src = which == 0 ? gsp : gap;
+						if (!stage) continue;
+						if (sink->direct) {
+							long long fo2 = 0;
+							for (int u = u0; u < u0 + nu; ++u) {
+								const size_t ulen = sizeof(double) * (size_t)f_len[u] * bins_;
+								if (rows[u]) WC_HIP(hipMemcpyAsync(rows[u], src + fo2 * bins_, ulen, hipMemcpyDeviceToHost, p->s_copy));
+								fo2 += f_len[u];
+							}
+						} else {
+							WC_HIP(hipMemcpyAsync(stage + off, src, len, hipMemcpyDeviceToHost, p->s_copy));
 						}
-					} else {
-						if (sink->stage_sp) WC_HIP(hipMemcpyAsync(sink->stage_sp + off, gsp, len, hipMemcpyDeviceToHost, p->s_copy));
-						if (sink->stage_ap) WC_HIP(hipMemcpyAsync(sink->stage_ap + off, gap, len, hipMemcpyDeviceToHost, p->s_copy));
 					}
 					WC_HIP(hipEventRecord(p->e_copy[g], p->s_copy));
 				}
@@ -317,10 +334,12 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 				if ((rc = syn_pulses(G.sy, G.main, gf, gsp, gap, gy, d4c_end_positions(G.d4)))) return rc;
 			}
 			dev->time_tag = -1;
+			pmark("both halves enqueued");
 			if (sink && attempt == 0 && (sink->stage_sp || sink->stage_ap)) {
 				// the rows of each half batch go to the caller's buffers as soon as their copy has landed: half A's while B computes
 				for (int g = 0; g < 2; ++g) {
 					WC_HIP(hipEventSynchronize(p->e_copy[g]));
+					pmark(g == 0 ? "rows of half A landed" : "rows of half B landed");
 					if (sink->direct) { sink->overlapped[g] = true; continue; }
 					std::vector<CopyJob> jobs;
 					long long fo = sl[g].fo;
@@ -340,6 +359,7 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 				const int u0 = g == 0 ? 0 : n_utt / 2;
 				bool o1 = false, o2 = false;
 				if ((rc = syn_finish(G.sy, G.main, rng_pos ? rng_pos + u0 : nullptr, &o2))) return rc;
+				pmark(g == 0 ? "half A finished" : "half B finished");
 				if ((rc = hv_overflowed(G.hv, G.main, &o1))) return rc;
 				full[g][0] = full[g][0] || o1;
 				full[g][1] = full[g][1] || o2;
@@ -416,6 +436,9 @@ int wc_pipeline_run_batch_host(wc_pipeline *p, int n_utt, const void *const *x, 
 	DeviceLock lock(p->dev);
 	hipStream_t s = p->dev->active();
 	const int bins = p->fft_size / 2 + 1;
+	// WC_PIPELINE_TIMING=1: wall-clock marks of the phases on stderr (development aid)
+	g_mark0 = std::chrono::steady_clock::now();
+	auto mark = [&](const char *what) { pmark(what); };
 	std::vector<int> f_len(n_utt), y_len(n_utt);
 	long long nx = 0, nf = 0, ny = 0;
 	for (int u = 0; u < n_utt; ++u) {
@@ -444,6 +467,7 @@ int wc_pipeline_run_batch_host(wc_pipeline *p, int n_utt, const void *const *x, 
 		}
 		parallel_copy(jobs);
 	}
+	mark("inputs gathered");
 	if (x_is_pcm16 == 1) {
 		WC_HIP(hipMemcpyAsync(p->b_pcm.p, p->st_in.p, sizeof(int16_t) * nx, hipMemcpyHostToDevice, s));
 		if ((rc = wc_pcm16_to_double_device(p->b_pcm.as<int16_t>(), nx, p->b_x.as<double>()))) return rc;
@@ -469,12 +493,16 @@ int wc_pipeline_run_batch_host(wc_pipeline *p, int n_utt, const void *const *x, 
 	sink.sp = sp; sink.ap = ap; sink.f_len = f_len.data(); sink.bins = bins;
 	// a caller who hands over page-locked rows (hipHostMalloc / hipHostRegister, a pinned torch tensor) gets them written by the
 	// copy engine directly: no staging copy, no host-side scatter of the 2 GB
-	sink.direct = (sp || ap);
+	{
+		const char *env = getenv("WC_PIPELINE_DIRECT");  // 0: always through the staging buffer (A/B)
+		sink.direct = (sp || ap) && !(env && env[0] == '0');
+	}
 	for (int u = 0; u < n_utt && sink.direct; ++u)
 		sink.direct = (!sp || !sp[u] || is_pinned(sp[u])) && (!ap || !ap[u] || is_pinned(ap[u]));
 	if ((rc = pipeline_run(p, n_utt, p->b_x.as<double>(), x_length, p->b_t.as<double>(), p->b_f.as<double>(),
 						   p->b_sp.as<double>(), p->b_ap.as<double>(), p->b_y.as<double>(), rng_pos, &sink)))
 		return rc;
+	mark("pipeline_run returned");
 	if (total == 0) return WC_OK;
 	const bool rows_done = sink.overlapped[0] && sink.overlapped[1];
 	if (tpos) WC_HIP(hipMemcpyAsync(out + off_t, p->b_t.p, sizeof(double) * nf, hipMemcpyDeviceToHost, s));
@@ -491,6 +519,7 @@ int wc_pipeline_run_batch_host(wc_pipeline *p, int n_utt, const void *const *x, 
 		}
 	}
 	WC_HIP(hipStreamSynchronize(s));
+	mark("small outputs on the host");
 	std::vector<CopyJob> jobs;
 	long long fo = 0, yo = 0;
 	for (int u = 0; u < n_utt; ++u) {
@@ -505,6 +534,7 @@ int wc_pipeline_run_batch_host(wc_pipeline *p, int n_utt, const void *const *x, 
 		yo += y_len[u];
 	}
 	parallel_copy(jobs);
+	mark("scattered");
 	return WC_OK;
 }
 

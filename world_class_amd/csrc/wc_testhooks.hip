@@ -148,6 +148,20 @@ __global__ __launch_bounds__(128) void hook_wave2_r2c_kernel(const double *__res
 		for (int q = 0; q < 8; ++q) X[wf2_bin(t, g, q)] = make_double2(0.5 * re[8 * g + q], 0.5 * im[8 * g + q]);
 	if (t == 0) X[2048] = make_double2(0.5 * nyq, 0.0);
 }
+// streaming read of n doubles, 8 bytes per lane and load (WIDE = false) or 16 (WIDE = true): the known byte count the
+// FETCH_SIZE counter is calibrated against (tools/fetch_calibrate.py, MI355X_MICROARCH.md HBM section)
+template <bool WIDE>
+__global__ __launch_bounds__(256) void hook_stream_read_kernel(const double *__restrict__ in, long long n, double *__restrict__ out) {
+	double acc = 0.0;
+	const long long stride = (long long)gridDim.x * blockDim.x;
+	if (WIDE) {
+		const double2 *p = reinterpret_cast<const double2 *>(in);
+		for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n / 2; i += stride) { const double2 v = p[i]; acc += v.x + v.y; }
+	} else {
+		for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) acc += in[i];
+	}
+	if (acc == 123.456) out[0] = acc;  // (keeps the loads)
+}
 // kind 0: wf_log, 1: wf_exp
 __global__ void hook_logexp_kernel(int kind, const double *__restrict__ in, double *__restrict__ out, long long n,
 								   const double2 *__restrict__ tw) {
@@ -288,6 +302,27 @@ int wc_debug_logexp(int kind, long long n, const double *in, double *out) {
 					   static_cast<double *>(d_out.p), n, dev->twiddle);
 	WC_HIP(hipGetLastError());
 	WC_HIP(hipMemcpyAsync(out, d_out.p, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+	WC_HIP(hipStreamSynchronize(s));
+	return WC_OK;
+}
+
+// reads `n` doubles of a device buffer it allocates (filled with ones) with 8-byte (wide = 0) or 16-byte (wide = 1) loads per
+// lane, `reps` times; the byte count is n * 8 * reps (calibration of the HBM read counter)
+int wc_debug_stream_read(long long n, int wide, int reps) {
+	if (n <= 0 || reps <= 0) return fail(WC_ERR_INVALID, "debug stream read: bad argument");
+	Device *dev = current_device();
+	if (!dev) return WC_ERR_DEVICE;
+	DeviceLock lock(dev);
+	hipStream_t s = dev->active();
+	Scoped d_in, d_out;
+	WC_HIP(hipMalloc(&d_in.p, sizeof(double) * n));
+	WC_HIP(hipMalloc(&d_out.p, sizeof(double)));
+	WC_HIP(hipMemsetAsync(d_in.p, 0, sizeof(double) * n, s));
+	for (int r = 0; r < reps; ++r) {
+		if (wide) hipLaunchKernelGGL(hook_stream_read_kernel<true>, dim3(256 * 16), dim3(256), 0, s, static_cast<const double *>(d_in.p), n, static_cast<double *>(d_out.p));
+		else hipLaunchKernelGGL(hook_stream_read_kernel<false>, dim3(256 * 16), dim3(256), 0, s, static_cast<const double *>(d_in.p), n, static_cast<double *>(d_out.p));
+	}
+	WC_HIP(hipGetLastError());
 	WC_HIP(hipStreamSynchronize(s));
 	return WC_OK;
 }

@@ -14,6 +14,7 @@ import torch.distributed as dist
 SHARD_SIGNATURES = {
     "wc_shard_partition": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "wc_gather_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_longlong), C.c_void_p]),
+    "wc_gather_to_root_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_longlong), C.c_void_p]),
 }
 
 
@@ -64,6 +65,25 @@ def gather_ragged(local: torch.Tensor, group=None) -> List[torch.Tensor]:
     return [o[:s] for o, s in zip(out, sizes)]
 
 
+def gather_ragged_to_root(local: torch.Tensor, sizes: Sequence[int], root: int = 0, group=None):
+    """Gather 1-D tensors of known, rank-dependent lengths on ONE rank: every other rank posts one send, the root the
+    world - 1 receives in one batch (RCCL: grouped ncclSend / ncclRecv, each peer over its own xGMI link at once) -- no
+    padding to the longest shard, no copy of the total on the other ranks.  Returns the per-rank list on the root, None elsewhere."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    assert len(sizes) == world and int(sizes[rank]) == local.numel()
+    if rank != root:
+        if local.numel() > 0:
+            for w_ in dist.batch_isend_irecv([dist.P2POp(dist.isend, local.contiguous(), root, group)]):
+                w_.wait()
+        return None
+    out = [local if r == root else torch.empty(int(sizes[r]), dtype=local.dtype, device=local.device) for r in range(world)]
+    ops = [dist.P2POp(dist.irecv, out[r], r, group) for r in range(world) if r != root and int(sizes[r]) > 0]
+    if ops:
+        for w_ in dist.batch_isend_irecv(ops):
+            w_.wait()
+    return out
+
+
 def scatter_back(parts: List[List[int]], gathered: List[torch.Tensor], lengths_per_item: Sequence[int]) -> List[torch.Tensor]:
     """Undo `partition`: gathered[r] is the concatenation of rank r's items (in parts[r] order); returns the
     items in original utterance order."""
@@ -102,6 +122,18 @@ class ShardLayout:
     def gather_samples(self, local: torch.Tensor, group=None) -> List[torch.Tensor]:
         """output waveforms of every rank -> list over all utterances in their original order"""
         return scatter_back(self.parts, gather_ragged(local.reshape(-1), group), self.all_y_len)
+
+    def gather_frames_to_root(self, local: torch.Tensor, width: int = 1, root: int = 0, group=None):
+        """per-frame rows of every rank on the ROOT only (None elsewhere), all utterances in their original order"""
+        sizes = [sum(self.all_f_len[i] for i in p) * width for p in self.parts]
+        got = gather_ragged_to_root(local.reshape(-1), sizes, root, group)
+        return None if got is None else scatter_back(self.parts, got, [f * width for f in self.all_f_len])
+
+    def gather_samples_to_root(self, local: torch.Tensor, root: int = 0, group=None):
+        """output waveforms of every rank on the ROOT only (None elsewhere), all utterances in their original order"""
+        sizes = [sum(self.all_y_len[i] for i in p) for p in self.parts]
+        got = gather_ragged_to_root(local.reshape(-1), sizes, root, group)
+        return None if got is None else scatter_back(self.parts, got, self.all_y_len)
 
 
 # ---- the few collectives of a sharded run besides the final gather: used by bench.py over RCCL and by the gloo tests ----------
