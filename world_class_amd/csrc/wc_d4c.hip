@@ -728,6 +728,9 @@ constexpr int kD4Lds = 2304;  // doubles: the smoothings' 2049 + 2 b + 1 terms, 
 // (minus for the odd half; windows longer than 2048 samples -- F0 below 94 Hz at 48 kHz -- reach the second term).
 // type 1 = Hanning, 2 = Blackman.  rng: the frame's draws for this window.  weighted: sample i times (i + 1) (the second
 // transform of the centroid).  Returns the window length; sumsq = sum of squares of the (unweighted) samples.
+// SLOTS = 16: the window is known to be at most 2048 samples long (every lane's 16 slots hold all of it, z[n + 1024] = 0, `odd`
+// plays no part: the caller forms both halves' inputs from the one result); SLOTS = 32: any length.
+template <int SLOTS>
 __device__ __forceinline__ int d4c2_windowed(int type, const double *__restrict__ x, int x_last, int fs, double f0, double pos, double ratio,
 											 const uint32_t *__restrict__ rng, int odd, bool weighted, double (&re)[16],
 											 double (&im)[16], double &sumsq, int lane) {
@@ -752,7 +755,7 @@ __device__ __forceinline__ int d4c2_windowed(int type, const double *__restrict_
 		constexpr int LOADS = decltype(loads_c)::value;
 		double ce = ce0, se = se0, co = co0, so = so0;
 #pragma unroll
-		for (int qg = 0; qg < 32; qg += 4) {
+		for (int qg = 0; qg < SLOTS; qg += 4) {
 			if (qg * 128 >= wl) break;
 			double xs[8];
 			uint32_t ns[8];
@@ -813,6 +816,10 @@ __device__ __forceinline__ int d4c2_groups(int wl) { return wl > 2048 ? 4 : (wl 
 #ifndef WC_D4C2_LT_OCC
 #define WC_D4C2_LT_OCC 2
 #endif
+// LONG = false: frames whose window fits 2048 samples (and the unvoiced ones): the window is formed once and serves both
+// halves of the transform; LONG = true: the others (F0 below 70 Hz at 48 kHz), window formed per half.  Every frame is done by
+// exactly one of the two launches.
+template <bool LONG>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_D4C2_LT_OCC, WC_D4C2_LT_OCC))) void d4c2_lovetrain_kernel(D4cArgs a) {
 	constexpr int N = 4096, M = 2048;
 	__shared__ __attribute__((aligned(16))) double L[kWfLds];
@@ -822,23 +829,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_D4C2_LT_O
 	const int bins_out = a.fft_size_out / 2 + 1;
 	double *__restrict__ row = a.ap + g * (long long)bins_out;
 	const double f0v = a.f0[g];
+	const int fs = a.fs;
+	const double f0c = uniform_d(fmax(f0v, 40.0));
+	const bool is_long = f0v != 0.0 && 2 * mround(3.0 * fs / f0c / 2.0) + 1 > 2048;
+	if (is_long != LONG) return;
 	double ap0 = 0.0;
 	if (f0v != 0.0) {
 		const int u = find_utt(a.utts, a.n_utt, g);
 		const UttDesc ud = a.utts[u];
-		const int fs = a.fs;
-		const double f0c = uniform_d(fmax(f0v, 40.0));
 		// cumulative powers above 100 Hz up to 4000 Hz and 7900 Hz (reference :184-186, :226-235); a common factor (the
 		// unpacking's 2) does not matter to their ratio
 		const int b0 = (int)ceil(100.0 * N / fs);
 		const int b1 = (int)ceil(4000.0 * N / fs);
 		const int b2 = min((int)ceil(7900.0 * N / fs), M);
 		double p1 = 0.0, p2 = 0.0;
+		double mr[16], mi[16], unused;
+		int wl = 0;
+		if (!LONG) wl = d4c2_windowed<16>(2, a.x + ud.x_off, ud.x_len - 1, fs, f0c, a.tpos[g], 3.0, a.rng_table + (a.rng_off[g] - a.rng_base), 0,
+										  false, mr, mi, unused, lane);
 #pragma unroll 1
 		for (int odd = 0; odd < 2; ++odd) {
-			double re[16], im[16], nyq, unused;
-			const int wl = d4c2_windowed(2, a.x + ud.x_off, ud.x_len - 1, fs, f0c, a.tpos[g], 3.0,
-											a.rng_table + (a.rng_off[g] - a.rng_base), odd, false, re, im, unused, lane);
+			double re[16], im[16], nyq;
+			if (LONG) {
+				wl = d4c2_windowed<32>(2, a.x + ud.x_off, ud.x_len - 1, fs, f0c, a.tpos[g], 3.0, a.rng_table + (a.rng_off[g] - a.rng_base), odd,
+									   false, re, im, unused, lane);
+			} else {
+#pragma unroll
+				for (int q = 0; q < 16; ++q) { re[q] = mr[q]; im[q] = mi[q]; }
+			}
 			wf_r2c4096_half(re, im, nyq, d4c2_groups(wl), L, a.tw, lane, odd);
 #pragma unroll
 			for (int gq = 0; gq < 4; ++gq) {
@@ -987,6 +1005,10 @@ __device__ __forceinline__ void d4c2_smooth(D4Bins &s, double width, int fs, dou
 #define D4_STAMP(i) do { } while (0)
 #endif
 // gated frames up to the static group delay (reference :308-460), which the band kernel reads back
+// LONG = false: frames whose windows fit 2048 samples (F0 of 94 Hz and above at 48 kHz): a window is formed once per position,
+// parked in the frame's row and read back by both halves and both transforms; LONG = true: the others, window formed per half
+// and transform.  Every gated frame is done by exactly one of the two launches.
+template <bool LONG>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_D4C2_OCC, WC_D4C2_OCC))) void d4c2_frames_kernel(D4cArgs a) {
 	constexpr int M = 2048;
 	__shared__ __attribute__((aligned(16))) double L[kD4Lds];
@@ -1014,8 +1036,101 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_D4C2_OCC,
 	// of the same signal times (n + 1), and the power spectrum of the Hanning-windowed frame (reference :411-434); bin by
 	// bin, so half by half.  Jobs 0, 1: the centroid's two positions, job 2: the power spectrum, through one copy of the code.
 	const int wl = __builtin_amdgcn_readfirstlane(2 * mround(4.0 * fs / f0 / 2.0) + 1);
+	if ((wl > 2048) != LONG) return;
 	const int ng = d4c2_groups(wl);
 	double cenM = 0.0, spsM = 0.0;  // bin 2048 (lane 0, even half)
+	if constexpr (!LONG) {
+#pragma unroll 1
+		for (int job = 0; job < 3; ++job) {
+			int ln = lane;
+			WC_FRESH(ln);
+			const double p = (job == 0) ? pos - 0.25 / f0 : (job == 1) ? pos + 0.25 / f0 : pos;
+			double pw;
+			{
+				// the mean-removed window, once; parked in the row's second half (free until job 2 puts the power spectrum there)
+				double mr[16], mi[16], sumsq;
+				d4c2_windowed<16>(job == 2 ? 1 : 2, x, x_last, fs, f0, p, 4.0, rng + (long long)job * wl, 0, false, mr, mi, sumsq, ln);
+				// (the reference divides every sample by the norm: an ulp apart); half of it: the transforms below then yield X, not
+				// 2 X.  The power spectrum's window is not normalised: its 2 X is put right by the 0.25 below.
+				pw = (job == 2) ? 1.0 : 0.5 * (1.0 / sqrt(sumsq));
+#pragma unroll
+				for (int q = 0; q < 16; ++q) {
+					if (q < 4 * ng) {
+						park[2048 + 64 * q + ln] = mr[q] * pw;
+						park[3072 + 64 * q + ln] = mi[q] * pw;
+					}
+				}
+			}
+			// (what a lane parks it reads back itself: program order is all the ordering the round trip needs)
+			auto master = [&](double (&re)[16], double (&im)[16], bool weighted) {
+				int ln = lane;
+				WC_FRESH(ln);  // (the weights below must not be hoisted out of the loop over the halves and spilled)
+				const double *pk = park;
+				asm volatile("" : "+s"(pk));  // (an opaque pointer: a real load from L2, not the stored values kept in registers)
+#pragma unroll
+				for (int q = 0; q < 16; ++q) {
+					re[q] = im[q] = 0.0;
+					if (q < 4 * ng) {
+						re[q] = pk[2048 + 64 * q + ln];
+						im[q] = pk[3072 + 64 * q + ln];
+					}
+				}
+				WF_SCHED_FENCE();
+				if (weighted) {
+#pragma unroll
+					for (int q = 0; q < 16; ++q) {
+						const int i0 = 2 * ln + 128 * q;
+						re[q] *= i0 + 1.0;
+						im[q] *= i0 + 2.0;
+					}
+				}
+			};
+#pragma unroll 1
+			for (int odd = 0; odd < 2; ++odd) {
+				double re[16], im[16], nyq1;
+				master(re, im, false);
+				wf_r2c4096_half(re, im, nyq1, ng, L, a.tw, ln, odd);
+				if (job == 2) {
+					// (the master copy of job 2 has been read by both halves only after the odd half's load above: the even
+					// half's power goes to the row's FIRST quarter pair for now and is moved below)
+					double pwr[16];
+#pragma unroll
+					for (int s = 0; s < 16; ++s) pwr[s] = 0.25 * fma(re[s], re[s], im[s] * im[s]);
+					if (odd == 0) {
+						spsM = 0.25 * (nyq1 * nyq1);
+#pragma unroll
+						for (int s = 0; s < 16; ++s) L[kWfLds + 64 * s + ln] = pwr[s];  // (LDS behind the exchange buffer: 1024 doubles)
+					} else {
+#pragma unroll
+						for (int s = 0; s < 16; ++s) {
+							park[3072 + 64 * s + ln] = pwr[s];
+							park[2048 + 64 * s + ln] = L[kWfLds + 64 * s + ln];
+						}
+					}
+				} else {
+					double ar[16], ai[16], nyq2;
+					master(ar, ai, true);
+					wf_r2c4096_half(ar, ai, nyq2, ng, L, a.tw, ln, odd);
+					double acc[16];
+#pragma unroll
+					for (int s = 0; s < 16; ++s) acc[s] = fma(re[s], ar[s], im[s] * ai[s]);
+					if (job == 1) {
+						double prev[16];
+						const double *pk = park;
+						asm volatile("" : "+s"(pk));
+#pragma unroll
+						for (int s = 0; s < 16; ++s) prev[s] = pk[1024 * odd + 64 * s + ln];
+						WF_SCHED_FENCE();
+#pragma unroll
+						for (int s = 0; s < 16; ++s) acc[s] += prev[s];
+					}
+#pragma unroll
+					for (int s = 0; s < 16; ++s) park[1024 * odd + 64 * s + ln] = acc[s];
+					if (odd == 0) cenM += nyq1 * nyq2;
+				}
+			}
+		}
+	} else
 #pragma unroll 1
 	for (int odd = 0; odd < 2; ++odd) {
 		double acc[16], accM = 0.0;
@@ -1027,7 +1142,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_D4C2_OCC,
 			WC_FRESH(ln);  // (what derives from the lane index must not be hoisted out of the loops and spilled)
 			double ar[16], ai[16], re[16], im[16], sumsq, nyq1;
 			const double p = (job == 0) ? pos - 0.25 / f0 : (job == 1) ? pos + 0.25 / f0 : pos;
-			d4c2_windowed(job == 2 ? 1 : 2, x, x_last, fs, f0, p, 4.0, rng + (long long)job * wl, odd, false, ar, ai, sumsq, ln);
+			d4c2_windowed<32>(job == 2 ? 1 : 2, x, x_last, fs, f0, p, 4.0, rng + (long long)job * wl, odd, false, ar, ai, sumsq, ln);
 			if (odd == 0 && job == 0) D4_STAMP(1);
 			// (the reference divides every sample by the norm: an ulp apart); half of it: the transforms below then yield X, not 2 X.
 			// The power spectrum's window is not normalised: its 2 X is put right by the 0.25 below.
@@ -1046,7 +1161,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_D4C2_OCC,
 			} else {
 				double nyq2;
 				if (wl > 2048) {  // the weights (i + 1) differ between the two samples folded into a slot: form them again
-					d4c2_windowed(2, x, x_last, fs, f0, p, 4.0, rng + (long long)job * wl, odd, true, ar, ai, sumsq, ln);
+					d4c2_windowed<32>(2, x, x_last, fs, f0, p, 4.0, rng + (long long)job * wl, odd, true, ar, ai, sumsq, ln);
 #pragma unroll
 					for (int q = 0; q < 16; ++q) { ar[q] *= pw; ai[q] *= pw; }
 				} else {
@@ -1314,7 +1429,10 @@ int d4c_enqueue(wc_d4c *d, hipStream_t s, int n_utt, const double *d_x, const in
 	const bool lt2 = d->wave2 && d->fft_size_lt == 4096;
 	const bool main2 = d->wave2 && split && d->fft_size_d4c == 4096 && d->window_length <= 1023;
 	if ((rc = dev->time_begin("d4c_lovetrain", s))) return rc;
-	if (lt2) hipLaunchKernelGGL(d4c2_lovetrain_kernel, dim3((unsigned)blocks8), dim3(64), 0, s, a);
+	if (lt2) {
+		hipLaunchKernelGGL(d4c2_lovetrain_kernel<false>, dim3((unsigned)blocks8), dim3(64), 0, s, a);
+		hipLaunchKernelGGL(d4c2_lovetrain_kernel<true>, dim3((unsigned)blocks8), dim3(64), 0, s, a);
+	}
 	else switch (d->fft_size_lt) {
 		case 1024: launch_lt<1024>(a, s); break;
 		case 2048: launch_lt<2048>(a, s); break;
@@ -1332,7 +1450,8 @@ int d4c_enqueue(wc_d4c *d, hipStream_t s, int n_utt, const double *d_x, const in
 		if ((rc = dev->time_begin(name, s))) return rc;
 		if (main2 && part == 0) {
 			// one wavefront per frame; the frames it leaves out (F0 above ~1.4 kHz, d4c2_can) by the block kernel behind them
-			hipLaunchKernelGGL(d4c2_frames_kernel, dim3((unsigned)blocks8), dim3(64), 0, s, a);
+			hipLaunchKernelGGL(d4c2_frames_kernel<false>, dim3((unsigned)blocks8), dim3(64), 0, s, a);
+			hipLaunchKernelGGL(d4c2_frames_kernel<true>, dim3((unsigned)blocks8), dim3(64), 0, s, a);
 			a.rare_only = 1;
 			hipLaunchKernelGGL((d4c_frames_kernel<4096, 512, true>), dim3((unsigned)blocks8), dim3(512), 0, s, a);
 			a.rare_only = 0;
