@@ -115,7 +115,7 @@ PIPELINE_CASES = ["c1_16k_2s_floor71", "c1_16k_2s_floor40", "m48k_1s", "m24k_1s_
 
 
 def headline_case(u):
-    """utterance u (0, 1) of the benchmark's workload at its full size, 48 kHz x 10 s, with what the real reference's full
+    """utterance u (0 .. 7) of the benchmark's workload at its full size, 48 kHz x 10 s, with what the real reference's full
     pipeline returns for it (tests/golden/headline_48k_10s.npz, oracle/gen_golden_headline.py): x and a dict of f0, sp/ap row
     sums and every `stride`-th row, block sums and windows of the waveform"""
     import hashlib

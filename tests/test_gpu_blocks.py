@@ -141,3 +141,42 @@ def test_cumulative_sum_of_many_random_spectra(hooks):
     # a tree-ordered sum is NOT what the reference computes: the test above would not pass with one
     tree = np.cumsum(v.astype(np.longdouble), axis=1).astype(np.float64)
     assert not np.array_equal(tree, sequential(v))
+
+
+def signed_cases(n, rng):
+    """Terms of either sign: the running sum crosses zero, cancels to nothing against its own history, changes binade in both
+    directions, meets ties -- everything the clean / dirty test of seq_cumsum_signed_wave has to sort out."""
+    cases = [c * rng.choice([-1.0, 1.0], n) for c in cumsum_cases(n, rng)]
+    cases += [-c for c in cumsum_cases(n, rng)[:6]]                                   # all negative: the mirror of the unsigned case
+    c = rng.normal(size=n); cases.append(c)                                           # a random walk around zero
+    c = rng.normal(size=n) + 0.3; cases.append(c)                                     # drifting away from zero
+    c = rng.normal(size=n) * 1e-3; c[0] = 1.0; cases.append(c)                        # small terms on a large sum: one binade
+    c = rng.normal(size=n) * 1e-3; c[0] = 1.0; c[n // 2] = -1.0; cases.append(c)      # ... which then cancels
+    c = rng.normal(size=n); c[1::2] = -c[0::2][: len(c[1::2])]; cases.append(c)       # exact cancellation every other term
+    c = (rng.integers(-4, 5, n) * 2.0 ** -52); c[0] = 1.0; cases.append(c)            # ties against an odd / even sum
+    c = (rng.integers(-4, 5, n) * 2.0 ** -53); c[0] = -1.0; cases.append(c)
+    c = np.sin(np.arange(n) * 0.05) * np.exp(rng.normal(size=n)); cases.append(c)     # slowly alternating sign
+    c = rng.normal(size=n) * 10.0 ** rng.uniform(-12, 3, n); cases.append(c)          # twelve decades
+    return np.stack(cases)
+
+
+@pytest.mark.parametrize("n", [1035, 1150, 2291, 2304, 7, 64, 65, 1153, 1100, 1029])
+def test_signed_cumulative_sum_is_the_sequential_one_bit_for_bit(hooks, n):
+    """seq_cumsum_signed_wave (D4C's group-delay smoothing, reference src/d4c.cpp:440-460 through src/world_common.cpp:82-116)."""
+    v = signed_cases(n, np.random.default_rng(7000 + n))
+    got = hooks.cumsum(v, -64)
+    want = sequential(v)
+    bad = np.argwhere(got.view(np.int64) != want.view(np.int64))
+    assert bad.size == 0, (bad[:5], got[tuple(bad[0])], want[tuple(bad[0])])
+
+
+def test_signed_cumulative_sum_of_many_random_group_delays(hooks):
+    rng = np.random.default_rng(98)
+    # shaped like the numerator D4C smooths: a signed spectrum, strong near the harmonics, of any overall scale
+    k = np.arange(1100)
+    v = rng.normal(size=(600, 1100)) * np.exp(2.0 * np.cos(k * rng.uniform(0.05, 0.6, (600, 1)))) * 10.0 ** rng.uniform(-20, 10, (600, 1))
+    v += rng.uniform(-0.5, 0.5, (600, 1)) * np.abs(v).mean(axis=1, keepdims=True)
+    got = hooks.cumsum(v, -64)
+    assert np.array_equal(got, sequential(v))
+    tree = np.cumsum(v.astype(np.longdouble), axis=1).astype(np.float64)
+    assert not np.array_equal(tree, sequential(v))

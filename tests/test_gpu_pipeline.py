@@ -276,8 +276,8 @@ def test_headline_workload_against_the_reference(wca):
     """The benchmark's own workload at full size -- 48 kHz x 10 s utterances through the fused pipeline in one batch --
     against what the real reference returns for the same samples: F0 on every frame, every spectrogram / aperiodicity row
     through its sum and every 50th in full, the waveform through block sums and sixteen 4096-sample windows."""
-    cases = [headline_case(u) for u in range(2)]
-    res = wca.Pipeline(48000).run_batch([x for x, _ in cases] * 2)  # both halves of the batch schedule see both utterances
+    cases = [headline_case(u) for u in range(8)]  # the bench's eight distinct utterances
+    res = wca.Pipeline(48000).run_batch([x for x, _ in cases] * 2)  # both halves of the batch schedule see every utterance
     for (x, g), r in zip(cases * 2, res):
         check_headline(r, g, 1e-6, 1e-7, 1e-7, 1e-8)
 

@@ -949,26 +949,9 @@ __device__ __forceinline__ void d4c2_smooth(D4Bins &s, double width, int fs, dou
 	if (NONNEG) {
 		seq_cumsum_nonneg_wave<36>(L, len, lane);
 	} else {
-		// every lane's chunk of <= 36 terms through registers: read at once, summed, scanned over the lanes, written at once
-		const int ch = (len + 63) / 64;
-		const int lo = min(lane * ch, len), n = min(len, lo + ch) - lo;
-		double c[36];
-#pragma unroll
-		for (int k = 0; k < 36; ++k) c[k] = L[min(lo + k, len - 1)];
-		wf_fence();
-		double loc = 0.0;
-#pragma unroll
-		for (int k = 0; k < 36; ++k) {
-			c[k] = (k < n) ? c[k] : 0.0;
-			loc += c[k];
-		}
-		double run = wave_incl_scan(loc, lane) - loc;
-#pragma unroll
-		for (int k = 0; k < 36; ++k) {
-			run = c[k] + run;
-			if (k < n) L[lo + k] = run;
-		}
-		wf_fence();
+		// the reference's sequential sum bit for bit here too (seq_cumsum_signed_wave): the group-delay numerator of a noise-free
+		// band is a difference of neighbourhoods of this sum, decided by how every single addition rounded
+		seq_cumsum_signed_wave<36>(L, len, lane);
 	}
 	const double step = (double)fs / N;
 	const double origin_axis = -(b - 0.5) * fs / N;

@@ -68,13 +68,15 @@ __global__ __launch_bounds__(T) void hook_cumsum_kernel(const double *__restrict
 }
 
 // seq_cumsum_nonneg_wave: one wavefront per sequence of n <= 2304 terms
+template <bool SIGNED>
 __global__ __launch_bounds__(64) void hook_cumsum_wave_kernel(const double *__restrict__ v, int n, double *__restrict__ out) {
 	__shared__ double S[2304];
 	const int lane = threadIdx.x;
 	const double *src = v + (size_t)blockIdx.x * n;
 	for (int i = lane; i < n; i += 64) S[i] = src[i];
 	__syncthreads();
-	if (n <= 1152) seq_cumsum_nonneg_wave<18>(S, n, lane);
+	if (SIGNED) seq_cumsum_signed_wave<36>(S, n, lane);
+	else if (n <= 1152) seq_cumsum_nonneg_wave<18>(S, n, lane);
 	else seq_cumsum_nonneg_wave<36>(S, n, lane);
 	for (int i = lane; i < n; i += 64) out[(size_t)blockIdx.x * n + i] = S[i];
 }
@@ -241,9 +243,9 @@ int wc_debug_fft(int kind, int n, int batch, const double *in, double *out) {
 }
 
 // `batch` sequences of n (<= 4096) non-negative terms each: out = their cumulative sums as seq_cumsum_nonneg forms them
-// (threads: 256 or 512, the two block sizes the stages use)
+// (threads: 256 or 512, the two block sizes the stages use; 64: the one-wavefront form; -64: its form for signed terms)
 int wc_debug_seq_cumsum(const double *v, int n, int batch, int threads, double *out) {
-	if (!v || !out || n <= 0 || n > 4096 || batch <= 0 || (threads != 64 && threads != 256 && threads != 512) || (threads == 64 && n > 2304)) return fail(WC_ERR_INVALID, "debug cumsum: bad argument");
+	if (!v || !out || n <= 0 || n > 4096 || batch <= 0 || (threads != 64 && threads != -64 && threads != 256 && threads != 512) || ((threads == 64 || threads == -64) && n > 2304)) return fail(WC_ERR_INVALID, "debug cumsum: bad argument");
 	Device *dev = current_device();
 	if (!dev) return WC_ERR_DEVICE;
 	DeviceLock lock(dev);
@@ -253,7 +255,8 @@ int wc_debug_seq_cumsum(const double *v, int n, int batch, int threads, double *
 	WC_HIP(hipMalloc(&d_in.p, sizeof(double) * total));
 	WC_HIP(hipMalloc(&d_out.p, sizeof(double) * total));
 	WC_HIP(hipMemcpyAsync(d_in.p, v, sizeof(double) * total, hipMemcpyHostToDevice, s));
-	if (threads == 64) hipLaunchKernelGGL(hook_cumsum_wave_kernel, dim3(batch), dim3(64), 0, s, static_cast<const double *>(d_in.p), n, static_cast<double *>(d_out.p));
+	if (threads == -64) hipLaunchKernelGGL(hook_cumsum_wave_kernel<true>, dim3(batch), dim3(64), 0, s, static_cast<const double *>(d_in.p), n, static_cast<double *>(d_out.p));
+	else if (threads == 64) hipLaunchKernelGGL(hook_cumsum_wave_kernel<false>, dim3(batch), dim3(64), 0, s, static_cast<const double *>(d_in.p), n, static_cast<double *>(d_out.p));
 	else if (threads == 256) hipLaunchKernelGGL(hook_cumsum_kernel<256>, dim3(batch), dim3(256), 0, s, static_cast<const double *>(d_in.p), n, static_cast<double *>(d_out.p));
 	else hipLaunchKernelGGL(hook_cumsum_kernel<512>, dim3(batch), dim3(512), 0, s, static_cast<const double *>(d_in.p), n, static_cast<double *>(d_out.p));
 	WC_HIP(hipGetLastError());

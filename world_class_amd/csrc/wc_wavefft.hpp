@@ -814,6 +814,113 @@ __device__ __forceinline__ void seq_cumsum_nonneg_wave(double *S, int len, int l
 	wf_fence();
 }
 
+// The same for terms of either sign (D4C's two smoothings of the group-delay numerator, reference src/d4c.cpp:440-460 through
+// src/world_common.cpp:82-116).  While the running sum c stays inside one binade and keeps its sign, fl(c + v) = c + u rn(v / u)
+// (u = the binade's ulp) for v of either sign, so a lane whose chunk provably keeps c inside one binade and meets no tie is
+// "clean" exactly as above; its increment is formed on a stand-in C for c (the estimate snapped to 2^-20 of the binade, so
+// that C + partial sums stay inside the binade with c).  "Provably": from a tree-ordered estimate of c whose error is bounded
+// against the sum of the ABSOLUTE values so far (cancellation makes c small against its own rounding history), with that
+// bound and the snapping as margins.  Everything else -- zero crossings, binade changes, ties -- is walked in order.
+template <int CHMAX>
+__device__ __forceinline__ void seq_cumsum_signed_wave(double *S, int len, int lane) {
+	const int ch = (len + 63) / 64;
+	const int lo = min(lane * ch, len), hi = min(len, lo + ch), n = hi - lo;
+	double v[CHMAX];
+#pragma unroll
+	for (int k = 0; k < CHMAX; ++k) v[k] = S[min(lo + k, len - 1)];
+	wf_fence();
+	double loc = 0.0, aloc = 0.0;
+#pragma unroll
+	for (int k = 0; k < CHMAX; ++k) {
+		v[k] = (k < n) ? v[k] : 0.0;
+		loc += v[k];
+		aloc += fabs(v[k]);
+	}
+	const double e0 = wave_incl_scan(loc, lane) - loc;           // estimate of c in front of this lane's terms
+	const double a1 = wave_incl_scan(aloc, lane);                // sum of |v| up to and including them
+	double emin = e0, emax = e0;
+	{
+		double e = e0;
+#pragma unroll
+		for (int k = 0; k < CHMAX; ++k) {
+			e += v[k];
+			emin = fmin(emin, e);
+			emax = fmax(emax, e);
+		}
+	}
+	// margins: the estimate against the sequential sum (both within ~2304 half-ulps of sum |v| of the exact sum), the snapping
+	const double m = a1 * 0x1p-40 + fmax(fabs(emin), fabs(emax)) * 0x1p-19;
+	const double lower = emin - m, upper = emax + m;
+	const int E = (__double2hiint(lower) >> 20) & 0x7ff;
+	bool dirty = lane == 0 || !(a1 < __builtin_huge_val()) || !(lower * upper > 0.0) || E != ((__double2hiint(upper) >> 20) & 0x7ff) ||
+				 E < 64 || E > 1984;
+	double d = 0.0;
+	if (n <= 0) {
+		dirty = lane == 0;
+	} else if (!dirty) {
+		const double rulp = __hiloint2double((2098 - E) << 20, 0);  // 2^(52 - e) = 1 / ulp
+		const double grid = __hiloint2double((E - 20) << 20, 0);     // 2^(e - 20)
+		const double C = rint(e0 / grid) * grid;                     // same binade as c (the margins above), a multiple of 2^32 ulps
+		double r = C;
+#pragma unroll
+		for (int k = 0; k < CHMAX; ++k) {
+			const double t = v[k] * rulp;
+			dirty = dirty || (t - floor(t)) == 0.5;
+			r = v[k] + r;
+		}
+		d = dirty ? 0.0 : r - C;
+	}
+	double x = d;
+	int f = dirty ? 1 : 0;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const double xo = __shfl_up(x, o, 64);
+		const int fo = __shfl_up(f, o, 64);
+		if (lane >= o) {
+			if (!f) x += xo;
+			f |= fo;
+		}
+	}
+	unsigned long long mk = __ballot(dirty);
+	const unsigned long long msk = mk;
+	double so = 0.0, endv = 0.0;
+	int prev = -1;
+	while (mk) {
+		const int t = __ffsll((long long)mk) - 1;
+		mk &= mk - 1;
+		const double xp = __shfl(x, max(t - 1, 0), 64);
+		const double si = prev < 0 ? -0.0 : (t == prev + 1 ? so : so + xp);  // (-0 + v = v for every v: the first sum is the first term)
+		if (lane == t) {
+			double run = si;
+#pragma unroll
+			for (int k = 0; k < CHMAX; ++k) {
+				run = (k < n) ? v[k] + run : run;  // (a signed sum may be -0: adding the padding's +0 would flip it)
+				v[k] = run;
+			}
+			endv = run;
+		}
+		so = __shfl(endv, t, 64);
+		prev = t;
+	}
+	{
+		const unsigned long long below = msk & ((1ull << lane) - 1ull);
+		const int j = below ? 63 - __clzll((long long)below) : 0;
+		const double start = __shfl(endv, j, 64) + (x - d);
+		if (!dirty) {
+			double run = start;
+#pragma unroll
+			for (int k = 0; k < CHMAX; ++k) {
+				run = (k < n) ? v[k] + run : run;
+				v[k] = run;
+			}
+		}
+	}
+#pragma unroll
+	for (int k = 0; k < CHMAX; ++k)
+		if (k < n) S[lo + k] = v[k];
+	wf_fence();
+}
+
 // ---- lean log / exp ------------------------------------------------------------------------------------------------------
 // log(x) for finite x > 0 to ~3e-16 absolute (relative for |log x| > 1): x = 2^e m, m in [1/2, 1); the top seven mantissa
 // bits pick c_i with (1 / c_i, log c_i) tabulated; log m = log c_i + log1p(r), r = m / c_i - 1, |r| < 2^-8, degree-6 series.
