@@ -83,12 +83,13 @@ def test_other_signal_kinds_48k_1ms_hop(wca, P):
     xs = [make_signal(fs, 1.0, s) for s in seeds]
     res = wca.Pipeline(fs, frame_period=1.0).run_batch(xs)
     for s, x, r in zip(seeds, xs, res):
-        # A noise-free chirp at 48 kHz leaves D4C's static group delay (a ratio of two smoothed spectra whose bands above the
-        # chirp hold rounding noise only) ill-conditioned in every implementation -- the reference itself returns NaN rows for
-        # some such signals -- and its two signed cumulative sums are block-scanned here, not order-faithful
-        # like the power-spectrum one: 3e-7 measured on this signal, 1e-6 stated for it; every other kind holds 1e-7.
+        # A noise-free chirp at 48 kHz leaves D4C's static group delay -- a ratio of two smoothed spectra whose bands above the
+        # chirp hold rounding noise only -- ill-conditioned in every implementation (the reference itself returns NaN rows for some
+        # such signals).  Both of its cumulative sums run in the reference's order here (seq_cumsum_signed_wave,
+        # bit for bit in tests/test_gpu_blocks.py), which took this signal from 2.8e-7 to 2.1e-7; what is left is the rounding of
+        # the transforms themselves in bands that hold nothing else.  3e-7 stated for it; every other kind holds 1e-7.
         kind = SIGNAL_KINDS[s % len(SIGNAL_KINDS)]
-        check(r, P.pipeline(x, fs, frame_period=1.0), x, "seed %d (%s)" % (s, kind), ap_abs=1e-6 if kind == "chirp" else 1e-7)
+        check(r, P.pipeline(x, fs, frame_period=1.0), x, "seed %d (%s)" % (s, kind), ap_abs=3e-7 if kind == "chirp" else 1e-7)
 
 
 def test_stages_on_arbitrary_contours(wca, P):

@@ -575,6 +575,7 @@ struct SynArgs {
 	const double2 *tw;
 	const double *dc_remover;
 	double *out;
+	double *resp;  // the one-wavefront kernel: [pulse][N] responses in output order, summed by syn_overlap_add_kernel (NULL: atomics into out)
 	long long total_pulses;  // launch size (capacity); the real count is pulse_prefix[n_utt]
 	const unsigned long long *rng_start;  // per-utterance stream position (device), NULL = utts[u].rng_pos
 	unsigned long long *trace;  // WC_SYN_TRACE builds: 16 shader-clock stamps per pulse
@@ -970,14 +971,6 @@ __device__ __forceinline__ void minimum_phase_wave(const double (&ls)[16], doubl
 #ifndef WC_SYN_TRACE
 #define WC_SYN_TRACE 0
 #endif
-#ifndef WC_SYN_NOATOMIC
-#define WC_SYN_NOATOMIC 0  // 1: timing ablation (wrong results): plain stores instead of the atomic overlap-add
-#endif
-#if WC_SYN_NOATOMIC
-#define SYN_ADD(p, v) (*(p) = (v))
-#else
-#define SYN_ADD(p, v) atomicAdd((p), (v))
-#endif
 #if WC_SYN_TRACE
 #define SYN_STAMP(i) do { if (lane == 0) a.trace[gp * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
@@ -1045,8 +1038,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_SYN_WAVE_
 	// fractional delay / the noise spectrum, back to the time domain ----
 	double dc = 0.0;
 	const double sq = sqrt((double)noise_size);
-	double *__restrict__ out = a.out + ud.y_off;
-	const int index = pidx - M;
+	double *__restrict__ resp = a.resp + gp * N;
 	const bool has_periodic = !(vuv <= 0.5 || ar0 > 0.999);
 #pragma unroll 1
 	for (int part = has_periodic ? 0 : 1; part < 2; ++part) {
@@ -1164,38 +1156,93 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_SYN_WAVE_
 #pragma unroll
 			for (int q = 0; q < 8; ++q) {
 				dc += wr[q] + wi[q];
-#pragma unroll
-				for (int h = 0; h < 2; ++h) {
-					const int o = index + 1 + M + 2 * ln + 128 * q + h;
-					if (o >= 0 && o < ud.y_len) SYN_ADD(&out[o], (h ? wi[q] : wr[q]) * sq / N);
-				}
+				// (parked in the pulse's own row of the response buffer, unscaled; the mix below picks it up)
+				*reinterpret_cast<double2 *>(resp + M + 2 * ln + 128 * q) = make_double2(wr[q] * sq, wi[q] * sq);
 			}
 			dc = wave_sum_all(dc);
 			SYN_STAMP(5);
 		} else {
 			// ---- mix + overlap-add (reference :339-343, :118-139): shifted sample j is unshifted sample j - M (j >= M) / j + M ----
-			double dr[16];
-#pragma unroll
-			for (int q = 0; q < 8; ++q) {
-				dr[2 * q] = a.dc_remover[2 * ln + 128 * q];
-				dr[2 * q + 1] = a.dc_remover[2 * ln + 128 * q + 1];
-			}
-			WF_SCHED_FENCE();
+			// The response (periodic sqrt(noise_size) + aperiodic) / fft_size goes to the pulse's row of the response buffer in output
+			// order; syn_overlap_add_kernel sums the rows into y pulse after pulse, the reference's order (:118-139) -- no atomics,
+			// the same bits on every run.
 			const double dcs = has_periodic ? -dc * sq : 0.0;
 #pragma unroll
-			for (int q = 0; q < 16; ++q) {
+			for (int q0 = 0; q0 < 8; q0 += 4) {
+				double2 dr[4], pp[4];
 #pragma unroll
-				for (int h = 0; h < 2; ++h) {
-					const int n = 2 * ln + 128 * q + h;  // unshifted sample
-					const double r = fma(dcs, dr[2 * (q & 7) + h], h ? wi[q] : wr[q]) / N;
-					const int o = index + 1 + (q < 8 ? n + M : n - M);
-					if (o >= 0 && o < ud.y_len) SYN_ADD(&out[o], r);
+				for (int q = 0; q < 4; ++q) {
+					dr[q] = *reinterpret_cast<const double2 *>(a.dc_remover + 2 * ln + 128 * (q0 + q));
+					pp[q] = has_periodic ? *reinterpret_cast<const double2 *>(resp + M + 2 * ln + 128 * (q0 + q)) : make_double2(0.0, 0.0);
+				}
+				WF_SCHED_FENCE();
+#pragma unroll
+				for (int q = 0; q < 4; ++q) {
+					const int n = 2 * ln + 128 * (q0 + q);  // unshifted samples n, n + 1 (output place n + M) and n + M, n + M + 1 (place n)
+					const double r0 = fma(dcs, dr[q].x, wr[q0 + q]) + pp[q].x, r1 = fma(dcs, dr[q].y, wi[q0 + q]) + pp[q].y;
+					*reinterpret_cast<double2 *>(resp + n + M) = make_double2(r0 / N, r1 / N);
+					const double r2 = fma(dcs, dr[q].x, wr[q0 + q + 8]), r3 = fma(dcs, dr[q].y, wi[q0 + q + 8]);
+					*reinterpret_cast<double2 *>(resp + n) = make_double2(r2 / N, r3 / N);
 				}
 			}
 			SYN_STAMP(10);
 		}
 	}
 
+}
+
+// Overlap-add of the response rows (reference :118-139: y[index + 1 + j] += response[j], pulse after pulse).  One workgroup per
+// tile of OA_TILE output samples: the pulses that reach into the tile are a contiguous run of the utterance's (sorted) pulse
+// list, found by bisection; every thread adds the rows' samples to its four outputs in pulse order, so y carries the
+// reference's own summation order.  Writes every sample of y (zeros where no pulse reaches): no clearing pass.
+constexpr int OA_T = 256, OA_K = 4, OA_TILE = OA_T * OA_K;
+__global__ __launch_bounds__(OA_T) void syn_overlap_add_kernel(SynArgs a) {
+	constexpr int N = 2048, M = 1024;
+	const int u = blockIdx.y;
+	const UttDesc ud = a.utts[u];
+	const int t0 = blockIdx.x * OA_TILE;
+	if (t0 >= ud.y_len) return;
+	const long long pre = a.pulse_prefix[u];
+	const int n_p = (int)(a.pulse_prefix[u + 1] - pre);
+	const int *__restrict__ pidx = a.p.index + a.cap_off[u];
+	// pulse i covers outputs pidx[i] - M + 1 .. pidx[i] + M: those with pidx in [t0 - M, t0 + OA_TILE - 2 + M] touch the tile
+	int lo = 0, hi = n_p;
+	while (lo < hi) {
+		const int mid = (lo + hi) >> 1;
+		if (pidx[mid] < t0 - M) lo = mid + 1; else hi = mid;
+	}
+	const int last = t0 + OA_TILE - 2 + M;
+	double acc[OA_K];
+#pragma unroll
+	for (int m = 0; m < OA_K; ++m) acc[m] = 0.0;
+	const int o0 = t0 + threadIdx.x;
+	const double *__restrict__ rows = a.resp + pre * N;
+	constexpr int PB = 4;  // pulses per trip: their loads are requested together, the additions stay in pulse order
+	for (int i = lo; i < n_p; i += PB) {
+		if (pidx[i] > last) break;
+		double v[PB][OA_K];
+#pragma unroll
+		for (int b = 0; b < PB; ++b) {
+			const int ii = min(i + b, n_p - 1);
+			const int start = pidx[ii] - M + 1;
+			const bool on = i + b < n_p && pidx[ii] <= last;
+#pragma unroll
+			for (int m = 0; m < OA_K; ++m) {
+				const int j = o0 + m * OA_T - start;
+				v[b][m] = (on && j >= 0 && j < N) ? rows[(long long)ii * N + j] : 0.0;
+			}
+		}
+#pragma unroll
+		for (int b = 0; b < PB; ++b)
+#pragma unroll
+			for (int m = 0; m < OA_K; ++m) acc[m] += v[b][m];
+	}
+	double *__restrict__ out = a.out + ud.y_off;
+#pragma unroll
+	for (int m = 0; m < OA_K; ++m) {
+		const int o = o0 + m * OA_T;
+		if (o < ud.y_len) out[o] = acc[m];
+	}
 }
 
 }  // namespace wc
@@ -1206,13 +1253,13 @@ struct wc_synthesis {
 	int fs, fft_size;
 	double frame_period;  // seconds
 	Device *dev;
-	DevBuf dc_remover, utts, meta, pulses, incs, phase, tile_cnt, d_f0, d_sp, d_ap, d_out;
+	DevBuf dc_remover, utts, meta, pulses, incs, phase, tile_cnt, resp, d_f0, d_sp, d_ap, d_out;
 	bool pulses_by_utterance;  // WC_SYN_PULSES=utterance: one workgroup walks an utterance's tiles (A/B and the bit-identity test)
 	bool wave;  // N = 2048: one wavefront per pulse (default; WC_SYN_IMPL=block: the workgroup-per-pulse kernel)
 	bool serial_timebase;  // WC_SYN_TIMEBASE=serial: the one-wavefront sequential accumulation instead of the exact parallel one
 	HostBuf h_stage;
 	long long total_out = 0, cap_total = 0;  // of the most recent syn_prepare
-	int n_utt = 0;
+	int n_utt = 0, max_out = 0;
 };
 
 template <int N>
@@ -1268,10 +1315,12 @@ int syn_prepare(wc_synthesis *sy, hipStream_t s, int n_utt, const double *d_f0, 
 	const long long total_out = yo;
 	sy->total_out = total_out;
 	sy->n_utt = n_utt;
+	sy->max_out = max_out;
 	sy->cap_total = 0;
 	if (total_out == 0) return WC_OK;
 	int rc;
-	WC_HIP(hipMemsetAsync(d_out, 0, sizeof(double) * total_out, s));
+	// (the one-wavefront pulse kernel goes through response rows and syn_overlap_add_kernel, which writes every sample)
+	if (!(sy->wave && sy->fft_size == 2048)) WC_HIP(hipMemsetAsync(d_out, 0, sizeof(double) * total_out, s));
 	// meta layout (device): cap_off[n] (i64) | pulse_prefix[n+1] (i64) | inc_off[n] (i64) | end_pos[n] (u64) |
 	//                       cap[n] | count[n] | first_index[n] | last_index[n] | overflow
 	const size_t meta_bytes = sizeof(long long) * (4 * (size_t)n_utt + 1) + sizeof(int) * (4 * (size_t)n_utt + 1);
@@ -1388,6 +1437,12 @@ int syn_pulses(wc_synthesis *sy, hipStream_t s, const double *d_f0, const double
 	a.only_pulse = -1;
 #endif
 	a.trace = nullptr;
+	a.resp = nullptr;
+	if (sy->wave && sy->fft_size == 2048) {
+		// a response row per pulse slot of the rate bound (only the rows of real pulses are ever touched)
+		if ((rc = sy->resp.reserve(sizeof(double) * 2048 * (size_t)co))) return rc;
+		a.resp = sy->resp.as<double>();
+	}
 #if WC_SYN_TRACE
 	static DevBuf tracebuf;
 	if (tracebuf.reserve(sizeof(unsigned long long) * 16 * (size_t)co)) return WC_ERR_DEVICE;
@@ -1399,8 +1454,12 @@ int syn_pulses(wc_synthesis *sy, hipStream_t s, const double *d_f0, const double
 		case 512: launch_pulses<512>(a, s); break;
 		case 1024: launch_pulses<1024>(a, s); break;
 		case 2048:
-			if (sy->wave) hipLaunchKernelGGL(syn_pulse_wave_kernel, dim3((unsigned)(8 * ((a.total_pulses + 7) / 8))), dim3(64), 0, s, a);
-			else launch_pulses<2048>(a, s);
+			if (sy->wave) {
+				hipLaunchKernelGGL(syn_pulse_wave_kernel, dim3((unsigned)(8 * ((a.total_pulses + 7) / 8))), dim3(64), 0, s, a);
+				hipLaunchKernelGGL(syn_overlap_add_kernel, dim3((unsigned)((sy->max_out + OA_TILE - 1) / OA_TILE), n_utt), dim3(OA_T), 0, s, a);
+			} else {
+				launch_pulses<2048>(a, s);
+			}
 			break;
 		case 4096: launch_pulses<4096>(a, s); break;
 		default: return fail(WC_ERR_UNSUPPORTED, "synthesis: fft_size must be 512, 1024, 2048 or 4096");
@@ -1501,7 +1560,7 @@ wc_synthesis *wc_synthesis_create(int fs, int fft_size, double frame_period_ms) 
 void wc_synthesis_destroy(wc_synthesis *s) {
 	if (!s) return;
 	s->dev->quiesce();
-	s->dc_remover.release(); s->utts.release(); s->meta.release(); s->pulses.release(); s->incs.release(); s->phase.release(); s->tile_cnt.release();
+	s->dc_remover.release(); s->utts.release(); s->meta.release(); s->pulses.release(); s->incs.release(); s->phase.release(); s->tile_cnt.release(); s->resp.release();
 	s->d_f0.release(); s->d_sp.release(); s->d_ap.release(); s->d_out.release(); s->h_stage.release();
 	delete s;
 }
