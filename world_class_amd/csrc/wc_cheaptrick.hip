@@ -603,6 +603,9 @@ struct wc_cheaptrick {
 	Device *dev;
 	DevBuf utts, cnt, uidx, off, endpos, d_x, d_tpos, d_f0, d_sp;
 	HostBuf h_stage;
+	// the pass over the frames the one-wavefront kernel leaves out runs beside whatever follows on the caller's stream
+	hipStream_t side = nullptr;
+	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 // Threads per frame: eight samples per thread up to N = 2048 (one radix-4 butterfly per thread and pass, nobody idle): 256
@@ -666,7 +669,8 @@ int ct_prepare(wc_cheaptrick *c, hipStream_t s, int n_utt, const int *x_length, 
 }
 
 int ct_frames(wc_cheaptrick *c, hipStream_t s, int n_utt, const double *d_x, const double *d_tpos, const double *d_f0,
-			  double *d_sp, long long total) {
+			  double *d_sp, long long total, hipEvent_t *rows_done) {
+	if (rows_done) *rows_done = nullptr;
 	Device *dev = c->dev;
 	if (total == 0) return WC_OK;
 	int rc;
@@ -684,9 +688,22 @@ int ct_frames(wc_cheaptrick *c, hipStream_t s, int n_utt, const double *d_x, con
 			if (c->wave) {
 				// one wavefront per frame; the frames it leaves out (F0 above ~2 kHz, ct_wave_can) are found and done by a
 				// small grid of the block kernel behind it
+				// small grid of the block kernel -- on a stream of its own: its workgroups (four wavefronts, 18 KB) wait long for a
+				// place while one-wavefront kernels fill the CUs, and nothing on the caller's stream needs its rows before the
+				// spectrogram is read.  rows_done: the caller makes the readers wait (NULL: this stream does, before returning).
+				if (!c->side) {
+					WC_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+					WC_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+					WC_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+				}
+				WC_HIP(hipEventRecord(c->ev_fork, s));
+				WC_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
 				hipLaunchKernelGGL(ct_wave_kernel, dim3((unsigned)(((total + 7) / 8) * 8)), dim3(64), 0, s, a);
 				a.rare_only = 1;
-				hipLaunchKernelGGL((ct_frames_kernel<2048, WC_CT_THREADS, true>), dim3(256), dim3(WC_CT_THREADS), 0, s, a);
+				hipLaunchKernelGGL((ct_frames_kernel<2048, WC_CT_THREADS, true>), dim3(256), dim3(WC_CT_THREADS), 0, c->side, a);
+				WC_HIP(hipEventRecord(c->ev_join, c->side));
+				if (rows_done) *rows_done = c->ev_join;
+				else WC_HIP(hipStreamWaitEvent(s, c->ev_join, 0));
 			} else {
 				launch_ct<2048>(a, s);
 			}
@@ -723,7 +740,7 @@ static int ct_run_device(wc_cheaptrick *c, int n_utt, const double *d_x, const i
 	}
 	if ((rc = ct_prepare(c, s, n_utt, x_length, d_f0, f0_length, rng_pos, &total, &min_pos, &max_end))) return rc;
 	if (total == 0) return WC_OK;
-	if ((rc = ct_frames(c, s, n_utt, d_x, d_tpos, d_f0, d_sp, total))) return rc;
+	if ((rc = ct_frames(c, s, n_utt, d_x, d_tpos, d_f0, d_sp, total, nullptr))) return rc;
 	if (rng_pos) {
 		std::vector<uint64_t> h_end(n_utt);
 		WC_HIP(hipMemcpyAsync(h_end.data(), c->endpos.p, sizeof(uint64_t) * n_utt, hipMemcpyDeviceToHost, s));
@@ -766,6 +783,9 @@ void wc_cheaptrick_destroy(wc_cheaptrick *c) {
 	c->utts.release(); c->cnt.release(); c->uidx.release(); c->off.release(); c->endpos.release();
 	c->d_x.release(); c->d_tpos.release(); c->d_f0.release(); c->d_sp.release();
 	c->h_stage.release();
+	if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
+	if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+	if (c->ev_join) (void)hipEventDestroy(c->ev_join);
 	delete c;
 }
 int wc_cheaptrick_get_fft_size(const wc_cheaptrick *c) { return c ? c->fft_size : WC_ERR_INVALID; }

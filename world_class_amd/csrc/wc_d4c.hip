@@ -49,6 +49,7 @@ struct D4cArgs {
 	int fs, fft_size_out, n_ap, window_length;
 	double threshold;
 	long long sgd_stride;  // doubles per frame in sgd
+	const int *uidx;  // [total_frames] utterance of every frame (d4c_lt_count_kernel): the one-wavefront kernels read it instead of bisecting
 	int rare_only;  // d4c_frames_kernel behind d4c2_frames_kernel: only the frames that one leaves out (d4c2_can)
 };
 
@@ -196,9 +197,11 @@ __device__ __forceinline__ bool d4c2_can(double f0, int fs) {
 }
 
 // number of draws of one frame's LoveTrain window / of its three D4C windows
-__global__ void d4c_lt_count_kernel(const double *__restrict__ f0, long long total, int fs, uint32_t *__restrict__ cnt) {
+__global__ void d4c_lt_count_kernel(const double *__restrict__ f0, long long total, int fs, uint32_t *__restrict__ cnt,
+									const UttDesc *__restrict__ utts, int n_utt, int *__restrict__ uidx) {
 	long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 	if (g >= total) return;
+	uidx[g] = find_utt(utts, n_utt, g);  // (looked up once here rather than by every frame's wavefront, a chain of dependent loads each)
 	double f = f0[g];
 	cnt[g] = (f == 0.0) ? 0u : (uint32_t)(2 * mround(3.0 * fs / fmax(f, 40.0) / 2.0) + 1);
 }
@@ -835,7 +838,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_D4C2_LT_O
 	if (is_long != LONG) return;
 	double ap0 = 0.0;
 	if (f0v != 0.0) {
-		const int u = find_utt(a.utts, a.n_utt, g);
+		const int u = a.uidx[g];
 		const UttDesc ud = a.utts[u];
 		// cumulative powers above 100 Hz up to 4000 Hz and 7900 Hz (reference :184-186, :226-235); a common factor (the
 		// unpacking's 2) does not matter to their ratio
@@ -1003,7 +1006,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_D4C2_OCC,
 	const int fs = a.fs;
 	const double f0 = uniform_d(fmax(47.0, f0v));
 	if (!d4c2_can(f0, fs)) return;
-	const int u = find_utt(a.utts, a.n_utt, g);
+	const int wl = __builtin_amdgcn_readfirstlane(2 * mround(4.0 * fs / f0 / 2.0) + 1);
+	if ((wl > 2048) != LONG) return;  // (before anything else is fetched: one of the two launches leaves here for every frame)
+	const int u = a.uidx[g];
 	const UttDesc ud = a.utts[u];
 	const double *__restrict__ x = a.x + ud.x_off;
 	const int x_last = ud.x_len - 1;
@@ -1018,8 +1023,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_D4C2_OCC,
 	// ---- static centroid (reference :339-405): at t -+ T0/4, Re S1 Re S2 + Im S1 Im S2 of the unit-energy windowed signal and
 	// of the same signal times (n + 1), and the power spectrum of the Hanning-windowed frame (reference :411-434); bin by
 	// bin, so half by half.  Jobs 0, 1: the centroid's two positions, job 2: the power spectrum, through one copy of the code.
-	const int wl = __builtin_amdgcn_readfirstlane(2 * mround(4.0 * fs / f0 / 2.0) + 1);
-	if ((wl > 2048) != LONG) return;
 	const int ng = d4c2_groups(wl);
 	double cenM = 0.0, spsM = 0.0;  // bin 2048 (lane 0, even half)
 	if constexpr (!LONG) {
@@ -1325,7 +1328,7 @@ struct wc_d4c {
 	bool split;  // band loop and row output as separate kernels (default; WC_D4C_SPLIT=0: one fused kernel)
 	bool wave2;  // 4096-point transforms by two wavefronts per frame (d4c2_*; default where they apply, WC_D4C_IMPL=block: never)
 	Device *dev;
-	DevBuf nuttall, utts, cnt, off, endpos, endpos2, ap0, sgd, coarse, d_x, d_tpos, d_f0, d_ap;
+	DevBuf nuttall, utts, cnt, uidx, off, endpos, endpos2, ap0, sgd, coarse, d_x, d_tpos, d_f0, d_ap;
 	HostBuf h_stage;
 };
 
@@ -1381,6 +1384,7 @@ int d4c_enqueue(wc_d4c *d, hipStream_t s, int n_utt, const double *d_x, const in
 	int rc;
 	if ((rc = d->utts.reserve(sizeof(UttDesc) * n_utt))) return rc;
 	if ((rc = d->cnt.reserve(sizeof(uint32_t) * total))) return rc;
+	if ((rc = d->uidx.reserve(sizeof(int) * total))) return rc;
 	if ((rc = d->off.reserve(sizeof(uint64_t) * total))) return rc;
 	if ((rc = d->ap0.reserve(sizeof(double) * total))) return rc;
 	const bool split = d->split;
@@ -1396,13 +1400,14 @@ int d4c_enqueue(wc_d4c *d, hipStream_t s, int n_utt, const double *d_x, const in
 	WC_HIP(hipMemcpyAsync(d->utts.p, d->h_stage.p, sizeof(UttDesc) * n_utt, hipMemcpyHostToDevice, s));
 	if ((rc = d->h_stage.mark(s))) return rc;
 	const unsigned grid1 = (unsigned)((total + 255) / 256);
-	hipLaunchKernelGGL(d4c_lt_count_kernel, dim3(grid1), dim3(256), 0, s, d_f0, total, d->fs, d->cnt.as<uint32_t>());
+	hipLaunchKernelGGL(d4c_lt_count_kernel, dim3(grid1), dim3(256), 0, s, d_f0, total, d->fs, d->cnt.as<uint32_t>(), d->utts.as<UttDesc>(), n_utt,
+					   d->uidx.as<int>());
 	hipLaunchKernelGGL(utt_scan_kernel, dim3(n_utt), dim3(256), 0, s, d->cnt.as<uint32_t>(), d->utts.as<UttDesc>(),
 					   d_start, d->off.as<unsigned long long>(), d->endpos.as<unsigned long long>());
 	D4cArgs a;
 	a.x = d_x; a.utts = d->utts.as<UttDesc>(); a.n_utt = n_utt; a.tpos = d_tpos; a.f0 = d_f0;
 	a.rng_off = d->off.as<unsigned long long>(); a.rng_table = dev->rng_table.as<uint32_t>(); a.rng_base = dev->rng_base;
-	a.tw = dev->twiddle; a.ap = d_ap; a.ap0 = d->ap0.as<double>(); a.cnt = d->cnt.as<uint32_t>();
+	a.tw = dev->twiddle; a.ap = d_ap; a.ap0 = d->ap0.as<double>(); a.cnt = d->cnt.as<uint32_t>(); a.uidx = d->uidx.as<int>();
 	a.sgd = d->sgd.as<double>(); a.coarse = d->coarse.as<double>();
 	a.nuttall = d->nuttall.as<double>(); a.total_frames = total; a.fs = d->fs; a.fft_size_out = fft_size;
 	a.n_ap = d->n_ap; a.window_length = d->window_length; a.threshold = d->threshold;
@@ -1547,7 +1552,7 @@ wc_d4c *wc_d4c_create(int fs, double threshold) {
 void wc_d4c_destroy(wc_d4c *d) {
 	if (!d) return;
 	d->dev->quiesce();
-	d->nuttall.release(); d->utts.release(); d->cnt.release(); d->off.release(); d->endpos.release(); d->endpos2.release();
+	d->nuttall.release(); d->utts.release(); d->cnt.release(); d->uidx.release(); d->off.release(); d->endpos.release(); d->endpos2.release();
 	d->ap0.release(); d->sgd.release(); d->coarse.release(); d->d_x.release(); d->d_tpos.release(); d->d_f0.release(); d->d_ap.release(); d->h_stage.release();
 	delete d;
 }

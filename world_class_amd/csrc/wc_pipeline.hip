@@ -300,11 +300,13 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 				WC_HIP(hipEventRecord(G.e0, G.main));
 				WC_HIP(hipStreamWaitEvent(G.aux, G.e0, 0));
 				if (g == 0) WC_HIP(hipStreamWaitEvent(G.aux, p->grp[1].e_mid, 0));
-				if ((rc = ct_frames(G.ct, G.aux, nu, gx, gt, gf, gsp, total))) return rc;
+				hipEvent_t ct_rows = nullptr;  // CheapTrick's pass over the frames its one-wavefront kernel leaves out, on a stream of its own
+				if ((rc = ct_frames(G.ct, G.aux, nu, gx, gt, gf, gsp, total, &ct_rows))) return rc;
 				WC_HIP(hipEventRecord(G.e_ct, G.aux));
 				if ((rc = d4c_enqueue(G.d4, G.aux, nu, gx, x_length + u0, gt, gf, f_len.data() + u0, p->fft_size, gap, nullptr,
 									  ct_end_positions(G.ct))))
 					return rc;
+				if (ct_rows) WC_HIP(hipStreamWaitEvent(G.aux, ct_rows, 0));  // (the pulses wait for e_aux)
 				WC_HIP(hipEventRecord(G.e_aux, G.aux));
 				if (sink && attempt == 0 && (sink->stage_sp || sink->stage_ap)) {
 					const size_t off = sizeof(double) * (size_t)sl[g].fo * bins_, len = sizeof(double) * (size_t)(fo_end[g] - sl[g].fo) * bins_;
@@ -312,6 +314,7 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 					// stretch of a run with all outputs (2.1 GB at ~50 GB/s), so it starts as early as it can
 					for (int which = 0; which < 2; ++which) {
 						WC_HIP(hipStreamWaitEvent(p->s_copy, which == 0 ? G.e_ct : G.e_aux, 0));
+						if (which == 0 && ct_rows) WC_HIP(hipStreamWaitEvent(p->s_copy, ct_rows, 0));
 						char *stage = which == 0 ? sink->stage_sp : sink->stage_ap;
 						double *const *rows = which == 0 ? sink->sp : sink->ap;
 						const double *src = which == 0 ? gsp : gap;
@@ -396,7 +399,7 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 		// CheapTrick's frames go to the second Harvest stream when there is one: HIP multiplexes streams onto a few
 		// hardware queues, and two streams that land on the same queue would serialise CheapTrick and D4C
 		hipStream_t sct = ns > 1 ? p->hs[1] : p->s1;
-		if ((rc = ct_frames(p->ct, sct, n_utt, d_x, d_tpos, d_f0, d_sp, total))) return rc;
+		if ((rc = ct_frames(p->ct, sct, n_utt, d_x, d_tpos, d_f0, d_sp, total, nullptr))) return rc;
 		WC_HIP(hipEventRecord(p->e1, sct));
 		if ((rc = d4c_enqueue(p->d4, p->s2, n_utt, d_x, x_length, d_tpos, d_f0, f_len.data(), p->fft_size, d_ap, nullptr,
 							  ct_end_positions(p->ct))))

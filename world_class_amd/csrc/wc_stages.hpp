@@ -16,7 +16,7 @@ double *hv_score_rows(wc_harvest *h);
 int ct_prepare(wc_cheaptrick *c, hipStream_t s, int n_utt, const int *x_length, const double *d_f0, const int *f0_length,
 			   const uint64_t *rng_pos, long long *total_out, uint64_t *min_pos_out, uint64_t *max_end_out);
 int ct_frames(wc_cheaptrick *c, hipStream_t s, int n_utt, const double *d_x, const double *d_tpos, const double *d_f0,
-			  double *d_sp, long long total);
+			  double *d_sp, long long total, hipEvent_t *rows_done);
 const unsigned long long *ct_end_positions(const wc_cheaptrick *c);
 
 int d4c_enqueue(wc_d4c *d, hipStream_t s, int n_utt, const double *d_x, const int *x_length, const double *d_tpos,

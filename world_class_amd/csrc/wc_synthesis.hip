@@ -269,119 +269,151 @@ __global__ __launch_bounds__(64) void syn_timebase_kernel(TbArgs a, const double
 constexpr int TB_T = WC_TB_T, TB_K = WC_TB_K, TB_W = TB_T * TB_K;  // threads, samples per thread, samples per window
 constexpr int TB_SERIAL = 64;                             // serial stretch at the start and after back-to-back exceptions
 
+// Windows of TB_W samples are staged in LDS with coalesced loads (the next window's are in flight while this one is summed),
+// summed in place -- a stretch up to the first exceptional sample per pass over the window, the exceptional sample by one exact
+// addition, the rest in the next pass without touching memory again -- and leave with coalesced stores.
 __global__ __launch_bounds__(TB_T) void syn_phase_kernel(TbArgs a, const double *__restrict__ inc_all, double *__restrict__ phase_all) {
+	__shared__ double W[TB_W + TB_W / 16];  // |increment| of the window, replaced sample by sample with the running sum
 	__shared__ unsigned long long wsum[TB_T / 64];
 	__shared__ int wmin[TB_T / 64];
-	__shared__ double s_state;  // exact sum up to sample p - 1
-	__shared__ int s_p, s_serial;
+	__shared__ double s_state;  // exact sum up to the sample in front of s_off
+	__shared__ int s_off, s_serial;
 	const UttDesc ud = a.utts[blockIdx.x];
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const int n = ud.y_len;
 	const double *__restrict__ inc = inc_all + a.inc_off[blockIdx.x];
 	double *__restrict__ phase = phase_all + a.inc_off[blockIdx.x];
-	if (tid == 0) { s_state = 0.0; s_p = 0; s_serial = 1; }
-	__syncthreads();
-	while (true) {
-		int p = s_p;
-		if (p >= n) break;
-		if (s_serial) {  // serial stretch by one thread: plain floating-point adds, the reference's own operation
-			if (tid == 0) {
-				double S = s_state;
-				const int end = min(n, p + TB_SERIAL);
-				for (int i = p; i < end; ++i) {
-					S = S + fabs(inc[i]);
-					phase[i] = S;
+	auto pad = [](int i) { return i + (i >> 4); };  // a thread's TB_K consecutive samples against the lanes' stride of TB_K
+	double nxt[TB_K];
+#pragma unroll
+	for (int k = 0; k < TB_K; ++k) {
+		const int i = k * TB_T + tid;
+		nxt[k] = i < n ? inc[i] : 0.0;
+	}
+	if (tid == 0) { s_state = 0.0; s_serial = 1; }
+	for (int base = 0; base < n; base += TB_W) {
+#pragma unroll
+		for (int k = 0; k < TB_K; ++k) W[pad(k * TB_T + tid)] = fabs(nxt[k]);
+#pragma unroll
+		for (int k = 0; k < TB_K; ++k) {
+			const int i = base + TB_W + k * TB_T + tid;
+			nxt[k] = i < n ? inc[i] : 0.0;
+		}
+		if (tid == 0) s_off = 0;
+		__syncthreads();
+		const int wn = min(TB_W, n - base);
+		while (true) {
+			const int off = s_off;
+			if (off >= wn) break;
+			if (s_serial) {  // serial stretch by one thread: plain floating-point adds, the reference's own operation
+				__syncthreads();  // (everyone has read s_off / s_serial)
+				if (tid == 0) {
+					double S = s_state;
+					const int end = min(wn, off + TB_SERIAL);
+					for (int i = off; i < end; ++i) {
+						S = S + W[pad(i)];
+						W[pad(i)] = S;
+					}
+					s_state = S;
+					s_off = end;
+					s_serial = 0;
 				}
-				s_state = S;
-				s_p = end;
-				s_serial = 0;
+				__syncthreads();
+				continue;
+			}
+			const double S = s_state;
+			const long long sb = __double_as_longlong(S);
+			const int e = (int)((sb >> 52) & 0x7ff);               // biased exponent of the running sum (S > 0, normal)
+			const unsigned long long m0 = (unsigned long long)((sb & 0xfffffffffffffll) | (1ll << 52));  // S = m0 * 2^(e - 1075)
+			// this thread's samples of the window that are still to do
+			const int r0 = tid * TB_K;
+			unsigned long long d[TB_K];  // (unsigned: partial sums past the first crossing may wrap, harmlessly)
+			int exc = TB_W;  // first exceptional sample of the pass (window-relative), TB_W = none
+			unsigned long long loc = 0;
+#pragma unroll
+			for (int k = 0; k < TB_K; ++k) {
+				const int r = r0 + k;
+				unsigned long long dk = 0;
+				if (r >= off && r < wn) {
+					const long long vb = __double_as_longlong(W[pad(r)]);
+					const int ev = (int)((vb >> 52) & 0x7ff);
+					const long long mant = (vb & 0xfffffffffffffll) | (1ll << 52);
+					const int sh = e - ev;  // v = mant * 2^(ev - 1075) = (mant >> sh) u + remainder
+					if (ev == 0 || sh < 0) {  // zero / subnormal increment or one larger than the sum: leave it to the exact add
+						exc = min(exc, r);
+					} else if (sh == 0) {
+						dk = (unsigned long long)mant;
+					} else if (sh <= 53) {
+						const long long rem = mant & ((1ll << sh) - 1ll), half = 1ll << (sh - 1);
+						dk = (unsigned long long)(mant >> sh);
+						if (rem > half) dk += 1;
+						else if (rem == half) exc = min(exc, r);  // tie: parity decides
+					}  // sh > 53: less than half a unit, the sum does not move
+				}
+				d[k] = dk;
+				loc += dk;
+			}
+			// block exclusive scan of the per-thread sums
+			unsigned long long incl = loc;
+#pragma unroll
+			for (int o = 1; o < 64; o <<= 1) {
+				const unsigned long long t = __shfl_up(incl, o, 64);
+				if (lane >= o) incl += t;
+			}
+			if (lane == 63) wsum[wv] = incl;
+			__syncthreads();
+			unsigned long long bsum = m0;
+#pragma unroll
+			for (int w = 0; w < TB_T / 64; ++w) if (w < wv) bsum += wsum[w];
+			unsigned long long run = bsum + incl - loc;
+			// partial sums of this thread's samples; the first one that reaches 2^53 has left the binade
+			unsigned long long mk[TB_K];
+#pragma unroll
+			for (int k = 0; k < TB_K; ++k) {
+				run += d[k];
+				mk[k] = run;
+				if (run >= (1ull << 53) && r0 + k >= off && r0 + k < wn) exc = min(exc, r0 + k);
+			}
+			// first exception of the pass over the block
+			int mn = exc;
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) mn = min(mn, __shfl_xor(mn, o, 64));
+			if (lane == 0) wmin[wv] = mn;
+			__syncthreads();
+			int x = TB_W;
+#pragma unroll
+			for (int w = 0; w < TB_T / 64; ++w) x = min(x, wmin[w]);
+			const int vend = min(x, wn);  // samples off .. vend - 1 are exact integer sums
+			const double unit = __longlong_as_double((long long)(e - 52) << 52);  // 2^(e - 1023 - 52), e >= 53 here
+#pragma unroll
+			for (int k = 0; k < TB_K; ++k) {
+				const int r = r0 + k;
+				if (r >= off && r < vend) {
+					const double v = (double)mk[k] * unit;
+					W[pad(r)] = v;
+					if (r == vend - 1) s_state = v;  // (no exact sample leaves the state alone)
+				}
 			}
 			__syncthreads();
-			continue;
-		}
-		const double S = s_state;
-		const long long sb = __double_as_longlong(S);
-		const int e = (int)((sb >> 52) & 0x7ff);               // biased exponent of the running sum (S > 0, normal)
-		const unsigned long long m0 = (unsigned long long)((sb & 0xfffffffffffffll) | (1ll << 52));  // S = m0 * 2^(e - 1075)
-		// this thread's samples of the window
-		const int j0 = p + tid * TB_K;
-		unsigned long long d[TB_K];  // (unsigned: partial sums past the first crossing may wrap, harmlessly)
-		int exc = TB_W;  // first exceptional sample of the window (relative index), TB_W = none
-		unsigned long long loc = 0;
-#pragma unroll
-		for (int k = 0; k < TB_K; ++k) {
-			const int j = j0 + k;
-			unsigned long long dk = 0;
-			if (j < n) {
-				const long long vb = __double_as_longlong(fabs(inc[j]));
-				const int ev = (int)((vb >> 52) & 0x7ff);
-				const long long mant = (vb & 0xfffffffffffffll) | (1ll << 52);
-				const int sh = e - ev;  // v = mant * 2^(ev - 1075) = (mant >> sh) u + remainder
-				if (ev == 0 || sh < 0) {  // zero / subnormal increment or one larger than the sum: leave it to the exact add
-					exc = min(exc, tid * TB_K + k);
-				} else if (sh == 0) {
-					dk = (unsigned long long)mant;
-				} else if (sh <= 53) {
-					const long long rem = mant & ((1ll << sh) - 1ll), half = 1ll << (sh - 1);
-					dk = (unsigned long long)(mant >> sh);
-					if (rem > half) dk += 1;
-					else if (rem == half) exc = min(exc, tid * TB_K + k);  // tie: parity decides
-				}  // sh > 53: less than half a unit, the sum does not move
+			if (tid == 0) {
+				int np = vend;
+				int serial = 0;
+				if (x < TB_W && np < wn) {  // the exceptional sample: one exact floating-point add
+					const double Sx = s_state + W[pad(np)];
+					W[pad(np)] = Sx;
+					s_state = Sx;
+					++np;
+					serial = (vend == off);  // two exceptions in a row: walk a stretch serially
+				}
+				s_off = np;
+				s_serial = serial;
 			}
-			d[k] = dk;
-			loc += dk;
+			__syncthreads();
 		}
-		// block exclusive scan of the per-thread sums
-		unsigned long long incl = loc;
-#pragma unroll
-		for (int o = 1; o < 64; o <<= 1) {
-			const unsigned long long t = __shfl_up(incl, o, 64);
-			if (lane >= o) incl += t;
-		}
-		if (lane == 63) wsum[wv] = incl;
-		__syncthreads();
-		unsigned long long base = m0;
-#pragma unroll
-		for (int w = 0; w < TB_T / 64; ++w) if (w < wv) base += wsum[w];
-		unsigned long long run = base + incl - loc;
-		// partial sums of this thread's samples; the first one that reaches 2^53 has left the binade
-		unsigned long long mk[TB_K];
 #pragma unroll
 		for (int k = 0; k < TB_K; ++k) {
-			run += d[k];
-			mk[k] = run;
-			if (run >= (1ull << 53) && j0 + k < n) exc = min(exc, tid * TB_K + k);
-		}
-		// first exception of the window over the block
-		int mn = exc;
-#pragma unroll
-		for (int o = 32; o > 0; o >>= 1) mn = min(mn, __shfl_xor(mn, o, 64));
-		if (lane == 0) wmin[wv] = mn;
-		__syncthreads();
-		int x = TB_W;
-#pragma unroll
-		for (int w = 0; w < TB_T / 64; ++w) x = min(x, wmin[w]);
-		const int valid = min(x, n - p);  // samples p .. p + valid - 1 are exact integer sums
-		const double unit = __longlong_as_double((long long)(e - 52) << 52);  // 2^(e - 1023 - 52), e >= 53 here
-#pragma unroll
-		for (int k = 0; k < TB_K; ++k) {
-			const int r = tid * TB_K + k;
-			if (r < valid) phase[p + r] = (double)mk[k] * unit;
-			if (r == valid - 1) s_state = (double)mk[k] * unit;  // (valid == 0 leaves the state alone)
-		}
-		__syncthreads();
-		if (tid == 0) {
-			int np = p + valid;
-			int serial = 0;
-			if (x < TB_W && np < n) {  // the exceptional sample: one exact floating-point add
-				const double Sx = s_state + fabs(inc[np]);
-				phase[np] = Sx;
-				s_state = Sx;
-				++np;
-				serial = (valid == 0);  // two exceptions in a row: walk a stretch serially
-			}
-			s_p = np;
-			s_serial = serial;
+			const int i = k * TB_T + tid;
+			if (i < wn) phase[base + i] = W[pad(i)];
 		}
 		__syncthreads();
 	}
