@@ -110,7 +110,8 @@ struct wc_pipeline {
 	wc_cheaptrick *ct;
 	wc_d4c *d4;
 	wc_synthesis *sy;
-	hipStream_t s1, s2, s_copy;
+	hipStream_t s1, s2, s_copy, s_copy2;  // (s_copy2: the aperiodicity rows leave beside the spectrogram rows, on a DMA engine of their own)
+	hipEvent_t e_copy2[2];
 	hipEvent_t e0, e1, e2, e_copy[2];
 	// host batch front-end (wc_pipeline_run_batch_host): device-resident batch + pinned staging, grow-only
 	DevBuf b_x, b_pcm, b_t, b_f, b_sp, b_ap, b_y, b_ypcm, b_coded;
@@ -158,6 +159,14 @@ wc_pipeline *wc_pipeline_create(int fs, double frame_period, double harvest_f0_f
 	ok = ok && hipEventCreateWithFlags(&p->e1, hipEventDisableTiming) == hipSuccess;
 	ok = ok && hipEventCreateWithFlags(&p->e2, hipEventDisableTiming) == hipSuccess;
 	ok = ok && hipStreamCreateWithFlags(&p->s_copy, hipStreamNonBlocking) == hipSuccess;
+	{
+		const char *env = getenv("WC_PIPELINE_COPY_STREAMS");
+		if (ok && !(env && atoi(env) == 1)) {
+			ok = hipStreamCreateWithFlags(&p->s_copy2, hipStreamNonBlocking) == hipSuccess &&
+				 hipEventCreateWithFlags(&p->e_copy2[0], hipEventDisableTiming) == hipSuccess &&
+				 hipEventCreateWithFlags(&p->e_copy2[1], hipEventDisableTiming) == hipSuccess;
+		}
+	}
 	ok = ok && hipEventCreateWithFlags(&p->e_copy[0], hipEventDisableTiming) == hipSuccess;
 	ok = ok && hipEventCreateWithFlags(&p->e_copy[1], hipEventDisableTiming) == hipSuccess;
 	if (ok && p->mode == 1) {
@@ -198,6 +207,8 @@ void wc_pipeline_destroy(wc_pipeline *p) {
 	if (p->e1) (void)hipEventDestroy(p->e1);
 	if (p->e2) (void)hipEventDestroy(p->e2);
 	if (p->s_copy) (void)hipStreamDestroy(p->s_copy);
+	if (p->s_copy2) (void)hipStreamDestroy(p->s_copy2);
+	for (int g = 0; g < 2; ++g) if (p->e_copy2[g]) (void)hipEventDestroy(p->e_copy2[g]);
 	for (int g = 0; g < 2; ++g) if (p->e_copy[g]) (void)hipEventDestroy(p->e_copy[g]);
 	for (int g = 0; g < 2; ++g) {
 		PipeGroup &G = p->grp[g];
@@ -313,8 +324,9 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 					// the spectrogram rows leave as soon as CheapTrick is through, the aperiodicity rows behind D4C: PCIe is the longest
 					// stretch of a run with all outputs (2.1 GB at ~50 GB/s), so it starts as early as it can
 					for (int which = 0; which < 2; ++which) {
-						WC_HIP(hipStreamWaitEvent(p->s_copy, which == 0 ? G.e_ct : G.e_aux, 0));
-						if (which == 0 && ct_rows) WC_HIP(hipStreamWaitEvent(p->s_copy, ct_rows, 0));
+						hipStream_t sc = (which == 1 && p->s_copy2) ? p->s_copy2 : p->s_copy;
+						WC_HIP(hipStreamWaitEvent(sc, which == 0 ? G.e_ct : G.e_aux, 0));
+						if (which == 0 && ct_rows) WC_HIP(hipStreamWaitEvent(sc, ct_rows, 0));
 						char *stage = which == 0 ? sink->stage_sp : sink->stage_ap;
 						double *const *rows = which == 0 ? sink->sp : sink->ap;
 						const double *src = which == 0 ? gsp : gap;
@@ -323,13 +335,14 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 							long long fo2 = 0;
 							for (int u = u0; u < u0 + nu; ++u) {
 								const size_t ulen = sizeof(double) * (size_t)f_len[u] * bins_;
-								if (rows[u]) WC_HIP(hipMemcpyAsync(rows[u], src + fo2 * bins_, ulen, hipMemcpyDeviceToHost, p->s_copy));
+								if (rows[u]) WC_HIP(hipMemcpyAsync(rows[u], src + fo2 * bins_, ulen, hipMemcpyDeviceToHost, sc));
 								fo2 += f_len[u];
 							}
 						} else {
-							WC_HIP(hipMemcpyAsync(stage + off, src, len, hipMemcpyDeviceToHost, p->s_copy));
+							WC_HIP(hipMemcpyAsync(stage + off, src, len, hipMemcpyDeviceToHost, sc));
 						}
 					}
+					if (p->s_copy2) WC_HIP(hipEventRecord(p->e_copy2[g], p->s_copy2));
 					WC_HIP(hipEventRecord(p->e_copy[g], p->s_copy));
 				}
 				if ((rc = syn_prepare(G.sy, G.main, nu, gf, f_len.data() + u0, y_len.data() + u0, gy, nullptr, full[g][1]))) return rc;
@@ -342,6 +355,7 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 				// the rows of each half batch go to the caller's buffers as soon as their copy has landed: half A's while B computes
 				for (int g = 0; g < 2; ++g) {
 					WC_HIP(hipEventSynchronize(p->e_copy[g]));
+					if (p->s_copy2) WC_HIP(hipEventSynchronize(p->e_copy2[g]));
 					pmark(g == 0 ? "rows of half A landed" : "rows of half B landed");
 					if (sink->direct) { sink->overlapped[g] = true; continue; }
 					std::vector<CopyJob> jobs;
