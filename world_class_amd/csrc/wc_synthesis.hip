@@ -607,6 +607,7 @@ struct SynArgs {
 	const double2 *tw;
 	const double *dc_remover;
 	double *out;
+	const int *pulse_utt;  // the one-wavefront kernel: utterance of every pulse of the compact numbering (syn_pulse_utt_kernel)
 	double *resp;  // the one-wavefront kernel: [pulse][N] responses in output order, summed by syn_overlap_add_kernel (NULL: atomics into out)
 	long long total_pulses;  // launch size (capacity); the real count is pulse_prefix[n_utt]
 	const unsigned long long *rng_start;  // per-utterance stream position (device), NULL = utts[u].rng_pos
@@ -998,6 +999,9 @@ __device__ __forceinline__ void minimum_phase_wave(const double (&ls)[16], doubl
 #ifndef WC_SYN_WAVE_OCC
 #define WC_SYN_WAVE_OCC 2
 #endif
+#ifndef WC_SYN_ROWS_G
+#define WC_SYN_ROWS_G 2
+#endif
 // WC_SYN_TRACE (development builds only): lane 0 stamps the shader clock at the phase boundaries of every pulse;
 // WC_SYN_TRACE_FILE=<file> dumps them after the call (tools/syn_trace.py)
 #ifndef WC_SYN_TRACE
@@ -1018,12 +1022,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_SYN_WAVE_
 	const long long gp = xcd_frame(blockIdx.x, total_p);
 	if (gp >= total_p) return;
 	if (a.only_pulse >= 0 && gp != a.only_pulse) return;
-	int lo = 0, hi = a.n_utt - 1;
-	while (lo < hi) {
-		int mid = (lo + hi + 1) >> 1;
-		if (a.pulse_prefix[mid] <= gp) lo = mid; else hi = mid - 1;
-	}
-	const int u = lo;
+	const int u = a.pulse_utt[gp];  // (one load instead of a bisection of the prefix: a chain of dependent loads in front of everything)
+	wf_tables_to_lds(T, a.tw, lane);  // (requested first: in flight while the pulse's own data are looked up)
 	const UttDesc ud = a.utts[u];
 	const long long slot = a.cap_off[u] + (gp - a.pulse_prefix[u]);
 	const int pidx = a.p.index[slot];
@@ -1062,7 +1062,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_SYN_WAVE_
 		ar0 = uniform_d(ar0);
 	}
 	SYN_STAMP(0);
-	wf_tables_to_lds(T, a.tw, lane);
 	SYN_STAMP(1);
 
 	// ---- periodic response (reference :403-474; what survives of it is wave[n] - dc remover[n], n < M), then the aperiodic
@@ -1127,19 +1126,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_SYN_WAVE_
 				return wf_log_l(part == 0 ? env * (1.0 - ar) + kSafe : (vuv != 0.0 ? env * ar : env), T) / 2.0;
 			};
 #pragma unroll
-			for (int g = 0; g < 4; ++g) {
-				double v[4][4];
+			for (int g0 = 0; g0 < 4; g0 += WC_SYN_ROWS_G) {
+				// (the rows of WC_SYN_ROWS_G groups of four bins requested together: the first touch of a pulse's rows is an HBM round
+				// trip, the longest single wait of the kernel)
+				double v[4 * WC_SYN_ROWS_G][4];
 #pragma unroll
-				for (int q = 0; q < 4; ++q) {
-					const int k = wf_bin(ln, g, q);
+				for (int q = 0; q < 4 * WC_SYN_ROWS_G; ++q) {
+					const int k = wf_bin(ln, g0 + (q >> 2), q & 3);
 					v[q][0] = sf[k]; v[q][1] = sc[k]; v[q][2] = af[k]; v[q][3] = ac[k];
 				}
 				WF_SCHED_FENCE();
 #pragma unroll
-				for (int q = 0; q < 4; ++q) {
+				for (int q = 0; q < 4 * WC_SYN_ROWS_G; ++q) {
 					double env, ar;
 					blend(v[q][0], v[q][1], v[q][2], v[q][3], env, ar);
-					ls[4 * g + q] = logspec(env, ar);
+					ls[4 * g0 + q] = logspec(env, ar);
 				}
 			}
 			double env, ar;
@@ -1223,6 +1224,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_SYN_WAVE_
 
 }
 
+// utterance of every pulse of the compact numbering (prefix[u] <= gp < prefix[u + 1]); one workgroup per utterance
+__global__ void syn_pulse_utt_kernel(const long long *__restrict__ prefix, int *__restrict__ pulse_utt) {
+	const int u = blockIdx.x;
+	const long long lo = prefix[u], hi = prefix[u + 1];
+	for (long long g = lo + threadIdx.x; g < hi; g += blockDim.x) pulse_utt[g] = u;
+}
+
 // Overlap-add of the response rows (reference :118-139: y[index + 1 + j] += response[j], pulse after pulse).  One workgroup per
 // tile of OA_TILE output samples: the pulses that reach into the tile are a contiguous run of the utterance's (sorted) pulse
 // list, found by bisection; every thread adds the rows' samples to its four outputs in pulse order, so y carries the
@@ -1285,7 +1293,7 @@ struct wc_synthesis {
 	int fs, fft_size;
 	double frame_period;  // seconds
 	Device *dev;
-	DevBuf dc_remover, utts, meta, pulses, incs, phase, tile_cnt, resp, d_f0, d_sp, d_ap, d_out;
+	DevBuf dc_remover, utts, meta, pulses, incs, phase, tile_cnt, resp, pulse_utt, d_f0, d_sp, d_ap, d_out;
 	bool pulses_by_utterance;  // WC_SYN_PULSES=utterance: one workgroup walks an utterance's tiles (A/B and the bit-identity test)
 	bool wave;  // N = 2048: one wavefront per pulse (default; WC_SYN_IMPL=block: the workgroup-per-pulse kernel)
 	bool serial_timebase;  // WC_SYN_TIMEBASE=serial: the one-wavefront sequential accumulation instead of the exact parallel one
@@ -1470,10 +1478,14 @@ int syn_pulses(wc_synthesis *sy, hipStream_t s, const double *d_f0, const double
 #endif
 	a.trace = nullptr;
 	a.resp = nullptr;
+	a.pulse_utt = nullptr;
 	if (sy->wave && sy->fft_size == 2048) {
 		// a response row per pulse slot of the rate bound (only the rows of real pulses are ever touched)
 		if ((rc = sy->resp.reserve(sizeof(double) * 2048 * (size_t)co))) return rc;
 		a.resp = sy->resp.as<double>();
+		if ((rc = sy->pulse_utt.reserve(sizeof(int) * (size_t)co))) return rc;
+		a.pulse_utt = sy->pulse_utt.as<int>();
+		hipLaunchKernelGGL(syn_pulse_utt_kernel, dim3(n_utt), dim3(256), 0, s, (const long long *)d_prefix, sy->pulse_utt.as<int>());
 	}
 #if WC_SYN_TRACE
 	static DevBuf tracebuf;
@@ -1592,7 +1604,7 @@ wc_synthesis *wc_synthesis_create(int fs, int fft_size, double frame_period_ms) 
 void wc_synthesis_destroy(wc_synthesis *s) {
 	if (!s) return;
 	s->dev->quiesce();
-	s->dc_remover.release(); s->utts.release(); s->meta.release(); s->pulses.release(); s->incs.release(); s->phase.release(); s->tile_cnt.release(); s->resp.release();
+	s->dc_remover.release(); s->utts.release(); s->meta.release(); s->pulses.release(); s->incs.release(); s->phase.release(); s->tile_cnt.release(); s->resp.release(); s->pulse_utt.release();
 	s->d_f0.release(); s->d_sp.release(); s->d_ap.release(); s->d_out.release(); s->h_stage.release();
 	delete s;
 }
