@@ -1,6 +1,19 @@
 mkdir -p gpurun_out; rm -f gpurun_out/*.log
-timeout 1200 python -m pytest tests/test_gpu_synthesis.py -m gpu -x -q 2>&1 | grep -E "passed|failed|Error" > gpurun_out/t1.log
+R=$GRAFT_REPO_ROOT
+timeout 1200 python -m pytest tests/test_gpu_synthesis.py tests/test_gpu_pipeline.py -m gpu -x -q 2>&1 | grep -E "passed|failed|Error|assert" > gpurun_out/t1.log
 cat gpurun_out/t1.log
-for v in "" world_class_amd/_variants/rows4.so world_class_amd/_variants/rows1.so ""; do
-WC_LIB_PATH=$v python tools/microbench.py --stages cds --utts 64 --iters 5 2>&1 | grep -E "synthesis_pulses"
-done
+python tools/latency_probe.py 2>&1 | grep utter
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace -d $R/gpurun_out/one -o p --output-format csv -- python $R/tools/_one.py > $R/gpurun_out/one.log 2>&1
+python - <<'PY'
+import csv,glob
+f=glob.glob('/root/repo/gpurun_out/one/**/*kernel_trace.csv',recursive=True)[0]
+rows=list(csv.DictReader(open(f)))
+rows.sort(key=lambda r:int(r['Start_Timestamp']))
+idx=[i for i,r in enumerate(rows) if 'syn_overlap' in r['Kernel_Name']]
+a,b=idx[-2]+1,idx[-1]+1
+t0=int(rows[a]['Start_Timestamp'])
+for r in rows[a:b]:
+    s=int(r['Start_Timestamp']);e=int(r['End_Timestamp'])
+    if e-s>12000 or 'phase' in r['Kernel_Name']: print(f"{(s-t0)/1e3:9.1f} {(e-s)/1e3:8.1f} q{r['Queue_Id']} {r['Kernel_Name'][:60]:60} grid {r['Grid_Size_X']}x{r['Grid_Size_Y']}")
+PY

@@ -419,6 +419,335 @@ __global__ __launch_bounds__(TB_T) void syn_phase_kernel(TbArgs a, const double 
 	}
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same sum over many workgroups (default; WC_SYN_PHASE=single: the kernel above).  A segment of PH_W samples whose
+// running sum provably stays inside one binade and meets no tie is summed as integers without knowing where it starts:
+//   syn_phase_est_kernel    tree-ordered sum of every segment (an estimate, good to ~1e-13 relative);
+//   syn_phase_local_kernel  from the estimated start and end (margin 2^-30 relative, against the 2^-34 a sequential sum of
+//                           half a million terms can be off by) the binade; the integer increments in its unit, their prefix
+//                           sums within the segment (left in the phase array as integers) and their total; "dirty" when the
+//                           estimates straddle a binade edge, an increment ties, is zero or larger than the sum;
+//   syn_phase_walk_kernel   one workgroup per utterance walks the segments in order: a clean one adds its total to the exact
+//                           running sum (an integer add), a dirty one -- the ~15 binade crossings of an utterance, the first
+//                           segment, the odd tie -- goes through the in-place passes of the kernel above with the exact start;
+//   syn_phase_apply_kernel  clean segments: (mantissa at the segment's start + local prefix) x unit.
+// Every value written is the reference's own floating-point sum: same argument as above, the segments only decide who adds.
+// ------------------------------------------------------------------------------------------------
+constexpr int PH_T = 256, PH_K = 8, PH_W = PH_T * PH_K;
+constexpr int PH_MAXSEG = 2048;  // segments per utterance the walk keeps in LDS (87 s at 48 kHz); longer ones take the single-workgroup kernel
+
+// integer increment of |v| (bits vb) in units of 2^(e - 1075); false: exceptional (zero / subnormal, larger than the sum, a tie)
+__device__ __forceinline__ bool phase_increment(long long vb, int e, unsigned long long &dk) {
+	const int ev = (int)((vb >> 52) & 0x7ff);
+	const long long mant = (vb & 0xfffffffffffffll) | (1ll << 52);
+	const int sh = e - ev;  // v = mant * 2^(ev - 1075) = (mant >> sh) u + remainder
+	dk = 0;
+	if (ev == 0 || sh < 0) return false;
+	if (sh == 0) { dk = (unsigned long long)mant; return true; }
+	if (sh <= 53) {
+		const long long rem = mant & ((1ll << sh) - 1ll), half = 1ll << (sh - 1);
+		dk = (unsigned long long)(mant >> sh);
+		if (rem > half) dk += 1;
+		else if (rem == half) return false;  // tie: parity decides
+	}  // sh > 53: less than half a unit, the sum does not move
+	return true;
+}
+
+struct PhArgs {
+	TbArgs t;
+	const double *inc;
+	double *phase;
+	double *segsum;             // [utt][nseg_max]
+	unsigned long long *segD;   // [utt][nseg_max] integer total of a clean segment
+	unsigned long long *segM0;  // [utt][nseg_max] mantissa of the exact sum in front of a clean segment
+	int *segflag;               // [utt][nseg_max] biased exponent of a clean segment's binade, -1: dirty
+	int nseg_max;
+};
+
+__global__ __launch_bounds__(PH_T) void syn_phase_est_kernel(PhArgs a) {
+	__shared__ double red[PH_T / 64];
+	const UttDesc ud = a.t.utts[blockIdx.y];
+	const int n = ud.y_len, base = blockIdx.x * PH_W;
+	if (base >= n) return;
+	const double *__restrict__ inc = a.inc + a.t.inc_off[blockIdx.y] + base;
+	const int wn = min(PH_W, n - base);
+	double s = 0.0;
+#pragma unroll
+	for (int k = 0; k < PH_K; ++k) {
+		const int i = k * PH_T + threadIdx.x;
+		s += i < wn ? fabs(inc[i]) : 0.0;
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+	if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		double t = 0.0;
+		for (int w = 0; w < PH_T / 64; ++w) t += red[w];
+		a.segsum[(long long)blockIdx.y * a.nseg_max + blockIdx.x] = t;
+	}
+}
+
+__global__ __launch_bounds__(PH_T) void syn_phase_local_kernel(PhArgs a) {
+	__shared__ double W[PH_W + PH_W / PH_K];
+	__shared__ double red[PH_T / 64];
+	__shared__ unsigned long long wsum[PH_T / 64];
+	__shared__ int s_bad;
+	const UttDesc ud = a.t.utts[blockIdx.y];
+	const int n = ud.y_len, seg = blockIdx.x, base = seg * PH_W;
+	if (base >= n) return;
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const long long so = (long long)blockIdx.y * a.nseg_max;
+	auto pad = [](int i) { return i + (i >> 3); };
+	const double *__restrict__ inc = a.inc + a.t.inc_off[blockIdx.y] + base;
+	const int wn = min(PH_W, n - base);
+	// stage the segment (coalesced), estimate its start meanwhile
+	double v[PH_K];
+#pragma unroll
+	for (int k = 0; k < PH_K; ++k) {
+		const int i = k * PH_T + tid;
+		v[k] = i < wn ? fabs(inc[i]) : 0.0;
+	}
+	double es = 0.0;
+	for (int j = tid; j < seg; j += PH_T) es += a.segsum[so + j];
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) es += __shfl_xor(es, o, 64);
+	if (lane == 0) red[wv] = es;
+	if (tid == 0) s_bad = 0;
+#pragma unroll
+	for (int k = 0; k < PH_K; ++k) W[pad(k * PH_T + tid)] = v[k];
+	__syncthreads();
+	double est0 = 0.0;
+	for (int w = 0; w < PH_T / 64; ++w) est0 += red[w];
+	const double est1 = est0 + a.segsum[so + seg];
+	const double lo = est0 * (1.0 - 0x1p-30), hi = est1 * (1.0 + 0x1p-30);
+	const int e = (int)((__double_as_longlong(lo) >> 52) & 0x7ff);
+	const bool one_binade = seg > 0 && lo > 0.0 && e == (int)((__double_as_longlong(hi) >> 52) & 0x7ff) && e >= 64 && e < 2046;
+	if (!one_binade) {
+		if (tid == 0) a.segflag[so + seg] = -1;
+		return;
+	}
+	unsigned long long d[PH_K], loc = 0;
+	bool bad = false;
+#pragma unroll
+	for (int k = 0; k < PH_K; ++k) {
+		const int r = tid * PH_K + k;
+		unsigned long long dk = 0;
+		if (r < wn) bad = !phase_increment(__double_as_longlong(W[pad(r)]), e, dk) || bad;
+		d[k] = dk;
+		loc += dk;
+	}
+	if (bad) s_bad = 1;
+	unsigned long long incl = loc;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const unsigned long long t = __shfl_up(incl, o, 64);
+		if (lane >= o) incl += t;
+	}
+	if (lane == 63) wsum[wv] = incl;
+	__syncthreads();
+	if (s_bad) {
+		if (tid == 0) a.segflag[so + seg] = -1;
+		return;
+	}
+	unsigned long long run = incl - loc, tot = 0;
+#pragma unroll
+	for (int w = 0; w < PH_T / 64; ++w) {
+		if (w < wv) run += wsum[w];
+		tot += wsum[w];
+	}
+	// the local prefix sums leave through LDS, coalesced, as integers in the phase array
+	unsigned long long *Wi = reinterpret_cast<unsigned long long *>(W);
+#pragma unroll
+	for (int k = 0; k < PH_K; ++k) {
+		run += d[k];
+		Wi[pad(tid * PH_K + k)] = run;
+	}
+	__syncthreads();
+	unsigned long long *__restrict__ out = reinterpret_cast<unsigned long long *>(a.phase + a.t.inc_off[blockIdx.y] + base);
+#pragma unroll
+	for (int k = 0; k < PH_K; ++k) {
+		const int i = k * PH_T + tid;
+		if (i < wn) out[i] = Wi[pad(i)];
+	}
+	if (tid == 0) {
+		a.segD[so + seg] = tot;
+		a.segflag[so + seg] = e;
+	}
+}
+
+__global__ __launch_bounds__(PH_T) void syn_phase_walk_kernel(PhArgs a) {
+	__shared__ double W[PH_W + PH_W / PH_K];
+	__shared__ unsigned long long s_D[PH_MAXSEG];
+	__shared__ short s_flag[PH_MAXSEG];
+	__shared__ unsigned long long wsum[PH_T / 64];
+	__shared__ int wmin[PH_T / 64];
+	__shared__ double s_state;
+	__shared__ int s_off, s_serial, s_seg;
+	const UttDesc ud = a.t.utts[blockIdx.x];
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int n = ud.y_len;
+	const int nseg = (n + PH_W - 1) / PH_W;
+	const long long so = (long long)blockIdx.x * a.nseg_max;
+	const double *__restrict__ inc = a.inc + a.t.inc_off[blockIdx.x];
+	double *__restrict__ phase = a.phase + a.t.inc_off[blockIdx.x];
+	auto pad = [](int i) { return i + (i >> 3); };
+	for (int j = tid; j < nseg; j += PH_T) {
+		s_flag[j] = (short)a.segflag[so + j];
+		s_D[j] = a.segD[so + j];
+	}
+	if (tid == 0) { s_state = 0.0; s_serial = 1; s_seg = 0; }
+	__syncthreads();
+	while (true) {
+		// a run of clean segments: integer adds by one thread
+		if (tid == 0) {
+			double S = s_state;
+			int j = s_seg;
+			while (j < nseg && s_flag[j] >= 0) {
+				const int e = s_flag[j];
+				const long long sb = __double_as_longlong(S);
+				const unsigned long long m0 = (unsigned long long)((sb & 0xfffffffffffffll) | (1ll << 52));
+				const unsigned long long m1 = m0 + s_D[j];
+				if ((int)((sb >> 52) & 0x7ff) != e || m1 >= (1ull << 53)) {  // (cannot happen within the margins; the segment is simply walked)
+					s_flag[j] = -1;
+					a.segflag[so + j] = -1;
+					break;
+				}
+				a.segM0[so + j] = m0;
+				S = (double)m1 * __longlong_as_double((long long)(e - 52) << 52);
+				++j;
+			}
+			s_state = S;
+			s_seg = j;
+			s_off = 0;
+		}
+		__syncthreads();
+		const int seg = s_seg;
+		if (seg >= nseg) break;
+		// a dirty segment: the in-place passes of syn_phase_kernel from the exact running sum
+		const int base = seg * PH_W;
+		const int wn = min(PH_W, n - base);
+#pragma unroll
+		for (int k = 0; k < PH_K; ++k) {
+			const int i = k * PH_T + tid;
+			W[pad(i)] = i < wn ? fabs(inc[base + i]) : 0.0;
+		}
+		__syncthreads();
+		while (true) {
+			const int off = s_off;
+			if (off >= wn) break;
+			if (s_serial) {
+				__syncthreads();
+				if (tid == 0) {
+					double S = s_state;
+					const int end = min(wn, off + TB_SERIAL);
+					for (int i = off; i < end; ++i) {
+						S = S + W[pad(i)];
+						W[pad(i)] = S;
+					}
+					s_state = S;
+					s_off = end;
+					s_serial = 0;
+				}
+				__syncthreads();
+				continue;
+			}
+			const double S = s_state;
+			const long long sb = __double_as_longlong(S);
+			const int e = (int)((sb >> 52) & 0x7ff);
+			const unsigned long long m0 = (unsigned long long)((sb & 0xfffffffffffffll) | (1ll << 52));
+			const int r0 = tid * PH_K;
+			unsigned long long d[PH_K], loc = 0;
+			int exc = PH_W;
+#pragma unroll
+			for (int k = 0; k < PH_K; ++k) {
+				const int r = r0 + k;
+				unsigned long long dk = 0;
+				if (r >= off && r < wn && !phase_increment(__double_as_longlong(W[pad(r)]), e, dk)) exc = min(exc, r);
+				d[k] = dk;
+				loc += dk;
+			}
+			unsigned long long incl = loc;
+#pragma unroll
+			for (int o = 1; o < 64; o <<= 1) {
+				const unsigned long long t = __shfl_up(incl, o, 64);
+				if (lane >= o) incl += t;
+			}
+			if (lane == 63) wsum[wv] = incl;
+			__syncthreads();
+			unsigned long long run = m0 + incl - loc;
+#pragma unroll
+			for (int w = 0; w < PH_T / 64; ++w) if (w < wv) run += wsum[w];
+			unsigned long long mk[PH_K];
+#pragma unroll
+			for (int k = 0; k < PH_K; ++k) {
+				run += d[k];
+				mk[k] = run;
+				if (run >= (1ull << 53) && r0 + k >= off && r0 + k < wn) exc = min(exc, r0 + k);
+			}
+			int mn = exc;
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) mn = min(mn, __shfl_xor(mn, o, 64));
+			if (lane == 0) wmin[wv] = mn;
+			__syncthreads();
+			int x = PH_W;
+#pragma unroll
+			for (int w = 0; w < PH_T / 64; ++w) x = min(x, wmin[w]);
+			const int vend = min(x, wn);
+			const double unit = __longlong_as_double((long long)(e - 52) << 52);
+#pragma unroll
+			for (int k = 0; k < PH_K; ++k) {
+				const int r = r0 + k;
+				if (r >= off && r < vend) {
+					const double v = (double)mk[k] * unit;
+					W[pad(r)] = v;
+					if (r == vend - 1) s_state = v;
+				}
+			}
+			__syncthreads();
+			if (tid == 0) {
+				int np = vend;
+				int serial = 0;
+				if (x < PH_W && np < wn) {
+					const double Sx = s_state + W[pad(np)];
+					W[pad(np)] = Sx;
+					s_state = Sx;
+					++np;
+					serial = (vend == off);
+				}
+				s_off = np;
+				s_serial = serial;
+			}
+			__syncthreads();
+		}
+#pragma unroll
+		for (int k = 0; k < PH_K; ++k) {
+			const int i = k * PH_T + tid;
+			if (i < wn) phase[base + i] = W[pad(i)];
+		}
+		if (tid == 0) s_seg = seg + 1;
+		__syncthreads();
+	}
+}
+
+__global__ __launch_bounds__(PH_T) void syn_phase_apply_kernel(PhArgs a) {
+	const UttDesc ud = a.t.utts[blockIdx.y];
+	const int n = ud.y_len, seg = blockIdx.x, base = seg * PH_W;
+	if (base >= n) return;
+	const long long so = (long long)blockIdx.y * a.nseg_max;
+	const int e = a.segflag[so + seg];
+	if (e < 0) return;  // walked: its phases are in place
+	const unsigned long long m0 = a.segM0[so + seg];
+	const double unit = __longlong_as_double((long long)(e - 52) << 52);
+	double *__restrict__ ph = a.phase + a.t.inc_off[blockIdx.y] + base;
+	const int wn = min(PH_W, n - base);
+#pragma unroll
+	for (int k = 0; k < PH_K; ++k) {
+		const int i = k * PH_T + threadIdx.x;
+		if (i < wn) ph[i] = (double)(m0 + (unsigned long long)__double_as_longlong(ph[i])) * unit;
+	}
+}
+
 // Wrap, pulse detection (reference :262-288) and ordered compaction from the exact phases; one workgroup per utterance.
 __global__ __launch_bounds__(TB_T) void syn_pulses_from_phase_kernel(TbArgs a, const double *__restrict__ inc_all,
 																	 const double *__restrict__ phase_all) {
@@ -1293,9 +1622,10 @@ struct wc_synthesis {
 	int fs, fft_size;
 	double frame_period;  // seconds
 	Device *dev;
-	DevBuf dc_remover, utts, meta, pulses, incs, phase, tile_cnt, resp, pulse_utt, d_f0, d_sp, d_ap, d_out;
+	DevBuf dc_remover, utts, meta, pulses, incs, phase, phase_seg, tile_cnt, resp, pulse_utt, d_f0, d_sp, d_ap, d_out;
 	bool pulses_by_utterance;  // WC_SYN_PULSES=utterance: one workgroup walks an utterance's tiles (A/B and the bit-identity test)
 	bool wave;  // N = 2048: one wavefront per pulse (default; WC_SYN_IMPL=block: the workgroup-per-pulse kernel)
+	bool phase_single;  // WC_SYN_PHASE=single: the phase sum by one workgroup per utterance (A/B and the bit-identity test)
 	bool serial_timebase;  // WC_SYN_TIMEBASE=serial: the one-wavefront sequential accumulation instead of the exact parallel one
 	HostBuf h_stage;
 	long long total_out = 0, cap_total = 0;  // of the most recent syn_prepare
@@ -1418,7 +1748,24 @@ int syn_prepare(wc_synthesis *sy, hipStream_t s, int n_utt, const double *d_f0, 
 	if (sy->serial_timebase) {
 		hipLaunchKernelGGL(syn_timebase_kernel, dim3(n_utt), dim3(64), 0, s, ta, (const double *)sy->incs.as<double>());
 	} else {
-		hipLaunchKernelGGL(syn_phase_kernel, dim3(n_utt), dim3(TB_T), 0, s, ta, (const double *)sy->incs.as<double>(), sy->phase.as<double>());
+		const int nseg_max = (max_out + PH_W - 1) / PH_W;
+		if (sy->phase_single || nseg_max > PH_MAXSEG) {
+			hipLaunchKernelGGL(syn_phase_kernel, dim3(n_utt), dim3(TB_T), 0, s, ta, (const double *)sy->incs.as<double>(), sy->phase.as<double>());
+		} else {
+			const size_t per = (size_t)nseg_max * n_utt;
+			if ((rc = sy->phase_seg.reserve(per * (3 * sizeof(double) + sizeof(int))))) return rc;
+			PhArgs pa;
+			pa.t = ta; pa.inc = sy->incs.as<double>(); pa.phase = sy->phase.as<double>();
+			pa.segsum = sy->phase_seg.as<double>();
+			pa.segD = reinterpret_cast<unsigned long long *>(pa.segsum + per);
+			pa.segM0 = pa.segD + per;
+			pa.segflag = reinterpret_cast<int *>(pa.segM0 + per);
+			pa.nseg_max = nseg_max;
+			hipLaunchKernelGGL(syn_phase_est_kernel, dim3(nseg_max, n_utt), dim3(PH_T), 0, s, pa);
+			hipLaunchKernelGGL(syn_phase_local_kernel, dim3(nseg_max, n_utt), dim3(PH_T), 0, s, pa);
+			hipLaunchKernelGGL(syn_phase_walk_kernel, dim3(n_utt), dim3(PH_T), 0, s, pa);
+			hipLaunchKernelGGL(syn_phase_apply_kernel, dim3(nseg_max, n_utt), dim3(PH_T), 0, s, pa);
+		}
 		if (sy->pulses_by_utterance) {
 			hipLaunchKernelGGL(syn_pulses_from_phase_kernel, dim3(n_utt), dim3(TB_T), 0, s, ta, (const double *)sy->incs.as<double>(),
 							   (const double *)sy->phase.as<double>());
@@ -1579,6 +1926,8 @@ wc_synthesis *wc_synthesis_create(int fs, int fft_size, double frame_period_ms) 
 	{
 		const char *tb = getenv("WC_SYN_TIMEBASE");
 		s->serial_timebase = tb && std::string(tb) == "serial";
+		const char *ph = getenv("WC_SYN_PHASE");
+		s->phase_single = ph && std::string(ph) == "single";
 		const char *pu = getenv("WC_SYN_PULSES");
 		s->pulses_by_utterance = pu && std::string(pu) == "utterance";
 		const char *impl = getenv("WC_SYN_IMPL");
@@ -1604,7 +1953,7 @@ wc_synthesis *wc_synthesis_create(int fs, int fft_size, double frame_period_ms) 
 void wc_synthesis_destroy(wc_synthesis *s) {
 	if (!s) return;
 	s->dev->quiesce();
-	s->dc_remover.release(); s->utts.release(); s->meta.release(); s->pulses.release(); s->incs.release(); s->phase.release(); s->tile_cnt.release(); s->resp.release(); s->pulse_utt.release();
+	s->dc_remover.release(); s->utts.release(); s->meta.release(); s->pulses.release(); s->incs.release(); s->phase.release(); s->tile_cnt.release(); s->phase_seg.release(); s->resp.release(); s->pulse_utt.release();
 	s->d_f0.release(); s->d_sp.release(); s->d_ap.release(); s->d_out.release(); s->h_stage.release();
 	delete s;
 }
