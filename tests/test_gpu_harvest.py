@@ -159,6 +159,29 @@ def test_harvest_edges(wca, port):
         wca.Harvest(fs, f0_floor=10.0)   # band-pass longer than the kernel supports
 
 
+def test_bandpass_with_eight_lanes_per_band_is_bit_identical(wca):
+    """The sliding band-pass gives a (band, chunk) one lane for batches and the seven sliding sums of it seven lanes of a group of
+    eight for small ones (WC_HARVEST_SDFT_LANES=1 / 8 force either): the same instructions per sum, so the same raw candidates
+    and the same contour bit for bit -- what keeps a batch's results equal to those of its utterances one by one."""
+    import os
+    from world_class_amd.synth import make_signal
+    for fs, xs in ((48000, [make_utterance(48000, 3.0, 515), make_signal(48000, 1.3, 40007)]),
+                   (16000, [make_utterance(16000, 2.5, 516), make_utterance(16000, 0.4, 9), make_signal(16000, 2.0, 230003)])):
+        got = {}
+        for lanes in ("1", "8"):
+            os.environ["WC_HARVEST_SDFT_LANES"] = lanes
+            try:
+                h = wca.Harvest(fs)
+            finally:
+                del os.environ["WC_HARVEST_SDFT_LANES"]
+            res = h.compute_batch(xs)
+            got[lanes] = ([f for _, f in res], [h.debug_fetch("raw", u) for u in range(len(xs))])
+        for u in range(len(xs)):
+            assert np.array_equal(got["1"][1][u], got["8"][1][u]), (fs, u)
+            assert np.array_equal(got["1"][0][u], got["8"][0][u]), (fs, u)
+        assert sum(int((f > 0).sum()) for f in got["8"][0]) > 100
+
+
 def test_decimation_staged_through_lds_is_bit_identical(wca):
     """the decimator that stages every lane's stream through LDS (default) against the one that reads the streams directly
     (WC_HARVEST_DECIMATE=direct): same recursion, same chunk and warm-up boundaries, so the same bits -- at every

@@ -1,6 +1,6 @@
 mkdir -p gpurun_out; rm -f gpurun_out/*.log
 R=$GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests/test_gpu_synthesis.py tests/test_gpu_pipeline.py -m gpu -x -q 2>&1 | grep -E "passed|failed|Error|assert" > gpurun_out/t1.log
+timeout 1200 python -m pytest tests/test_gpu_harvest.py tests/test_gpu_pipeline.py -m gpu -x -q 2>&1 | grep -E "passed|failed|Error|assert" > gpurun_out/t1.log
 cat gpurun_out/t1.log
 python tools/latency_probe.py 2>&1 | grep utter
 cd /tmp && export TMPDIR=/tmp
@@ -15,5 +15,5 @@ a,b=idx[-2]+1,idx[-1]+1
 t0=int(rows[a]['Start_Timestamp'])
 for r in rows[a:b]:
     s=int(r['Start_Timestamp']);e=int(r['End_Timestamp'])
-    if e-s>12000 or 'phase' in r['Kernel_Name']: print(f"{(s-t0)/1e3:9.1f} {(e-s)/1e3:8.1f} q{r['Queue_Id']} {r['Kernel_Name'][:60]:60} grid {r['Grid_Size_X']}x{r['Grid_Size_Y']}")
+    if e-s>30000: print(f"{(s-t0)/1e3:9.1f} {(e-s)/1e3:8.1f} q{r['Queue_Id']} {r['Kernel_Name'][:60]:60} grid {r['Grid_Size_X']}x{r['Grid_Size_Y']}")
 PY

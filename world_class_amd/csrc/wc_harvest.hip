@@ -554,6 +554,153 @@ __global__ __launch_bounds__(64, WC_SDFT_WAVES) void hv_bandpass_sdft_kernel(SdA
 	}
 }
 
+// The same arithmetic with the seven sliding sums of a (band, chunk) in seven lanes of a group of eight (small batches: a
+// single utterance has only 95 wavefronts of the kernel above, each a serial walk over ~2800 samples -- 0.76 ms with most of
+// the chip idle).  Lane s of a group holds D_v for v = 0, -, 1, 2, 3, 4, 5, 6: every recurrence runs the instructions it runs
+// above, the +- pairs of the Nuttall sum meet through one quad exchange (an addition is commutative), lane 0 collects the three
+// pair sums in the order of out() above and runs the detectors.  Same bits in the slots, eight times the wavefronts, about
+// half the instructions per sample and wavefront.
+template <int X>
+__device__ __forceinline__ double sd8_xor(double v) {
+	int w[2] = {__double2loint(v), __double2hiint(v)};
+#pragma unroll
+	for (int k = 0; k < 2; ++k) {
+		if (X == 1) w[k] = __builtin_amdgcn_mov_dpp(w[k], 0xB1, 0xF, 0xF, true);       // quad_perm:[1,0,3,2]
+		else if (X == 2) w[k] = __builtin_amdgcn_mov_dpp(w[k], 0x4E, 0xF, 0xF, true);  // quad_perm:[2,3,0,1]
+		else {
+			int r = __builtin_amdgcn_update_dpp(w[k], w[k], 0x104, 0xF, 0x5, false);   // row_shl:4 -> lanes 0-3, 8-11
+			w[k] = __builtin_amdgcn_update_dpp(r, w[k], 0x114, 0xF, 0xA, false);       // row_shr:4 -> lanes 4-7, 12-15
+		}
+	}
+	return __hiloint2double(w[1], w[0]);
+}
+
+__global__ __launch_bounds__(64) void hv_bandpass_sdft8_kernel(SdArgs a) {
+	const int lane = threadIdx.x, sub = lane & 7;
+	const HvUtt u = a.utts[blockIdx.y];
+	const int item = blockIdx.x * 8 + (lane >> 3);
+	const bool valid = item < a.n_bands * a.n_chunks;
+	const int chunk = valid ? item / a.n_bands : 0;
+	const int band = valid ? item - chunk * a.n_bands : 0;
+	const int i0 = chunk * SD_CH;
+	const bool live = valid && i0 < u.y_len;
+	const bool head = sub == 0;
+	if (__ballot(live) == 0ull) {
+		if (valid && head) {
+			int *c = a.slot_count + (((long long)blockIdx.y * a.n_bands + band) * a.n_chunks + chunk) * 4;
+			c[0] = c[1] = c[2] = c[3] = 0;
+		}
+		return;
+	}
+	const int hl = live ? a.half_len[band] : 0;
+	const double *__restrict__ y = a.y + u.y_off;
+	const int ylen = u.y_len;
+	const int v = sub == 0 ? 0 : sub - 1;  // (lane 1 idles on a copy of v = 0; its sum is never read)
+	const double2 R = a.rot[band * 7 + v];
+	double2 D = make_double2(0.0, 0.0);
+	const double2 P = a.p0[band];
+	int hlmax = hl;
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) hlmax = max(hlmax, __shfl_xor(hlmax, o, 64));
+	const int qb = live ? i0 + 1 + hl - 2 * hlmax : 0;
+	for (int sidx = 0; sidx <= 2 * hlmax; ++sidx) {
+		const int q = qb + sidx;
+		const double yv = (live && sidx >= 2 * (hlmax - hl)) ? y[q] : 0.0;
+		const double ux = yv * P.x, uy = yv * P.y;
+		const double nx = fma(R.x, D.x, fma(-R.y, D.y, ux));
+		const double ny = fma(R.x, D.y, fma(R.y, D.x, uy));
+		D = make_double2(nx, ny);
+	}
+	auto out_of = [&](double dx) -> double {  // (meaningful in lane 0 of the group)
+		const double pr = head ? dx : dx + sd8_xor<1>(dx);  // lanes 2, 4, 6: the +- pairs
+		const double p2 = sd8_xor<2>(pr), p4 = sd8_xor<4>(pr), p6 = sd8_xor<4>(p2);
+		double f = 0.355768 * pr;
+		f = fma(-0.243698, p2, f);
+		f = fma(0.072116, p4, f);
+		f = fma(-0.006302, p6, f);
+		return f;
+	};
+	auto out = [&]() -> double { return out_of(D.x); };
+	auto quot = [](double n, double d) -> double {
+		double r = __builtin_amdgcn_rcp(d);
+		r = fma(fma(-d, r, 1.0), r, r);
+		r = fma(fma(-d, r, 1.0), r, r);
+		const double q = n * r;
+		return fma(fma(-d, q, n), r, q);
+	};
+	auto slide = [&](double yn, double yo) {
+		const double ux = yn * P.x, uy = yn * P.y;
+		const double vx = yo * P.x, vy = -(yo * P.y);
+		const double tx = D.x - vx, ty = D.y - vy;
+		const double nx = fma(R.x, tx, fma(-R.y, ty, ux));
+		const double ny = fma(R.x, ty, fma(R.y, tx, uy));
+		D = make_double2(nx, ny);
+	};
+	const double *__restrict__ pn = y + (live ? i0 + 2 + hl : 0), *__restrict__ po = y + (live ? i0 + 1 - hl : 0);
+	double s0 = out();
+	slide(pn[0], po[0]);
+	double s1 = out();
+	const int cap = a.slot_cap[band];
+	double *__restrict__ slot = a.slots + blockIdx.y * a.slots_per_utt + a.slot_off[band] + (long long)chunk * 4 * cap;
+	int cnt[4] = {0, 0, 0, 0};
+	const int i_end = live ? min(i0 + SD_CH, ylen) : i0;
+	int steps = i_end - i0;
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) steps = max(steps, __shfl_xor(steps, o, 64));
+	constexpr int U = WC_SDFT_U;
+	double yn[U], yo[U];
+#pragma unroll
+	for (int k = 0; k < U; ++k) { yn[k] = pn[1 + k]; yo[k] = po[1 + k]; }
+	for (int st = 0; st < steps; st += U) {
+		double cn[U], co[U];
+#pragma unroll
+		for (int k = 0; k < U; ++k) { cn[k] = yn[k]; co[k] = yo[k]; }
+#pragma unroll
+		for (int k = 0; k < U; ++k) { yn[k] = pn[st + U + 1 + k]; yo[k] = po[st + U + 1 + k]; }
+		// the sums of the trip first (a chain of dependent operations per sum), then the outputs, then the detectors: the
+		// branches of the detectors would otherwise fence every step's chain off from the next one's
+		double sx[U];
+#pragma unroll
+		for (int k = 0; k < U; ++k) {
+			slide(cn[k], co[k]);
+			sx[k] = D.x;
+		}
+		double so[U];
+#pragma unroll
+		for (int k = 0; k < U; ++k) so[k] = out_of(sx[k]);
+#pragma unroll
+		for (int k = 0; k < U; ++k) {
+			const int i = i0 + st + k;
+			const double s2 = so[k];
+			const double d0 = s1 - s0, d1 = s2 - s1;
+			const bool in1 = head && i < i_end && i + 1 < ylen, in2 = head && i < i_end && i + 2 < ylen;
+			const bool neg = in1 && 0.0 < s0 && s1 <= 0.0, pos = in1 && 0.0 < -s0 && -s1 <= 0.0;
+			const bool pk = in2 && 0.0 < d0 && d1 <= 0.0, dp = in2 && 0.0 < -d0 && -d1 <= 0.0;
+			if (neg || pos) {
+				const double fine = (i + 1) - quot(s0, d0);
+				const int c = neg ? cnt[0] : cnt[1];
+				if (c < cap) slot[(neg ? 0 : cap) + c] = fine;
+				cnt[0] += neg ? 1 : 0;
+				cnt[1] += pos ? 1 : 0;
+			}
+			if (pk || dp) {
+				const double fine = (i + 1) - quot(d0, d1 - d0);
+				const int c = pk ? cnt[2] : cnt[3];
+				if (c < cap) slot[(pk ? 2 * cap : 3 * cap) + c] = fine;
+				cnt[2] += pk ? 1 : 0;
+				cnt[3] += dp ? 1 : 0;
+			}
+			s0 = s1;
+			s1 = s2;
+		}
+	}
+	if (valid && head) {
+		int *c = a.slot_count + (((long long)blockIdx.y * a.n_bands + band) * a.n_chunks + chunk) * 4;
+#pragma unroll
+		for (int ty = 0; ty < 4; ++ty) c[ty] = cnt[ty];
+	}
+}
+
 struct CpArgs {
 	const HvUtt *utts;
 	const long long *slot_off;
@@ -1681,13 +1828,18 @@ __device__ __forceinline__ double hv_search_score(double f0, const double *__res
 
 // init + p[0] + p[1] + ... + p[n-1] added strictly in that order (the reference's running sums), with the
 // loads spread over the lanes: 64 values per step, then a 64-step dependent chain on broadcast values.
+__device__ __forceinline__ double hv_readlane(double v, int k) {  // (k a constant: two v_readlane_b32, the sum then adds a scalar pair)
+	return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), k), __builtin_amdgcn_readlane(__double2loint(v), k));
+}
 __device__ __forceinline__ double hv_ordered_sum(const double *__restrict__ p, int n, double init, int lane) {
 	double run = init;
+	double nxt = (lane < n) ? p[lane] : 0.0;
 	for (int base = 0; base < n; base += 64) {
-		const int i = base + lane;
-		const double v = (i < n) ? p[i] : 0.0;  // + 0.0 is exact
+		const double v = nxt;  // + 0.0 past the end is exact
+		const int i = base + 64 + lane;
+		nxt = (i < n) ? p[i] : 0.0;  // (the next 64 values are in flight while these are added)
 #pragma unroll
-		for (int k = 0; k < 64; ++k) run = run + __shfl(v, k, 64);
+		for (int k = 0; k < 64; ++k) run = run + hv_readlane(v, k);
 	}
 	return run;
 }
@@ -1696,20 +1848,31 @@ __device__ __forceinline__ double hv_ordered_sum(const double *__restrict__ p, i
 // sec[2k] = first frame, sec[2k+1] = last frame.  Executed by all 64 lanes, ordered by ballot.
 __device__ int hv_sections(const double *__restrict__ f0, int n, int *__restrict__ sec, int max_sec, int lane) {
 	int nb = 0;  // boundaries so far (wave-uniform)
-	for (int base = 1; base < n; base += 64) {
-		int i = base + lane;
-		int cur = 0, prv = 0;
-		if (i < n) {
-			cur = (i >= 1 && i < n - 1 && f0[i] > 0) ? 1 : 0;
-			prv = (i - 1 >= 1 && i - 1 < n - 1 && f0[i - 1] > 0) ? 1 : 0;
+	constexpr int B = 4;  // batches of 64 frames whose loads are requested together (a single wavefront: latency is all there is)
+	for (int base = 1; base < n; base += 64 * B) {
+		double c[B], p[B];
+#pragma unroll
+		for (int b = 0; b < B; ++b) {
+			const int i = base + 64 * b + lane;
+			c[b] = i < n ? f0[i] : 0.0;
+			p[b] = i < n ? f0[i - 1] : 0.0;
 		}
-		const bool ch = (i < n) && (cur != prv);
-		const unsigned long long m = __ballot(ch);
-		if (ch) {
-			int k = nb + __popcll(m & ((1ull << lane) - 1ull));
-			if (k < 2 * max_sec) sec[k] = i - (k & 1);
+#pragma unroll
+		for (int b = 0; b < B; ++b) {
+			const int i = base + 64 * b + lane;
+			int cur = 0, prv = 0;
+			if (i < n) {
+				cur = (i >= 1 && i < n - 1 && c[b] > 0) ? 1 : 0;
+				prv = (i - 1 >= 1 && i - 1 < n - 1 && p[b] > 0) ? 1 : 0;
+			}
+			const bool ch = (i < n) && (cur != prv);
+			const unsigned long long m = __ballot(ch);
+			if (ch) {
+				int k = nb + __popcll(m & ((1ull << lane) - 1ull));
+				if (k < 2 * max_sec) sec[k] = i - (k & 1);
+			}
+			nb += __popcll(m);
 		}
-		nb += __popcll(m);
 	}
 	return nb / 2;
 }
@@ -1751,14 +1914,28 @@ __global__ __launch_bounds__(64) void hv_contour_kernel(CtrArgs a) {
 	if (PHASE == 0) {
 	// searchF0Base (reference :254-272) was evaluated by hv_unreliable_kernel
 	// fixStep1 (reference :277-291; entries the reference never writes are 0)
-	for (int i = lane; i < L; i += 64) {
-		double v = 0.0;
-		if (i >= 2 && base[i] != 0.0) {
-			double ref = base[i - 1] * 2 - base[i - 2];
-			v = (fabs((base[i] - ref) / ref) > 0.008 && fabs((base[i] - base[i - 1])) / base[i - 1] > 0.008) ? 0.0 : base[i];
+	for (int i0 = lane; i0 < L; i0 += 256) {  // (four batches of 64 frames per trip, their loads requested together)
+		double b0[4], b1[4], b2[4];
+#pragma unroll
+		for (int b = 0; b < 4; ++b) {
+			const int i = i0 + 64 * b;
+			b0[b] = i < L ? base[i] : 0.0;
+			b1[b] = (i >= 2 && i < L) ? base[i - 1] : 0.0;
+			b2[b] = (i >= 2 && i < L) ? base[i - 2] : 0.0;
 		}
-		s1[i] = v;
-		s2[i] = v;
+#pragma unroll
+		for (int b = 0; b < 4; ++b) {
+			const int i = i0 + 64 * b;
+			double v = 0.0;
+			if (i >= 2 && b0[b] != 0.0) {
+				double ref = b1[b] * 2 - b2[b];
+				v = (fabs((b0[b] - ref) / ref) > 0.008 && fabs((b0[b] - b1[b])) / b1[b] > 0.008) ? 0.0 : b0[b];
+			}
+			if (i < L) {
+				s1[i] = v;
+				s2[i] = v;
+			}
+		}
 	}
 	wave_sync();
 	// fixStep2 (reference :319-334)
@@ -1772,7 +1949,13 @@ __global__ __launch_bounds__(64) void hv_contour_kernel(CtrArgs a) {
 	}
 	wave_sync();
 	// fixStep3 (reference :560-585)
-	for (int i = lane; i < L; i += 64) s3[i] = s2[i];
+	for (int i0 = lane; i0 < L; i0 += 256) {
+		double v[4];
+#pragma unroll
+		for (int b = 0; b < 4; ++b) v[b] = i0 + 64 * b < L ? s2[i0 + 64 * b] : 0.0;
+#pragma unroll
+		for (int b = 0; b < 4; ++b) if (i0 + 64 * b < L) s3[i0 + 64 * b] = v[b];
+	}
 	ns = hv_sections(s2, L, sec, a.max_sec, lane);
 	wave_sync();
 	ns = min(ns, a.max_sec);
@@ -1859,7 +2042,20 @@ __global__ __launch_bounds__(64) void hv_contour_kernel(CtrArgs a) {
 	if (ns > 0) {
 		// merged = the row at position 0, whatever its rank in time
 		const int ch0 = perm[0];
-		for (int i = lane; i < L; i += 64) s3[i] = chv(ch0, i);
+		{
+			const int lo0 = clo[ch0], len0 = clen[ch0];
+			const double *__restrict__ row0 = cdata + coff[ch0];
+			for (int i0 = lane; i0 < L; i0 += 256) {  // (four batches of 64 frames per trip; the row is zero outside its window)
+				double v[4];
+#pragma unroll
+				for (int b = 0; b < 4; ++b) {
+					const int d = i0 + 64 * b - lo0;
+					v[b] = (d >= 0 && d < len0) ? row0[d] : 0.0;
+				}
+#pragma unroll
+				for (int b = 0; b < 4; ++b) if (i0 + 64 * b < L) s3[i0 + 64 * b] = v[b];
+			}
+		}
 		// order[] = positions 0..count-1 sorted by start frame the way the reference's std::sort leaves them: sections
 		// that start on the same frame (several can extend back to frame 0) keep libstdc++'s order, see wc_argsort.hpp
 		if (lane == 0) {
@@ -1900,7 +2096,13 @@ __global__ __launch_bounds__(64) void hv_contour_kernel(CtrArgs a) {
 	}
 	wave_sync();
 	// fixStep4 (reference :590-614)
-	for (int i = lane; i < L; i += 64) s4[i] = s3[i];
+	for (int i0 = lane; i0 < L; i0 += 256) {
+		double v[4];
+#pragma unroll
+		for (int b = 0; b < 4; ++b) v[b] = i0 + 64 * b < L ? s3[i0 + 64 * b] : 0.0;
+#pragma unroll
+		for (int b = 0; b < 4; ++b) if (i0 + 64 * b < L) s4[i0 + 64 * b] = v[b];
+	}
 	ns = hv_sections(s3, L, sec, a.max_sec, lane);
 	wave_sync();
 	ns = min(ns, a.max_sec);
@@ -1941,16 +2143,26 @@ __global__ __launch_bounds__(64) void hv_smooth_kernel(SmArgs a) {
 	// sections of the padded contour: padding is unvoiced, so they are the sections of f0 with the ends
 	// (frames 0 and L-1) allowed to be voiced -- getBoundaryList on the padded array forces only ITS ends to 0
 	int nb = 0;
-	for (int base = 1; base < n; base += 64) {
-		int i = base + lane;
-		auto vu = [&](int q) { int fq = q - lag; return (q >= 1 && q < n - 1 && fq >= 0 && fq < L && f0[fq] > 0) ? 1 : 0; };
-		const bool ch = (i < n) && (vu(i) != vu(i - 1));
-		const unsigned long long m = __ballot(ch);
-		if (ch) {
-			int k = nb + __popcll(m & ((1ull << lane) - 1ull));
-			if (k < 2 * a.max_sec) sec[k] = i - (k & 1);
+	for (int base = 1; base < n; base += 256) {  // (four batches of 64 frames per trip, their loads requested together)
+		double c[4], p[4];
+#pragma unroll
+		for (int b = 0; b < 4; ++b) {
+			const int fq = base + 64 * b + lane - lag;
+			c[b] = (fq >= 0 && fq < L) ? f0[fq] : 0.0;
+			p[b] = (fq - 1 >= 0 && fq - 1 < L) ? f0[fq - 1] : 0.0;
 		}
-		nb += __popcll(m);
+#pragma unroll
+		for (int b = 0; b < 4; ++b) {
+			const int i = base + 64 * b + lane;
+			const int cur = (i >= 1 && i < n - 1 && c[b] > 0) ? 1 : 0, prv = (i - 1 >= 1 && i - 1 < n - 1 && p[b] > 0) ? 1 : 0;
+			const bool ch = (i < n) && (cur != prv);
+			const unsigned long long m = __ballot(ch);
+			if (ch) {
+				int k = nb + __popcll(m & ((1ull << lane) - 1ull));
+				if (k < 2 * a.max_sec) sec[k] = i - (k & 1);
+			}
+			nb += __popcll(m);
+		}
 	}
 	__syncthreads();
 	const int ns = min(nb / 2, a.max_sec);
@@ -2141,6 +2353,7 @@ struct wc_harvest {
 	DevBuf d_taps, d_tap_off, d_half_len, d_band_f0, d_ev_band_off, d_ev_cap, d_rot;
 	DevBuf d_sd_rot, d_sd_p0, d_slot_off, d_slot_cap, slots, slot_count;
 	bool debug_small_caps;  // WC_DEBUG_SMALL_CAPS, read once at creation: tiny rate-bounded buffers, so that the overflow retry runs (tests)
+	int sdft_lanes;  // WC_HARVEST_SDFT_LANES=1 / 8: lanes per (band, chunk) of the sliding band-pass (default 0: eight for small batches; A/B and the bit-identity test)
 	bool use_fir;  // WC_HARVEST_BANDPASS=fir: the direct FIR band-pass instead of the sliding DFT (A/B and tests)
 	bool use_cos_table;  // HarvestOption::use_cos_table
 	DevBuf d_cos_table;
@@ -2358,7 +2571,12 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 			sa.slots_per_utt = slots_per_utt; sa.slots = h->slots.as<double>(); sa.slot_count = h->slot_count.as<int>();
 			h->slots_per_utt = slots_per_utt;
 			sa.n_bands = nb; sa.n_chunks = n_tiles;
-			hipLaunchKernelGGL(hv_bandpass_sdft_kernel, dim3((nb * n_tiles + 63) / 64, n_utt), dim3(64), 0, s, sa);
+			// small batches leave most of the chip idle with a lane per (band, chunk): eight lanes each then (same bits)
+			const long long waves1 = (long long)((nb * n_tiles + 63) / 64) * n_utt;
+			if (h->sdft_lanes == 8 || (h->sdft_lanes == 0 && waves1 * 8 <= 3072))
+				hipLaunchKernelGGL(hv_bandpass_sdft8_kernel, dim3((nb * n_tiles + 7) / 8, n_utt), dim3(64), 0, s, sa);
+			else
+				hipLaunchKernelGGL(hv_bandpass_sdft_kernel, dim3((nb * n_tiles + 63) / 64, n_utt), dim3(64), 0, s, sa);
 			CpArgs ca;
 			ca.utts = du; ca.slot_off = sa.slot_off; ca.slot_cap = sa.slot_cap; ca.slots_per_utt = slots_per_utt; ca.slots = sa.slots;
 			ca.slot_count = sa.slot_count; ca.ev_band_off = ba.ev_band_off; ca.ev_cap = ba.ev_cap; ca.events = ba.events;
@@ -2549,6 +2767,8 @@ wc_harvest *wc_harvest_create(int fs, double f0_floor, double f0_ceil, double fr
 			 hipMemcpy(h->d_sd_p0.p, sd_p0.data(), sizeof(double2) * sd_p0.size(), hipMemcpyHostToDevice) == hipSuccess;
 		const char *bp = getenv("WC_HARVEST_BANDPASS");
 		h->use_fir = bp && std::strcmp(bp, "fir") == 0;
+		const char *sl = getenv("WC_HARVEST_SDFT_LANES");
+		h->sdft_lanes = sl ? atoi(sl) : 0;
 		h->debug_small_caps = getenv("WC_DEBUG_SMALL_CAPS") != nullptr;
 		const char *dm = getenv("WC_HARVEST_DECIMATE");
 		h->direct_decimation = dm && std::strcmp(dm, "direct") == 0;
