@@ -1819,11 +1819,29 @@ __device__ __forceinline__ double hv_select_best(double ref, const double *__res
 	return best_k >= 0 ? best_v : 0.0;
 }
 // reference :463-470
-__device__ __forceinline__ double hv_search_score(double f0, const double *__restrict__ c, const double *__restrict__ s, int nc) {
-	double score = 0.0;
-	for (int k = 0; k < nc; ++k)
-		if (f0 == c[k] && score < s[k]) score = s[k];
-	return score;
+// (for two contour values of the same frame at once -- mergeF0Sub asks for both -- with the row requested eight candidates at
+// a time: a lane walks its own frame's row, so every dependent load is a round trip of its own)
+__device__ __forceinline__ void hv_search_score2(double fa, double fb, const double *__restrict__ c, const double *__restrict__ s, int nc,
+												 double &score_a, double &score_b) {
+	double sa = 0.0, sb = 0.0;
+	for (int k0 = 0; k0 < nc; k0 += 8) {
+		double cv[8], sv[8];
+#pragma unroll
+		for (int e = 0; e < 8; ++e) {
+			const int k = min(k0 + e, nc - 1);
+			cv[e] = c[k];
+			sv[e] = s[k];
+		}
+#pragma unroll
+		for (int e = 0; e < 8; ++e) {
+			if (k0 + e < nc) {
+				if (fa == cv[e] && sa < sv[e]) sa = sv[e];
+				if (fb == cv[e] && sb < sv[e]) sb = sv[e];
+			}
+		}
+	}
+	score_a = sa;
+	score_b = sb;
 }
 
 // init + p[0] + p[1] + ... + p[n-1] added strictly in that order (the reference's running sums), with the
@@ -1942,10 +1960,10 @@ __global__ __launch_bounds__(64) void hv_contour_kernel(CtrArgs a) {
 	ns = hv_sections(s1, L, sec, a.max_sec, lane);
 	wave_sync();
 	ns = min(ns, a.max_sec);
-	for (int k = 0; k < ns; ++k) {
-		int st = sec[2 * k], ed = sec[2 * k + 1];
+	for (int k = lane; k < ns; k += 64) {  // (a lane per section: the short ones have at most six frames to clear)
+		const int st = sec[2 * k], ed = sec[2 * k + 1];
 		if (ed - st >= 6) continue;
-		for (int j = st + lane; j <= ed; j += 64) s2[j] = 0.0;
+		for (int j = st; j <= ed; ++j) s2[j] = 0.0;
 	}
 	wave_sync();
 	// fixStep3 (reference :560-585)
@@ -2021,10 +2039,18 @@ __global__ __launch_bounds__(64) void hv_contour_kernel(CtrArgs a) {
 	int count = 0;
 	{
 		double mean_f0 = 0.0;
+		int m_st = 0, m_ed = 0, m_at = 0;  // lane l: boundaries and row address of section k0 + l (the swaps below touch positions <= k only)
 		for (int k = 0; k < ns; ++k) {
-			const int st = bl[2 * k], ed = bl[2 * k + 1];
-			const int ch = perm[k];
-			mean_f0 = hv_ordered_sum(cdata + coff[ch] + (st - clo[ch]), ed - st, mean_f0, lane);
+			if ((k & 63) == 0) {
+				const int kk = k + lane;
+				if (kk < ns) {
+					const int ch = perm[kk];
+					m_st = bl[2 * kk]; m_ed = bl[2 * kk + 1];
+					m_at = coff[ch] + (m_st - clo[ch]);
+				}
+			}
+			const int st = __shfl(m_st, k & 63, 64), ed = __shfl(m_ed, k & 63, 64);
+			mean_f0 = hv_ordered_sum(cdata + __shfl(m_at, k & 63, 64), ed - st, mean_f0, lane);
 			mean_f0 /= ed - st;
 			if (2200.0 / mean_f0 < ed - st) {
 				wave_sync();
@@ -2078,8 +2104,10 @@ __global__ __launch_bounds__(64) void hv_contour_kernel(CtrArgs a) {
 				if (!(st1 <= st2 && ed1 >= ed2)) {
 					double sc1 = 0.0, sc2 = 0.0;
 					for (int j = st2 + lane; j <= ed1; j += 64) {
-						sc1 += hv_search_score(s3[j], cand + (long long)j * nc, score + (long long)j * nc, nc);
-						sc2 += hv_search_score(chv(ch, j), cand + (long long)j * nc, score + (long long)j * nc, nc);
+						double q1, q2;
+						hv_search_score2(s3[j], chv(ch, j), cand + (long long)j * nc, score + (long long)j * nc, nc, q1, q2);
+						sc1 += q1;
+						sc2 += q2;
 					}
 #pragma unroll
 					for (int o = 32; o > 0; o >>= 1) { sc1 += __shfl_xor(sc1, o, 64); sc2 += __shfl_xor(sc2, o, 64); }
@@ -2106,13 +2134,13 @@ __global__ __launch_bounds__(64) void hv_contour_kernel(CtrArgs a) {
 	ns = hv_sections(s3, L, sec, a.max_sec, lane);
 	wave_sync();
 	ns = min(ns, a.max_sec);
-	for (int k = 0; k + 1 < ns; ++k) {
+	for (int k = lane; k + 1 < ns; k += 64) {  // (a lane per gap: the ones that are filled have at most eight frames)
 		const int e0 = sec[2 * k + 1], b1 = sec[2 * (k + 1)];
 		const int distance = b1 - e0 - 1;
 		if (distance >= 9) continue;
 		const double t0 = s3[e0] + 1, t1 = s3[b1] - 1;
 		const double coef = (t1 - t0) / (distance + 1.0);
-		for (int j = e0 + 1 + lane; j <= b1 - 1; j += 64) s4[j] = t0 + coef * (j - e0);
+		for (int j = e0 + 1; j <= b1 - 1; ++j) s4[j] = t0 + coef * (j - e0);
 	}
 }
 
