@@ -2381,6 +2381,8 @@ struct wc_harvest {
 	DevBuf d_taps, d_tap_off, d_half_len, d_band_f0, d_ev_band_off, d_ev_cap, d_rot;
 	DevBuf d_sd_rot, d_sd_p0, d_slot_off, d_slot_cap, slots, slot_count;
 	bool debug_small_caps;  // WC_DEBUG_SMALL_CAPS, read once at creation: tiny rate-bounded buffers, so that the overflow retry runs (tests)
+	bool tables_valid;  // the capacity tables on the device are those of (tables_ylen, tables_full, tables_tiles)
+	int tables_ylen, tables_full, tables_tiles;
 	int sdft_lanes;  // WC_HARVEST_SDFT_LANES=1 / 8: lanes per (band, chunk) of the sliding band-pass (default 0: eight for small batches; A/B and the bit-identity test)
 	bool use_fir;  // WC_HARVEST_BANDPASS=fir: the direct FIR band-pass instead of the sliding DFT (A/B and tests)
 	bool use_cos_table;  // HarvestOption::use_cos_table
@@ -2550,11 +2552,17 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 		std::memcpy(hs + o3a, slot_off.data(), sizeof(long long) * nb);
 		std::memcpy(hs + o4, slot_cap.data(), sizeof(int) * nb);
 		WC_HIP(hipMemcpyAsync(h->utts.p, hs, sizeof(HvUtt) * n_utt, hipMemcpyHostToDevice, s));
-		WC_HIP(hipMemcpyAsync(h->d_ev_band_off.p, hs + o1, sizeof(long long) * nb, hipMemcpyHostToDevice, s));
-		WC_HIP(hipMemcpyAsync(h->d_ev_cap.p, hs + o2, sizeof(int) * nb, hipMemcpyHostToDevice, s));
-		if (!h->use_fir) {
-			WC_HIP(hipMemcpyAsync(h->d_slot_off.p, hs + o3a, sizeof(long long) * nb, hipMemcpyHostToDevice, s));
-			WC_HIP(hipMemcpyAsync(h->d_slot_cap.p, hs + o4, sizeof(int) * nb, hipMemcpyHostToDevice, s));
+		// the per-band capacity tables depend on the longest utterance and the retry flag only: a call like the one before (the usual
+		// case of a stream of equal-sized batches) finds them on the device already -- four copies less in front of the first kernel
+		const bool same_tables = h->tables_valid && h->tables_ylen == max_ylen && h->tables_full == (full ? 1 : 0) && h->tables_tiles == n_tiles;
+		if (!same_tables) {
+			WC_HIP(hipMemcpyAsync(h->d_ev_band_off.p, hs + o1, sizeof(long long) * nb, hipMemcpyHostToDevice, s));
+			WC_HIP(hipMemcpyAsync(h->d_ev_cap.p, hs + o2, sizeof(int) * nb, hipMemcpyHostToDevice, s));
+			if (!h->use_fir) {
+				WC_HIP(hipMemcpyAsync(h->d_slot_off.p, hs + o3a, sizeof(long long) * nb, hipMemcpyHostToDevice, s));
+				WC_HIP(hipMemcpyAsync(h->d_slot_cap.p, hs + o4, sizeof(int) * nb, hipMemcpyHostToDevice, s));
+			}
+			h->tables_valid = true; h->tables_ylen = max_ylen; h->tables_full = full ? 1 : 0; h->tables_tiles = n_tiles;
 		}
 		if ((rc = h->h_stage.mark(s))) return rc;
 		WC_HIP(hipMemsetAsync(h->overflow.p, 0, sizeof(int), s));
@@ -2797,6 +2805,7 @@ wc_harvest *wc_harvest_create(int fs, double f0_floor, double f0_ceil, double fr
 		h->use_fir = bp && std::strcmp(bp, "fir") == 0;
 		const char *sl = getenv("WC_HARVEST_SDFT_LANES");
 		h->sdft_lanes = sl ? atoi(sl) : 0;
+		h->tables_valid = false;
 		h->debug_small_caps = getenv("WC_DEBUG_SMALL_CAPS") != nullptr;
 		const char *dm = getenv("WC_HARVEST_DECIMATE");
 		h->direct_decimation = dm && std::strcmp(dm, "direct") == 0;
