@@ -1,12 +1,16 @@
 mkdir -p gpurun_out; rm -f gpurun_out/*.log
-timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|Error|assert" > gpurun_out/tall.log
-cat gpurun_out/tall.log
-python tools/latency_probe.py 2>&1 | grep utter
-timeout 300 python bench.py --steps 10 --warmup 3 > gpurun_out/b1.log 2>&1; python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/b1.log').read().strip().splitlines()[-1])
-print(d['ms_per_step'], d['value'], d['roofline']['all_kernels_ms'])
-print({k:v['ms'] for k,v in d['with_transfers'].items()})
-print(d['cpu_baseline'])
-print(d['stages']['dropin_single_utterance']['steady'])
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+NUTT=2 rocprofv3 --kernel-trace -d $R/gpurun_out/one -o p --output-format csv -- python $R/tools/_one.py > $R/gpurun_out/one.log 2>&1
+python - <<'PY'
+import csv,glob
+f=glob.glob('/root/repo/gpurun_out/one/**/*kernel_trace.csv',recursive=True)[0]
+rows=list(csv.DictReader(open(f)))
+rows.sort(key=lambda r:int(r['Start_Timestamp']))
+idx=[i for i,r in enumerate(rows) if 'syn_overlap' in r['Kernel_Name']]
+a,b=idx[-3]+1,idx[-1]+1
+t0=int(rows[a]['Start_Timestamp'])
+for r in rows[a:b]:
+    s=int(r['Start_Timestamp']);e=int(r['End_Timestamp'])
+    if e-s>60000: print(f"{(s-t0)/1e3:9.1f} {(e-s)/1e3:8.1f} q{r['Queue_Id']} {r['Kernel_Name'][:60]:60} grid {r['Grid_Size_X']}x{r['Grid_Size_Y']}")
 PY

@@ -53,7 +53,7 @@ __global__ void ct_count_kernel(const double *__restrict__ f0, long long total, 
 // 48 kHz -- every contour Harvest can produce (ceiling 800 Hz) and anything a caller could mean by a pitch.  Frames above
 // that go to the block kernel, launched behind it on a small grid that looks for them.
 template <int N>
-__device__ __forceinline__ bool ct_wave_can(double f0c, int fs) {
+__host__ __device__ __forceinline__ bool ct_wave_can(double f0c, int fs) {
 	const int b = (int)(f0c * 2.0 / 3.0 * N / fs) + 1;
 	const int upper = 2 + (int)(f0c * N / fs);
 	return b <= 60 && upper <= 120;
@@ -603,6 +603,7 @@ struct wc_cheaptrick {
 	Device *dev;
 	DevBuf utts, cnt, uidx, off, endpos, d_x, d_tpos, d_f0, d_sp;
 	HostBuf h_stage;
+	double f0_bound = 0.0;  // > 0: the caller vouches that no F0 of the contour exceeds it (the pipeline: Harvest's ceiling)
 	// the pass over the frames the one-wavefront kernel leaves out runs beside whatever follows on the caller's stream
 	hipStream_t side = nullptr;
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -691,19 +692,24 @@ int ct_frames(wc_cheaptrick *c, hipStream_t s, int n_utt, const double *d_x, con
 				// small grid of the block kernel -- on a stream of its own: its workgroups (four wavefronts, 18 KB) wait long for a
 				// place while one-wavefront kernels fill the CUs, and nothing on the caller's stream needs its rows before the
 				// spectrogram is read.  rows_done: the caller makes the readers wait (NULL: this stream does, before returning).
-				if (!c->side) {
-					WC_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-					WC_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-					WC_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+				if (c->f0_bound > 0.0 && ct_wave_can<2048>(c->f0_bound, c->fs)) {
+					// a contour out of Harvest (ceiling far below the limit) holds no such frame: no second launch at all
+					hipLaunchKernelGGL(ct_wave_kernel, dim3((unsigned)(((total + 7) / 8) * 8)), dim3(64), 0, s, a);
+				} else {
+					if (!c->side) {
+						WC_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+						WC_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+						WC_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+					}
+					WC_HIP(hipEventRecord(c->ev_fork, s));
+					WC_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+					hipLaunchKernelGGL(ct_wave_kernel, dim3((unsigned)(((total + 7) / 8) * 8)), dim3(64), 0, s, a);
+					a.rare_only = 1;
+					hipLaunchKernelGGL((ct_frames_kernel<2048, WC_CT_THREADS, true>), dim3(256), dim3(WC_CT_THREADS), 0, c->side, a);
+					WC_HIP(hipEventRecord(c->ev_join, c->side));
+					if (rows_done) *rows_done = c->ev_join;
+					else WC_HIP(hipStreamWaitEvent(s, c->ev_join, 0));
 				}
-				WC_HIP(hipEventRecord(c->ev_fork, s));
-				WC_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
-				hipLaunchKernelGGL(ct_wave_kernel, dim3((unsigned)(((total + 7) / 8) * 8)), dim3(64), 0, s, a);
-				a.rare_only = 1;
-				hipLaunchKernelGGL((ct_frames_kernel<2048, WC_CT_THREADS, true>), dim3(256), dim3(WC_CT_THREADS), 0, c->side, a);
-				WC_HIP(hipEventRecord(c->ev_join, c->side));
-				if (rows_done) *rows_done = c->ev_join;
-				else WC_HIP(hipStreamWaitEvent(s, c->ev_join, 0));
 			} else {
 				launch_ct<2048>(a, s);
 			}
@@ -715,6 +721,7 @@ int ct_frames(wc_cheaptrick *c, hipStream_t s, int n_utt, const double *d_x, con
 	return dev->time_end("cheaptrick_frames", s);
 }
 
+void ct_set_f0_bound(wc_cheaptrick *c, double f0_bound) { c->f0_bound = f0_bound; }
 const unsigned long long *ct_end_positions(const wc_cheaptrick *c) { return c->endpos.as<unsigned long long>(); }
 
 static int ct_run_device(wc_cheaptrick *c, int n_utt, const double *d_x, const int *x_length, const double *d_tpos,

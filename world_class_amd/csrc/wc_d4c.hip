@@ -49,6 +49,7 @@ struct D4cArgs {
 	int fs, fft_size_out, n_ap, window_length;
 	double threshold;
 	long long sgd_stride;  // doubles per frame in sgd
+	int *long_list, *long_cnt;  // gated frames whose windows exceed 2048 samples: left by d4c2_frames_kernel<false>, done by <true>
 	const int *uidx;  // [total_frames] utterance of every frame (d4c_lt_count_kernel): the one-wavefront kernels read it instead of bisecting
 	int rare_only;  // d4c_frames_kernel behind d4c2_frames_kernel: only the frames that one leaves out (d4c2_can)
 };
@@ -191,16 +192,17 @@ __device__ __forceinline__ void linear_smoothing_lds(const double *P, double *S,
 // Which gated frames the two-wavefront kernels (d4c2_*, N = 4096) take: their 18 KB of LDS hold the mirrored segment of the
 // widest smoothing (2049 + 2 b + 1 terms, b = f0 N / fs + 1) and the low bins of the DC correction for F0 below ~1.4 kHz at
 // 48 kHz (Harvest's ceiling is 800 Hz).  Frames above that go through d4c_frames_kernel, launched behind with rare_only.
-__device__ __forceinline__ bool d4c2_can(double f0, int fs) {
+__host__ __device__ __forceinline__ bool d4c2_can(double f0, int fs) {
 	const int v = (int)(f0 * 4096 / fs);
 	return v + 1 <= 120 && v + 2 <= 122;
 }
 
 // number of draws of one frame's LoveTrain window / of its three D4C windows
 __global__ void d4c_lt_count_kernel(const double *__restrict__ f0, long long total, int fs, uint32_t *__restrict__ cnt,
-									const UttDesc *__restrict__ utts, int n_utt, int *__restrict__ uidx) {
+									const UttDesc *__restrict__ utts, int n_utt, int *__restrict__ uidx, int *__restrict__ long_cnt) {
 	long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 	if (g >= total) return;
+	if (g == 0) *long_cnt = 0;
 	uidx[g] = find_utt(utts, n_utt, g);  // (looked up once here rather than by every frame's wavefront, a chain of dependent loads each)
 	double f = f0[g];
 	cnt[g] = (f == 0.0) ? 0u : (uint32_t)(2 * mround(3.0 * fs / fmax(f, 40.0) / 2.0) + 1);
@@ -995,19 +997,20 @@ __device__ __forceinline__ void d4c2_smooth(D4Bins &s, double width, int fs, dou
 // parked in the frame's row and read back by both halves and both transforms; LONG = true: the others, window formed per half
 // and transform.  Every gated frame is done by exactly one of the two launches.
 template <bool LONG>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_D4C2_OCC, WC_D4C2_OCC))) void d4c2_frames_kernel(D4cArgs a) {
+__device__ __forceinline__ void d4c2_frame(const D4cArgs &a, const long long g, double *L, const int lane) {
 	constexpr int M = 2048;
-	__shared__ __attribute__((aligned(16))) double L[kD4Lds];
-	const int lane = threadIdx.x;
-	const long long g = xcd_frame(blockIdx.x, a.total_frames);
-	if (g >= a.total_frames) return;
 	const double f0v = a.f0[g];
 	if (f0v == 0.0 || a.ap0[g] <= a.threshold) return;  // reference :147
 	const int fs = a.fs;
 	const double f0 = uniform_d(fmax(47.0, f0v));
 	if (!d4c2_can(f0, fs)) return;
 	const int wl = __builtin_amdgcn_readfirstlane(2 * mround(4.0 * fs / f0 / 2.0) + 1);
-	if ((wl > 2048) != LONG) return;  // (before anything else is fetched: one of the two launches leaves here for every frame)
+	if constexpr (!LONG) {
+		if (wl > 2048) {  // left for the second launch (before anything else is fetched)
+			if (lane == 0) a.long_list[1 + atomicAdd(a.long_cnt, 1)] = (int)g;
+			return;
+		}
+	}
 	const int u = a.uidx[g];
 	const UttDesc ud = a.utts[u];
 	const double *__restrict__ x = a.x + ud.x_off;
@@ -1214,6 +1217,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_D4C2_OCC,
 	D4_STAMP(10);
 }
 
+// LONG = false: a wavefront per frame.  LONG = true: the frames with longer windows (F0 below 94 Hz) are few or none, and a grid
+// of one workgroup per frame that leaves at once still costs a launch of 64 k workgroups with 256 registers and scratch each
+// (0.29 ms per half batch): the first launch lists them, a grid sized for the chip walks the list.
+template <bool LONG>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_D4C2_OCC, WC_D4C2_OCC))) void d4c2_frames_kernel(D4cArgs a) {
+	__shared__ __attribute__((aligned(16))) double L[kD4Lds];
+	const int lane = threadIdx.x;
+	if constexpr (!LONG) {
+		const long long g = xcd_frame(blockIdx.x, a.total_frames);
+		if (g >= a.total_frames) return;
+		d4c2_frame<false>(a, g, L, lane);
+	} else {
+		const int n_long = *a.long_cnt;
+#pragma unroll 1
+		for (int i = blockIdx.x; i < n_long; i += gridDim.x) {
+			d4c2_frame<true>(a, a.long_list[1 + i], L, lane);
+			wf_fence();
+		}
+	}
+}
+
 #ifndef WC_D4C2_BAND_OCC
 #define WC_D4C2_BAND_OCC 2
 #endif
@@ -1328,7 +1352,8 @@ struct wc_d4c {
 	bool split;  // band loop and row output as separate kernels (default; WC_D4C_SPLIT=0: one fused kernel)
 	bool wave2;  // 4096-point transforms by two wavefronts per frame (d4c2_*; default where they apply, WC_D4C_IMPL=block: never)
 	Device *dev;
-	DevBuf nuttall, utts, cnt, uidx, off, endpos, endpos2, ap0, sgd, coarse, d_x, d_tpos, d_f0, d_ap;
+	double f0_bound = 0.0;  // > 0: the caller vouches that no F0 of the contour exceeds it (the pipeline: Harvest's ceiling)
+	DevBuf nuttall, utts, cnt, uidx, long_list, off, endpos, endpos2, ap0, sgd, coarse, d_x, d_tpos, d_f0, d_ap;
 	HostBuf h_stage;
 };
 
@@ -1385,6 +1410,7 @@ int d4c_enqueue(wc_d4c *d, hipStream_t s, int n_utt, const double *d_x, const in
 	if ((rc = d->utts.reserve(sizeof(UttDesc) * n_utt))) return rc;
 	if ((rc = d->cnt.reserve(sizeof(uint32_t) * total))) return rc;
 	if ((rc = d->uidx.reserve(sizeof(int) * total))) return rc;
+	if ((rc = d->long_list.reserve(sizeof(int) * (total + 1)))) return rc;  // [0]: the count
 	if ((rc = d->off.reserve(sizeof(uint64_t) * total))) return rc;
 	if ((rc = d->ap0.reserve(sizeof(double) * total))) return rc;
 	const bool split = d->split;
@@ -1401,13 +1427,13 @@ int d4c_enqueue(wc_d4c *d, hipStream_t s, int n_utt, const double *d_x, const in
 	if ((rc = d->h_stage.mark(s))) return rc;
 	const unsigned grid1 = (unsigned)((total + 255) / 256);
 	hipLaunchKernelGGL(d4c_lt_count_kernel, dim3(grid1), dim3(256), 0, s, d_f0, total, d->fs, d->cnt.as<uint32_t>(), d->utts.as<UttDesc>(), n_utt,
-					   d->uidx.as<int>());
+					   d->uidx.as<int>(), d->long_list.as<int>());
 	hipLaunchKernelGGL(utt_scan_kernel, dim3(n_utt), dim3(256), 0, s, d->cnt.as<uint32_t>(), d->utts.as<UttDesc>(),
 					   d_start, d->off.as<unsigned long long>(), d->endpos.as<unsigned long long>());
 	D4cArgs a;
 	a.x = d_x; a.utts = d->utts.as<UttDesc>(); a.n_utt = n_utt; a.tpos = d_tpos; a.f0 = d_f0;
 	a.rng_off = d->off.as<unsigned long long>(); a.rng_table = dev->rng_table.as<uint32_t>(); a.rng_base = dev->rng_base;
-	a.tw = dev->twiddle; a.ap = d_ap; a.ap0 = d->ap0.as<double>(); a.cnt = d->cnt.as<uint32_t>(); a.uidx = d->uidx.as<int>();
+	a.tw = dev->twiddle; a.ap = d_ap; a.ap0 = d->ap0.as<double>(); a.cnt = d->cnt.as<uint32_t>(); a.uidx = d->uidx.as<int>(); a.long_cnt = d->long_list.as<int>(); a.long_list = d->long_list.as<int>();
 	a.sgd = d->sgd.as<double>(); a.coarse = d->coarse.as<double>();
 	a.nuttall = d->nuttall.as<double>(); a.total_frames = total; a.fs = d->fs; a.fft_size_out = fft_size;
 	a.n_ap = d->n_ap; a.window_length = d->window_length; a.threshold = d->threshold;
@@ -1439,10 +1465,12 @@ int d4c_enqueue(wc_d4c *d, hipStream_t s, int n_utt, const double *d_x, const in
 		if (main2 && part == 0) {
 			// one wavefront per frame; the frames it leaves out (F0 above ~1.4 kHz, d4c2_can) by the block kernel behind them
 			hipLaunchKernelGGL(d4c2_frames_kernel<false>, dim3((unsigned)blocks8), dim3(64), 0, s, a);
-			hipLaunchKernelGGL(d4c2_frames_kernel<true>, dim3((unsigned)blocks8), dim3(64), 0, s, a);
-			a.rare_only = 1;
-			hipLaunchKernelGGL((d4c_frames_kernel<4096, 512, true>), dim3((unsigned)blocks8), dim3(512), 0, s, a);
-			a.rare_only = 0;
+			hipLaunchKernelGGL(d4c2_frames_kernel<true>, dim3((unsigned)std::min<long long>(blocks8, 4096)), dim3(64), 0, s, a);
+			if (!(d->f0_bound > 0.0 && d4c2_can(d->f0_bound, d->fs))) {  // (a contour out of Harvest cannot hold such frames: no launch)
+				a.rare_only = 1;
+				hipLaunchKernelGGL((d4c_frames_kernel<4096, 512, true>), dim3((unsigned)blocks8), dim3(512), 0, s, a);
+				a.rare_only = 0;
+			}
 		} else if (main2 && part == 1) {
 			if (a.n_ap > 0) hipLaunchKernelGGL(d4c2_band_kernel, dim3((unsigned)(blocks8 * a.n_ap)), dim3(64), 0, s, a);
 			hipLaunchKernelGGL(d4c_rows_kernel, dim3((unsigned)a.total_frames), dim3(256), 0, s, a);
@@ -1473,6 +1501,7 @@ int d4c_enqueue(wc_d4c *d, hipStream_t s, int n_utt, const double *d_x, const in
 	return WC_OK;
 }
 
+void d4c_set_f0_bound(wc_d4c *d, double f0_bound) { d->f0_bound = f0_bound; }
 const unsigned long long *d4c_end_positions(const wc_d4c *d) { return d->endpos2.as<unsigned long long>(); }
 
 // upper bound of the stream positions one utterance can consume (LoveTrain + three windows per frame)
@@ -1552,7 +1581,7 @@ wc_d4c *wc_d4c_create(int fs, double threshold) {
 void wc_d4c_destroy(wc_d4c *d) {
 	if (!d) return;
 	d->dev->quiesce();
-	d->nuttall.release(); d->utts.release(); d->cnt.release(); d->uidx.release(); d->off.release(); d->endpos.release(); d->endpos2.release();
+	d->nuttall.release(); d->utts.release(); d->cnt.release(); d->uidx.release(); d->long_list.release(); d->off.release(); d->endpos.release(); d->endpos2.release();
 	d->ap0.release(); d->sgd.release(); d->coarse.release(); d->d_x.release(); d->d_tpos.release(); d->d_f0.release(); d->d_ap.release(); d->h_stage.release();
 	delete d;
 }

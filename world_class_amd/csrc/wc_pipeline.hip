@@ -153,6 +153,10 @@ wc_pipeline *wc_pipeline_create(int fs, double frame_period, double harvest_f0_f
 	p->d4 = p->ct ? wc_d4c_create(fs, d4c_threshold) : nullptr;
 	p->sy = p->d4 ? wc_synthesis_create(fs, p->fft_size, frame_period) : nullptr;
 	bool ok = p->sy != nullptr;
+	if (ok) {  // (the contour these stages see comes out of Harvest, see below)
+		ct_set_f0_bound(p->ct, 1.25 * harvest_f0_ceil);
+		d4c_set_f0_bound(p->d4, 1.25 * harvest_f0_ceil);
+	}
 	ok = ok && hipStreamCreateWithFlags(&p->s1, hipStreamNonBlocking) == hipSuccess;
 	ok = ok && hipStreamCreateWithFlags(&p->s2, hipStreamNonBlocking) == hipSuccess;
 	ok = ok && hipEventCreateWithFlags(&p->e0, hipEventDisableTiming) == hipSuccess;
@@ -177,6 +181,12 @@ wc_pipeline *wc_pipeline_create(int fs, double frame_period, double harvest_f0_f
 			G.d4 = G.ct ? wc_d4c_create(fs, d4c_threshold) : nullptr;
 			G.sy = G.d4 ? wc_synthesis_create(fs, p->fft_size, frame_period) : nullptr;
 			ok = G.sy != nullptr;
+			if (ok) {
+				// the contour these stages see comes out of Harvest: candidates outside [floor, ceil] are struck (reference
+				// src/harvest.cpp:974-979) and the smoothing filter overshoots by a few per cent at most
+				ct_set_f0_bound(G.ct, 1.25 * harvest_f0_ceil);
+				d4c_set_f0_bound(G.d4, 1.25 * harvest_f0_ceil);
+			}
 			if (g == 0) { G.main = dev->active(); G.aux = p->s1; }
 			else { G.main = p->n_split > 1 ? p->hs[1] : p->s2; G.aux = p->s2; }
 			ok = ok && hipEventCreateWithFlags(&G.e0, hipEventDisableTiming) == hipSuccess;

@@ -18,6 +18,9 @@ int ct_prepare(wc_cheaptrick *c, hipStream_t s, int n_utt, const int *x_length, 
 int ct_frames(wc_cheaptrick *c, hipStream_t s, int n_utt, const double *d_x, const double *d_tpos, const double *d_f0,
 			  double *d_sp, long long total, hipEvent_t *rows_done);
 const unsigned long long *ct_end_positions(const wc_cheaptrick *c);
+// the caller vouches that no F0 handed to the stage exceeds f0_bound (0: no promise): passes over frames with F0 in the kHz are not launched
+void ct_set_f0_bound(wc_cheaptrick *c, double f0_bound);
+void d4c_set_f0_bound(wc_d4c *d, double f0_bound);
 
 int d4c_enqueue(wc_d4c *d, hipStream_t s, int n_utt, const double *d_x, const int *x_length, const double *d_tpos,
 				const double *d_f0, const int *f0_length, int fft_size, double *d_ap, const uint64_t *rng_pos,
