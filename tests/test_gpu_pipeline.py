@@ -180,6 +180,22 @@ def test_host_batch_front_end_pinned_rows_and_coded_outputs(wca):
         assert c["csp"].shape == (len(r["f0"]), nd)
         assert np.abs(c["csp"] - pc.code_spectral_envelope(r["sp"], fs, p.fft_size, nd)).max() < 1e-10
         assert np.abs(c["cap"] - pc.code_aperiodicity(r["ap"], fs, p.fft_size)).max() < 1e-10
+    # page-locked utterances are read by the copy engine where they lie, half batch by half batch (no gather into staging);
+    # page-locked waveform rows are written per half behind its pulses: the same numbers either way
+    xs_pinned = p.host_inputs(xs)
+    for g in pinned:
+        for v in g.values():
+            v.fill(-2.0)
+    p.run_batch_host(xs_pinned, out=pinned)
+    for r, g in zip(ref, pinned):
+        assert np.array_equal(g["tpos"], r["tpos"]) and np.array_equal(g["f0"], r["f0"])
+        assert np.array_equal(g["sp"], r["sp"]) and np.array_equal(g["ap"], r["ap"])
+        assert np.abs(g["y"] - r["y"]).max() < 1e-10
+    cbuf = p.coded_host_buffers([len(x) for x in xs], number_of_dimensions=nd, pinned=True)
+    p.run_batch_host_coded(xs_pinned, number_of_dimensions=nd, out=cbuf)
+    for c, b in zip(coded, cbuf):
+        assert all(np.array_equal(c[k], b[k]) for k in ("f0", "csp", "cap"))
+        assert np.abs(c["y"] - b["y"]).max() < 1e-10
 
 
 def test_pipeline_at_96_khz_golden(wca):

@@ -97,6 +97,33 @@ class Pipeline:
             res.append(r)
         return res
 
+    def host_inputs(self, xs):
+        """Page-locked copies of the utterances (float64): run_batch_host then lets the copy engine read them where they lie,
+        half batch by half batch, instead of gathering them into its own pinned staging first."""
+        import torch
+        out = []
+        for v in xs:
+            t = torch.empty(len(v), dtype=torch.float64, pin_memory=True)
+            a = t.numpy()
+            a[:] = v
+            out.append(a)
+        return out
+
+    def coded_host_buffers(self, x_lengths, number_of_dimensions=60, want=("f0", "csp", "cap", "y"), y_pcm16=False, pinned=True):
+        """Result buffers for run_batch_host_coded(..., out=...), one dict per utterance (page-locked when `pinned`)."""
+        import torch
+        from .codec import number_of_aperiodicities
+        fl, yl = self.lengths(list(x_lengths))
+        n_ap = number_of_aperiodicities(self.fs)
+
+        def arr(shape, dtype):
+            if pinned:
+                return torch.empty(shape, dtype={np.float64: torch.float64, np.int16: torch.int16}[dtype], pin_memory=True).numpy()
+            return np.empty(shape, dtype=dtype)
+        shapes = {"tpos": lambda f, m: (f,), "f0": lambda f, m: (f,), "csp": lambda f, m: (f, number_of_dimensions),
+                  "cap": lambda f, m: (f, n_ap), "y": lambda f, m: (m,)}
+        return [{k: arr(shapes[k](f, m), np.int16 if (k == "y" and y_pcm16) else np.float64) for k in want} for f, m in zip(fl, yl)]
+
     def run_batch_host_coded(self, xs, number_of_dimensions=60, want=("f0", "csp", "cap", "y"), y_pcm16=False, rng_pos=None, out=None):
         """wc_pipeline_run_batch_host_coded: the host front-end with the reference's feature codec as the epilogue -- per frame
         `number_of_dimensions` mel-cepstral coefficients ("csp") and the band aperiodicities ("cap") instead of the rows."""

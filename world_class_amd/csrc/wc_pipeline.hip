@@ -85,6 +85,12 @@ struct HostSink {
 	int bins = 0;
 	bool overlapped[2] = {false, false};  // group g was copied and scattered during the run (first attempt only)
 	bool direct = false;  // every destination row lies in pinned host memory: the copy engine writes the rows where they belong
+	// the waveforms (float64) straight into the caller's page-locked rows, each half as soon as its pulses are summed
+	double *const *y = nullptr;
+	const int *y_len = nullptr;
+	bool y_done = false;
+	hipEvent_t x_b = nullptr;  // the samples of the second half batch are on the device (their upload runs beside the first half's Harvest)
+	bool eager = false;        // the first half's CheapTrick / D4C do not wait for the second half's Harvest: their rows leave earlier
 };
 
 // true when p lies in page-locked host memory (hipHostMalloc / hipHostRegister; e.g. a pinned torch tensor)
@@ -110,9 +116,9 @@ struct wc_pipeline {
 	wc_cheaptrick *ct;
 	wc_d4c *d4;
 	wc_synthesis *sy;
-	hipStream_t s1, s2, s_copy, s_copy2;  // (s_copy2: the aperiodicity rows leave beside the spectrogram rows, on a DMA engine of their own)
+	hipStream_t s1, s1_hi, s2, s_copy, s_copy2;  // (s_copy2: the aperiodicity rows leave beside the spectrogram rows, on a DMA engine of their own)
 	hipEvent_t e_copy2[2];
-	hipEvent_t e0, e1, e2, e_copy[2];
+	hipEvent_t e0, e1, e2, e_copy[2], e_y[2], e_ycopy[2], e_xb;
 	// host batch front-end (wc_pipeline_run_batch_host): device-resident batch + pinned staging, grow-only
 	DevBuf b_x, b_pcm, b_t, b_f, b_sp, b_ap, b_y, b_ypcm, b_coded;
 	HostBuf st_in, st_out;
@@ -162,17 +168,37 @@ wc_pipeline *wc_pipeline_create(int fs, double frame_period, double harvest_f0_f
 	ok = ok && hipEventCreateWithFlags(&p->e0, hipEventDisableTiming) == hipSuccess;
 	ok = ok && hipEventCreateWithFlags(&p->e1, hipEventDisableTiming) == hipSuccess;
 	ok = ok && hipEventCreateWithFlags(&p->e2, hipEventDisableTiming) == hipSuccess;
-	ok = ok && hipStreamCreateWithFlags(&p->s_copy, hipStreamNonBlocking) == hipSuccess;
+	// The copy streams are created with a priority of their own: HIP multiplexes the streams of one priority onto a few hardware
+	// queues (four by default), and a copy that shares a queue with a compute stream sits behind that stream's kernels -- and
+	// holds up the kernels behind it while it waits for its rows (measured: the second half's CheapTrick started 15 ms late
+	// behind the first half's rows).  Streams of another priority get queues of their own.  WC_PIPELINE_COPY_PRIORITY=0: plain streams (A/B).
+	int prio_lo = 0, prio_hi = 0;
+	(void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+	const bool copy_prio = !(getenv("WC_PIPELINE_COPY_PRIORITY") && getenv("WC_PIPELINE_COPY_PRIORITY")[0] == '0') && prio_hi != prio_lo;
+	auto copy_stream = [&](hipStream_t *st) {
+		return (copy_prio ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(st, hipStreamNonBlocking)) == hipSuccess;
+	};
+	ok = ok && copy_stream(&p->s_copy);
+	// ... and so does the stream the first half's CheapTrick / D4C take in a run whose rows leave for the host: there they are
+	// enqueued beside the second half's Harvest (HostSink::eager) and should get the CUs first, because PCIe waits for their rows
+	// (measured: 61 -> 58 ms per 64 utterances with all five outputs).  WC_PIPELINE_AUX_PRIORITY=0: the plain stream.
+	if (ok && copy_prio && !(getenv("WC_PIPELINE_AUX_PRIORITY") && getenv("WC_PIPELINE_AUX_PRIORITY")[0] == '0'))
+		ok = hipStreamCreateWithPriority(&p->s1_hi, hipStreamNonBlocking, prio_hi) == hipSuccess;
 	{
 		const char *env = getenv("WC_PIPELINE_COPY_STREAMS");
 		if (ok && !(env && atoi(env) == 1)) {
-			ok = hipStreamCreateWithFlags(&p->s_copy2, hipStreamNonBlocking) == hipSuccess &&
+			ok = copy_stream(&p->s_copy2) &&
 				 hipEventCreateWithFlags(&p->e_copy2[0], hipEventDisableTiming) == hipSuccess &&
 				 hipEventCreateWithFlags(&p->e_copy2[1], hipEventDisableTiming) == hipSuccess;
 		}
 	}
 	ok = ok && hipEventCreateWithFlags(&p->e_copy[0], hipEventDisableTiming) == hipSuccess;
 	ok = ok && hipEventCreateWithFlags(&p->e_copy[1], hipEventDisableTiming) == hipSuccess;
+	for (int g = 0; g < 2; ++g) {
+		ok = ok && hipEventCreateWithFlags(&p->e_y[g], hipEventDisableTiming) == hipSuccess;
+		ok = ok && hipEventCreateWithFlags(&p->e_ycopy[g], hipEventDisableTiming) == hipSuccess;
+	}
+	ok = ok && hipEventCreateWithFlags(&p->e_xb, hipEventDisableTiming) == hipSuccess;
 	if (ok && p->mode == 1) {
 		for (int g = 0; g < 2 && ok; ++g) {
 			PipeGroup &G = p->grp[g];
@@ -213,6 +239,7 @@ void wc_pipeline_destroy(wc_pipeline *p) {
 	p->st_out.release();
 	if (p->s1) { (void)hipStreamSynchronize(p->s1); (void)hipStreamDestroy(p->s1); }
 	if (p->s2) { (void)hipStreamSynchronize(p->s2); (void)hipStreamDestroy(p->s2); }
+	if (p->s1_hi) { (void)hipStreamSynchronize(p->s1_hi); (void)hipStreamDestroy(p->s1_hi); }
 	if (p->e0) (void)hipEventDestroy(p->e0);
 	if (p->e1) (void)hipEventDestroy(p->e1);
 	if (p->e2) (void)hipEventDestroy(p->e2);
@@ -220,6 +247,9 @@ void wc_pipeline_destroy(wc_pipeline *p) {
 	if (p->s_copy2) (void)hipStreamDestroy(p->s_copy2);
 	for (int g = 0; g < 2; ++g) if (p->e_copy2[g]) (void)hipEventDestroy(p->e_copy2[g]);
 	for (int g = 0; g < 2; ++g) if (p->e_copy[g]) (void)hipEventDestroy(p->e_copy[g]);
+	for (int g = 0; g < 2; ++g) if (p->e_y[g]) (void)hipEventDestroy(p->e_y[g]);
+	for (int g = 0; g < 2; ++g) if (p->e_ycopy[g]) (void)hipEventDestroy(p->e_ycopy[g]);
+	if (p->e_xb) (void)hipEventDestroy(p->e_xb);
 	for (int g = 0; g < 2; ++g) {
 		PipeGroup &G = p->grp[g];
 		if (G.e0) (void)hipEventDestroy(G.e0);
@@ -279,6 +309,7 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 		//   Harvest_A heavy | tail_A next to Harvest_B heavy | tail_B next to CheapTrick/D4C_A | pulses_A | D4C_B | pulses_B
 		// (tail = unreliable-candidate test, contour logic, smoothing; the Synthesis time bases hide the same way)
 		p->grp[0].main = s0;  // chain A runs on the calling thread's stream (wc_set_stream) -- resolved per call, not at creation
+		p->grp[0].aux = (sink && sink->eager && p->s1_hi) ? p->s1_hi : p->s1;
 		bool full[2][2] = {{false, false}, {false, false}};
 		for (int attempt = 0; attempt < 3; ++attempt) {
 			const int bins_ = p->fft_size / 2 + 1;
@@ -298,6 +329,7 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 			//    caller's kernels): its decimation reads d_x right away.  (The aux streams follow their main streams through e0.)
 			WC_HIP(hipEventRecord(p->e1, s0));
 			WC_HIP(hipStreamWaitEvent(p->grp[1].main, p->e1, 0));
+			if (sink && sink->x_b) WC_HIP(hipStreamWaitEvent(p->grp[1].main, sink->x_b, 0));
 			// 1. both Harvest chains; B's starts when A's refinement kernel is done
 			for (int g = 0; g < 2; ++g) {
 				PipeGroup &G = p->grp[g];
@@ -320,7 +352,9 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 				if ((rc = ct_prepare(G.ct, G.main, nu, x_length + u0, gf, f_len.data() + u0, grp_rng, &total, &a0, &a1))) return rc;
 				WC_HIP(hipEventRecord(G.e0, G.main));
 				WC_HIP(hipStreamWaitEvent(G.aux, G.e0, 0));
-				if (g == 0) WC_HIP(hipStreamWaitEvent(G.aux, p->grp[1].e_mid, 0));
+				// (a run whose rows leave for the host is bound by PCIe, not by the kernels: there the first half's rows are wanted
+				// as early as they can be had, even if its CheapTrick / D4C then share the CUs with the second half's Harvest)
+				if (g == 0 && !(sink && sink->eager)) WC_HIP(hipStreamWaitEvent(G.aux, p->grp[1].e_mid, 0));
 				hipEvent_t ct_rows = nullptr;  // CheapTrick's pass over the frames its one-wavefront kernel leaves out, on a stream of its own
 				if ((rc = ct_frames(G.ct, G.aux, nu, gx, gt, gf, gsp, total, &ct_rows))) return rc;
 				WC_HIP(hipEventRecord(G.e_ct, G.aux));
@@ -333,22 +367,29 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 					const size_t off = sizeof(double) * (size_t)sl[g].fo * bins_, len = sizeof(double) * (size_t)(fo_end[g] - sl[g].fo) * bins_;
 					// the spectrogram rows leave as soon as CheapTrick is through, the aperiodicity rows behind D4C: PCIe is the longest
 					// stretch of a run with all outputs (2.1 GB at ~50 GB/s), so it starts as early as it can
+					// (direct rows: each array's utterances are dealt to the two copy streams alternately, so that both engines work
+					// on whatever is ready and finish together; staged: spectrogram on one stream, aperiodicity on the other)
 					for (int which = 0; which < 2; ++which) {
-						hipStream_t sc = (which == 1 && p->s_copy2) ? p->s_copy2 : p->s_copy;
-						WC_HIP(hipStreamWaitEvent(sc, which == 0 ? G.e_ct : G.e_aux, 0));
-						if (which == 0 && ct_rows) WC_HIP(hipStreamWaitEvent(sc, ct_rows, 0));
 						char *stage = which == 0 ? sink->stage_sp : sink->stage_ap;
 						double *const *rows = which == 0 ? sink->sp : sink->ap;
 						const double *src = which == 0 ? gsp : gap;
 						if (!stage) continue;
+						for (int lane = 0; lane < 2; ++lane) {
+							hipStream_t sc = (lane == 1 && p->s_copy2) ? p->s_copy2 : p->s_copy;
+							if (lane == 1 && !p->s_copy2) break;
+							WC_HIP(hipStreamWaitEvent(sc, which == 0 ? G.e_ct : G.e_aux, 0));
+							if (which == 0 && ct_rows) WC_HIP(hipStreamWaitEvent(sc, ct_rows, 0));
+						}
 						if (sink->direct) {
 							long long fo2 = 0;
 							for (int u = u0; u < u0 + nu; ++u) {
 								const size_t ulen = sizeof(double) * (size_t)f_len[u] * bins_;
+								hipStream_t sc = (p->s_copy2 && ((u - u0) & 1)) ? p->s_copy2 : p->s_copy;
 								if (rows[u]) WC_HIP(hipMemcpyAsync(rows[u], src + fo2 * bins_, ulen, hipMemcpyDeviceToHost, sc));
 								fo2 += f_len[u];
 							}
 						} else {
+							hipStream_t sc = (which == 1 && p->s_copy2) ? p->s_copy2 : p->s_copy;
 							WC_HIP(hipMemcpyAsync(stage + off, src, len, hipMemcpyDeviceToHost, sc));
 						}
 					}
@@ -358,6 +399,23 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 				if ((rc = syn_prepare(G.sy, G.main, nu, gf, f_len.data() + u0, y_len.data() + u0, gy, nullptr, full[g][1]))) return rc;
 				WC_HIP(hipStreamWaitEvent(G.main, G.e_aux, 0));
 				if ((rc = syn_pulses(G.sy, G.main, gf, gsp, gap, gy, d4c_end_positions(G.d4)))) return rc;
+				if (sink && sink->y) {
+					// (every attempt: a re-run after an overflow rewrites the waveform, and its copies land behind the first ones)
+					WC_HIP(hipEventRecord(p->e_y[g], G.main));
+					WC_HIP(hipStreamWaitEvent(p->s_copy, p->e_y[g], 0));
+					if (p->s_copy2) WC_HIP(hipStreamWaitEvent(p->s_copy2, p->e_y[g], 0));
+					long long yo2 = 0;
+					for (int u = u0; u < u0 + nu; ++u) {
+						hipStream_t sc = (p->s_copy2 && ((u - u0) & 1)) ? p->s_copy2 : p->s_copy;
+						if (sink->y[u]) WC_HIP(hipMemcpyAsync(sink->y[u], gy + yo2, sizeof(double) * (size_t)y_len[u], hipMemcpyDeviceToHost, sc));
+						yo2 += y_len[u];
+					}
+					if (p->s_copy2) {  // (one event for both streams: the first waits for the second)
+						WC_HIP(hipEventRecord(p->e_ycopy[g], p->s_copy2));
+						WC_HIP(hipStreamWaitEvent(p->s_copy, p->e_ycopy[g], 0));
+					}
+					WC_HIP(hipEventRecord(p->e_ycopy[g], p->s_copy));
+				}
 			}
 			dev->time_tag = -1;
 			pmark("both halves enqueued");
@@ -393,6 +451,11 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 				again = again || o1 || o2;
 			}
 			if (again && sink) sink->overlapped[0] = sink->overlapped[1] = false;  // the re-run rewrites the rows
+			if (!again && sink && sink->y) {
+				for (int g = 0; g < 2; ++g) WC_HIP(hipEventSynchronize(p->e_ycopy[g]));
+				sink->y_done = true;
+				pmark("waveforms landed");
+			}
 			if (!again) return WC_OK;
 		}
 		return fail(WC_ERR_DEVICE, "pipeline: buffer overflow");
@@ -485,26 +548,55 @@ int wc_pipeline_run_batch_host(wc_pipeline *p, int n_utt, const void *const *x, 
 	if ((rc = p->b_sp.reserve(sizeof(double) * nf * bins))) return rc;
 	if ((rc = p->b_ap.reserve(sizeof(double) * nf * bins))) return rc;
 	if ((rc = p->b_y.reserve(sizeof(double) * ny))) return rc;
-	{  // gather the utterances into pinned memory (a few threads: 245 MB of doubles take 40 ms on one)
-		std::vector<CopyJob> jobs(n_utt);
+	// The samples go up half batch by half batch: the first half's Harvest starts behind its own upload while the second
+	// half's is still on the wire (copy stream).  Page-locked utterances are read by the copy engine where they lie; others
+	// are gathered into pinned staging by a few threads (245 MB of doubles take 40 ms on one).
+	HostSink sink;
+	{
+		const bool halves = p->mode == 1 && n_utt >= 2 && x_is_pcm16 == 0;
+		const int uB = halves ? n_utt / 2 : n_utt;
+		bool pinned_in = halves && !(getenv("WC_PIPELINE_DIRECT") && getenv("WC_PIPELINE_DIRECT")[0] == '0');
+		for (int u = 0; u < n_utt && pinned_in; ++u) pinned_in = is_pinned(x[u]);
 		char *dst = static_cast<char *>(p->st_in.p);
-		for (int u = 0; u < n_utt; ++u) {
-			jobs[u] = {dst, x[u], in_elem * x_length[u]};
-			dst += in_elem * x_length[u];
+		long long xo = 0;
+		for (int part = 0; part < (halves ? 2 : 1); ++part) {
+			const int u0 = part == 0 ? 0 : uB, u1 = part == 0 ? uB : n_utt;
+			hipStream_t sc = part == 0 ? s : p->s_copy;
+			long long n_part = 0;
+			for (int u = u0; u < u1; ++u) n_part += x_length[u];
+			if (pinned_in) {
+				long long o = xo;
+				for (int u = u0; u < u1; ++u) {
+					WC_HIP(hipMemcpyAsync(p->b_x.as<double>() + o, x[u], sizeof(double) * (size_t)x_length[u], hipMemcpyHostToDevice, sc));
+					o += x_length[u];
+				}
+			} else {
+				std::vector<CopyJob> jobs;
+				char *d0 = dst;
+				for (int u = u0; u < u1; ++u) {
+					jobs.push_back({dst, x[u], in_elem * x_length[u]});
+					dst += in_elem * x_length[u];
+				}
+				parallel_copy(jobs);
+				if (part == 0) mark("inputs gathered");
+				if (x_is_pcm16 == 1) {
+					WC_HIP(hipMemcpyAsync(p->b_pcm.p, p->st_in.p, sizeof(int16_t) * nx, hipMemcpyHostToDevice, s));
+					if ((rc = wc_pcm16_to_double_device(p->b_pcm.as<int16_t>(), nx, p->b_x.as<double>()))) return rc;
+				} else if (x_is_pcm16 == 2) {
+					WC_HIP(hipMemcpyAsync(p->b_pcm.p, p->st_in.p, sizeof(float) * nx, hipMemcpyHostToDevice, s));
+					if ((rc = wc_float_to_double_device(p->b_pcm.as<float>(), nx, p->b_x.as<double>()))) return rc;
+				} else {
+					WC_HIP(hipMemcpyAsync(p->b_x.as<double>() + xo, d0, sizeof(double) * (size_t)n_part, hipMemcpyHostToDevice, sc));
+				}
+			}
+			if (part == 1) {
+				WC_HIP(hipEventRecord(p->e_xb, sc));
+				sink.x_b = p->e_xb;
+			}
+			xo += n_part;
 		}
-		parallel_copy(jobs);
 	}
-	mark("inputs gathered");
-	if (x_is_pcm16 == 1) {
-		WC_HIP(hipMemcpyAsync(p->b_pcm.p, p->st_in.p, sizeof(int16_t) * nx, hipMemcpyHostToDevice, s));
-		if ((rc = wc_pcm16_to_double_device(p->b_pcm.as<int16_t>(), nx, p->b_x.as<double>()))) return rc;
-	} else if (x_is_pcm16 == 2) {
-		WC_HIP(hipMemcpyAsync(p->b_pcm.p, p->st_in.p, sizeof(float) * nx, hipMemcpyHostToDevice, s));
-		if ((rc = wc_float_to_double_device(p->b_pcm.as<float>(), nx, p->b_x.as<double>()))) return rc;
-	} else {
-		WC_HIP(hipMemcpyAsync(p->b_x.p, p->st_in.p, sizeof(double) * nx, hipMemcpyHostToDevice, s));
-	}
-	if ((rc = p->st_in.mark(s))) return rc;
+	mark("inputs on their way");
 	// outputs: one packed region of pinned memory, [tpos | f0 | sp | ap | y]
 	const size_t y_elem = y_is_pcm16 ? sizeof(int16_t) : sizeof(double);
 	size_t off_t = 0, off_f = off_t + (tpos ? sizeof(double) * nf : 0), off_sp = off_f + (f0 ? sizeof(double) * nf : 0);
@@ -514,7 +606,6 @@ int wc_pipeline_run_batch_host(wc_pipeline *p, int n_utt, const void *const *x, 
 	char *out = static_cast<char *>(p->st_out.p);
 	// The big arrays (spectrogram, aperiodicity) leave per half batch while the rest of the batch still computes, and are
 	// handed to the caller's rows by several threads (pipeline_run, HostSink).
-	HostSink sink;
 	sink.stage_sp = sp ? out + off_sp : nullptr;
 	sink.stage_ap = ap ? out + off_ap : nullptr;
 	sink.sp = sp; sink.ap = ap; sink.f_len = f_len.data(); sink.bins = bins;
@@ -526,17 +617,31 @@ int wc_pipeline_run_batch_host(wc_pipeline *p, int n_utt, const void *const *x, 
 	}
 	for (int u = 0; u < n_utt && sink.direct; ++u)
 		sink.direct = (!sp || !sp[u] || is_pinned(sp[u])) && (!ap || !ap[u] || is_pinned(ap[u]));
+	{
+		const char *env = getenv("WC_PIPELINE_EAGER");  // 0: the device-resident schedule (A/B)
+		sink.eager = (sp || ap) && !(env && env[0] == '0');
+	}
+	if (y && !y_is_pcm16 && p->mode == 1 && n_utt >= 2 && !(getenv("WC_PIPELINE_DIRECT") && getenv("WC_PIPELINE_DIRECT")[0] == '0')) {
+		bool all = true;
+		for (int u = 0; u < n_utt && all; ++u) all = !y[u] || is_pinned(y[u]);
+		if (all) {
+			sink.y = reinterpret_cast<double *const *>(y);
+			sink.y_len = y_len.data();
+		}
+	}
 	if ((rc = pipeline_run(p, n_utt, p->b_x.as<double>(), x_length, p->b_t.as<double>(), p->b_f.as<double>(),
 						   p->b_sp.as<double>(), p->b_ap.as<double>(), p->b_y.as<double>(), rng_pos, &sink)))
 		return rc;
 	mark("pipeline_run returned");
+	if ((rc = p->st_in.mark(s))) return rc;  // (both uploads are long done: the run has been waited for)
 	if (total == 0) return WC_OK;
 	const bool rows_done = sink.overlapped[0] && sink.overlapped[1];
 	if (tpos) WC_HIP(hipMemcpyAsync(out + off_t, p->b_t.p, sizeof(double) * nf, hipMemcpyDeviceToHost, s));
 	if (f0) WC_HIP(hipMemcpyAsync(out + off_f, p->b_f.p, sizeof(double) * nf, hipMemcpyDeviceToHost, s));
 	if (sp && !rows_done) WC_HIP(hipMemcpyAsync(out + off_sp, p->b_sp.p, sizeof(double) * nf * bins, hipMemcpyDeviceToHost, s));
 	if (ap && !rows_done) WC_HIP(hipMemcpyAsync(out + off_ap, p->b_ap.p, sizeof(double) * nf * bins, hipMemcpyDeviceToHost, s));
-	if (y) {
+	const bool y_staged = y && !sink.y_done;
+	if (y_staged) {
 		if (y_is_pcm16) {
 			if ((rc = p->b_ypcm.reserve(sizeof(int16_t) * ny))) return rc;
 			if ((rc = wc_double_to_pcm16_device(p->b_y.as<double>(), ny, p->b_ypcm.as<int16_t>()))) return rc;
@@ -556,7 +661,7 @@ int wc_pipeline_run_batch_host(wc_pipeline *p, int n_utt, const void *const *x, 
 			if (sp && sp[u]) jobs.push_back({sp[u], out + off_sp + sizeof(double) * fo * bins, sizeof(double) * f_len[u] * bins});
 			if (ap && ap[u]) jobs.push_back({ap[u], out + off_ap + sizeof(double) * fo * bins, sizeof(double) * f_len[u] * bins});
 		}
-		if (y && y[u]) jobs.push_back({y[u], out + off_y + y_elem * yo, y_elem * y_len[u]});
+		if (y_staged && y[u]) jobs.push_back({y[u], out + off_y + y_elem * yo, y_elem * y_len[u]});
 		fo += f_len[u];
 		yo += y_len[u];
 	}
