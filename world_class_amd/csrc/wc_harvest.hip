@@ -427,6 +427,9 @@ struct SdArgs {
 #ifndef WC_SDFT_WAVES
 #define WC_SDFT_WAVES 1  // minimum wavefronts per SIMD asked of the register allocator
 #endif
+#ifndef WC_SDFT_RING
+#define WC_SDFT_RING 1   // edges leave for their slots in whole 32-byte sectors (below)
+#endif
 __global__ __launch_bounds__(64, WC_SDFT_WAVES) void hv_bandpass_sdft_kernel(SdArgs a) {
 	const int lane = threadIdx.x;
 	const HvUtt u = a.utts[blockIdx.y];
@@ -499,6 +502,27 @@ __global__ __launch_bounds__(64, WC_SDFT_WAVES) void hv_bandpass_sdft_kernel(SdA
 	const int cap = a.slot_cap[band];
 	double *__restrict__ slot = a.slots + blockIdx.y * a.slots_per_utt + a.slot_off[band] + (long long)chunk * 4 * cap;
 	int cnt[4] = {0, 0, 0, 0};
+	// An edge goes to its slot four at a time: a lone 8-byte store leaves a cache line that is evicted long before the lane's
+	// next edge of that type arrives (a wave's lanes write 256 separate streams; 4.4 GB of write traffic per 64 utterances for
+	// 1.1 GB of edges, one 32-byte sector per edge).  The lane parks edges c = 4 m .. 4 m + 2 in LDS and writes the whole
+	// 32-byte sector when edge 4 m + 3 arrives; what is left at the end of the chunk follows then.  (cap is a multiple of 4 and
+	// the slots are 32-byte aligned.)  WC_SDFT_RING=0: every edge stored as it appears.
+#if WC_SDFT_RING
+	__shared__ double ring[16 * 64];  // [type][c & 3][lane]
+	auto put = [&](int ty, int c, double fine) {
+		const int k = c & 3;
+		if (k != 3) {
+			ring[(ty * 4 + k) * 64 + lane] = fine;
+		} else {
+			const double e0 = ring[(ty * 4 + 0) * 64 + lane], e1 = ring[(ty * 4 + 1) * 64 + lane], e2 = ring[(ty * 4 + 2) * 64 + lane];
+			double2 *dst = reinterpret_cast<double2 *>(slot + (long long)ty * cap + (c - 3));
+			dst[0] = make_double2(e0, e1);
+			dst[1] = make_double2(e2, fine);
+		}
+	};
+#else
+	auto put = [&](int ty, int c, double fine) { slot[(long long)ty * cap + c] = fine; };
+#endif
 	const int i_end = live ? min(i0 + SD_CH, ylen) : i0;
 	int steps = i_end - i0;  // (lanes of one wave may sit in two different chunks)
 #pragma unroll
@@ -532,14 +556,14 @@ __global__ __launch_bounds__(64, WC_SDFT_WAVES) void hv_bandpass_sdft_kernel(SdA
 			if (neg || pos) {
 				const double fine = (i + 1) - quot(s0, d0);
 				const int c = neg ? cnt[0] : cnt[1];
-				if (c < cap) slot[(neg ? 0 : cap) + c] = fine;
+				if (c < cap) put(neg ? 0 : 1, c, fine);
 				cnt[0] += neg ? 1 : 0;
 				cnt[1] += pos ? 1 : 0;
 			}
 			if (pk || dp) {
 				const double fine = (i + 1) - quot(d0, d1 - d0);
 				const int c = pk ? cnt[2] : cnt[3];
-				if (c < cap) slot[(pk ? 2 * cap : 3 * cap) + c] = fine;
+				if (c < cap) put(pk ? 2 : 3, c, fine);
 				cnt[2] += pk ? 1 : 0;
 				cnt[3] += dp ? 1 : 0;
 			}
@@ -547,6 +571,15 @@ __global__ __launch_bounds__(64, WC_SDFT_WAVES) void hv_bandpass_sdft_kernel(SdA
 			s1 = s2;
 		}
 	}
+#if WC_SDFT_RING
+	if (live) {
+#pragma unroll
+		for (int ty = 0; ty < 4; ++ty) {
+			const int stored = min(cnt[ty], cap), rem = stored & 3;
+			for (int k = 0; k < rem; ++k) slot[(long long)ty * cap + (stored - rem) + k] = ring[(ty * 4 + k) * 64 + lane];
+		}
+	}
+#endif
 	if (valid) {
 		int *c = a.slot_count + (((long long)blockIdx.y * a.n_bands + band) * a.n_chunks + chunk) * 4;
 #pragma unroll
@@ -2532,7 +2565,7 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 			const int hard = SD_CH / 2 + 2;
 			int soft = static_cast<int>(2.5 * h->band_f0[b] * (SD_CH / h->fs_d)) + 16;
 			if (h->debug_small_caps) soft = 3;
-			slot_cap[b] = full ? hard : std::min(hard, soft);
+			slot_cap[b] = ((full ? hard : std::min(hard, soft)) + 3) & ~3;  // (whole 32-byte sectors: the sliding band-pass writes its edges four at a time)
 			slot_off[b] = slots_per_utt;
 			slots_per_utt += 4ll * n_tiles * slot_cap[b];
 		}
