@@ -1331,6 +1331,9 @@ __device__ __forceinline__ void minimum_phase_wave(const double (&ls)[16], doubl
 #ifndef WC_SYN_ROWS_G
 #define WC_SYN_ROWS_G 2
 #endif
+#ifndef WC_SYN_PARK_NOISE
+#define WC_SYN_PARK_NOISE 1
+#endif
 // WC_SYN_TRACE (development builds only): lane 0 stamps the shader clock at the phase boundaries of every pulse;
 // WC_SYN_TRACE_FILE=<file> dumps them after the call (tools/syn_trace.py)
 #ifndef WC_SYN_TRACE
@@ -1345,6 +1348,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_SYN_WAVE_
 	constexpr int N = 2048, M = 1024;
 	__shared__ __attribute__((aligned(16))) double L[kWfLds];
 	__shared__ __attribute__((aligned(16))) double T[kWfTabLds];
+#if WC_SYN_PARK_NOISE
+	__shared__ __attribute__((aligned(16))) double P[1024];
+#endif
 	const int lane = threadIdx.x;
 	const long long total_p = a.pulse_prefix[a.n_utt];
 	if ((long long)blockIdx.x >= 8 * ((total_p + 7) / 8)) return;
@@ -1446,6 +1452,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_SYN_WAVE_
 			wf_fft1024_dit_rest<+1>(nr, ni, L, a.tw, ln);
 			wf_r2c_unpack(nr, ni, nsM, a.tw, ln);  // twice the noise spectrum
 			SYN_STAMP(6);
+#if WC_SYN_PARK_NOISE
+			// The noise spectrum waits outside the registers while the minimum phase is worked out (held, it pushes the two
+			// transforms in between over 256 registers: 368 bytes of scratch per lane, half the kernel's memory traffic): its real
+			// parts in LDS, its imaginary parts in the first half of the pulse's own response row (free until the mix below).
+#pragma unroll
+			for (int sI = 0; sI < 16; ++sI) {
+				P[64 * sI + ln] = nr[sI];
+				resp[64 * sI + ln] = ni[sI];
+			}
+			wf_fence();
+#endif
 		}
 		// the part's log spectrum from the two rows around the pulse: log(env (1 - ar) + safeguard) / 2 for the periodic part
 		// (reference :416-417), log(env ar) / 2 or, unvoiced, log(env) / 2 for the aperiodic one (:490-497)
@@ -1499,6 +1516,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_SYN_WAVE_
 			wf_sincos(coef * M, sn_, reM);
 			yM = mM * reM;
 		} else {
+#if WC_SYN_PARK_NOISE
+			{
+				const double *rp = resp;
+				asm volatile("" : "+s"(rp));  // (an opaque pointer: real loads, not the stored values kept in registers)
+#pragma unroll
+				for (int sI = 0; sI < 16; ++sI) {
+					ni[sI] = rp[64 * sI + ln];
+					nr[sI] = P[64 * sI + ln];
+				}
+				WF_SCHED_FENCE();
+			}
+#endif
 #pragma unroll
 			for (int sI = 0; sI < 16; ++sI) {
 				const double x = wr[sI], y = wi[sI], nx = 0.5 * nr[sI], ny = 0.5 * ni[sI];

@@ -174,6 +174,40 @@ __device__ __forceinline__ void wf_t2_apply(double (&re)[16], double (&im)[16], 
 	for (int r = 1; r < 16; ++r) wrot(re[r], im[r], w[r].x, S > 0 ? w[r].y : -w[r].y);
 }
 
+// The second stage's 256 twiddles in LDS (kWfT2Lds doubles, copied once per wavefront by wf_t2_to_lds): held in registers
+// they are 60 VGPRs across the exchange in front of the stage -- what tips a kernel that keeps another 32 complex values
+// alive across a transform (a noise spectrum, a first transform's result) over its 256 registers and into scratch memory.
+// From LDS they are fetched five at a time right where they are used, the next five requested while these are applied.
+constexpr int kWfT2Lds = 512;
+__device__ __forceinline__ void wf_t2_to_lds(double *T2, const double2 *__restrict__ tw, int lane) {
+	double2 v[4];
+#pragma unroll
+	for (int i = 0; i < 4; ++i) v[i] = tw_load(tw + kTwT2, lane + 64 * i);
+	WF_SCHED_FENCE();
+#pragma unroll
+	for (int i = 0; i < 4; ++i) reinterpret_cast<double2 *>(T2)[lane + 64 * i] = v[i];
+	// (the caller's wf_fence() / the first exchange orders these writes before the first look-up)
+}
+template <int S>
+__device__ __forceinline__ void wf_t2_apply_lds(double (&re)[16], double (&im)[16], const double *T2, int lane) {
+	const double2 *t = reinterpret_cast<const double2 *>(T2) + (lane & 15);
+	double2 w[2][5];
+#pragma unroll
+	for (int k = 0; k < 5; ++k) w[0][k] = t[16 * (1 + k)];
+#pragma unroll
+	for (int b = 0; b < 3; ++b) {
+		if (b < 2) {
+#pragma unroll
+			for (int k = 0; k < 5; ++k) w[(b + 1) & 1][k] = t[16 * (1 + 5 * (b + 1) + k)];
+		}
+#pragma unroll
+		for (int k = 0; k < 5; ++k) {
+			const int r = 1 + 5 * b + k;
+			wrot(re[r], im[r], w[b & 1][k].x, S > 0 ? w[b & 1][k].y : -w[b & 1][k].y);
+		}
+	}
+}
+
 struct WfIdx {
 	int jb[4];       // padded element index of butterfly g's first input: j + (j >> 4)
 	int x1w, x1r;    // exchange 1: write 17 t (+ q), read t + (t >> 4) (+ 68 r)
@@ -226,10 +260,14 @@ __device__ __forceinline__ void wf_tw3(const double2 *__restrict__ tw, int lane,
 // zero padding) on the strided data
 template <int S>
 __device__ __forceinline__ void wf_fft1024_dit_rest(double (&re)[16], double (&im)[16], double *lds, const double2 *__restrict__ tw_,
-													 int lane) {
+													 int lane, const double *T2 = nullptr) {
 	const double2 *__restrict__ tw = tw_fresh(tw_);
 	const WfIdx ix = wf_idx(lane);
-	{
+	if (T2) {
+		wf_xchg<1, 68>(re, lds, ix.x1w, ix.x1r);
+		wf_xchg<1, 68>(im, lds, ix.x1w, ix.x1r);
+		wf_t2_apply_lds<S>(re, im, T2, lane);
+	} else {
 		double2 w2[16];
 		wf_t2_load(w2, tw, lane);
 		wf_xchg<1, 68>(re, lds, ix.x1w, ix.x1r);
@@ -251,14 +289,14 @@ __device__ __forceinline__ void wf_fft1024_dit_rest(double (&re)[16], double (&i
 // strided -> paired
 template <int S>
 __device__ __forceinline__ void wf_fft1024_dit(double (&re)[16], double (&im)[16], double *lds, const double2 *__restrict__ tw,
-												int lane) {
+												int lane, const double *T2 = nullptr) {
 	wdft16<S>(re, im);
-	wf_fft1024_dit_rest<S>(re, im, lds, tw, lane);
+	wf_fft1024_dit_rest<S>(re, im, lds, tw, lane, T2);
 }
 // paired -> strided
 template <int S>
 __device__ __forceinline__ void wf_fft1024_dif(double (&re)[16], double (&im)[16], double *lds, const double2 *__restrict__ tw_,
-												int lane) {
+												int lane, const double *T2 = nullptr) {
 	const double2 *__restrict__ tw = tw_fresh(tw_);
 	const WfIdx ix = wf_idx(lane);
 	{
@@ -271,7 +309,12 @@ __device__ __forceinline__ void wf_fft1024_dif(double (&re)[16], double (&im)[16
 			for (int r = 1; r <= 3; ++r) wrot(re[4 * g + r], im[4 * g + r], wr[g][r - 1], wi[g][r - 1]);
 		}
 	}
-	{
+	if (T2) {
+		wf_xchg_out3(re, lds, ix.jb, ix.x2);
+		wf_xchg_out3(im, lds, ix.jb, ix.x2);
+		wdft16<S>(re, im);
+		wf_t2_apply_lds<S>(re, im, T2, lane);
+	} else {
 		double2 w2[16];
 		wf_t2_load(w2, tw, lane);
 		wf_xchg_out3(re, lds, ix.jb, ix.x2);
@@ -447,10 +490,14 @@ __device__ __forceinline__ WfIdx wf_idx_p(int lane, int odd) {
 // strided -> paired layout of parity `odd`; the caller has run the leading wdft16<S, NG>
 template <int S>
 __device__ __forceinline__ void wf_fft1024_dit_rest_p(double (&re)[16], double (&im)[16], double *lds, const double2 *__restrict__ tw_,
-													   int lane, int odd) {
+													   int lane, int odd, const double *T2 = nullptr) {
 	const double2 *__restrict__ tw = tw_fresh(tw_);
 	const WfIdx ix = wf_idx_p(lane, odd);
-	{
+	if (T2) {
+		wf_xchg<1, 68>(re, lds, ix.x1w, ix.x1r);
+		wf_xchg<1, 68>(im, lds, ix.x1w, ix.x1r);
+		wf_t2_apply_lds<S>(re, im, T2, lane);
+	} else {
 		double2 w2[16];
 		wf_t2_load(w2, tw, lane);
 		wf_xchg<1, 68>(re, lds, ix.x1w, ix.x1r);
@@ -507,7 +554,7 @@ __device__ __forceinline__ void wf_r2c_unpack_odd(double (&re)[16], double (&im)
 // z[n] + z[n + 1024], the odd half's (z[n] - z[n + 1024]) before the twist, which is applied here).  ng: the input's slots
 // 4 ng .. 15 are zero.  Out: slot (g, q) = 2 X[2 (j_g + 256 q) + odd]; even half: lane 0's A_0 = (2 X[0], 0), nyq = 2 X[2048].
 __device__ __forceinline__ void wf_r2c4096_half(double (&re)[16], double (&im)[16], double &nyq, int ng, double *lds,
-												const double2 *__restrict__ tw, int lane, int odd) {
+												const double2 *__restrict__ tw, int lane, int odd, const double *T2 = nullptr) {
 	WC_FRESH(lane);  // (lane-derived addresses must not be hoisted out of the caller's loops and spilled)
 	if (odd) {
 		if (ng <= 1) wf_odd_twist(re, im, tw, lane, 4);
@@ -517,7 +564,7 @@ __device__ __forceinline__ void wf_r2c4096_half(double (&re)[16], double (&im)[1
 	if (ng <= 1) wdft16<+1, 1>(re, im);
 	else if (ng == 2) wdft16<+1, 2>(re, im);
 	else wdft16<+1, 4>(re, im);
-	wf_fft1024_dit_rest_p<+1>(re, im, lds, tw, lane, odd);
+	wf_fft1024_dit_rest_p<+1>(re, im, lds, tw, lane, odd, T2);
 	nyq = 0.0;
 	if (odd) wf_r2c_unpack_odd(re, im, tw, lane);
 	else wf_r2c_unpack(re, im, nyq, tw, lane);
