@@ -1,0 +1,13 @@
+# full evidence pass of a build: bash tools/_round.sh TAG
+TAG=$1
+mkdir -p gpurun_out
+python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_gputest.log 2>&1; tail -3 gpurun_out/${TAG}_gputest.log
+python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+bash tools/profile_round.sh $TAG > gpurun_out/${TAG}_profile.log 2>&1
+python tools/microbench.py --utts 64 --iters 3 > gpurun_out/${TAG}_mb64.txt 2>&1
+python tools/microbench.py --utts 16 --iters 3 > gpurun_out/${TAG}_mb16.txt 2>&1
+python tools/microbench.py --utts 1 --iters 5 > gpurun_out/${TAG}_mb1.txt 2>&1
+python tools/latency_probe.py > gpurun_out/${TAG}_latency.txt 2>&1
+python -c "
+import json; d=json.load(open('gpurun_out/${TAG}_bench.json')); print(d['ms_per_step'], d['value'], d['roofline']['kernel'], d['roofline']['frac'], d['roofline'].get('fp64_vector')); print({k:(round(v['ms'],1) if 'ms' in v else v) for k,v in d['with_transfers'].items()}); print(d['stages']['cheaptrick_config3'])"
+cat gpurun_out/${TAG}_latency.txt

@@ -6,7 +6,8 @@ import sys
 import numpy as np
 a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 16)[:, :11].astype(np.int64)
 a = a[(a[:, 10] > a[:, 0]) & (a[:, 0] > 0)]
-names = ["setup->window(job0,even)", "transform 1", "weights+transform 2+products", "rest of the even half (jobs 1, 2)", "odd half", "reload parked",
+# (windows of at most 2048 samples, the usual case: job-major; the longer ones stamp half-major: "rest of the even half", "odd half")
+names = ["set-up, window of job 0, parked", "job 0 even: master read + transform", "job 0 even: weighted read + transform + products + park", "job 0 odd half", "jobs 1 and 2", "reload parked",
          "dc corrections", "power smoothing (order-faithful)", "division + two signed smoothings", "store"]
 d = np.diff(a, axis=1)
 print("%d gated frames traced; shader-clock cycles per phase (mean / median):" % len(a))

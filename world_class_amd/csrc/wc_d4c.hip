@@ -982,6 +982,9 @@ __device__ __forceinline__ void d4c2_smooth(D4Bins &s, double width, int fs, dou
 #ifndef WC_D4C2_OCC
 #define WC_D4C2_OCC 2
 #endif
+#ifndef WC_D4C2_MASTER_LDS
+#define WC_D4C2_MASTER_LDS 1
+#endif
 // WC_D4C2_TRACE (development builds only): lane 0 stamps the shader clock at the phase boundaries of every gated frame into
 // the tail of the frame's row (doubles 4128 .. 4143), which WC_D4C_TRACE=<file> dumps after the call (tools/d4c_trace.py)
 #ifndef WC_D4C2_TRACE
@@ -1045,10 +1048,14 @@ __device__ __forceinline__ void d4c2_frame(const D4cArgs &a, const long long g, 
 #pragma unroll
 				for (int q = 0; q < 16; ++q) {
 					if (q < 4 * ng) {
-						park[2048 + 64 * q + ln] = mr[q] * pw;
+						// (jobs 0, 1 read their window four times: its even samples wait in the LDS behind the exchange buffer,
+						// free until job 2 puts the even half's power there)
+						if (WC_D4C2_MASTER_LDS && job != 2) L[kWfLds + 64 * q + ln] = mr[q] * pw;
+						else park[2048 + 64 * q + ln] = mr[q] * pw;
 						park[3072 + 64 * q + ln] = mi[q] * pw;
 					}
 				}
+				if (job == 0) D4_STAMP(1);
 			}
 			// (what a lane parks it reads back itself: program order is all the ordering the round trip needs)
 			auto master = [&](double (&re)[16], double (&im)[16], bool weighted) {
@@ -1060,7 +1067,8 @@ __device__ __forceinline__ void d4c2_frame(const D4cArgs &a, const long long g, 
 				for (int q = 0; q < 16; ++q) {
 					re[q] = im[q] = 0.0;
 					if (q < 4 * ng) {
-						re[q] = pk[2048 + 64 * q + ln];
+						if (WC_D4C2_MASTER_LDS && job != 2) re[q] = L[kWfLds + 64 * q + ln];
+						else re[q] = pk[2048 + 64 * q + ln];
 						im[q] = pk[3072 + 64 * q + ln];
 					}
 				}
@@ -1079,6 +1087,7 @@ __device__ __forceinline__ void d4c2_frame(const D4cArgs &a, const long long g, 
 				double re[16], im[16], nyq1;
 				master(re, im, false);
 				wf_r2c4096_half(re, im, nyq1, ng, L, a.tw, ln, odd);
+				if (job == 0 && odd == 0) D4_STAMP(2);
 				if (job == 2) {
 					// (the master copy of job 2 has been read by both halves only after the odd half's load above: the even
 					// half's power goes to the row's FIRST quarter pair for now and is moved below)
@@ -1116,8 +1125,10 @@ __device__ __forceinline__ void d4c2_frame(const D4cArgs &a, const long long g, 
 #pragma unroll
 					for (int s = 0; s < 16; ++s) park[1024 * odd + 64 * s + ln] = acc[s];
 					if (odd == 0) cenM += nyq1 * nyq2;
+					if (job == 0 && odd == 0) D4_STAMP(3);
 				}
 			}
+			if (job == 0) D4_STAMP(4);
 		}
 	} else
 #pragma unroll 1
