@@ -217,9 +217,11 @@ class CheapTrick:
         self.fft_size = lib().wc_cheaptrick_get_fft_size(self._h)
         self.bins = self.fft_size // 2 + 1
 
-    def compute(self, x, temporal_positions, f0):
+    def compute(self, x, temporal_positions, f0, out=None):
+        """out: a (frames, bins) float64 array of an earlier call to be written again (the caller's buffer, as in the reference
+        demo, which allocates its rows once: reference test/test.cpp:92-101)"""
         x, t, f = _c(x), _c(temporal_positions), _c(f0)
-        sp = np.empty((len(f), self.bins))
+        sp = out if out is not None else np.empty((len(f), self.bins))
         _check(lib().wc_cheaptrick_compute(self._h, _p(x), len(x), _p(t), _p(f), len(f), _rows(sp)))
         return sp
 
@@ -261,9 +263,9 @@ class D4C:
         self.fs = fs
         self._h = _handle(lib().wc_d4c_create(fs, threshold))
 
-    def compute(self, x, temporal_positions, f0, fft_size):
+    def compute(self, x, temporal_positions, f0, fft_size, out=None):
         x, t, f = _c(x), _c(temporal_positions), _c(f0)
-        ap = np.empty((len(f), fft_size // 2 + 1))
+        ap = out if out is not None else np.empty((len(f), fft_size // 2 + 1))
         _check(lib().wc_d4c_compute(self._h, _p(x), len(x), _p(t), _p(f), len(f), fft_size, _rows(ap)))
         return ap
 

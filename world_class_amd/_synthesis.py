@@ -18,12 +18,12 @@ class Synthesis:
     def out_length(self, f0_length):
         return synthesis_out_length(f0_length, self.frame_period, self.fs)  # reference test/test.cpp:362-363
 
-    def compute(self, f0, spectrogram, aperiodicity, out_length=None):
+    def compute(self, f0, spectrogram, aperiodicity, out_length=None, out=None):
         f = _c(f0)
         sp, ap = _c(spectrogram), _c(aperiodicity)
         if out_length is None:
-            out_length = self.out_length(len(f))
-        out = np.zeros(out_length)
+            out_length = self.out_length(len(f)) if out is None else len(out)
+        out = np.zeros(out_length) if out is None else out
         _check(lib().wc_synthesis_compute(self._h, _p(f), len(f), _rows(sp), _rows(ap), out_length, _p(out)))
         return out
 

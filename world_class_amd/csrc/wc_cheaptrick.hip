@@ -17,6 +17,7 @@
 #include "wc_internal.hpp"
 #include "wc_frames.hpp"
 #include "wc_wavefft.hpp"
+#include "wc_hostcopy.hpp"
 
 namespace wc {
 
@@ -602,7 +603,7 @@ struct wc_cheaptrick {
 	double q1, f0_floor_opt, f0_floor;
 	Device *dev;
 	DevBuf utts, cnt, uidx, off, endpos, d_x, d_tpos, d_f0, d_sp;
-	HostBuf h_stage;
+	HostBuf h_stage, h_rows;
 	double f0_bound = 0.0;  // > 0: the caller vouches that no F0 of the contour exceeds it (the pipeline: Harvest's ceiling)
 	// the pass over the frames the one-wavefront kernel leaves out runs beside whatever follows on the caller's stream
 	hipStream_t side = nullptr;
@@ -790,6 +791,7 @@ void wc_cheaptrick_destroy(wc_cheaptrick *c) {
 	c->utts.release(); c->cnt.release(); c->uidx.release(); c->off.release(); c->endpos.release();
 	c->d_x.release(); c->d_tpos.release(); c->d_f0.release(); c->d_sp.release();
 	c->h_stage.release();
+	c->h_rows.release();
 	if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
 	if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
 	if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -830,10 +832,13 @@ int wc_cheaptrick_compute(wc_cheaptrick *c, const double *x, int x_length, const
 					   c->d_sp.as<double>(), &pos);
 	if (rc) return rc;
 	set_global_rng_position(pos);
-	std::vector<double> host((size_t)f0_length * bins);
-	WC_HIP(hipMemcpyAsync(host.data(), c->d_sp.p, sizeof(double) * host.size(), hipMemcpyDeviceToHost, s));
+	// the rows come down into page-locked staging (a pageable destination takes the copy engine's slow path, and a fresh 16 MB
+	// vector per call is 4096 page faults) and go to the caller's rows by a few threads
+	const size_t n_sp = (size_t)f0_length * bins;
+	if ((rc = c->h_rows.reserve(sizeof(double) * n_sp))) return rc;
+	WC_HIP(hipMemcpyAsync(c->h_rows.p, c->d_sp.p, sizeof(double) * n_sp, hipMemcpyDeviceToHost, s));
 	WC_HIP(hipStreamSynchronize(s));
-	for (int i = 0; i < f0_length; ++i) std::memcpy(spectrogram[i], &host[(size_t)i * bins], sizeof(double) * bins);
+	rows_copy(spectrogram, f0_length, bins, c->h_rows.as<double>(), true);
 	return WC_OK;
 }
 

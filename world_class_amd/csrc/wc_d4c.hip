@@ -24,6 +24,7 @@
 #include "wc_internal.hpp"
 #include "wc_frames.hpp"
 #include "wc_wavefft.hpp"
+#include "wc_hostcopy.hpp"
 
 namespace wc {
 
@@ -1365,7 +1366,7 @@ struct wc_d4c {
 	Device *dev;
 	double f0_bound = 0.0;  // > 0: the caller vouches that no F0 of the contour exceeds it (the pipeline: Harvest's ceiling)
 	DevBuf nuttall, utts, cnt, uidx, long_list, off, endpos, endpos2, ap0, sgd, coarse, d_x, d_tpos, d_f0, d_ap;
-	HostBuf h_stage;
+	HostBuf h_stage, h_rows;
 };
 
 template <int N>
@@ -1593,7 +1594,7 @@ void wc_d4c_destroy(wc_d4c *d) {
 	if (!d) return;
 	d->dev->quiesce();
 	d->nuttall.release(); d->utts.release(); d->cnt.release(); d->uidx.release(); d->long_list.release(); d->off.release(); d->endpos.release(); d->endpos2.release();
-	d->ap0.release(); d->sgd.release(); d->coarse.release(); d->d_x.release(); d->d_tpos.release(); d->d_f0.release(); d->d_ap.release(); d->h_stage.release();
+	d->ap0.release(); d->sgd.release(); d->coarse.release(); d->d_x.release(); d->d_tpos.release(); d->d_f0.release(); d->d_ap.release(); d->h_stage.release(); d->h_rows.release();
 	delete d;
 }
 
@@ -1628,10 +1629,11 @@ int wc_d4c_compute(wc_d4c *d, const double *x, int x_length, const double *tempo
 						fft_size, d->d_ap.as<double>(), &pos);
 	if (rc) return rc;
 	set_global_rng_position(pos);
-	std::vector<double> host((size_t)f0_length * bins);
-	WC_HIP(hipMemcpyAsync(host.data(), d->d_ap.p, sizeof(double) * host.size(), hipMemcpyDeviceToHost, s));
+	const size_t n_ap = (size_t)f0_length * bins;  // (page-locked staging, rows handed over by a few threads: see wc_cheaptrick_compute)
+	if ((rc = d->h_rows.reserve(sizeof(double) * n_ap))) return rc;
+	WC_HIP(hipMemcpyAsync(d->h_rows.p, d->d_ap.p, sizeof(double) * n_ap, hipMemcpyDeviceToHost, s));
 	WC_HIP(hipStreamSynchronize(s));
-	for (int i = 0; i < f0_length; ++i) std::memcpy(aperiodicity[i], &host[(size_t)i * bins], sizeof(double) * bins);
+	rows_copy(aperiodicity, f0_length, bins, d->h_rows.as<double>(), true);
 	return WC_OK;
 }
 

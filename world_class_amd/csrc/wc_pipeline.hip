@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "wc_stages.hpp"
+#include "wc_hostcopy.hpp"
 #include "../../include/world_class_io.h"
 #include "../../include/world_class_codec.h"
 
@@ -52,29 +53,6 @@ static void pmark(const char *what) {
 	static const bool on = getenv("WC_PIPELINE_TIMING") != nullptr;
 	if (on) std::fprintf(stderr, "  [pipeline] %-30s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g_mark0).count());
 }
-struct CopyJob { void *dst; const void *src; size_t bytes; };
-static void parallel_copy(const std::vector<CopyJob> &jobs) {
-	constexpr size_t kPiece = 2u << 20;
-	struct Piece { char *dst; const char *src; size_t bytes; };
-	std::vector<Piece> pieces;
-	size_t total = 0;
-	for (const CopyJob &j : jobs)
-		for (size_t o = 0; o < j.bytes; o += kPiece) {
-			pieces.push_back({static_cast<char *>(j.dst) + o, static_cast<const char *>(j.src) + o, std::min(kPiece, j.bytes - o)});
-			total += pieces.back().bytes;
-		}
-	unsigned hw = std::thread::hardware_concurrency();
-	size_t nt = std::min<size_t>({hw ? hw : 4u, 16u, total / (8u << 20) + 1, pieces.size()});
-	std::atomic<size_t> next{0};
-	auto work = [&]() {
-		for (size_t i = next.fetch_add(1); i < pieces.size(); i = next.fetch_add(1)) std::memcpy(pieces[i].dst, pieces[i].src, pieces[i].bytes);
-	};
-	std::vector<std::thread> th;
-	for (size_t t = 1; t < nt; ++t) th.emplace_back(work);
-	work();
-	for (std::thread &t : th) t.join();
-}
-
 // What wc_pipeline_run_batch_host asks of a run: the spectrogram / aperiodicity rows of each half batch start their way
 // to the host as soon as that half's D4C is through (copy stream, pinned staging), and are handed to the caller's
 // per-utterance buffers while the other half still computes.

@@ -22,6 +22,7 @@
 #include "wc_internal.hpp"
 #include "wc_frames.hpp"
 #include "wc_wavefft.hpp"
+#include "wc_hostcopy.hpp"
 
 namespace wc {
 
@@ -1656,7 +1657,7 @@ struct wc_synthesis {
 	bool wave;  // N = 2048: one wavefront per pulse (default; WC_SYN_IMPL=block: the workgroup-per-pulse kernel)
 	bool phase_single;  // WC_SYN_PHASE=single: the phase sum by one workgroup per utterance (A/B and the bit-identity test)
 	bool serial_timebase;  // WC_SYN_TIMEBASE=serial: the one-wavefront sequential accumulation instead of the exact parallel one
-	HostBuf h_stage;
+	HostBuf h_stage, h_rows;
 	long long total_out = 0, cap_total = 0;  // of the most recent syn_prepare
 	int n_utt = 0, max_out = 0;
 };
@@ -1983,7 +1984,7 @@ void wc_synthesis_destroy(wc_synthesis *s) {
 	if (!s) return;
 	s->dev->quiesce();
 	s->dc_remover.release(); s->utts.release(); s->meta.release(); s->pulses.release(); s->incs.release(); s->phase.release(); s->tile_cnt.release(); s->phase_seg.release(); s->resp.release(); s->pulse_utt.release();
-	s->d_f0.release(); s->d_sp.release(); s->d_ap.release(); s->d_out.release(); s->h_stage.release();
+	s->d_f0.release(); s->d_sp.release(); s->d_ap.release(); s->d_out.release(); s->h_stage.release(); s->h_rows.release();
 	delete s;
 }
 
@@ -2010,21 +2011,24 @@ int wc_synthesis_compute(wc_synthesis *s, const double *f0, int f0_length, const
 	if ((rc = s->d_sp.reserve(sizeof(double) * (size_t)f0_length * bins))) return rc;
 	if ((rc = s->d_ap.reserve(sizeof(double) * (size_t)f0_length * bins))) return rc;
 	if ((rc = s->d_out.reserve(sizeof(double) * out_length))) return rc;
-	std::vector<double> hsp((size_t)f0_length * bins), hap((size_t)f0_length * bins);
-	for (int i = 0; i < f0_length; ++i) {
-		std::memcpy(&hsp[(size_t)i * bins], spectrogram[i], sizeof(double) * bins);
-		std::memcpy(&hap[(size_t)i * bins], aperiodicity[i], sizeof(double) * bins);
-	}
+	// the rows are gathered into page-locked staging by a few threads (runs of rows that lie one behind the other as one piece)
+	// and go up from there; the waveform comes down into staging as well (a pageable destination takes the slow path)
+	const size_t n_rows = (size_t)f0_length * bins;
+	if ((rc = s->h_rows.reserve(sizeof(double) * (2 * n_rows + (size_t)out_length)))) return rc;
+	double *hsp = s->h_rows.as<double>(), *hap = hsp + n_rows, *hy = hap + n_rows;
+	rows_copy(const_cast<double *const *>(spectrogram), f0_length, bins, hsp, false);
+	rows_copy(const_cast<double *const *>(aperiodicity), f0_length, bins, hap, false);
 	WC_HIP(hipMemcpyAsync(s->d_f0.p, f0, sizeof(double) * f0_length, hipMemcpyHostToDevice, st));
-	WC_HIP(hipMemcpyAsync(s->d_sp.p, hsp.data(), sizeof(double) * hsp.size(), hipMemcpyHostToDevice, st));
-	WC_HIP(hipMemcpyAsync(s->d_ap.p, hap.data(), sizeof(double) * hap.size(), hipMemcpyHostToDevice, st));
+	WC_HIP(hipMemcpyAsync(s->d_sp.p, hsp, sizeof(double) * n_rows, hipMemcpyHostToDevice, st));
+	WC_HIP(hipMemcpyAsync(s->d_ap.p, hap, sizeof(double) * n_rows, hipMemcpyHostToDevice, st));
 	uint64_t pos = global_rng_position();
 	rc = syn_run_device(s, 1, s->d_f0.as<double>(), &f0_length, s->d_sp.as<double>(), s->d_ap.as<double>(), &out_length,
 						s->d_out.as<double>(), &pos);
 	if (rc) return rc;
 	set_global_rng_position(pos);
-	WC_HIP(hipMemcpyAsync(out, s->d_out.p, sizeof(double) * out_length, hipMemcpyDeviceToHost, st));
+	WC_HIP(hipMemcpyAsync(hy, s->d_out.p, sizeof(double) * out_length, hipMemcpyDeviceToHost, st));
 	WC_HIP(hipStreamSynchronize(st));
+	parallel_copy({{out, hy, sizeof(double) * (size_t)out_length}});
 	return WC_OK;
 }
 
