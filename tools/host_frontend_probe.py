@@ -1,3 +1,5 @@
+"""The host front-end on the headline batch (development aid): wc_pipeline_run_batch_host with page-locked rows, three timed runs;
+WC_PIPELINE_TIMING=1 prints the phase marks, PIN_IN=1 page-locks the utterances too, CODED=1 adds the coded-output variant."""
 import sys, time, os, numpy as np
 sys.path.insert(0, '/root/repo')
 import world_class_amd as w

@@ -1,3 +1,7 @@
+"""Kernels and copies of a host front-end run on one time line (development aid), from
+    rocprofv3 --kernel-trace --memory-copy-trace -f csv -d DIR -o p -- python tools/host_frontend_probe.py
+    python tools/trace_host_frontend.py DIR
+Runs of consecutive copies / blit kernels are merged; times in ms from the start of the last run's uploads."""
 import csv, sys
 d = sys.argv[1]
 kt = list(csv.DictReader(open(d + '/p_kernel_trace.csv')))
