@@ -2304,45 +2304,61 @@ __global__ __launch_bounds__(64) void hv_smooth_kernel(SmArgs a) {
 				return yv;
 			};
 			// ---- forward, lead-in: i = 0 .. st - 1 under the constant xs ----
+			// (whole periods of eight steps between the comparisons, nothing else in the loop: a lone wavefront issues one
+			// instruction per ~5 cycles, and a step's own dependent chain -- multiply, add, add -- is ~40; the loop counter,
+			// the test of i & 7 and the divergent loop exit per step tripled that.  Where the comparison falls does not matter
+			// to the result: skipping whole periods of a state that repeats leaves it as it is.)
+			auto advance = [&](double xv) {  // the state alone (no output wanted)
+				const double wt = xv + a0 * w0 + a1 * w1;
+				w1 = w0; w0 = wt;
+			};
 			{
 				int i = 0;
 				double p0 = w0, p1 = w1;
 				bool periodic = false;
-				while (i < st) {
-					if ((i & 7) == 0 && i > 0) {
-						if (bits(w0) == bits(p0) && bits(w1) == bits(p1)) { periodic = true; break; }
-						p0 = w0; p1 = w1;
-					}
-					(void)step(xs);
-					++i;
+				while (i + 8 <= st) {
+#pragma unroll
+					for (int e = 0; e < 8; ++e) advance(xs);
+					i += 8;
+					if (bits(w0) == bits(p0) && bits(w1) == bits(p1)) { periodic = true; break; }
+					p0 = w0; p1 = w1;
 				}
 				if (periodic) i += ((st - i) / 8) * 8;
-				for (; i < st; ++i) (void)step(xs);
+				for (; i < st; ++i) advance(xs);
 			}
 			// ---- forward, section: outputs to tmp[i - st] ----
 			for (int i0 = st; i0 <= ed; i0 += SM_PF) {
 				double xin[SM_PF];
 #pragma unroll
 				for (int e = 0; e < SM_PF; ++e) xin[e] = f0[clampi(i0 + e - lag, 0, L - 1)];
+				if (__all(i0 + SM_PF - 1 <= ed)) {  // (whole blocks without the per-step test: all but each lane's last)
+					double *__restrict__ tp = tmp + (long long)(i0 - st) * 64 + lane;
 #pragma unroll
-				for (int e = 0; e < SM_PF; ++e) {
-					const int i = i0 + e;
-					if (i <= ed) tmp[(long long)(i - st) * 64 + lane] = step(xin[e]);
+					for (int e = 0; e < SM_PF; ++e) tp[e * 64] = step(xin[e]);
+				} else {
+#pragma unroll
+					for (int e = 0; e < SM_PF; ++e) {
+						const int i = i0 + e;
+						if (i <= ed) tmp[(long long)(i - st) * 64 + lane] = step(xin[e]);
+					}
 				}
 			}
 			// ---- forward, tail: constant xe until the outputs repeat with period 8 (or the array ends) ----
 			int pend = ed + 1;
 			{
 				double q0 = w0, q1 = w1;
-				int c = 0;
-				while (pend < n) {
-					tmp[(long long)(pend - st) * 64 + lane] = step(xe);
-					++pend;
-					if ((++c & 7) == 0) {
-						if (bits(w0) == bits(q0) && bits(w1) == bits(q1)) break;
-						q0 = w0; q1 = w1;
-					}
+				bool settled = false;
+				double *__restrict__ tp = tmp + (long long)(pend - st) * 64 + lane;
+				while (pend + 8 <= n) {
+#pragma unroll
+					for (int e = 0; e < 8; ++e) tp[e * 64] = step(xe);
+					tp += 8 * 64;
+					pend += 8;
+					if (bits(w0) == bits(q0) && bits(w1) == bits(q1)) { settled = true; break; }
+					q0 = w0; q1 = w1;
 				}
+				if (!settled)
+					for (; pend < n; ++pend) tmp[(long long)(pend - st) * 64 + lane] = step(xe);
 			}
 			// ---- backward, periodic part of the tail: j = n - 1 .. pend, input y[j] = y[pend - 8 + ((j - pend) & 7)] ----
 			w0 = w1 = 0.0;
@@ -2350,23 +2366,46 @@ __global__ __launch_bounds__(64) void hv_smooth_kernel(SmArgs a) {
 			if (j >= pend) {
 #pragma unroll
 				for (int m = 0; m < 8; ++m) per[m * 64 + lane] = tmp[(long long)(pend - 8 + m - st) * 64 + lane];
+				// single steps down to a period boundary (phase 7 next), then whole periods from registers
+				while (j >= pend && ((j - pend) & 7) != 7) { advance(per[((j - pend) & 7) * 64 + lane]); --j; }
+				double pv[8];
+#pragma unroll
+				for (int m = 0; m < 8; ++m) pv[m] = per[m * 64 + lane];
 				double p0 = w0, p1 = w1;
-				int c = 0;
 				bool periodic = false;
-				while (j >= pend) {
-					(void)step(per[((j - pend) & 7) * 64 + lane]);
-					--j;
-					if ((++c & 7) == 0) {
-						if (bits(w0) == bits(p0) && bits(w1) == bits(p1)) { periodic = true; break; }
-						p0 = w0; p1 = w1;
-					}
+				while (j - 7 >= pend) {
+#pragma unroll
+					for (int m = 7; m >= 0; --m) advance(pv[m]);
+					j -= 8;
+					if (bits(w0) == bits(p0) && bits(w1) == bits(p1)) { periodic = true; break; }
+					p0 = w0; p1 = w1;
 				}
 				if (periodic) j -= ((j - pend + 1) / 8) * 8;
-				for (; j >= pend; --j) (void)step(per[((j - pend) & 7) * 64 + lane]);
+				for (; j >= pend; --j) advance(per[((j - pend) & 7) * 64 + lane]);
 			}
 			// ---- backward, explicit tail and section: j = pend - 1 .. st ----
 			for (int j0 = j; j0 >= st; j0 -= SM_PF) {
 				double tin[SM_PF];
+				if (__all(j0 - (SM_PF - 1) >= st)) {  // (whole blocks without the per-step tests; in the tail nothing is stored either)
+					const double *__restrict__ tp = tmp + (long long)(j0 - st) * 64 + lane;
+#pragma unroll
+					for (int e = 0; e < SM_PF; ++e) tin[e] = tp[-(e * 64)];
+					if (__all(j0 - (SM_PF - 1) > ed)) {
+#pragma unroll
+						for (int e = 0; e < SM_PF; ++e) advance(tin[e]);
+					} else if (__all(j0 <= ed)) {
+						double *__restrict__ op = out + (j0 - lag);
+#pragma unroll
+						for (int e = 0; e < SM_PF; ++e) op[-e] = step(tin[e]);
+					} else {
+#pragma unroll
+						for (int e = 0; e < SM_PF; ++e) {
+							const double yv = step(tin[e]);
+							if (j0 - e <= ed) out[j0 - e - lag] = yv;
+						}
+					}
+					continue;
+				}
 #pragma unroll
 				for (int e = 0; e < SM_PF; ++e) tin[e] = (j0 - e >= st) ? tmp[(long long)(j0 - e - st) * 64 + lane] : 0.0;
 #pragma unroll
