@@ -333,6 +333,9 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 #ifndef WC_CT_WAVE_OCC
 #define WC_CT_WAVE_OCC 2
 #endif
+#ifndef WC_CT_PRELOAD
+#define WC_CT_PRELOAD 1
+#endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_CT_WAVE_OCC, WC_CT_WAVE_OCC))) void ct_wave_kernel(CtArgs a) {
 	constexpr int N = 2048, M = 1024;
 	__shared__ __attribute__((aligned(16))) double L[kWfLds];
@@ -368,6 +371,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_CT_WAVE_O
 	// values of the slot's two samples, advanced by a rotation recurrence from the exact start phases.  LOADS = 1: the group's
 	// sixteen loads (signal and draws) are issued together and fenced off from their uses, so that they are in flight at once
 	// (left alone, the scheduler waits for every one of them in turn).
+#if WC_CT_PRELOAD
+	// every live sample and draw of the window requested now: the requests are in flight while the first walk below (the window's
+	// norm: arithmetic only) runs, instead of four dependent round trips in front of the second walk's four groups
+	double xs_all[32];
+	uint32_t ns_all[32];
+#pragma unroll
+	for (int qg = 0; qg < 16; qg += 4) {
+		if (qg * 128 < wl) {
+#pragma unroll
+			for (int k = 0; k < 8; ++k) {
+				const int i = 2 * lane + 128 * (qg + (k >> 1)) + (k & 1);
+				xs_all[2 * qg + k] = x[clampi(base + i, 0, x_last)];
+				ns_all[2 * qg + k] = rng[i < wl ? i : 0];
+			}
+		}
+	}
+	WF_SCHED_FENCE();
+#endif
 	auto walk = [&](auto loads_c, auto &&body) {
 		constexpr int LOADS = decltype(loads_c)::value;
 		double ce = ce0, se = se0, co = co0, so = so0;
@@ -377,6 +398,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_CT_WAVE_O
 			double xs[8];
 			uint32_t ns[8];
 			if (LOADS) {
+#if WC_CT_PRELOAD
+#pragma unroll
+				for (int k = 0; k < 8; ++k) { xs[k] = xs_all[2 * qg + k]; ns[k] = ns_all[2 * qg + k]; }
+#else
 #pragma unroll
 				for (int k = 0; k < 8; ++k) {
 					const int i = 2 * lane + 128 * (qg + (k >> 1)) + (k & 1);
@@ -384,6 +409,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_CT_WAVE_O
 					ns[k] = rng[i < wl ? i : 0];
 				}
 				WF_SCHED_FENCE();
+#endif
 			}
 #pragma unroll
 			for (int k = 0; k < 4; ++k) {
