@@ -1253,6 +1253,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_D4C2_OCC,
 #ifndef WC_D4C2_BAND_OCC
 #define WC_D4C2_BAND_OCC 2
 #endif
+#ifndef WC_D4C2_BRACKET
+#define WC_D4C2_BRACKET 1
+#endif
+#ifndef WC_D4C2_BRACKET_FIRST
+#define WC_D4C2_BRACKET_FIRST 0x1p-14
+#endif
 // one wavefront per (gated frame, band) (reference :466-503): Nuttall-windowed group delay (<= 1023 samples) -> the two
 // halves of the 4096-point transform with pruned leading stages -> power spectrum in registers (33 keys per lane) -> the sum
 // of the K = bins - boundary - 1 smallest powers by bisecting the bit patterns (non-negative doubles order like integers):
@@ -1320,7 +1326,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_D4C2_BAND
 	mx = uniform_d(mx);
 	long long lo = -1, hi = __double_as_longlong(mx);
 	unsigned int c_lo = 0;
-	for (int it = 0; it < 64 && hi - lo > 1; ++it) {
+#if WC_D4C2_BRACKET
+	{
+		// The keys left out of the sum are the boundary + 1 largest of a smooth spectrum (the main lobe of its strongest line,
+		// mostly): they lie within a few binades of the largest one, so the search starts from a threshold 2^-14 below it where
+		// that holds (at most K keys at or below it), else from 2^-40 -- seven steps fewer than from the whole range of bit patterns.
+		auto count_le = [&](long long t) {
+			unsigned int c = (unsigned int)__popcll(__ballot(lane == 0 && __double_as_longlong(keyM) <= t));
+#pragma unroll
+			for (int s = 0; s < 16; ++s) {
+				c += (unsigned int)__popcll(__ballot(__double_as_longlong(key[0][s]) <= t));
+				c += (unsigned int)__popcll(__ballot(__double_as_longlong(key[1][s]) <= t));
+			}
+			return c;
+		};
+#pragma unroll 1
+		for (int tr = 0; tr < 2; ++tr) {
+			const long long cand = __double_as_longlong(mx * (tr == 0 ? WC_D4C2_BRACKET_FIRST : 0x1p-40));
+			const unsigned int c = count_le(cand);
+			if (c <= K && cand > 0) { lo = cand; c_lo = c; break; }
+			hi = cand > 0 && c >= K ? cand : hi;  // (more than K below: the K-th smallest is at or below cand)
+		}
+	}
+#endif
+	for (int it = 0; it < 64 && hi - lo > 1 && c_lo != K; ++it) {
 		const long long mid = lo + ((hi - lo) >> 1);
 		unsigned int c = (unsigned int)__popcll(__ballot(lane == 0 && __double_as_longlong(keyM) <= mid));
 #pragma unroll
