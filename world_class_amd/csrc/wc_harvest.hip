@@ -2528,9 +2528,15 @@ static void launch_refine(const RefArgs &fa, hipStream_t s, bool by_slots, bool 
 	}
 }
 
+// part: 3 = the whole chain; 1 = the front only (decimation .. refinement); 2 = the tail of a chain whose front an earlier call
+// with the same arguments has enqueued on the same stream (nothing is uploaded or cleared again).  bp_done: recorded behind the
+// band-pass; tail_after: the tail waits for it.  (The pipeline's two staggered chains: the first chain's tail -- a few long-lived
+// wavefronts -- starts when the second chain's band-pass is through, see wc_pipeline.hip.)
 int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const int *x_length, double *d_tpos, double *d_f0,
-			   bool full, hipEvent_t mid_event, hipEvent_t start_after) {
+			   bool full, hipEvent_t mid_event, hipEvent_t start_after, int part, hipEvent_t bp_done, hipEvent_t tail_after) {
 	Device *dev = h->dev;
+	const int phases = h->phases & part;
+	const bool resume = part == 2;
 	const int r = h->decim;
 	const int lag = (r == 1) ? 0 : static_cast<int>(std::ceil(140.0 / r) * r);
 	std::vector<HvUtt> utts(n_utt);
@@ -2616,18 +2622,21 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 		}
 		const size_t o1 = sizeof(HvUtt) * n_utt, o2 = o1 + sizeof(long long) * nb, o3 = o2 + sizeof(int) * nb + 8;
 		const size_t o3a = o3 & ~size_t(7), o4 = o3a + sizeof(long long) * nb;
-		if ((rc = h->h_stage.reserve(o4 + sizeof(int) * nb + 64))) return rc;
-		char *hs = static_cast<char *>(h->h_stage.p);
-		std::memcpy(hs, utts.data(), sizeof(HvUtt) * n_utt);
-		std::memcpy(hs + o1, ev_band_off.data(), sizeof(long long) * nb);
-		std::memcpy(hs + o2, ev_cap.data(), sizeof(int) * nb);
-		std::memcpy(hs + o3a, slot_off.data(), sizeof(long long) * nb);
-		std::memcpy(hs + o4, slot_cap.data(), sizeof(int) * nb);
-		WC_HIP(hipMemcpyAsync(h->utts.p, hs, sizeof(HvUtt) * n_utt, hipMemcpyHostToDevice, s));
+		char *hs = nullptr;
+		if (!resume) {
+			if ((rc = h->h_stage.reserve(o4 + sizeof(int) * nb + 64))) return rc;
+			hs = static_cast<char *>(h->h_stage.p);
+			std::memcpy(hs, utts.data(), sizeof(HvUtt) * n_utt);
+			std::memcpy(hs + o1, ev_band_off.data(), sizeof(long long) * nb);
+			std::memcpy(hs + o2, ev_cap.data(), sizeof(int) * nb);
+			std::memcpy(hs + o3a, slot_off.data(), sizeof(long long) * nb);
+			std::memcpy(hs + o4, slot_cap.data(), sizeof(int) * nb);
+		}
+		if (!resume) WC_HIP(hipMemcpyAsync(h->utts.p, hs, sizeof(HvUtt) * n_utt, hipMemcpyHostToDevice, s));
 		// the per-band capacity tables depend on the longest utterance and the retry flag only: a call like the one before (the usual
 		// case of a stream of equal-sized batches) finds them on the device already -- four copies less in front of the first kernel
 		const bool same_tables = h->tables_valid && h->tables_ylen == max_ylen && h->tables_full == (full ? 1 : 0) && h->tables_tiles == n_tiles;
-		if (!same_tables) {
+		if (!same_tables && !resume) {
 			WC_HIP(hipMemcpyAsync(h->d_ev_band_off.p, hs + o1, sizeof(long long) * nb, hipMemcpyHostToDevice, s));
 			WC_HIP(hipMemcpyAsync(h->d_ev_cap.p, hs + o2, sizeof(int) * nb, hipMemcpyHostToDevice, s));
 			if (!h->use_fir) {
@@ -2636,10 +2645,12 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 			}
 			h->tables_valid = true; h->tables_ylen = max_ylen; h->tables_full = full ? 1 : 0; h->tables_tiles = n_tiles;
 		}
-		if ((rc = h->h_stage.mark(s))) return rc;
-		WC_HIP(hipMemsetAsync(h->overflow.p, 0, sizeof(int), s));
+		if (!resume) {
+			if ((rc = h->h_stage.mark(s))) return rc;
+			WC_HIP(hipMemsetAsync(h->overflow.p, 0, sizeof(int), s));
+		}
 		const HvUtt *du = h->utts.as<HvUtt>();
-		if (h->phases & 1) {
+		if (phases & 1) {
 			WC_HIP(hipMemsetAsync(h->y.p, 0, sizeof(double) * yo, s));
 			if ((rc = dev->time_begin("harvest_decimate", s))) return rc;
 			if (r == 1) {
@@ -2662,8 +2673,8 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 		}
 		// a staggered twin chain holds its ALU-bound kernels back until the other chain's are through; the latency-bound
 		// decimation above may run underneath them
-		if (start_after) WC_HIP(hipStreamWaitEvent(s, start_after, 0));
-		if (h->phases & 1) {
+		if (start_after && (phases & 1)) WC_HIP(hipStreamWaitEvent(s, start_after, 0));
+		if (phases & 1) {
 		BpArgs ba;
 		ba.utts = du; ba.y = h->y.as<double>(); ba.taps = h->d_taps.as<double>(); ba.tap_off = h->d_tap_off.as<int>();
 		ba.half_len = h->d_half_len.as<int>(); ba.ev_band_off = h->d_ev_band_off.as<long long>(); ba.ev_cap = h->d_ev_cap.as<int>();
@@ -2694,10 +2705,11 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 		}
 		WC_HIP(hipGetLastError());
 		if ((rc = dev->time_end("harvest_bandpass", s))) return rc;
+		if (bp_done) WC_HIP(hipEventRecord(bp_done, s));
 		}
 	}
 	const HvUtt *du = h->utts.as<HvUtt>();
-	if (h->phases & 1) {
+	if (phases & 1) {
 	RawArgs ra;
 	ra.utts = du; ra.events = h->events.as<double>(); ra.ev_band_off = h->d_ev_band_off.as<long long>(); ra.ev_cap = h->d_ev_cap.as<int>();
 	ra.ev_count = h->ev_count.as<int>(); ra.band_f0 = h->d_band_f0.as<double>(); ra.raw = h->raw.as<double>(); ra.n_bands = nb;
@@ -2726,11 +2738,12 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 	}
 	// the ALU-bound part of this chain is enqueued: a staggered twin chain may start its own now, next to our
 	// latency-bound tail (contour logic, smoothing) and whatever the caller runs after us
-	if (mid_event) WC_HIP(hipEventRecord(mid_event, s));
-	if (!(h->phases & 2)) {
+	if (mid_event && !resume) WC_HIP(hipEventRecord(mid_event, s));
+	if (!(phases & 2)) {
 		h->last_utts = utts;
 		return WC_OK;
 	}
+	if (tail_after) WC_HIP(hipStreamWaitEvent(s, tail_after, 0));
 	if ((rc = dev->time_begin("harvest_contour", s))) return rc;  // the per-utterance tail: unreliable-candidate test, contour logic, smoothing
 	const size_t unr_lds = sizeof(double) * (size_t)(3 * UNR_F + 2) * nc + sizeof(int) * (2 * UNR_F + 2) + (size_t)UNR_F * nc;
 	hipLaunchKernelGGL(hv_unreliable_kernel, dim3((unsigned)((max_L1 + UNR_F - 1) / UNR_F), n_utt), dim3(256), unr_lds, s, du, h->cand1.as<double>(),
@@ -2783,7 +2796,7 @@ static int hv_run_device(wc_harvest *h, int n_utt, const double *d_x, const int 
 	hipStream_t s = h->dev->active();
 	int rc;
 	for (int attempt = 0; attempt < 2; ++attempt) {
-		if ((rc = hv_enqueue(h, s, n_utt, d_x, x_length, d_tpos, d_f0, attempt == 1, nullptr, nullptr))) return rc;
+		if ((rc = hv_enqueue(h, s, n_utt, d_x, x_length, d_tpos, d_f0, attempt == 1, nullptr, nullptr, 3, nullptr, nullptr))) return rc;
 		bool overflow = false;
 		if ((rc = hv_overflowed(h, s, &overflow))) return rc;
 		if (!overflow) return WC_OK;

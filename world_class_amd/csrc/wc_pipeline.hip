@@ -96,7 +96,7 @@ struct wc_pipeline {
 	wc_synthesis *sy;
 	hipStream_t s1, s1_hi, s2, s_copy, s_copy2;  // (s_copy2: the aperiodicity rows leave beside the spectrogram rows, on a DMA engine of their own)
 	hipEvent_t e_copy2[2];
-	hipEvent_t e0, e1, e2, e_copy[2], e_y[2], e_ycopy[2], e_xb;
+	hipEvent_t e0, e1, e2, e_copy[2], e_y[2], e_ycopy[2], e_xb, e_bp;
 	// host batch front-end (wc_pipeline_run_batch_host): device-resident batch + pinned staging, grow-only
 	DevBuf b_x, b_pcm, b_t, b_f, b_sp, b_ap, b_y, b_ypcm, b_coded;
 	HostBuf st_in, st_out;
@@ -177,6 +177,7 @@ wc_pipeline *wc_pipeline_create(int fs, double frame_period, double harvest_f0_f
 		ok = ok && hipEventCreateWithFlags(&p->e_ycopy[g], hipEventDisableTiming) == hipSuccess;
 	}
 	ok = ok && hipEventCreateWithFlags(&p->e_xb, hipEventDisableTiming) == hipSuccess;
+	ok = ok && hipEventCreateWithFlags(&p->e_bp, hipEventDisableTiming) == hipSuccess;
 	if (ok && p->mode == 1) {
 		for (int g = 0; g < 2 && ok; ++g) {
 			PipeGroup &G = p->grp[g];
@@ -228,6 +229,7 @@ void wc_pipeline_destroy(wc_pipeline *p) {
 	for (int g = 0; g < 2; ++g) if (p->e_y[g]) (void)hipEventDestroy(p->e_y[g]);
 	for (int g = 0; g < 2; ++g) if (p->e_ycopy[g]) (void)hipEventDestroy(p->e_ycopy[g]);
 	if (p->e_xb) (void)hipEventDestroy(p->e_xb);
+	if (p->e_bp) (void)hipEventDestroy(p->e_bp);
 	for (int g = 0; g < 2; ++g) {
 		PipeGroup &G = p->grp[g];
 		if (G.e0) (void)hipEventDestroy(G.e0);
@@ -308,12 +310,26 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 			WC_HIP(hipEventRecord(p->e1, s0));
 			WC_HIP(hipStreamWaitEvent(p->grp[1].main, p->e1, 0));
 			if (sink && sink->x_b) WC_HIP(hipStreamWaitEvent(p->grp[1].main, sink->x_b, 0));
-			// 1. both Harvest chains; B's starts when A's refinement kernel is done
+			// 1. both Harvest chains; B's front starts when A's refinement kernel is done, A's tail runs beside it.
+			// (WC_PIPELINE_TAIL_AFTER_BP=1, measured and rejected: A's tail held back until B's band-pass is through -- that kernel is one
+			// round of long-lived wavefronts, 3040 on 3072 places at three per SIMD, and the places A's tail takes push some of them into
+			// a second round, 2.6 instead of 1.8 ms.  But the tail then shares the chip with B's issue-bound raw candidates and refinement,
+			// ends later and holds up A's CheapTrick: 29.2 against 28.6 ms per batch.  Enqueued front A, chain B, tail A in that case: an
+			// event must have been recorded by the time a stream is told to wait for it.)
+			static const bool tail_late = getenv("WC_PIPELINE_TAIL_AFTER_BP") && getenv("WC_PIPELINE_TAIL_AFTER_BP")[0] == '1';
 			for (int g = 0; g < 2; ++g) {
 				PipeGroup &G = p->grp[g];
 				dev->time_tag = g;
 				if ((rc = hv_enqueue(G.hv, G.main, sl[g].nu, d_x + sl[g].xo, x_length + sl[g].u0, d_tpos + sl[g].fo, d_f0 + sl[g].fo,
-									 full[g][0], G.e_mid, g == 1 ? p->grp[0].e_mid : nullptr)))
+									 full[g][0], G.e_mid, g == 1 ? p->grp[0].e_mid : nullptr, (g == 0 && tail_late) ? 1 : 3,
+									 g == 1 ? p->e_bp : nullptr, nullptr)))
+					return rc;
+			}
+			if (tail_late) {
+				PipeGroup &G = p->grp[0];
+				dev->time_tag = 0;
+				if ((rc = hv_enqueue(G.hv, G.main, sl[0].nu, d_x + sl[0].xo, x_length + sl[0].u0, d_tpos + sl[0].fo, d_f0 + sl[0].fo,
+									 full[0][0], nullptr, nullptr, 2, nullptr, p->e_bp)))
 					return rc;
 			}
 			// 2. the rest of each chain; A's CheapTrick/D4C wait for B's refinement as well

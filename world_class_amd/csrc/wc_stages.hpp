@@ -3,8 +3,11 @@
 #pragma once
 #include "wc_internal.hpp"
 
+// part: 3 = the whole chain, 1 = its front only, 2 = the tail behind a front that an earlier call with the same arguments enqueued;
+// bp_done: recorded behind the band-pass; tail_after: the tail waits for it
 int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const int *x_length, double *d_tpos, double *d_f0,
-			   bool full, hipEvent_t mid_event, hipEvent_t start_after);
+			   bool full, hipEvent_t mid_event, hipEvent_t start_after, int part = 3, hipEvent_t bp_done = nullptr,
+			   hipEvent_t tail_after = nullptr);
 int hv_overflowed(wc_harvest *h, hipStream_t s, bool *overflow);
 // Harvest in two parts (incremental streams): phases 1 = front (decimation .. refinement), 2 = tail (unreliable .. output), 3 = both
 void hv_set_phases(wc_harvest *h, int mask);
