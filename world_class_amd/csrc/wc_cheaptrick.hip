@@ -340,6 +340,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_CT_WAVE_O
 	constexpr int N = 2048, M = 1024;
 	__shared__ __attribute__((aligned(16))) double L[kWfLds];
 	__shared__ __attribute__((aligned(16))) double T[kWfTabLds];  // the tables of the lean log / exp
+	__shared__ __attribute__((aligned(16))) double P[1026];       // the log spectrum, bins 0 .. 1024
 	const int lane = threadIdx.x;
 	const long long g = xcd_frame(blockIdx.x, a.total_frames);
 	if (g >= a.total_frames) return;
@@ -487,7 +488,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_CT_WAVE_O
 	int jg[4];
 #pragma unroll
 	for (int gq = 0; gq < 4; ++gq) jg[gq] = wf_bin(lane, gq, 0);
-	double lp[16], lpM;
 	{
 		const double width = f0c * 2.0 / 3.0;
 		const int b = __builtin_amdgcn_readfirstlane((int)(width * N / fs) + 1);  // <= 60 (ct_wave_can)
@@ -526,40 +526,40 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_CT_WAVE_O
 			odd = odd || !wf_log_ok(sm);
 			return wf_log_fast_l(sm, T);
 		};
+		// (every log value goes straight to its place in a second LDS array, the packed input of the second transform: held in
+		// registers until the segment L may be overwritten, the sixteen values per lane were spilled to scratch memory)
 #pragma unroll
 		for (int gq = 0; gq < 4; ++gq) {
 #pragma unroll
-			for (int q = 0; q < 4; ++q) lp[4 * gq + q] = smooth(jg[gq] + 256 * q, false);
+			for (int q = 0; q < 4; ++q) P[jg[gq] + 256 * q] = smooth(jg[gq] + 256 * q, false);
 			WF_SCHED_FENCE();  // (four bins at a time: interleaving all seventeen overflows the registers)
 		}
-		lpM = smooth(M, false);
+		{
+			const double lpM = smooth(M, false);
+			if (lane == 0) P[M] = lpM;
+		}
 		if (__any(odd)) {  // (never on signals with a noise floor)
 #pragma unroll
 			for (int gq = 0; gq < 4; ++gq)
 #pragma unroll
-				for (int q = 0; q < 4; ++q) lp[4 * gq + q] = smooth(jg[gq] + 256 * q, true);
-			lpM = smooth(M, true);
+				for (int q = 0; q < 4; ++q) P[jg[gq] + 256 * q] = smooth(jg[gq] + 256 * q, true);
+			const double lpM = smooth(M, true);
+			if (lane == 0) P[M] = lpM;
 		}
 		wf_fence();
 	}
 	// the mirrored log spectrum as the packed input of the second transform: sample n of slot q is 2 lane + 128 q (+ 1),
 	// samples beyond 1024 are the mirror images 2048 - n
 #pragma unroll
-	for (int gq = 0; gq < 4; ++gq)
-#pragma unroll
-		for (int q = 0; q < 4; ++q) L[jg[gq] + 256 * q] = lp[4 * gq + q];
-	if (lane == 0) L[M] = lpM;
-	wf_fence();
-#pragma unroll
 	for (int q = 0; q < 8; ++q) {
-		const double2 v = *reinterpret_cast<const double2 *>(&L[2 * lane + 128 * q]);
+		const double2 v = *reinterpret_cast<const double2 *>(&P[2 * lane + 128 * q]);
 		re[q] = v.x;
 		im[q] = v.y;
 	}
 #pragma unroll
 	for (int q = 8; q < 16; ++q) {
-		re[q] = L[2048 - 2 * lane - 128 * q];
-		im[q] = L[2047 - 2 * lane - 128 * q];
+		re[q] = P[2048 - 2 * lane - 128 * q];
+		im[q] = P[2047 - 2 * lane - 128 * q];
 	}
 	wf_fence();
 
