@@ -1265,7 +1265,8 @@ __global__ __launch_bounds__(T) void syn_pulse_kernel(SynArgs a) {
 //
 // MinimumPhaseAnalysis::compute (reference src/world_common.cpp:196-233): in: the log spectrum ls[4 g + q] of bin
 // j_g + 256 q and lsM of bin 1024 (lane 0); out: the minimum-phase spectrum (mr, mi) in the same layout, (mMr, 0) for bin 1024.
-__device__ __forceinline__ void minimum_phase_wave(const double (&ls)[16], double lsM, double (&mr)[16], double (&mi)[16], double &mMr,
+// (the caller has put the log spectrum into L itself, value by value as it formed them: L[bin], bins 0 .. 1024)
+__device__ __forceinline__ void minimum_phase_wave(double (&mr)[16], double (&mi)[16], double &mMr,
 												   double *L, const double *T, const double2 *__restrict__ tw, int lane) {
 	constexpr int N = 2048, M = 1024;
 	WC_FRESH(lane);
@@ -1273,11 +1274,6 @@ __device__ __forceinline__ void minimum_phase_wave(const double (&ls)[16], doubl
 #pragma unroll
 	for (int g = 0; g < 4; ++g) jg[g] = wf_bin(lane, g, 0);
 	// the mirrored log spectrum (reference :199-200) as the packed input of the first transform
-#pragma unroll
-	for (int g = 0; g < 4; ++g)
-#pragma unroll
-		for (int q = 0; q < 4; ++q) L[jg[g] + 256 * q] = ls[4 * g + q];
-	if (lane == 0) L[M] = lsM;
 	wf_fence();
 #pragma unroll
 	for (int q = 0; q < 8; ++q) {
@@ -1467,7 +1463,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_SYN_WAVE_
 		}
 		// the part's log spectrum from the two rows around the pulse: log(env (1 - ar) + safeguard) / 2 for the periodic part
 		// (reference :416-417), log(env ar) / 2 or, unvoiced, log(env) / 2 for the aperiodic one (:490-497)
-		double ls[16], lsM, mM;
+		double mM;
 		{
 			auto logspec = [&](double env, double ar) {
 				return wf_log_l(part == 0 ? env * (1.0 - ar) + kSafe : (vuv != 0.0 ? env * ar : env), T) / 2.0;
@@ -1487,15 +1483,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_SYN_WAVE_
 				for (int q = 0; q < 4 * WC_SYN_ROWS_G; ++q) {
 					double env, ar;
 					blend(v[q][0], v[q][1], v[q][2], v[q][3], env, ar);
-					ls[4 * g0 + q] = logspec(env, ar);
+					L[wf_bin(ln, g0 + (q >> 2), q & 3)] = logspec(env, ar);  // (straight to its place in the transform's input)
 				}
 			}
 			double env, ar;
 			blend(sf[M], sc[M], af[M], ac[M], env, ar);
-			lsM = logspec(env, ar);
+			const double lsM = logspec(env, ar);
+			if (ln == 0) L[M] = lsM;
 		}
 		SYN_STAMP(part ? 7 : 2);
-		minimum_phase_wave(ls, lsM, wr, wi, mM, L, T, a.tw, ln);
+		minimum_phase_wave(wr, wi, mM, L, T, a.tw, ln);
 		SYN_STAMP(part ? 8 : 3);
 		double yM;
 		if (part == 0) {
