@@ -1000,6 +1000,37 @@ __device__ __forceinline__ void d4c2_smooth(D4Bins &s, double width, int fs, dou
 // LONG = false: frames whose windows fit 2048 samples (F0 of 94 Hz and above at 48 kHz): a window is formed once per position,
 // parked in the frame's row and read back by both halves and both transforms; LONG = true: the others, window formed per half
 // and transform.  Every gated frame is done by exactly one of the two launches.
+// The frame's row of the group-delay array through a buffer resource: an access is one 32-bit offset register (shared by all
+// the accesses of a lane), an immediate and a scalar offset -- as plain pointers the parked layouts' offsets (up to 33 KB, beyond
+// the 4 KB immediate of a global access) made the compiler form a 64-bit vector address per access and keep dozens of them, half
+// of the kernel's scratch.  Intrinsic accesses are not forwarded through registers either: what is parked really leaves them.
+#ifndef WC_D4C2_BUFFER
+#define WC_D4C2_BUFFER 1
+#endif
+#if WC_D4C2_BUFFER
+typedef unsigned int d4_u2 __attribute__((ext_vector_type(2)));
+struct D4Row { __amdgpu_buffer_rsrc_t r; };
+__device__ __forceinline__ D4Row d4_row(double *p) {
+	D4Row w;
+	w.r = __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)(kD4Row * 8), 0x00020000);
+	return w;
+}
+__device__ __forceinline__ double d4_ld(const D4Row &w, int idx) {
+	const d4_u2 v = __builtin_amdgcn_raw_buffer_load_b64(w.r, idx * 8, 0, 0);
+	return __hiloint2double((int)v.y, (int)v.x);
+}
+__device__ __forceinline__ void d4_st(const D4Row &w, int idx, double d) {
+	d4_u2 v;
+	v.x = (unsigned)__double2loint(d);
+	v.y = (unsigned)__double2hiint(d);
+	__builtin_amdgcn_raw_buffer_store_b64(v, w.r, idx * 8, 0, 0);
+}
+#else
+struct D4Row { double *p; };
+__device__ __forceinline__ D4Row d4_row(double *p) { D4Row w; w.p = p; asm volatile("" : "+s"(w.p)); return w; }
+__device__ __forceinline__ double d4_ld(const D4Row &w, int idx) { return w.p[idx]; }
+__device__ __forceinline__ void d4_st(const D4Row &w, int idx, double d) { w.p[idx] = d; }
+#endif
 template <bool LONG>
 __device__ __forceinline__ void d4c2_frame(const D4cArgs &a, const long long g, double *L, const int lane) {
 	constexpr int M = 2048;
@@ -1025,6 +1056,7 @@ __device__ __forceinline__ void d4c2_frame(const D4cArgs &a, const long long g, 
 	// blocks of 1024) until both halves are through: nothing but the running products stays in registers across the
 	// transforms.  Every lane reads back what it wrote itself; the row's head is written for good at the end.
 	double *park = a.sgd + g * a.sgd_stride;
+	const D4Row row = d4_row(park);
 	D4_STAMP(0);
 
 	// ---- static centroid (reference :339-405): at t -+ T0/4, Re S1 Re S2 + Im S1 Im S2 of the unit-energy windowed signal and
@@ -1052,8 +1084,8 @@ __device__ __forceinline__ void d4c2_frame(const D4cArgs &a, const long long g, 
 						// (jobs 0, 1 read their window four times: its even samples wait in the LDS behind the exchange buffer,
 						// free until job 2 puts the even half's power there)
 						if (WC_D4C2_MASTER_LDS && job != 2) L[kWfLds + 64 * q + ln] = mr[q] * pw;
-						else park[2048 + 64 * q + ln] = mr[q] * pw;
-						park[3072 + 64 * q + ln] = mi[q] * pw;
+						else d4_st(row, 2048 + 64 * q + ln, mr[q] * pw);
+						d4_st(row, 3072 + 64 * q + ln, mi[q] * pw);
 					}
 				}
 				if (job == 0) D4_STAMP(1);
@@ -1062,15 +1094,13 @@ __device__ __forceinline__ void d4c2_frame(const D4cArgs &a, const long long g, 
 			auto master = [&](double (&re)[16], double (&im)[16], bool weighted) {
 				int ln = lane;
 				WC_FRESH(ln);  // (the weights below must not be hoisted out of the loop over the halves and spilled)
-				const double *pk = park;
-				asm volatile("" : "+s"(pk));  // (an opaque pointer: a real load from L2, not the stored values kept in registers)
 #pragma unroll
 				for (int q = 0; q < 16; ++q) {
 					re[q] = im[q] = 0.0;
 					if (q < 4 * ng) {
 						if (WC_D4C2_MASTER_LDS && job != 2) re[q] = L[kWfLds + 64 * q + ln];
-						else re[q] = pk[2048 + 64 * q + ln];
-						im[q] = pk[3072 + 64 * q + ln];
+						else re[q] = d4_ld(row, 2048 + 64 * q + ln);
+						im[q] = d4_ld(row, 3072 + 64 * q + ln);
 					}
 				}
 				WF_SCHED_FENCE();
@@ -1102,8 +1132,8 @@ __device__ __forceinline__ void d4c2_frame(const D4cArgs &a, const long long g, 
 					} else {
 #pragma unroll
 						for (int s = 0; s < 16; ++s) {
-							park[3072 + 64 * s + ln] = pwr[s];
-							park[2048 + 64 * s + ln] = L[kWfLds + 64 * s + ln];
+							d4_st(row, 3072 + 64 * s + ln, pwr[s]);
+							d4_st(row, 2048 + 64 * s + ln, L[kWfLds + 64 * s + ln]);
 						}
 					}
 				} else {
@@ -1115,16 +1145,14 @@ __device__ __forceinline__ void d4c2_frame(const D4cArgs &a, const long long g, 
 					for (int s = 0; s < 16; ++s) acc[s] = fma(re[s], ar[s], im[s] * ai[s]);
 					if (job == 1) {
 						double prev[16];
-						const double *pk = park;
-						asm volatile("" : "+s"(pk));
 #pragma unroll
-						for (int s = 0; s < 16; ++s) prev[s] = pk[1024 * odd + 64 * s + ln];
+						for (int s = 0; s < 16; ++s) prev[s] = d4_ld(row, 1024 * odd + 64 * s + ln);
 						WF_SCHED_FENCE();
 #pragma unroll
 						for (int s = 0; s < 16; ++s) acc[s] += prev[s];
 					}
 #pragma unroll
-					for (int s = 0; s < 16; ++s) park[1024 * odd + 64 * s + ln] = acc[s];
+					for (int s = 0; s < 16; ++s) d4_st(row, 1024 * odd + 64 * s + ln, acc[s]);
 					if (odd == 0) cenM += nyq1 * nyq2;
 					if (job == 0 && odd == 0) D4_STAMP(3);
 				}
@@ -1157,7 +1185,7 @@ __device__ __forceinline__ void d4c2_frame(const D4cArgs &a, const long long g, 
 			if (odd == 0 && job == 0) D4_STAMP(2);
 			if (job == 2) {
 #pragma unroll
-				for (int s = 0; s < 16; ++s) park[2048 + 1024 * odd + 64 * s + ln] = 0.25 * fma(re[s], re[s], im[s] * im[s]);
+				for (int s = 0; s < 16; ++s) d4_st(row, 2048 + 1024 * odd + 64 * s + ln, 0.25 * fma(re[s], re[s], im[s] * im[s]));
 				if (odd == 0) spsM = 0.25 * (nyq1 * nyq1);
 			} else {
 				double nyq2;
@@ -1181,7 +1209,7 @@ __device__ __forceinline__ void d4c2_frame(const D4cArgs &a, const long long g, 
 			}
 		}
 #pragma unroll
-		for (int s = 0; s < 16; ++s) park[1024 * odd + 64 * s + lane] = acc[s];
+		for (int s = 0; s < 16; ++s) d4_st(row, 1024 * odd + 64 * s + lane, acc[s]);
 		if (odd == 0) cenM = accM;
 		if (odd == 0) D4_STAMP(4);
 	}
@@ -1191,8 +1219,8 @@ __device__ __forceinline__ void d4c2_frame(const D4cArgs &a, const long long g, 
 	for (int p = 0; p < 2; ++p)
 #pragma unroll
 		for (int s = 0; s < 16; ++s) {
-			cen.v[p][s] = park[1024 * p + 64 * s + lane];
-			sps.v[p][s] = park[2048 + 1024 * p + 64 * s + lane];
+			cen.v[p][s] = d4_ld(row, 1024 * p + 64 * s + lane);
+			sps.v[p][s] = d4_ld(row, 2048 + 1024 * p + 64 * s + lane);
 		}
 	cen.vM = cenM;
 	sps.vM = spsM;
@@ -1216,16 +1244,15 @@ __device__ __forceinline__ void d4c2_frame(const D4cArgs &a, const long long g, 
 	}
 	// (sps: once smoothed; cen: twice)
 	D4_STAMP(9);
-	double *dst = park;
 #pragma unroll
 	for (int p = 0; p < 2; ++p)
 #pragma unroll
 		for (int gq = 0; gq < 4; ++gq) {
 			const int j = 2 * wf_j(lane, p, gq) + p;
 #pragma unroll
-			for (int q = 0; q < 4; ++q) dst[j + 512 * q] = sps.v[p][4 * gq + q] - cen.v[p][4 * gq + q];
+			for (int q = 0; q < 4; ++q) d4_st(row, j + 512 * q, sps.v[p][4 * gq + q] - cen.v[p][4 * gq + q]);
 		}
-	if (lane == 0) dst[M] = sps.vM - cen.vM;
+	if (lane == 0) d4_st(row, M, sps.vM - cen.vM);
 	D4_STAMP(10);
 }
 
