@@ -1,4 +1,5 @@
-# full evidence pass of a build: bash tools/_round.sh TAG
+# Full evidence pass of a build on the GPU box: GPU tests, bench.py in the driver-run shape, tools/profile_round.sh (all rocprofv3 passes),
+# stage-by-stage timings and the small-batch latency probe; outputs under gpurun_out/, copied into profiles/ by hand:  bash tools/evidence_round.sh TAG
 TAG=$1
 mkdir -p gpurun_out
 python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_gputest.log 2>&1; tail -3 gpurun_out/${TAG}_gputest.log
