@@ -23,7 +23,8 @@ def hooks():
         @staticmethod
         def fft(kind, x):
             x = np.ascontiguousarray(x, dtype=np.float64)
-            n_in, n_out = {0: (2048, 2050), 1: (2050, 2048), 2: (2048, 2050), 3: (4096, 4098)}[kind]
+            n_in, n_out = {0: (2048, 2050), 1: (2050, 2048), 2: (2048, 2050), 3: (4096, 4098),
+                           4: (1024, 1026), 5: (1026, 1024), 6: (1024, 1026), 7: (1024, 1026)}[kind]
             batch = x.size // n_in
             out = np.empty(batch * n_out)
             rc = L.wc_debug_wave_fft(kind, batch, x.ctypes.data_as(dp), out.ctypes.data_as(dp))
@@ -74,6 +75,42 @@ def test_wave_transforms_batched_against_numpy(hooks):
     got = hooks.fft(2, xz).reshape(batch, n // 2 + 1, 2)
     want = np.conj(np.fft.rfft(xz, axis=1))
     assert np.abs(got[..., 0] + 1j * got[..., 1] - want).max() < 1e-12
+
+
+def test_eight_points_per_lane_transforms_match_the_reference(golden, hooks):
+    """the 1024-point real transforms of CheapTrick / Synthesis at 16 and 24 kHz: 512 complex points, eight per lane (wf8_*)"""
+    n = 1024
+    x = golden[f"fft/r2c_in_{n}"]
+    want = golden[f"fft/r2c_out_{n}"]
+    got = hooks.fft(4, x).reshape(n // 2 + 1, 2)
+    assert np.abs(got - want).max() < 1e-13 * np.abs(want).max()
+    assert got[0, 1] == 0.0 and got[-1, 1] == 0.0
+    X = (want[:, 0] + 1j * want[:, 1]) * (1 + 0.5j)
+    back = hooks.fft(5, np.stack([X.real, X.imag], 1))[0]
+    want_back = golden[f"fft/c2r_out_{n}"]
+    assert np.abs(back - want_back).max() < 1e-13 * np.abs(want_back).max()
+
+
+def test_eight_points_per_lane_transforms_batched_against_numpy(hooks):
+    rng = np.random.default_rng(17)
+    batch, n = 41, 1024
+    x = rng.standard_normal((batch, n))
+    got = hooks.fft(4, x).reshape(batch, n // 2 + 1, 2)
+    want = np.conj(np.fft.rfft(x, axis=1))
+    assert np.abs(got[..., 0] + 1j * got[..., 1] - want).max() < 1e-12
+    Y = rng.standard_normal((batch, n // 2 + 1)) + 1j * rng.standard_normal((batch, n // 2 + 1))
+    back = hooks.fft(5, np.stack([Y.real, Y.imag], 2))
+    Yh = Y.copy()
+    Yh[:, 0] = Yh[:, 0].real
+    Yh[:, -1] = Yh[:, -1].real
+    want_back = np.fft.irfft(np.conj(Yh), n=n, axis=1) * n
+    assert np.abs(back - want_back).max() < 1e-12 * np.abs(want_back).max()
+    for kind, live in ((6, n // 4), (7, n // 2)):  # the pruned leading stages
+        xz = x.copy()
+        xz[:, live:] = 0.0
+        got = hooks.fft(kind, xz).reshape(batch, n // 2 + 1, 2)
+        want = np.conj(np.fft.rfft(xz, axis=1))
+        assert np.abs(got[..., 0] + 1j * got[..., 1] - want).max() < 1e-12
 
 
 def test_two_wavefront_transform_of_4096_points(golden, hooks):

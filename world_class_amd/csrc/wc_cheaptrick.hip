@@ -619,13 +619,280 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_CT_WAVE_O
 	if (lane == 0) out[M] = last;
 }
 
+
+// ---- one wavefront per frame at N = 1024 (16 / 22.05 / 24 kHz) ------------------------------------------------------------------
+// ct_wave_kernel at EIGHT complex points per lane on the 512-point transforms wf8_* (wc_wavefft.hpp): half the registers (four
+// wavefronts per SIMD instead of two), 7.7 KB of LDS.  The arithmetic is the wavefront kernel's, statement for statement; the
+// log spectrum waits in registers (eight values per lane fit) until the smoothing segment may be overwritten.
+#ifndef WC_CT_WAVE8_OCC
+#define WC_CT_WAVE8_OCC 4
+#endif
+constexpr int kCt8Lds = 640;  // doubles: the mirrored segment's 513 + 2 b + 1 terms, b <= 60 (ct_wave_can<1024>); the exchange buffer is its head
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_CT_WAVE8_OCC, WC_CT_WAVE8_OCC))) void ct_wave8_kernel(CtArgs a) {
+	constexpr int N = 1024, M = 512;
+	__shared__ __attribute__((aligned(16))) double L[kCt8Lds];
+	__shared__ __attribute__((aligned(16))) double T[kWfTabLds];  // the tables of the lean log / exp
+	const int lane = threadIdx.x;
+	const long long g = xcd_frame(blockIdx.x, a.total_frames);
+	if (g >= a.total_frames) return;
+	const int fs = a.fs;
+	const double f0v = a.f0[g];
+	const double f0c = uniform_d((f0v <= a.f0_floor) ? 500.0 : f0v);  // reference :77
+	if (!ct_wave_can<N>(f0c, fs)) return;
+	const UttDesc ud = a.utts[a.uidx[g]];
+	const double *__restrict__ x = a.x + ud.x_off;
+	const int x_last = ud.x_len - 1;
+	const double pos = a.tpos[g];
+	const uint32_t *__restrict__ rng = a.rng_table + (a.rng_off[g] - a.rng_base);
+	wf_tables_to_lds(T, a.tw, lane);
+
+	// ---- F0-adaptive window (reference :137-196): window sample i of slot q is 2 lane + 128 q (+ 1) ----
+	const int hw = __builtin_amdgcn_readfirstlane(mround(1.5 * fs / f0c));
+	const int wl = 2 * hw + 1;
+	const int base = __builtin_amdgcn_readfirstlane(mround(pos * fs + 0.001)) - hw;  // signal index of window sample 0
+	double ce0, se0, co0, so0, cd, sd;
+	{
+		const double kappa = f0c / 1.5 / fs;  // angle per sample in units of pi
+		wf_sincospi(kappa * (2 * lane - hw), se0, ce0);
+		wf_sincospi(kappa * (2 * lane + 1 - hw), so0, co0);
+		wf_sincospi(kappa * 128.0, sd, cd);
+		sd = uniform_d(sd);
+		cd = uniform_d(cd);
+	}
+	// every live sample and draw of the window requested now (see ct_wave_kernel)
+	double xs_all[16];
+	uint32_t ns_all[16];
+#pragma unroll
+	for (int qg = 0; qg < 8; qg += 4) {
+		if (qg * 128 < wl) {
+#pragma unroll
+			for (int k = 0; k < 8; ++k) {
+				const int i = 2 * lane + 128 * (qg + (k >> 1)) + (k & 1);
+				xs_all[2 * qg + k] = x[clampi(base + i, 0, x_last)];
+				ns_all[2 * qg + k] = rng[i < wl ? i : 0];
+			}
+		}
+	}
+	WF_SCHED_FENCE();
+	auto walk = [&](auto loads_c, auto &&body) {
+		constexpr int LOADS = decltype(loads_c)::value;
+		double ce = ce0, se = se0, co = co0, so = so0;
+#pragma unroll
+		for (int qg = 0; qg < 8; qg += 4) {
+			if (qg * 128 >= wl) break;
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const int q = qg + k, i0 = 2 * lane + 128 * q;
+				const double We = (i0 < wl) ? fma(0.5, ce, 0.5) : 0.0;
+				const double Wo = (i0 + 1 < wl) ? fma(0.5, co, 0.5) : 0.0;
+				body(q, i0, We, Wo, LOADS ? xs_all[2 * q] : 0.0, LOADS ? xs_all[2 * q + 1] : 0.0, LOADS ? ns_all[2 * q] : 0u, LOADS ? ns_all[2 * q + 1] : 0u);
+				const double cen = fma(ce, cd, -(se * sd)), con = fma(co, cd, -(so * sd));
+				se = fma(se, cd, ce * sd);
+				so = fma(so, cd, co * sd);
+				ce = cen;
+				co = con;
+			}
+		}
+	};
+	double re[8], im[8];
+#pragma unroll
+	for (int q = 0; q < 8; ++q) re[q] = im[q] = 0.0;
+	double ssq = 0.0;
+	walk(std::integral_constant<int, 0>(), [&](int, int, double We, double Wo, double, double, uint32_t, uint32_t) { ssq = fma(Wo, Wo, fma(We, We, ssq)); });
+	ssq = wave_sum_all(ssq);
+	const double hr = 0.5 * (1.0 / sqrt(ssq));  // half the window norm: the transform below then yields X, not 2 X
+	double s1 = 0.0, s2 = 0.0;
+	walk(std::integral_constant<int, 1>(), [&](int q, int i0, double We, double Wo, double xe, double xo, uint32_t re_, uint32_t ro_) {
+		const bool le = i0 < wl, lo = i0 + 1 < wl;
+		const double we = We * hr, wo = Wo * hr;
+		const double ne = (re_ / 268435456.0 - 6.0) * (0.5 * 0.000000000000001);
+		const double no = (ro_ / 268435456.0 - 6.0) * (0.5 * 0.000000000000001);
+		re[q] = le ? fma(xe, we, ne) : 0.0;
+		im[q] = lo ? fma(xo, wo, no) : 0.0;
+		s1 += re[q] + im[q];
+		s2 += we + wo;
+	});
+	s1 = wave_sum_all(s1);
+	s2 = wave_sum_all(s2);
+	const double wc = s1 / s2;
+	walk(std::integral_constant<int, 0>(), [&](int q, int, double We, double Wo, double, double, uint32_t, uint32_t) {
+		re[q] = fma(-(We * hr), wc, re[q]);
+		im[q] = fma(-(Wo * hr), wc, im[q]);
+	});
+
+	// ---- power spectrum (reference :198-218) ----
+	if (wl <= 256) wdft8p<+1, 1>(re, im);
+	else if (wl <= 512) wdft8p<+1, 2>(re, im);
+	else wdft8p<+1, 4>(re, im);
+	wf8_fft512_dit_rest<+1>(re, im, L, a.tw, lane);
+	double pw[8], pwM;
+	{
+		double nyq;
+		wf8_r2c_unpack(re, im, nyq, a.tw, lane);
+#pragma unroll
+		for (int s = 0; s < 8; ++s) pw[s] = fma(re[s], re[s], im[s] * im[s]);
+		pwM = nyq * nyq;
+	}
+	int jg[2];
+#pragma unroll
+	for (int gq = 0; gq < 2; ++gq) jg[gq] = wf8_bin(lane, gq, 0);
+	// DC correction (reference src/world_common.cpp:61-80): bins below upper - 1 <= 119, i.e. slot 0 (bin lane) and slot 4 (bins
+	// 64 .. 127), from bins <= upper + 1
+	{
+		const int upper = __builtin_amdgcn_readfirstlane(2 + (int)(f0c * N / fs));
+		const double dx = -(double)fs / N, rdx = 1.0 / dx;
+		L[lane] = pw[0];
+		L[jg[1]] = pw[4];
+		wf_fence();
+		auto rep = [&](int i) {
+			const double axis = (double)i * fs / N;
+			return interp1q_rcp(f0c, dx, rdx, [&](int b) { return L[min(max(b, 0), 127)]; }, upper + 1, axis);
+		};
+		if (lane < upper - 1) pw[0] += rep(lane);
+		if (upper - 1 > 64) {
+			if (jg[1] < upper - 1) pw[4] += rep(jg[1]);
+		}
+		wf_fence();
+	}
+
+	// ---- linear smoothing, width 2 f0 / 3 (reference src/world_common.cpp:27-52, :82-116), infinitesimal noise, log ----
+	double lp[8], lpM;
+	{
+		const double width = f0c * 2.0 / 3.0;
+		const int b = __builtin_amdgcn_readfirstlane((int)(width * N / fs) + 1);  // <= 60 (ct_wave_can)
+		const int len = M + 2 * b + 1;
+		// mirrored segment (reference src/world_common.cpp:33-44): position i holds bin b - i (i < b), bin i - b (b <= i < M + b),
+		// bin 2 M + b - i (M + b <= i <= M + 2 b).  The low mirror comes from slot 0 (bins 1 .. b of lanes 1 .. b), the high one
+		// from slot 7 (bins 512 - lane); bin 512 itself sits at M + b.
+#pragma unroll
+		for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+			for (int q = 0; q < 4; ++q) L[jg[gq] + 128 * q + b] = pw[4 * gq + q] * fs * (1.0 / N);
+		if (lane == 0) L[M + b] = pwM * fs * (1.0 / N);
+		if (lane >= 1 && lane <= b) {
+			L[b - lane] = pw[0] * fs * (1.0 / N);
+			L[M + b + lane] = pw[7] * fs * (1.0 / N);
+		}
+		wf_fence();
+		seq_cumsum_nonneg_wave<10>(L, len, lane);
+		const double step = (double)fs / N;
+		const double origin_axis = -(b - 0.5) * fs / N;
+		const double rstep = 1.0 / step;
+		const double rwidth = 1.0 / width;
+		const uint32_t *__restrict__ rngb = rng + wl;
+		bool odd = false;  // a smoothed value that is not a positive finite number (the reference then takes log of it all the same)
+		auto smooth = [&](int k, bool slow) {
+			// (the two abscissae in the reference's own per-bin arithmetic: see ct_wave_kernel)
+			const double lo_axis = (double)k / N * fs - width / 2.0, hi_axis = lo_axis + width;
+			const double lo_v = wf_interp1q(origin_axis, step, rstep, L, len, lo_axis);
+			const double hi_v = wf_interp1q(origin_axis, step, rstep, L, len, hi_axis);
+			double sm = (hi_v - lo_v) * rwidth;
+			// infinitesimal noise (reference :220-228) then log (reference :251-252)
+			sm = fma(fabs(randn_at(rngb, k)), 0.00000000000000022204460492503131, sm);
+			if (slow) return wf_log_libm(sm);
+			odd = odd || !wf_log_ok(sm);
+			return wf_log_fast_l(sm, T);
+		};
+#pragma unroll
+		for (int gq = 0; gq < 2; ++gq) {
+#pragma unroll
+			for (int q = 0; q < 4; ++q) lp[4 * gq + q] = smooth(jg[gq] + 128 * q, false);
+			WF_SCHED_FENCE();  // (four bins at a time)
+		}
+		lpM = smooth(M, false);
+		if (__any(odd)) {  // (never on signals with a noise floor)
+			// (bins from an opaque copy of the lane index: otherwise every address and fraction of the pass above is kept -- spilled --
+			// for this one to reuse)
+			int ln = lane, km = M;
+			WC_FRESH(ln);
+			WC_FRESH(km);
+#pragma unroll
+			for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+				for (int q = 0; q < 4; ++q) lp[4 * gq + q] = smooth(wf8_bin(ln, gq, q), true);
+			lpM = smooth(km, true);
+		}
+		wf_fence();
+	}
+	// the mirrored log spectrum as the packed input of the second transform: sample n of slot q is 2 lane + 128 q (+ 1),
+	// samples beyond 512 are the mirror images 1024 - n; through L (the segment has been read)
+#pragma unroll
+	for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+		for (int q = 0; q < 4; ++q) L[jg[gq] + 128 * q] = lp[4 * gq + q];
+	if (lane == 0) L[M] = lpM;
+	wf_fence();
+#pragma unroll
+	for (int q = 0; q < 4; ++q) {
+		const double2 v = *reinterpret_cast<const double2 *>(&L[2 * lane + 128 * q]);
+		re[q] = v.x;
+		im[q] = v.y;
+	}
+#pragma unroll
+	for (int q = 4; q < 8; ++q) {
+		re[q] = L[1024 - 2 * lane - 128 * q];
+		im[q] = L[1023 - 2 * lane - 128 * q];
+	}
+	wf_fence();
+
+	// ---- smoothing + recovery lifters in the cepstral domain (reference :230-276) ----
+	wf8_fft512_dit<+1>(re, im, L, a.tw, lane);
+	double yM;
+	{
+		double nyq;
+		wf8_r2c_unpack_re(re, im, nyq, a.tw, lane);  // 2 X, real
+		// lifters (see ct_wave_kernel); (cos, sin) of theta = pi f0 k / fs for every slot's bin by rotations from two exact sincos:
+		// E_t (the lane) and E_64, E_128 = E_64^2; slot c = E_t E_128^c, slot 4 + c = E_128^{c+1} conj(E_t) (lane 0: E_64 E_128^c)
+		const double q1 = a.q1;
+		const double ralpha = 1.0 / (kPi * f0c / fs);
+		const double scale = 0.5 / N;  // the halving left over from the unpacking and the reference's / fft_size
+		double ct, st, c64, s64;
+		wf_sincospi(f0c / fs * lane, st, ct);
+		wf_sincospi(f0c / fs * 64.0, s64, c64);
+		const double c128 = uniform_d(fma(-2.0 * s64, s64, 1.0)), s128 = uniform_d(2.0 * s64 * c64);
+		double ec[2], es[2];
+		ec[0] = ct; es[0] = st;
+		ec[1] = lane ? fma(c128, ct, s128 * st) : c64; es[1] = lane ? fma(s128, ct, -(c128 * st)) : s64;
+		const double cl0 = 1.0 - 2.0 * q1, cl1 = 2.0 * q1;
+		auto lift = [&](double v, double sn, int k) {
+			const double sl = sn * (ralpha * tw_load_d(a.tw + kTwInvK, k));
+			const double cl = fma(cl1, fma(-2.0 * sn, sn, 1.0), cl0);
+			return v * sl * cl * scale;
+		};
+#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+#pragma unroll
+			for (int gq = 0; gq < 2; ++gq) {
+				const int k = jg[gq] + 128 * q;
+				double v = lift(re[4 * gq + q], es[gq], k);
+				if (gq == 0 && q == 0) v = (lane == 0) ? re[0] * (cl0 + cl1) * scale : v;  // k = 0: sinc = 1
+				re[4 * gq + q] = v;
+				const double cn = fma(ec[gq], c128, -(es[gq] * s128));
+				es[gq] = fma(es[gq], c128, ec[gq] * s128);
+				ec[gq] = cn;
+			}
+		}
+		yM = lift(nyq, es[0], M);  // lane 0: slot 3 advanced once more is bin 512
+	}
+	wf8_c2r_pack_re(re, im, yM, a.tw, lane);
+	wf8_fft512_dif<-1>(re, im, L, a.tw, lane);
+	double *__restrict__ out = a.sp + g * (long long)(M + 1);
+#pragma unroll
+	for (int q = 0; q < 4; ++q) {
+		out[2 * lane + 128 * q] = wf_exp_l(re[q], T);
+		out[2 * lane + 128 * q + 1] = wf_exp_l(im[q], T);
+	}
+	const double last = wf_exp_l(re[4], T);
+	if (lane == 0) out[M] = last;
+}
+
 }  // namespace wc
 
 using namespace wc;
 
 struct wc_cheaptrick {
 	int fs, fft_size;
-	bool wave;  // N = 2048: one wavefront per frame (default; WC_CT_IMPL=block: the workgroup-per-frame kernel for every frame)
+	bool wave;  // N = 2048 / 1024: one wavefront per frame (default; WC_CT_IMPL=block: the workgroup-per-frame kernel for every frame)
 	double q1, f0_floor_opt, f0_floor;
 	Device *dev;
 	DevBuf utts, cnt, uidx, off, endpos, d_x, d_tpos, d_f0, d_sp;
@@ -711,7 +978,19 @@ int ct_frames(wc_cheaptrick *c, hipStream_t s, int n_utt, const double *d_x, con
 	a.rare_only = 0;
 	switch (c->fft_size) {
 		case 512: launch_ct<512>(a, s); break;
-		case 1024: launch_ct<1024>(a, s); break;
+		case 1024:
+			if (c->wave) {
+				// one wavefront per frame at eight points per lane; the frames it leaves out (ct_wave_can<1024>) by the block kernel
+				// behind it on the same stream (none for a contour out of Harvest: no second launch)
+				hipLaunchKernelGGL(ct_wave8_kernel, dim3((unsigned)(((total + 7) / 8) * 8)), dim3(64), 0, s, a);
+				if (!(c->f0_bound > 0.0 && ct_wave_can<1024>(c->f0_bound, c->fs))) {
+					a.rare_only = 1;
+					hipLaunchKernelGGL((ct_frames_kernel<1024, 128, true>), dim3(256), dim3(128), 0, s, a);
+				}
+			} else {
+				launch_ct<1024>(a, s);
+			}
+			break;
 		case 2048:
 			if (c->wave) {
 				// one wavefront per frame; the frames it leaves out (F0 above ~2 kHz, ct_wave_can) are found and done by a

@@ -261,6 +261,12 @@ Device *current_device() {
 			for (int j = 0; j < 256; ++j) tw[kTwP3 + 256 * (r - 1) + j] = tw[(4 * r * j) % kTwiddleN];
 		for (int n = 0; n <= 1024; ++n) tw[kTwU + n] = tw[2 * n];
 		for (int j = 0; j < 1024; ++j) tw[kTwUo + j] = tw[2 * j + 1];
+		// the 512-point transform at eight points per lane (wf8_*)
+		for (int n1 = 0; n1 < 8; ++n1)
+			for (int ka = 0; ka < 8; ++ka) tw[kTw8A + 8 * n1 + ka] = tw[(64 * n1 * ka) % kTwiddleN];
+		for (int kb = 0; kb < 8; ++kb)
+			for (int t = 0; t < 64; ++t) tw[kTw8B + 64 * kb + t] = tw[(8 * (t & 7) * ((t >> 3) + 8 * kb)) % kTwiddleN];
+		for (int n = 0; n <= 512; ++n) tw[kTw8U + n] = tw[4 * n];
 		for (int i = 0; i < 128; ++i) {
 			const double c = 0.5 + (i + 0.5) / 256.0, invc = 1.0 / c;
 			tw[kTwLog + i] = make_double2(invc, (double)-logl((long double)invc));

@@ -129,6 +129,55 @@ __global__ __launch_bounds__(64) void hook_wave_fft_kernel(const double *__restr
 		}
 	}
 }
+// The same at eight points per lane: a 1024-point real transform per 64-thread workgroup (wf8_*).
+// KIND 0: r2c (in 1024 doubles, out 513 complex); 1: c2r (in 513 complex, out 1024 doubles, unnormalised); 2 / 3: r2c with
+// the input zero beyond its first quarter / half, through the pruned leading stage
+template <int KIND>
+__global__ __launch_bounds__(64) void hook_wave8_fft_kernel(const double *__restrict__ in, double *__restrict__ out,
+															 const double2 *__restrict__ tw) {
+	__shared__ __attribute__((aligned(16))) double L[kWf8Lds];
+	const int lane = threadIdx.x;
+	double re[8], im[8];
+	if constexpr (KIND != 1) {
+		const double *x = in + (size_t)blockIdx.x * 1024;
+		double2 *X = reinterpret_cast<double2 *>(out) + (size_t)blockIdx.x * 513;
+#pragma unroll
+		for (int q = 0; q < 8; ++q) {
+			re[q] = x[2 * (lane + 64 * q)];
+			im[q] = x[2 * (lane + 64 * q) + 1];
+		}
+		if constexpr (KIND == 2) wdft8p<+1, 1>(re, im);
+		else if constexpr (KIND == 3) wdft8p<+1, 2>(re, im);
+		else wdft8p<+1, 4>(re, im);
+		wf8_fft512_dit_rest<+1>(re, im, L, tw, lane);
+		double nyq;
+		wf8_r2c_unpack(re, im, nyq, tw, lane);
+#pragma unroll
+		for (int g = 0; g < 2; ++g)
+#pragma unroll
+			for (int q = 0; q < 4; ++q) X[wf8_bin(lane, g, q)] = make_double2(0.5 * re[4 * g + q], 0.5 * im[4 * g + q]);
+		if (lane == 0) X[512] = make_double2(0.5 * nyq, 0.0);
+	} else {
+		const double2 *Y = reinterpret_cast<const double2 *>(in) + (size_t)blockIdx.x * 513;
+		double *y = out + (size_t)blockIdx.x * 1024;
+#pragma unroll
+		for (int g = 0; g < 2; ++g)
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				const double2 v = Y[wf8_bin(lane, g, q)];
+				re[4 * g + q] = v.x;
+				im[4 * g + q] = v.y;
+			}
+		const double nyq = Y[512].x;
+		wf8_c2r_pack(re, im, nyq, tw, lane);
+		wf8_fft512_dif<-1>(re, im, L, tw, lane);
+#pragma unroll
+		for (int q = 0; q < 8; ++q) {
+			y[2 * (lane + 64 * q)] = re[q];
+			y[2 * (lane + 64 * q) + 1] = im[q];
+		}
+	}
+}
 // 4096-point real transform by two wavefronts (one 128-thread workgroup): in 4096 doubles, out 2049 complex
 __global__ __launch_bounds__(128) void hook_wave2_r2c_kernel(const double *__restrict__ in, double *__restrict__ out,
 															 const double2 *__restrict__ tw) {
@@ -268,13 +317,15 @@ int wc_debug_seq_cumsum(const double *v, int n, int batch, int threads, double *
 // 2048-point real transforms by one wavefront each (wc_wavefft.hpp).  kind 0 r2c, 1 c2r, 2 r2c of an input whose last
 // three quarters are zero (pruned leading stage); host pointers; doubles in 2048 / 2050 / 2048, out 2050 / 2048 / 2050.
 int wc_debug_wave_fft(int kind, int batch, const double *in, double *out) {
-	if (kind < 0 || kind > 3 || batch <= 0 || !in || !out) return fail(WC_ERR_INVALID, "debug wave fft: bad argument");
+	if (kind < 0 || kind > 7 || batch <= 0 || !in || !out) return fail(WC_ERR_INVALID, "debug wave fft: bad argument");
 	Device *dev = current_device();
 	if (!dev) return WC_ERR_DEVICE;
 	DeviceLock lock(dev);
 	hipStream_t s = dev->active();
-	// (kind 3: the 4096-point r2c by two wavefronts, 4096 doubles in, 4098 out)
-	const size_t n_in = (kind == 3 ? 4096 : kind == 1 ? 2050 : 2048) * (size_t)batch, n_out = (kind == 3 ? 4098 : kind == 1 ? 2048 : 2050) * (size_t)batch;
+	// (kind 3: the 4096-point r2c by two wavefronts, 4096 doubles in, 4098 out; kinds 4 .. 7: the 1024-point transforms at eight
+	// points per lane -- r2c, c2r, r2c pruned to a quarter / a half: 1024 / 1026 / 1024 / 1024 doubles in, 1026 / 1024 / 1026 / 1026 out)
+	const size_t n_in = (kind >= 4 ? (kind == 5 ? 1026 : 1024) : kind == 3 ? 4096 : kind == 1 ? 2050 : 2048) * (size_t)batch;
+	const size_t n_out = (kind >= 4 ? (kind == 5 ? 1024 : 1026) : kind == 3 ? 4098 : kind == 1 ? 2048 : 2050) * (size_t)batch;
 	Scoped d_in, d_out;
 	WC_HIP(hipMalloc(&d_in.p, sizeof(double) * n_in));
 	WC_HIP(hipMalloc(&d_out.p, sizeof(double) * n_out));
@@ -284,7 +335,11 @@ int wc_debug_wave_fft(int kind, int batch, const double *in, double *out) {
 	if (kind == 0) hipLaunchKernelGGL(hook_wave_fft_kernel<0>, dim3(batch), dim3(64), 0, s, di, dout, dev->twiddle);
 	else if (kind == 1) hipLaunchKernelGGL(hook_wave_fft_kernel<1>, dim3(batch), dim3(64), 0, s, di, dout, dev->twiddle);
 	else if (kind == 2) hipLaunchKernelGGL(hook_wave_fft_kernel<2>, dim3(batch), dim3(64), 0, s, di, dout, dev->twiddle);
-	else hipLaunchKernelGGL(hook_wave2_r2c_kernel, dim3(batch), dim3(128), 0, s, di, dout, dev->twiddle);
+	else if (kind == 3) hipLaunchKernelGGL(hook_wave2_r2c_kernel, dim3(batch), dim3(128), 0, s, di, dout, dev->twiddle);
+	else if (kind == 4) hipLaunchKernelGGL(hook_wave8_fft_kernel<0>, dim3(batch), dim3(64), 0, s, di, dout, dev->twiddle);
+	else if (kind == 5) hipLaunchKernelGGL(hook_wave8_fft_kernel<1>, dim3(batch), dim3(64), 0, s, di, dout, dev->twiddle);
+	else if (kind == 6) hipLaunchKernelGGL(hook_wave8_fft_kernel<2>, dim3(batch), dim3(64), 0, s, di, dout, dev->twiddle);
+	else hipLaunchKernelGGL(hook_wave8_fft_kernel<3>, dim3(batch), dim3(64), 0, s, di, dout, dev->twiddle);
 	WC_HIP(hipGetLastError());
 	WC_HIP(hipMemcpyAsync(out, d_out.p, sizeof(double) * n_out, hipMemcpyDeviceToHost, s));
 	WC_HIP(hipStreamSynchronize(s));

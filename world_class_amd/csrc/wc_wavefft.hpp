@@ -156,7 +156,11 @@ constexpr int kTwInvK = kTwExp + 32;      // 1040 doubles 1 / k (k = 0: 0)
 constexpr int kTwP3 = kTwInvK + 520;      // 3 x 256 entries: W_1024^{r j} at [256 (r - 1) + j], j < 256 (radix-4 stage)
 constexpr int kTwU = kTwP3 + 768;         // 1040 entries: W_2048^n, n <= 1024 (real-transform unpacking; the odd half's twist)
 constexpr int kTwUo = kTwU + 1040;        // 1024 entries: W_4096^{2 j + 1} (unpacking of the odd half of a 4096-point transform)
-constexpr int kTwTotal = kTwUo + 1024;    // double2 entries of the whole table
+// tables of the 512-point transform at eight points per lane (wf8_*, below)
+constexpr int kTw8A = kTwUo + 1024;       // 64 entries: W_64^{n1 ka} at [8 n1 + ka] (second stage)
+constexpr int kTw8B = kTw8A + 64;         // 512 entries: W_512^{(t & 7) ((t >> 3) + 8 kb)} at [64 kb + t] (third stage)
+constexpr int kTw8U = kTw8B + 512;        // 528 entries: W_1024^n, n <= 512 (real-transform unpacking)
+constexpr int kTwTotal = kTw8U + 528;     // double2 entries of the whole table
 
 // Left alone, the scheduler puts every twiddle load right in front of its use (load, wait ~500 cycles, use, 15 times per
 // stage: measured, the transforms ran five times slower than their arithmetic).  The loads of a stage are therefore issued
@@ -1106,6 +1110,241 @@ __device__ __forceinline__ void wf_sincospi(double x, double &sn, double &cs) {
 	const double a = (q & 1) ? c : s, b = (q & 1) ? s : c;
 	sn = (q & 2) ? -a : a;
 	cs = ((q + 1) & 2) ? -b : b;
+}
+
+// ======== 512-point complex transform at EIGHT points per lane (CheapTrick / Synthesis at N = 1024: 16 and 24 kHz) ==========
+// The same construction one size down: 8 x 8 x 8 with two LDS exchanges and no barrier, half the registers of the 1024-point
+// transform (four wavefronts per SIMD instead of two).  A radix-8 last stage would leave bin k and bin 512 - k in different
+// lanes (k = j + 64 c is closed under negation only for j = 0, 32), so the last stage is split: a lane takes the EVEN outputs
+// of butterfly j = t and the ODD outputs of butterfly j' = 64 - t (lane 0: j' = 0), each a 4-point transform of sums /
+// differences of the butterfly's eight inputs -- the arithmetic of one radix-8 butterfly, twice its inputs read.  All twiddles
+// are applied on the strided side of the second exchange, so the paired side only meets eighth roots of unity and no lane
+// is special.  Layouts (t = lane, n0 = t & 7, n1 = t >> 3):
+//   strided   slot q (0..7) holds element t + 64 q
+//   paired8   slot c (0..3) holds element t + 128 c, slot 4 + c holds element 128 - t + 128 c (lane 0: 64 + 128 c): element k
+//             and element 512 - k share a lane (slot c with slot 7 - c; lane 0 pairs slot 1 with 3, 4 with 7, 5 with 6 and
+//             keeps the self-paired 0 and 256 in slots 0 and 2) -- the first two groups of the 1024-point "paired" layout
+// LDS: 576 doubles.  Exchange 1: strided side t + 72 ka, middle side n0 + 72 ka + 8 n1; exchange 2: middle side P n0 + j
+// (j = ka + 8 kb), paired side P m + t and P m + j'; P = 66 going to the paired layout, 68 coming from it (where rows
+// 0..3 hold the even-half sums and rows 4..7 the odd-half ones): every access is conflict-free for its instruction's lane
+// groups (ds_read_b64 32 lanes over 32 double-banks, ds_write_b64 16 lanes over 16).
+constexpr int kWf8Lds = 576;
+
+// 8-point DFT with only the first 2 NG inputs non-zero (NG = 4: all)
+template <int S, int NG>
+__device__ __forceinline__ void wdft8p(double (&xr)[8], double (&xi)[8]) {
+	if constexpr (NG >= 3) {
+		wdft8<S>(xr, xi);
+	} else {
+		if constexpr (NG == 2) {
+			wdft4_2<S>(xr[0], xi[0], xr[2], xi[2], xr[4], xi[4], xr[6], xi[6]);
+			wdft4_2<S>(xr[1], xi[1], xr[3], xi[3], xr[5], xi[5], xr[7], xi[7]);
+		} else {
+			xr[2] = xr[4] = xr[6] = xr[0]; xi[2] = xi[4] = xi[6] = xi[0];
+			xr[3] = xr[5] = xr[7] = xr[1]; xi[3] = xi[5] = xi[7] = xi[1];
+		}
+		{ const double x = xr[3], y = xi[3]; xr[3] = kH * (S > 0 ? x - y : x + y); xi[3] = kH * (S > 0 ? x + y : y - x); }
+		{ const double x = xr[5], y = xi[5]; xr[5] = S > 0 ? -y : y; xi[5] = S > 0 ? x : -x; }
+		{ const double x = xr[7], y = xi[7]; xr[7] = S > 0 ? -kH * (x + y) : kH * (y - x); xi[7] = S > 0 ? kH * (x - y) : -kH * (x + y); }
+		double tr[8], ti[8];
+#pragma unroll
+		for (int c = 0; c < 4; ++c) {
+			tr[c] = xr[2 * c] + xr[2 * c + 1]; ti[c] = xi[2 * c] + xi[2 * c + 1];
+			tr[c + 4] = xr[2 * c] - xr[2 * c + 1]; ti[c + 4] = xi[2 * c] - xi[2 * c + 1];
+		}
+#pragma unroll
+		for (int q = 0; q < 8; ++q) { xr[q] = tr[q]; xi[q] = ti[q]; }
+	}
+}
+template <int WS, int RS>
+__device__ __forceinline__ void wf8_xchg(double (&v)[8], double *lds, int wbase, int rbase) {
+#pragma unroll
+	for (int q = 0; q < 8; ++q) lds[wbase + q * WS] = v[q];
+	wf_fence();
+#pragma unroll
+	for (int r = 0; r < 8; ++r) v[r] = lds[rbase + r * RS];
+	wf_fence();
+}
+// slots 5, 6, 7 times W_8^{S}, W_8^{2 S}, W_8^{3 S}
+template <int S>
+__device__ __forceinline__ void wf8_rot_odd(double (&re)[8], double (&im)[8]) {
+	{ const double x = re[5], y = im[5]; re[5] = kH * (S > 0 ? x - y : x + y); im[5] = kH * (S > 0 ? x + y : y - x); }
+	{ const double x = re[6], y = im[6]; re[6] = S > 0 ? -y : y; im[6] = S > 0 ? x : -x; }
+	{ const double x = re[7], y = im[7]; re[7] = S > 0 ? -kH * (x + y) : kH * (y - x); im[7] = S > 0 ? kH * (x - y) : -kH * (x + y); }
+}
+// strided -> paired8; the caller has run the leading wdft8p<S, NG> on the strided data
+template <int S>
+__device__ __forceinline__ void wf8_fft512_dit_rest(double (&re)[8], double (&im)[8], double *lds, const double2 *__restrict__ tw_, int lane) {
+	const double2 *__restrict__ tw = tw_fresh(tw_);
+	const int mid = (lane & 7) + 72 * (lane >> 3);
+	{
+		double2 wa[8];
+#pragma unroll
+		for (int r = 1; r < 8; ++r) wa[r] = tw_load(tw + kTw8A + 8 * r, lane >> 3);
+		WF_SCHED_FENCE();
+		wf8_xchg<72, 8>(re, lds, lane, mid);
+		wf8_xchg<72, 8>(im, lds, lane, mid);
+#pragma unroll
+		for (int r = 1; r < 8; ++r) wrot(re[r], im[r], wa[r].x, S > 0 ? wa[r].y : -wa[r].y);
+	}
+	wdft8<S>(re, im);
+	{
+		double2 wb[8];
+#pragma unroll
+		for (int r = 0; r < 8; ++r) wb[r] = tw_load(tw + kTw8B + 64 * r, lane);
+		WF_SCHED_FENCE();
+#pragma unroll
+		for (int r = 0; r < 8; ++r) wrot(re[r], im[r], wb[r].x, S > 0 ? wb[r].y : -wb[r].y);
+	}
+	const int w2 = 66 * (lane & 7) + (lane >> 3), jp = (64 - lane) & 63;
+	auto half = [&](double (&v)[8]) {
+#pragma unroll
+		for (int q = 0; q < 8; ++q) lds[w2 + 8 * q] = v[q];
+		wf_fence();
+		double a[8], b[8];
+#pragma unroll
+		for (int m = 0; m < 8; ++m) { a[m] = lds[66 * m + lane]; b[m] = lds[66 * m + jp]; }
+		wf_fence();
+#pragma unroll
+		for (int m = 0; m < 4; ++m) { v[m] = a[m] + a[m + 4]; v[4 + m] = b[m] - b[m + 4]; }
+	};
+	half(re);
+	half(im);
+	wf8_rot_odd<S>(re, im);
+	wdft4<S>(re[0], im[0], re[1], im[1], re[2], im[2], re[3], im[3]);
+	wdft4<S>(re[4], im[4], re[5], im[5], re[6], im[6], re[7], im[7]);
+}
+template <int S>
+__device__ __forceinline__ void wf8_fft512_dit(double (&re)[8], double (&im)[8], double *lds, const double2 *__restrict__ tw, int lane) {
+	wdft8<S>(re, im);
+	wf8_fft512_dit_rest<S>(re, im, lds, tw, lane);
+}
+// paired8 -> strided
+template <int S>
+__device__ __forceinline__ void wf8_fft512_dif(double (&re)[8], double (&im)[8], double *lds, const double2 *__restrict__ tw_, int lane) {
+	const double2 *__restrict__ tw = tw_fresh(tw_);
+	wdft4<S>(re[0], im[0], re[1], im[1], re[2], im[2], re[3], im[3]);
+	wdft4<S>(re[4], im[4], re[5], im[5], re[6], im[6], re[7], im[7]);
+	wf8_rot_odd<S>(re, im);
+	const int jp = (64 - lane) & 63, r2 = 68 * (lane & 3) + (lane >> 3);
+	const double sg = (lane & 4) ? -1.0 : 1.0;
+	{
+		double2 wb[8];
+#pragma unroll
+		for (int r = 0; r < 8; ++r) wb[r] = tw_load(tw + kTw8B + 64 * r, lane);
+		WF_SCHED_FENCE();
+		auto half = [&](double (&v)[8]) {
+#pragma unroll
+			for (int m = 0; m < 4; ++m) { lds[68 * m + lane] = v[m]; lds[68 * (4 + m) + jp] = v[4 + m]; }
+			wf_fence();
+			double e[8], g[8];
+#pragma unroll
+			for (int q = 0; q < 8; ++q) { e[q] = lds[r2 + 8 * q]; g[q] = lds[r2 + 272 + 8 * q]; }
+			wf_fence();
+#pragma unroll
+			for (int q = 0; q < 8; ++q) v[q] = fma(sg, g[q], e[q]);  // (exact: sg = +-1)
+		};
+		half(re);
+		half(im);
+#pragma unroll
+		for (int r = 0; r < 8; ++r) wrot(re[r], im[r], wb[r].x, S > 0 ? wb[r].y : -wb[r].y);
+	}
+	wdft8<S>(re, im);
+	const int mid = (lane & 7) + 72 * (lane >> 3);
+	{
+		double2 wa[8];
+#pragma unroll
+		for (int r = 1; r < 8; ++r) wa[r] = tw_load(tw + kTw8A + 8 * r, lane >> 3);
+		WF_SCHED_FENCE();
+#pragma unroll
+		for (int r = 1; r < 8; ++r) wrot(re[r], im[r], wa[r].x, S > 0 ? wa[r].y : -wa[r].y);
+	}
+	wf8_xchg<8, 72>(re, lds, mid, lane);
+	wf8_xchg<8, 72>(im, lds, mid, lane);
+	wdft8<S>(re, im);
+}
+// bin held by slot 4 g + c of the paired8 layout
+__device__ __forceinline__ int wf8_bin(int lane, int g, int c) { return (g == 0 ? lane : (lane ? 128 - lane : 64)) + 128 * c; }
+
+// ---- real transforms of 1024 points on top of it: wf_r2c_unpack and friends on the first two groups --------------------------
+__device__ __forceinline__ void wf8_tw_real(const double2 *__restrict__ tw, int lane, double (&wr)[4], double (&wi)[4]) {
+#pragma unroll
+	for (int q = 0; q < 4; ++q) {
+		const double2 a = tw_load(tw + kTw8U + 128 * q, lane);
+		wr[q] = a.x; wi[q] = a.y;
+	}
+	WF_SCHED_FENCE();
+}
+// In: the paired8 output of wf8_fft512_dit<+1> on the packed signal z[m] = x[2 m] + i x[2 m + 1].  Out: slot (g, c) holds
+// 2 X[bin]; lane 0's slot 0 holds (2 X[0], 0) and nyq = 2 X[512] (valid on lane 0).
+__device__ __forceinline__ void wf8_r2c_unpack(double (&re)[8], double (&im)[8], double &nyq, const double2 *__restrict__ tw_, int lane) {
+	const double2 *__restrict__ tw = tw_fresh(tw_);
+	double wr[4], wi[4];
+	wf8_tw_real(tw, lane, wr, wi);
+	nyq = 0.0;
+	if (lane == 0) {
+		const double a = re[0], b = im[0];
+		re[0] = 2.0 * (a + b); im[0] = 0.0;
+		nyq = 2.0 * (a - b);
+		re[2] = 2.0 * re[2]; im[2] = 2.0 * im[2];                     // bin 256: X = Z
+		wf_r2c_pair(re[1], im[1], re[3], im[3], kH, kH);              // 128 | 384
+		wf_r2c_pair(re[4], im[4], re[7], im[7], kC8, kS8);            // 64 | 448
+		wf_r2c_pair(re[5], im[5], re[6], im[6], kS8, kC8);            // 192 | 320
+	} else {
+#pragma unroll
+		for (int q = 0; q < 4; ++q) wf_r2c_pair(re[q], im[q], re[7 - q], im[7 - q], wr[q], wi[q]);
+	}
+}
+__device__ __forceinline__ void wf8_c2r_pack(double (&re)[8], double (&im)[8], double nyq, const double2 *__restrict__ tw_, int lane) {
+	const double2 *__restrict__ tw = tw_fresh(tw_);
+	double wr[4], wi[4];
+	wf8_tw_real(tw, lane, wr, wi);
+	if (lane == 0) {
+		const double y0 = re[0];
+		re[0] = y0 + nyq; im[0] = y0 - nyq;
+		re[2] = 2.0 * re[2]; im[2] = 2.0 * im[2];
+		wf_c2r_pair(re[1], im[1], re[3], im[3], kH, kH);
+		wf_c2r_pair(re[4], im[4], re[7], im[7], kC8, kS8);
+		wf_c2r_pair(re[5], im[5], re[6], im[6], kS8, kC8);
+	} else {
+#pragma unroll
+		for (int q = 0; q < 4; ++q) wf_c2r_pair(re[q], im[q], re[7 - q], im[7 - q], wr[q], wi[q]);
+	}
+}
+// real parts only (the input is real and even) / a REAL spectrum in: see wf_r2c_unpack_re, wf_c2r_pack_re
+__device__ __forceinline__ void wf8_r2c_unpack_re(double (&re)[8], const double (&im)[8], double &nyq, const double2 *__restrict__ tw_, int lane) {
+	const double2 *__restrict__ tw = tw_fresh(tw_);
+	double wr[4], wi[4];
+	wf8_tw_real(tw, lane, wr, wi);
+	nyq = 0.0;
+	if (lane == 0) {
+		const double a = re[0], b = im[0];
+		re[0] = 2.0 * (a + b);
+		nyq = 2.0 * (a - b);
+		re[2] = 2.0 * re[2];
+		wf_r2c_pair_re(re[1], im[1], re[3], im[3], kH, kH);
+		wf_r2c_pair_re(re[4], im[4], re[7], im[7], kC8, kS8);
+		wf_r2c_pair_re(re[5], im[5], re[6], im[6], kS8, kC8);
+	} else {
+#pragma unroll
+		for (int q = 0; q < 4; ++q) wf_r2c_pair_re(re[q], im[q], re[7 - q], im[7 - q], wr[q], wi[q]);
+	}
+}
+__device__ __forceinline__ void wf8_c2r_pack_re(double (&re)[8], double (&im)[8], double nyq, const double2 *__restrict__ tw_, int lane) {
+	const double2 *__restrict__ tw = tw_fresh(tw_);
+	double wr[4], wi[4];
+	wf8_tw_real(tw, lane, wr, wi);
+	if (lane == 0) {
+		const double y0 = re[0];
+		re[0] = y0 + nyq; im[0] = y0 - nyq;
+		re[2] = 2.0 * re[2]; im[2] = 0.0;
+		wf_c2r_pair_re(re[1], im[1], re[3], im[3], kH, kH);
+		wf_c2r_pair_re(re[4], im[4], re[7], im[7], kC8, kS8);
+		wf_c2r_pair_re(re[5], im[5], re[6], im[6], kS8, kC8);
+	} else {
+#pragma unroll
+		for (int q = 0; q < 4; ++q) wf_c2r_pair_re(re[q], im[q], re[7 - q], im[7 - q], wr[q], wi[q]);
+	}
 }
 
 }  // namespace wc
