@@ -1580,6 +1580,286 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_SYN_WAVE_
 
 }
 
+// ==== N = 1024 (16 / 22.05 / 24 kHz): one wavefront per pulse at eight points per lane ========================================
+// syn_pulse_wave_kernel on the 512-point transforms wf8_* (wc_wavefft.hpp), statement for statement: half the registers, four
+// wavefronts per SIMD.  A workgroup is FOUR such wavefronts, each on a pulse of its own with its own exchange buffer and parking
+// array; all they share is the table of the lean log / exp (2.5 KB a wavefront would otherwise copy for itself: with it the
+// sixteen wavefronts of a CU would not fit its LDS), loaded in front of the only barrier of the kernel.
+__device__ __forceinline__ void minimum_phase_wave8(double (&mr)[8], double (&mi)[8], double &mMr,
+													double *L, const double *T, const double2 *__restrict__ tw, int lane) {
+	constexpr int N = 1024, M = 512;
+	WC_FRESH(lane);
+	int jg[2];
+#pragma unroll
+	for (int g = 0; g < 2; ++g) jg[g] = wf8_bin(lane, g, 0);
+	// the mirrored log spectrum (reference :199-200) as the packed input of the first transform
+	wf_fence();
+#pragma unroll
+	for (int q = 0; q < 4; ++q) {
+		const double2 v = *reinterpret_cast<const double2 *>(&L[2 * lane + 128 * q]);
+		mr[q] = v.x;
+		mi[q] = v.y;
+	}
+#pragma unroll
+	for (int q = 4; q < 8; ++q) {
+		mr[q] = L[1024 - 2 * lane - 128 * q];
+		mi[q] = L[1023 - 2 * lane - 128 * q];
+	}
+	wf_fence();
+	wf8_fft512_dit<+1>(mr, mi, L, tw, lane);
+	double nyq;
+	wf8_r2c_unpack_re(mr, mi, nyq, tw, lane);  // twice the (real) cepstrum
+	// folding (reference :207-217): bins 1 .. M-1 doubled, 0 and M kept, the upper half zero (see minimum_phase_wave)
+#pragma unroll
+	for (int g = 0; g < 2; ++g)
+#pragma unroll
+		for (int q = 0; q < 4; ++q) L[jg[g] + 128 * q] = (g == 0 && q == 0 && lane == 0) ? 0.5 * mr[0] : mr[4 * g + q];
+	if (lane == 0) L[M] = 0.5 * nyq;
+	wf_fence();
+#pragma unroll
+	for (int q = 0; q < 4; ++q) {
+		const double2 v = *reinterpret_cast<const double2 *>(&L[2 * lane + 128 * q]);
+		mr[q] = v.x;
+		mi[q] = v.y;
+	}
+	mr[4] = lane == 0 ? L[M] : 0.0;
+	mi[4] = 0.0;
+#pragma unroll
+	for (int q = 5; q < 8; ++q) mr[q] = mi[q] = 0.0;
+	wf_fence();
+	wf8_fft512_dit<+1>(mr, mi, L, tw, lane);
+	wf8_r2c_unpack(mr, mi, nyq, tw, lane);  // twice the spectrum of the folded cepstrum
+#pragma unroll
+	for (int s = 0; s < 8; ++s) {
+		const double t = wf_exp_l(mr[s] * (0.5 / N), T);
+		double sn, cs;
+		wf_sincos(mi[s] * (0.5 / N), sn, cs);
+		mr[s] = t * cs;
+		mi[s] = t * sn;
+	}
+	mMr = wf_exp_l(nyq * (0.5 / N), T);
+}
+
+#ifndef WC_SYN_WAVE8_OCC
+#define WC_SYN_WAVE8_OCC 4
+#endif
+constexpr int kSyn8Waves = 4;  // wavefronts (pulses) per workgroup
+__global__ __launch_bounds__(64 * kSyn8Waves) __attribute__((amdgpu_waves_per_eu(WC_SYN_WAVE8_OCC, WC_SYN_WAVE8_OCC))) void syn_pulse_wave8_kernel(SynArgs a) {
+	constexpr int N = 1024, M = 512;
+	__shared__ __attribute__((aligned(16))) double Ls[kSyn8Waves][kWf8Lds];
+	__shared__ __attribute__((aligned(16))) double T[kWfTabLds];
+	__shared__ __attribute__((aligned(16))) double Ps[kSyn8Waves][512];
+	const int lane = threadIdx.x & 63;
+	const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	double *L = Ls[wv], *P = Ps[wv];
+	if (threadIdx.x < 160) reinterpret_cast<double2 *>(T)[threadIdx.x] = tw_load(a.tw + kTwLog, threadIdx.x);  // 128 + 32 entries, contiguous
+	__syncthreads();
+	// (the pulses are dealt to the XCDs in contiguous eighths -- workgroup b runs on XCD b mod 8 -- and within an eighth four
+	// consecutive pulses to a workgroup: neighbours read the same spectrogram / aperiodicity rows)
+	const long long total_p = a.pulse_prefix[a.n_utt];
+	const long long per = (total_p + 7) / 8;
+	const long long idx = (long long)(blockIdx.x >> 3) * kSyn8Waves + wv;
+	if (idx >= per) return;
+	const long long gp = (blockIdx.x & 7) * per + idx;
+	if (gp >= total_p) return;
+	if (a.only_pulse >= 0 && gp != a.only_pulse) return;
+	const int u = a.pulse_utt[gp];
+	const UttDesc ud = a.utts[u];
+	const long long slot = a.cap_off[u] + (gp - a.pulse_prefix[u]);
+	const int pidx = a.p.index[slot];
+	const double shift = a.p.shift[slot];
+	const int noise_size = a.p.noise_size[slot];
+	const double vuv = (double)a.p.vuv[slot];
+	const int fs = a.fs, Lf = ud.f_len;
+	const double fp = a.frame_period;
+	const double t = pidx / (double)fs;  // time_axis[ii] (reference :227)
+
+	// ---- spectral envelope / aperiodic ratio at the pulse (reference :346-393), then the two log spectra ----
+	const int fl = min(Lf - 1, (int)floor(t / fp));
+	const int ce = min(Lf - 1, (int)ceil(t / fp));
+	const double ipol = uniform_d(t / fp - fl);
+	const double *__restrict__ sf = a.sp + (ud.f_off + fl) * (long long)(M + 1);
+	const double *__restrict__ sc = a.sp + (ud.f_off + ce) * (long long)(M + 1);
+	const double *__restrict__ af = a.ap + (ud.f_off + fl) * (long long)(M + 1);
+	const double *__restrict__ ac = a.ap + (ud.f_off + ce) * (long long)(M + 1);
+	const bool same = fl == ce;
+	auto blend = [&](double s0, double s1, double a0, double a1, double &env, double &ar) {
+		if (same) {
+			env = fabs(s0);
+			const double s = safe_ap(a0);
+			ar = s * s;
+		} else {
+			env = fma(1.0 - ipol, fabs(s0), ipol * fabs(s1));
+			// both products rounded as in the reference (:388-390), no fused multiply-add (see syn_pulse_kernel)
+			const double s = (1.0 - ipol) * safe_ap(a0) + ipol * safe_ap(a1);
+			ar = s * s;
+		}
+	};
+	double ar0;  // aperiodic_ratio[0] decides whether there is a periodic response (reference :410)
+	{
+		double env;
+		blend(sf[0], sc[0], af[0], ac[0], env, ar0);
+		ar0 = uniform_d(ar0);
+	}
+
+	// ---- periodic response, then the aperiodic response, through one copy of the code (see syn_pulse_wave_kernel) ----
+	double dc = 0.0;
+	const double sq = sqrt((double)noise_size);
+	double *__restrict__ resp = a.resp + gp * N;
+	const bool has_periodic = !(vuv <= 0.5 || ar0 > 0.999);
+#pragma unroll 1
+	for (int part = has_periodic ? 0 : 1; part < 2; ++part) {
+		int ln = lane;
+		WC_FRESH(ln);
+		double wr[8], wi[8];
+		double nr[8], ni[8], nsM = 0.0;
+		if (part == 1) {
+			// the noise (reference :514-530): noise_size draws from the pulse's place in the stream, mean removed
+			const unsigned long long rstart = a.rng_start ? a.rng_start[u] : ud.rng_pos;
+			const uint32_t *__restrict__ rng = a.rng_table + (rstart + (unsigned long long)(pidx - a.first_index[u]) - a.rng_base);
+			double s = 0.0;
+			{
+				uint32_t raw[16];
+#pragma unroll
+				for (int q = 0; q < 8; ++q) {
+					if ((q & 3) == 0 && q * 128 >= noise_size) break;
+					const int i0 = 2 * ln + 128 * q;
+					raw[2 * q] = rng[i0 < noise_size ? i0 : 0];
+					raw[2 * q + 1] = rng[i0 + 1 < noise_size ? i0 + 1 : 0];
+				}
+				WF_SCHED_FENCE();
+#pragma unroll
+				for (int q = 0; q < 8; ++q) {
+					nr[q] = ni[q] = 0.0;
+					if (q * 128 < ((noise_size + 511) & ~511)) {
+						const int i0 = 2 * ln + 128 * q;
+						if (i0 < noise_size) nr[q] = raw[2 * q] / 268435456.0 - 6.0;
+						if (i0 + 1 < noise_size) ni[q] = raw[2 * q + 1] / 268435456.0 - 6.0;
+						s += nr[q] + ni[q];
+					}
+				}
+			}
+			s = wave_sum_all(s);
+			const double avg = s / noise_size;
+#pragma unroll
+			for (int q = 0; q < 8; ++q) {
+				const int i0 = 2 * ln + 128 * q;
+				nr[q] = (i0 < noise_size) ? nr[q] - avg : 0.0;
+				ni[q] = (i0 + 1 < noise_size) ? ni[q] - avg : 0.0;
+			}
+			if (noise_size <= 256) wdft8p<+1, 1>(nr, ni);
+			else if (noise_size <= 512) wdft8p<+1, 2>(nr, ni);
+			else wdft8p<+1, 4>(nr, ni);
+			wf8_fft512_dit_rest<+1>(nr, ni, L, a.tw, ln);
+			wf8_r2c_unpack(nr, ni, nsM, a.tw, ln);  // twice the noise spectrum
+			// the noise spectrum waits outside the registers while the minimum phase is worked out: its real parts in LDS, its
+			// imaginary parts in the first half of the pulse's own response row (free until the mix below)
+#pragma unroll
+			for (int sI = 0; sI < 8; ++sI) {
+				P[64 * sI + ln] = nr[sI];
+				resp[64 * sI + ln] = ni[sI];
+			}
+			wf_fence();
+		}
+		// the part's log spectrum from the two rows around the pulse: log(env (1 - ar) + safeguard) / 2 for the periodic part
+		// (reference :416-417), log(env ar) / 2 or, unvoiced, log(env) / 2 for the aperiodic one (:490-497)
+		double mM;
+		{
+			auto logspec = [&](double env, double ar) {
+				return wf_log_l(part == 0 ? env * (1.0 - ar) + kSafe : (vuv != 0.0 ? env * ar : env), T) / 2.0;
+			};
+#pragma unroll
+			for (int g0 = 0; g0 < 2; ++g0) {
+				double v[4][4];
+#pragma unroll
+				for (int q = 0; q < 4; ++q) {
+					const int k = wf8_bin(ln, g0, q);
+					v[q][0] = sf[k]; v[q][1] = sc[k]; v[q][2] = af[k]; v[q][3] = ac[k];
+				}
+				WF_SCHED_FENCE();
+#pragma unroll
+				for (int q = 0; q < 4; ++q) {
+					double env, ar;
+					blend(v[q][0], v[q][1], v[q][2], v[q][3], env, ar);
+					L[wf8_bin(ln, g0, q)] = logspec(env, ar);  // (straight to its place in the transform's input)
+				}
+			}
+			double env, ar;
+			blend(sf[M], sc[M], af[M], ac[M], env, ar);
+			const double lsM = logspec(env, ar);
+			if (ln == 0) L[M] = lsM;
+		}
+		minimum_phase_wave8(wr, wi, mM, L, T, a.tw, ln);
+		double yM;
+		if (part == 0) {
+			// fractional time shift (reference :443-457)
+			const double coef = 2.0 * kPi * shift * fs / N;
+#pragma unroll
+			for (int g = 0; g < 2; ++g)
+#pragma unroll
+				for (int q = 0; q < 4; ++q) {
+					const int k = wf8_bin(ln, g, q);
+					double sn_, re2;
+					wf_sincos(coef * k, sn_, re2);
+					const double im2 = sqrt(1.0 - re2 * re2);
+					const double x = wr[4 * g + q], y = wi[4 * g + q];
+					wr[4 * g + q] = fma(x, re2, -(y * im2));
+					wi[4 * g + q] = fma(x, im2, y * re2);
+				}
+			double sn_, reM;
+			wf_sincos(coef * M, sn_, reM);
+			yM = mM * reM;
+		} else {
+			{
+				const double *rp = resp;
+				asm volatile("" : "+s"(rp));  // (an opaque pointer: real loads, not the stored values kept in registers)
+#pragma unroll
+				for (int sI = 0; sI < 8; ++sI) {
+					ni[sI] = rp[64 * sI + ln];
+					nr[sI] = P[64 * sI + ln];
+				}
+				WF_SCHED_FENCE();
+			}
+#pragma unroll
+			for (int sI = 0; sI < 8; ++sI) {
+				const double x = wr[sI], y = wi[sI], nx = 0.5 * nr[sI], ny = 0.5 * ni[sI];
+				wr[sI] = fma(x, nx, -(y * ny));
+				wi[sI] = fma(x, ny, y * nx);
+			}
+			yM = mM * (0.5 * nsM);
+		}
+		wf8_c2r_pack(wr, wi, yM, a.tw, ln);
+		wf8_fft512_dif<-1>(wr, wi, L, a.tw, ln);
+		if (part == 0) {
+			// DC removal (reference :459-474), see syn_pulse_wave_kernel: wave[0 .. M) is all that is left of the response itself
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				dc += wr[q] + wi[q];
+				*reinterpret_cast<double2 *>(resp + M + 2 * ln + 128 * q) = make_double2(wr[q] * sq, wi[q] * sq);
+			}
+			dc = wave_sum_all(dc);
+		} else {
+			// ---- mix (reference :339-343): shifted sample j is unshifted sample j - M (j >= M) / j + M; the row in output order ----
+			const double dcs = has_periodic ? -dc * sq : 0.0;
+			double2 dr[4], pp[4];
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				dr[q] = *reinterpret_cast<const double2 *>(a.dc_remover + 2 * ln + 128 * q);
+				pp[q] = has_periodic ? *reinterpret_cast<const double2 *>(resp + M + 2 * ln + 128 * q) : make_double2(0.0, 0.0);
+			}
+			WF_SCHED_FENCE();
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				const int n = 2 * ln + 128 * q;  // unshifted samples n, n + 1 (output place n + M) and n + M, n + M + 1 (place n)
+				const double r0 = fma(dcs, dr[q].x, wr[q]) + pp[q].x, r1 = fma(dcs, dr[q].y, wi[q]) + pp[q].y;
+				*reinterpret_cast<double2 *>(resp + n + M) = make_double2(r0 / N, r1 / N);
+				const double r2 = fma(dcs, dr[q].x, wr[q + 4]), r3 = fma(dcs, dr[q].y, wi[q + 4]);
+				*reinterpret_cast<double2 *>(resp + n) = make_double2(r2 / N, r3 / N);
+			}
+		}
+	}
+}
+
 // utterance of every pulse of the compact numbering (prefix[u] <= gp < prefix[u + 1]); one workgroup per utterance
 __global__ void syn_pulse_utt_kernel(const long long *__restrict__ prefix, int *__restrict__ pulse_utt) {
 	const int u = blockIdx.x;
@@ -1592,8 +1872,9 @@ __global__ void syn_pulse_utt_kernel(const long long *__restrict__ prefix, int *
 // list, found by bisection; every thread adds the rows' samples to its four outputs in pulse order, so y carries the
 // reference's own summation order.  Writes every sample of y (zeros where no pulse reaches): no clearing pass.
 constexpr int OA_T = 256, OA_K = 4, OA_TILE = OA_T * OA_K;
+template <int N>
 __global__ __launch_bounds__(OA_T) void syn_overlap_add_kernel(SynArgs a) {
-	constexpr int N = 2048, M = 1024;
+	constexpr int M = N / 2;
 	const int u = blockIdx.y;
 	const UttDesc ud = a.utts[u];
 	const int t0 = blockIdx.x * OA_TILE;
@@ -1651,7 +1932,9 @@ struct wc_synthesis {
 	Device *dev;
 	DevBuf dc_remover, utts, meta, pulses, incs, phase, phase_seg, tile_cnt, resp, pulse_utt, d_f0, d_sp, d_ap, d_out;
 	bool pulses_by_utterance;  // WC_SYN_PULSES=utterance: one workgroup walks an utterance's tiles (A/B and the bit-identity test)
-	bool wave;  // N = 2048: one wavefront per pulse (default; WC_SYN_IMPL=block: the workgroup-per-pulse kernel)
+	bool wave;  // N = 2048 / 1024: one wavefront per pulse (default; WC_SYN_IMPL=block: the workgroup-per-pulse kernel)
+	bool rows = false;  // of the most recent syn_prepare: pulses through response rows + syn_overlap_add_kernel (else atomics into the output)
+	size_t rows_budget = 0;  // bytes the response rows may take (an eighth of the device's memory; WC_SYN_ROWS_BUDGET_MB)
 	bool phase_single;  // WC_SYN_PHASE=single: the phase sum by one workgroup per utterance (A/B and the bit-identity test)
 	bool serial_timebase;  // WC_SYN_TIMEBASE=serial: the one-wavefront sequential accumulation instead of the exact parallel one
 	HostBuf h_stage, h_rows;
@@ -1716,8 +1999,6 @@ int syn_prepare(wc_synthesis *sy, hipStream_t s, int n_utt, const double *d_f0, 
 	sy->cap_total = 0;
 	if (total_out == 0) return WC_OK;
 	int rc;
-	// (the one-wavefront pulse kernel goes through response rows and syn_overlap_add_kernel, which writes every sample)
-	if (!(sy->wave && sy->fft_size == 2048)) WC_HIP(hipMemsetAsync(d_out, 0, sizeof(double) * total_out, s));
 	// meta layout (device): cap_off[n] (i64) | pulse_prefix[n+1] (i64) | inc_off[n] (i64) | end_pos[n] (u64) |
 	//                       cap[n] | count[n] | first_index[n] | last_index[n] | overflow
 	const size_t meta_bytes = sizeof(long long) * (4 * (size_t)n_utt + 1) + sizeof(int) * (4 * (size_t)n_utt + 1);
@@ -1750,6 +2031,13 @@ int syn_prepare(wc_synthesis *sy, hipStream_t s, int n_utt, const double *d_f0, 
 		co += cap;
 	}
 	sy->cap_total = co;
+	// The one-wavefront pulse kernels go through a response row per pulse slot and syn_overlap_add_kernel, which writes every
+	// sample.  The rows are reserved for the pulse CAPACITY (the real count is known on the device only): 157 MB per 10 s utterance
+	// at 48 kHz under the rate bound, but out_length + 1 rows per utterance on the overflow retry -- beyond the budget the
+	// atomics kernel takes over (into a cleared output) instead of an allocation that cannot succeed.
+	sy->rows = sy->wave && (sy->fft_size == 2048 || sy->fft_size == 1024) &&
+			   (double)co * sy->fft_size * sizeof(double) <= (double)sy->rows_budget;
+	if (!sy->rows) WC_HIP(hipMemsetAsync(d_out, 0, sizeof(double) * total_out, s));
 	if ((rc = sy->incs.reserve(sizeof(double) * inc_total))) return rc;
 	if (!sy->serial_timebase && (rc = sy->phase.reserve(sizeof(double) * inc_total))) return rc;
 	if ((rc = sy->pulses.reserve((size_t)co * (sizeof(int) * 3 + sizeof(double))))) return rc;
@@ -1853,9 +2141,9 @@ int syn_pulses(wc_synthesis *sy, hipStream_t s, const double *d_f0, const double
 	a.trace = nullptr;
 	a.resp = nullptr;
 	a.pulse_utt = nullptr;
-	if (sy->wave && sy->fft_size == 2048) {
+	if (sy->rows) {
 		// a response row per pulse slot of the rate bound (only the rows of real pulses are ever touched)
-		if ((rc = sy->resp.reserve(sizeof(double) * 2048 * (size_t)co))) return rc;
+		if ((rc = sy->resp.reserve(sizeof(double) * (size_t)sy->fft_size * (size_t)co))) return rc;
 		a.resp = sy->resp.as<double>();
 		if ((rc = sy->pulse_utt.reserve(sizeof(int) * (size_t)co))) return rc;
 		a.pulse_utt = sy->pulse_utt.as<int>();
@@ -1870,11 +2158,19 @@ int syn_pulses(wc_synthesis *sy, hipStream_t s, const double *d_f0, const double
 	if ((rc = dev->time_begin("synthesis_pulses", s))) return rc;
 	switch (sy->fft_size) {
 		case 512: launch_pulses<512>(a, s); break;
-		case 1024: launch_pulses<1024>(a, s); break;
+		case 1024:
+			if (sy->rows) {
+				const long long per = (a.total_pulses + 7) / 8;
+				hipLaunchKernelGGL(syn_pulse_wave8_kernel, dim3((unsigned)(8 * ((per + kSyn8Waves - 1) / kSyn8Waves))), dim3(64 * kSyn8Waves), 0, s, a);
+				hipLaunchKernelGGL(syn_overlap_add_kernel<1024>, dim3((unsigned)((sy->max_out + OA_TILE - 1) / OA_TILE), n_utt), dim3(OA_T), 0, s, a);
+			} else {
+				launch_pulses<1024>(a, s);
+			}
+			break;
 		case 2048:
-			if (sy->wave) {
+			if (sy->rows) {
 				hipLaunchKernelGGL(syn_pulse_wave_kernel, dim3((unsigned)(8 * ((a.total_pulses + 7) / 8))), dim3(64), 0, s, a);
-				hipLaunchKernelGGL(syn_overlap_add_kernel, dim3((unsigned)((sy->max_out + OA_TILE - 1) / OA_TILE), n_utt), dim3(OA_T), 0, s, a);
+				hipLaunchKernelGGL(syn_overlap_add_kernel<2048>, dim3((unsigned)((sy->max_out + OA_TILE - 1) / OA_TILE), n_utt), dim3(OA_T), 0, s, a);
 			} else {
 				launch_pulses<2048>(a, s);
 			}
@@ -1959,6 +2255,10 @@ wc_synthesis *wc_synthesis_create(int fs, int fft_size, double frame_period_ms) 
 		s->pulses_by_utterance = pu && std::string(pu) == "utterance";
 		const char *impl = getenv("WC_SYN_IMPL");
 		s->wave = !(impl && std::string(impl) == "block");
+		size_t free_b = 0, total_b = 0;
+		if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) total_b = (size_t)64 << 30;
+		s->rows_budget = total_b / 8;
+		if (const char *mb = getenv("WC_SYN_ROWS_BUDGET_MB")) s->rows_budget = (size_t)atoll(mb) << 20;
 	}
 	s->dev = dev;
 	// getDCRemover, reference :290-303
