@@ -182,8 +182,9 @@ class Port:
         sp = self.cheaptrick(x, fs, tpos, f0)
         fft_size = (sp.shape[1] - 1) * 2
         ap = self.d4c(x, fs, tpos, f0, fft_size)
+        syn_start = self.rng_position()  # (where Synthesis starts in the noise stream: to repeat that stage on other parameters)
         y = self.synthesis(f0, sp, ap, fs, frame_period)
-        return dict(tpos=tpos, f0=f0, sp=sp, ap=ap, y=y)
+        return dict(tpos=tpos, f0=f0, sp=sp, ap=ap, y=y, syn_start=syn_start)
 
     # ---- helpers ------------------------------------------------------------------------
     def matlab_round(self, x):

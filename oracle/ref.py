@@ -20,7 +20,9 @@ _ip = C.POINTER(C.c_int)
 
 
 def lib_path(omp=False):
-    return os.path.join(_HERE, "_ref", "libworld_ref_omp.so" if omp else "libworld_ref.so")
+    """omp: False serial (deterministic), True the OpenMP build, "fma" the serial build under -mfma -ffp-contract=fast"""
+    name = "libworld_ref_fma.so" if omp == "fma" else "libworld_ref_omp.so" if omp else "libworld_ref.so"
+    return os.path.join(_HERE, "_ref", name)
 
 
 def available(omp=False):

@@ -24,6 +24,10 @@
 #include "world_matlabfunctions.hpp"
 #include "world_fft.hpp"
 
+// (REF_PLAIN_NEW: the build that is only TIMED -- oracle/_ref/libworld_ref_omp.so, bench.py's cpu_baseline -- keeps the
+// toolchain's own operator new[]: the reference allocates and plans inside its OpenMP loops, and a calloc per allocation would
+// make the baseline slower than the reference really is)
+#ifndef REF_PLAIN_NEW
 void *operator new[](std::size_t n) {
 	void *p = std::calloc(1, n ? n : 1);
 	if (!p) throw std::bad_alloc();
@@ -31,6 +35,7 @@ void *operator new[](std::size_t n) {
 }
 void operator delete[](void *p) noexcept { std::free(p); }
 void operator delete[](void *p, std::size_t) noexcept { std::free(p); }
+#endif
 
 using namespace world_class;
 

@@ -114,13 +114,14 @@ def rate96k_case():
 PIPELINE_CASES = ["c1_16k_2s_floor71", "c1_16k_2s_floor40", "m48k_1s", "m24k_1s_1ms"]
 
 
-def headline_case(u):
+def headline_case(u, fixture="headline_48k_10s.npz"):
     """utterance u (0 .. 7) of the benchmark's workload at its full size, 48 kHz x 10 s, with what the real reference's full
     pipeline returns for it (tests/golden/headline_48k_10s.npz, oracle/gen_golden_headline.py): x and a dict of f0, sp/ap row
-    sums and every `stride`-th row, block sums and windows of the waveform"""
+    sums and every `stride`-th row, block sums and windows of the waveform.  fixture = "config2_16k_10s.npz": the same for
+    BASELINE config 2's 16 kHz x 10 s utterances (oracle/gen_golden_config2.py)."""
     import hashlib
     from world_class_amd.synth import make_utterance
-    z = np.load(os.path.join(ROOT, "tests", "golden", "headline_48k_10s.npz"))
+    z = np.load(os.path.join(ROOT, "tests", "golden", fixture))
     k = "u%d/" % u
     fs, sec, seed, stride, block, win = z[k + "meta"]
     x = make_utterance(int(fs), float(sec), int(seed))

@@ -13,6 +13,28 @@ from oracle import port  # noqa: E402  (a checker, which is why it lives under t
 from world_class_amd.synth import SIGNAL_KINDS as ZOO, make_signal as zoo_signal, make_utterance  # noqa: E402
 
 
+def sp_dev(a, b, f0, fs, f0_floor=None):
+    """Largest deviation of a spectral envelope from the checker's, relative, where the algorithm itself resolves the value.
+    LinearSmoothing returns (c[hi] - c[lo]) / width of a SEQUENTIAL cumulative sum c of the power spectrum (reference
+    src/world_common.cpp:47-51, :82-116): every one of its additions rounds at ulp(c), so a bin whose smoothed power is within a
+    few thousand ulp(sum) / width of nothing carries whichever way those roundings fell -- the real reference and its own CPU
+    restatement disagree by 1.9e-3 on such a bin (tests/golden/ref_self_spread.json: "restatement_vs_reference", a frame of an
+    undithered synthetic signal whose envelope falls 150 dB).  The deviation is therefore measured against
+    |b| + 3 ulp(sum b fs / N) / (width 1e-7): at the stated 1e-7 this allows three roundings of the sum on top of the relative
+    tolerance, which only bins ~120 dB and more below their frame's total ever notice."""
+    a, b = np.asarray(a), np.asarray(b)
+    n = (b.shape[1] - 1) * 2
+    floor = 3.0 * fs / (n - 3.0) if f0_floor is None else f0_floor  # reference src/cheaptrick.cpp:102-105
+    f0c = np.where(f0 <= floor, 500.0, f0)
+    total = np.where(np.isfinite(b), b, 0.0).sum(axis=1) * fs / n
+    quantum = 3.0 * np.spacing(np.maximum(total, 1e-300)) / (f0c * 2.0 / 3.0)
+    fa, fb = np.isfinite(a), np.isfinite(b)
+    if not np.array_equal(fa, fb):
+        return float("inf")
+    d = np.abs(a - b) / (np.abs(b) + quantum[:, None] / 1e-7)
+    return float(d[fa].max()) if fa.any() else 0.0
+
+
 def dev(a, b, rel=False):
     """largest deviation; NaN / inf have to sit in the same places with the same sign"""
     fa, fb = np.isfinite(a), np.isfinite(b)

@@ -141,3 +141,29 @@ def test_cheaptrick_one_wavefront_kernel_against_the_block_kernel_and_frames_it_
     port.rng_reset()
     assert rel(a, b) < SP_REL
     assert rel(a, ref) < SP_REL
+
+
+@pytest.mark.parametrize("fs,hop", [(16000, 5.0), (24000, 1.0), (22050, 5.0)])
+def test_cheaptrick_eight_points_per_lane_kernel_against_the_block_kernel_and_frames_it_leaves_out(wca, port, monkeypatch, fs, hop):
+    """N = 1024 (16 / 22.05 / 24 kHz) default: one wavefront per frame at eight points per lane (ct_wave8_kernel, transforms
+    wf8_* of wc_wavefft.hpp).  Against the workgroup-per-frame kernel on the same input, and on a contour with F0 above what its
+    LDS holds (ct_wave_can<1024>), which it lists for the block kernel behind it."""
+    x = make_utterance(fs, 0.5, 198)
+    tpos, f0 = port.harvest(x, fs, frame_period=hop)
+    f0 = f0.copy()
+    n = len(f0)
+    f0[n // 10:n // 10 + 10] = 2300.0   # frames the kernel leaves out
+    f0[n // 3:n // 3 + 4] = 1250.0      # just inside (16 kHz: the limit is 1382 Hz)
+    assert wca.cheaptrick_fft_size(fs) == 1024
+    wca.rng_set_position(555)
+    a = wca.CheapTrick(fs).compute(x, tpos, f0)
+    end = wca.rng_get_position()
+    monkeypatch.setenv("WC_CT_IMPL", "block")
+    wca.rng_set_position(555)
+    b = wca.CheapTrick(fs).compute(x, tpos, f0)
+    assert wca.rng_get_position() == end
+    port.rng_seek(555)
+    ref = port.cheaptrick(x, fs, tpos, f0)
+    port.rng_reset()
+    assert rel(a, b) < SP_REL
+    assert rel(a, ref) < SP_REL

@@ -145,3 +145,30 @@ def test_d4c_two_wavefront_kernels_against_the_block_kernels_and_frames_they_lea
     port.rng_reset()
     assert np.abs(a - b).max() < AP_ABS
     assert np.abs(a - ref).max() < AP_ABS
+
+
+@pytest.mark.parametrize("fs,hop", [(16000, 5.0), (24000, 1.0), (22050, 5.0)])
+def test_d4c_one_transform_kernels_against_the_block_kernels_and_frames_they_leave_out(wca, port, monkeypatch, fs, hop):
+    """N = 2048 (16 / 22.05 / 24 kHz) default: one wavefront per frame and per (frame, band) where a real transform is one
+    1024-point complex one (d4c1_*).  Against the workgroup-per-frame kernels on the same input, and on a contour with F0 above
+    what their LDS holds (d4c1_can: ~930 Hz at 16 kHz), which they list for the block kernel behind them."""
+    x = make_utterance(fs, 0.5, 199)
+    tpos, f0 = port.harvest(x, fs, frame_period=hop)
+    f0 = f0.copy()
+    n = len(f0)
+    f0[n // 10:n // 10 + 10] = 1700.0   # frames the kernels leave out
+    f0[n // 3:n // 3 + 4] = 880.0       # just inside at 16 kHz
+    f0[n // 2:n // 2 + 3] = 48.0        # the longest window (4 fs / 47 samples)
+    fft = wca.cheaptrick_fft_size(fs)
+    wca.rng_set_position(0)
+    a = wca.D4C(fs).compute(x, tpos, f0, fft)
+    end = wca.rng_get_position()
+    monkeypatch.setenv("WC_D4C_IMPL", "block")
+    wca.rng_set_position(0)
+    b = wca.D4C(fs).compute(x, tpos, f0, fft)
+    assert wca.rng_get_position() == end
+    port.rng_reset()
+    ref = port.d4c(x, fs, tpos, f0, fft)
+    port.rng_reset()
+    assert np.abs(a - b).max() < AP_ABS
+    assert np.abs(a - ref).max() < AP_ABS

@@ -298,6 +298,16 @@ def test_headline_workload_against_the_reference(wca):
         check_headline(r, g, 1e-6, 1e-7, 1e-7, 1e-8)
 
 
+def test_config2_workload_against_the_reference(wca):
+    """BASELINE config 2 at its full utterance size -- 16 kHz x 10 s through the fused pipeline in one batch (one-wavefront kernels
+    at eight points per lane for CheapTrick / Synthesis, one 1024-point transform per real transform for D4C) -- against what the
+    real reference returns for the same samples (tests/golden/config2_16k_10s.npz)."""
+    cases = [headline_case(u, "config2_16k_10s.npz") for u in range(8)]
+    res = wca.Pipeline(16000).run_batch([x for x, _ in cases] * 2)  # both halves of the batch schedule see every utterance
+    for (x, g), r in zip(cases * 2, res):
+        check_headline(r, g, 1e-6, 1e-7, 1e-7, 1e-8)
+
+
 def test_c_abi_gather_over_rccl(wca):
     """wc_gather_device (include/world_class_shard.h) on a communicator the caller owns.  One GPU here, so the group has one rank
     -- what this pins is the binding: RCCL found in the process, the grouped broadcasts enqueued on the caller's stream behind

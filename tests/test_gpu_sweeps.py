@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from parity_sweep import dev
+from parity_sweep import dev, sp_dev
 from stage_sweep import contour
 from world_class_amd.synth import SIGNAL_KINDS, make_signal, make_utterance
 
@@ -34,12 +34,24 @@ def P():
     p.rng_reset()
 
 
-def check(r, o, x, what, ap_abs=1e-7):
+def check(r, o, x, what, ap_abs=1e-7, fs=None, checker=None, fp=5.0):
     assert np.array_equal(r["f0"] == 0, o["f0"] == 0), what + ": voiced/unvoiced decisions differ"
     assert dev(r["f0"], o["f0"]) < 1e-6, what
-    assert dev(r["sp"], o["sp"], rel=True) < 1e-7, what
+    # (relative 1e-7, on top of three roundings of LinearSmoothing's cumulative sum: parity_sweep.sp_dev)
+    assert (dev(r["sp"], o["sp"], rel=True) if fs is None else sp_dev(r["sp"], o["sp"], o["f0"], fs)) < 1e-7, what
     assert dev(r["ap"], o["ap"]) < ap_abs, what
-    assert dev(r["y"], o["y"]) / max(1.0, float(np.abs(x).max())) < 1e-8, what
+    scale = max(1.0, float(np.abs(x).max()))
+    if fs is not None and not dev(r["y"], o["y"]) / scale < 1e-8 and not dev(r["sp"], o["sp"], rel=True) < 1e-7:
+        # A rounding of LinearSmoothing's cumulative sum fell the other way on some bin 120 dB down (sp_dev above): the minimum-phase
+        # response couples that bin's log magnitude to the phase of every other one (2e-7 on the waveform for 2e-3 on fifteen such
+        # bins).  Synthesis is then checked as a stage, the checker on the parameters the kernels produced (SURVEY.md section 8(c):
+        # "so an upstream flip does not cascade"), from the same place in the noise stream.
+        checker.rng_seek(o["syn_start"])
+        y2 = checker.synthesis(r["f0"], r["sp"], r["ap"], fs, fp)
+        checker.rng_reset()
+        assert dev(r["y"], y2) / scale < 1e-8, what
+        return
+    assert dev(r["y"], o["y"]) / scale < 1e-8, what
 
 
 def test_other_signal_kinds_16k(wca, P):
@@ -49,7 +61,7 @@ def test_other_signal_kinds_16k(wca, P):
     xs = [make_signal(fs, 1.5, s) for s in seeds]
     res = wca.Pipeline(fs).run_batch(xs)
     for s, x, r in zip(seeds, xs, res):
-        check(r, P.pipeline(x, fs), x, "seed %d (%s)" % (s, SIGNAL_KINDS[s % len(SIGNAL_KINDS)]))
+        check(r, P.pipeline(x, fs), x, "seed %d (%s)" % (s, SIGNAL_KINDS[s % len(SIGNAL_KINDS)]), fs=fs, checker=P)
 
 
 def test_impulse_trains_agree_in_voicing_and_within_a_window_length_step(wca, P):

@@ -152,3 +152,31 @@ def test_aperiodicity_next_to_its_clamp(wca, port):
     assert np.abs(ref).max() > 0.01
     assert np.abs(y - ref).max() < 1e-12
     port.rng_reset()
+
+
+@pytest.mark.parametrize("fs,fp,sec", [(16000, 5.0, 1.0), (24000, 1.0, 0.5), (48000, 5.0, 0.5)])
+def test_synthesis_wavefront_kernels_against_the_block_kernel_and_beyond_the_row_budget(wca, port, monkeypatch, fs, fp, sec):
+    """one wavefront per pulse (N = 1024: syn_pulse_wave8_kernel, eight points per lane; N = 2048: syn_pulse_wave_kernel) with
+    ordered overlap-add of response rows; against the workgroup-per-pulse kernel (atomics) on the same input, and with the rows'
+    memory budget set to nothing, where the atomics kernel has to take over on its own (an overflow retry of a large batch)."""
+    x = make_utterance(fs, sec, 77)
+    r = port.pipeline(x, fs, frame_period=fp)
+    n = (r["sp"].shape[1] - 1) * 2
+    port.rng_seek(4242)
+    ref = port.synthesis(r["f0"], r["sp"], r["ap"], fs, fp)
+    port.rng_reset()
+    ys = []
+    for env in ({}, {"WC_SYN_IMPL": "block"}, {"WC_SYN_ROWS_BUDGET_MB": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        wca.rng_set_position(4242)
+        ys.append(wca.Synthesis(fs, n, fp).compute(r["f0"], r["sp"], r["ap"]))
+        for k in env:
+            monkeypatch.delenv(k)
+    for y in ys:
+        assert np.abs(y - ref).max() < Y_ABS
+    assert np.abs(ys[0] - ys[1]).max() < 1e-12 and np.abs(ys[1] - ys[2]).max() < 1e-12
+    # rows: the same bits on every run (ordered sums, no atomics)
+    wca.rng_set_position(4242)
+    again = wca.Synthesis(fs, n, fp).compute(r["f0"], r["sp"], r["ap"])
+    assert np.array_equal(again, ys[0])

@@ -233,6 +233,17 @@ def test_headline_utterance_against_golden(port):
     check_headline(r, g, F0_ABS, SP_REL, AP_ABS, Y_ABS)
 
 
+def test_config2_utterance_against_golden(port):
+    """BASELINE config 2's utterance size (16 kHz, 10 s): the restatement against the real reference on every frame"""
+    x, g = headline_case(3, "config2_16k_10s.npz")
+    port.set_threads(8)
+    try:
+        r = port.pipeline(x, g["fs"])
+    finally:
+        port.set_threads(0)
+    check_headline(r, g, F0_ABS, SP_REL, AP_ABS, Y_ABS)
+
+
 def test_device_argsort_reproduces_std_sort(tmp_path):
     """world_class_amd/csrc/wc_argsort.hpp (what hv_contour_kernel runs) against std::sort of the library the reference is
     built with, on tie-heavy keys and on a sequence that drives introsort into its heap sort"""

@@ -35,14 +35,16 @@ struct CtArgs {
 	int fs;
 	double q1, f0_floor;  // f0_floor = 3 fs / (N - 3)
 	const int *uidx;      // utterance of every frame (ct_count_kernel)
-	int rare_only;        // the block kernel behind the wavefront kernel: only the frames that one leaves out (ct_wave_can)
+	int *rare_list;       // [0]: count, then the frames the one-wavefront kernels leave to the block kernel behind them (ct_wave_can)
 };
 
 // per-frame number of draws: window (2 hw + 1) then one per bin (reference :153, :227)
 __global__ void ct_count_kernel(const double *__restrict__ f0, long long total, int fs, double f0_floor,
-								int bins, uint32_t *__restrict__ cnt, const UttDesc *__restrict__ utts, int n_utt, int *__restrict__ uidx) {
+								int bins, uint32_t *__restrict__ cnt, const UttDesc *__restrict__ utts, int n_utt, int *__restrict__ uidx,
+								int *__restrict__ rare_list) {
 	long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 	if (g >= total) return;
+	if (g == 0) rare_list[0] = 0;
 	uidx[g] = find_utt(utts, n_utt, g);  // (looked up once here rather than by every frame's wavefront, eight dependent loads each)
 	double f = f0[g];
 	double f0c = (f <= f0_floor) ? 500.0 : f;
@@ -52,7 +54,7 @@ __global__ void ct_count_kernel(const double *__restrict__ f0, long long total, 
 // Which frames the one-wavefront kernel (ct_wave_kernel, N = 2048) takes: its 9 KB of LDS hold the mirrored segment of the
 // smoothing (1025 + 2 b + 1 terms, b = half width in bins) and the low bins of the DC correction only for F0 below ~2 kHz at
 // 48 kHz -- every contour Harvest can produce (ceiling 800 Hz) and anything a caller could mean by a pitch.  Frames above
-// that go to the block kernel, launched behind it on a small grid that looks for them.
+// that are listed (rare_list) and done by a small grid of the block kernel launched behind it.
 template <int N>
 __host__ __device__ __forceinline__ bool ct_wave_can(double f0c, int fs) {
 	const int b = (int)(f0c * 2.0 / 3.0 * N / fs) + 1;
@@ -291,25 +293,11 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 	__shared__ double scr[T + 2 * (T / 64)];
 	__shared__ double red[2 * (T / 64) + 2];
 	if constexpr (RARE) {
-		// every thread looks at a frame of its own; the (rare) hits of a sweep are then done one after the other by the block
-		__shared__ int hits[T];
-		__shared__ int nhit;
-		for (long long base = (long long)blockIdx.x * T; base < a.total_frames; base += (long long)gridDim.x * T) {
-			const long long g = base + threadIdx.x;
-			bool hit = false;
-			if (g < a.total_frames) {
-				const double f0v = a.f0[g];
-				hit = !ct_wave_can<N>((f0v <= a.f0_floor) ? 500.0 : f0v, a.fs);
-			}
-			if (threadIdx.x == 0) nhit = 0;
-			__syncthreads();
-			if (hit) hits[atomicAdd(&nhit, 1)] = threadIdx.x;
-			__syncthreads();
-			const int n = nhit;
-			for (int i = 0; i < n; ++i) {
-				ct_frame_block<N, T>(a, base + hits[i], A, scr, red);
-				__syncthreads();
-			}
+		// the frames the one-wavefront kernel in front of this one has listed (none for a contour out of Harvest)
+		const int n = a.rare_list[0];
+#pragma unroll 1
+		for (int i = blockIdx.x; i < n; i += gridDim.x) {
+			ct_frame_block<N, T>(a, a.rare_list[1 + i], A, scr, red);
 			__syncthreads();
 		}
 	} else {
@@ -347,7 +335,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_CT_WAVE_O
 	const int fs = a.fs;
 	const double f0v = a.f0[g];
 	const double f0c = uniform_d((f0v <= a.f0_floor) ? 500.0 : f0v);  // reference :77
-	if (!ct_wave_can<N>(f0c, fs)) return;
+	if (!ct_wave_can<N>(f0c, fs)) {  // left for the block kernel behind this one
+		if (lane == 0) a.rare_list[1 + atomicAdd(a.rare_list, 1)] = (int)g;
+		return;
+	}
 	const UttDesc ud = a.utts[a.uidx[g]];
 	const double *__restrict__ x = a.x + ud.x_off;
 	const int x_last = ud.x_len - 1;
@@ -638,7 +629,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_CT_WAVE8_
 	const int fs = a.fs;
 	const double f0v = a.f0[g];
 	const double f0c = uniform_d((f0v <= a.f0_floor) ? 500.0 : f0v);  // reference :77
-	if (!ct_wave_can<N>(f0c, fs)) return;
+	if (!ct_wave_can<N>(f0c, fs)) {  // left for the block kernel behind this one
+		if (lane == 0) a.rare_list[1 + atomicAdd(a.rare_list, 1)] = (int)g;
+		return;
+	}
 	const UttDesc ud = a.utts[a.uidx[g]];
 	const double *__restrict__ x = a.x + ud.x_off;
 	const int x_last = ud.x_len - 1;
@@ -895,12 +889,9 @@ struct wc_cheaptrick {
 	bool wave;  // N = 2048 / 1024: one wavefront per frame (default; WC_CT_IMPL=block: the workgroup-per-frame kernel for every frame)
 	double q1, f0_floor_opt, f0_floor;
 	Device *dev;
-	DevBuf utts, cnt, uidx, off, endpos, d_x, d_tpos, d_f0, d_sp;
+	DevBuf utts, cnt, uidx, rare, off, endpos, d_x, d_tpos, d_f0, d_sp;
 	HostBuf h_stage, h_rows;
-	double f0_bound = 0.0;  // > 0: the caller vouches that no F0 of the contour exceeds it (the pipeline: Harvest's ceiling)
-	// the pass over the frames the one-wavefront kernel leaves out runs beside whatever follows on the caller's stream
-	hipStream_t side = nullptr;
-	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+	double f0_bound = 0.0;  // (a caller's promise about the contour's highest F0: no longer relied on -- the frames the wavefront kernels leave out are listed on the device)
 };
 
 // Threads per frame: eight samples per thread up to N = 2048 (one radix-4 butterfly per thread and pass, nobody idle): 256
@@ -949,6 +940,7 @@ int ct_prepare(wc_cheaptrick *c, hipStream_t s, int n_utt, const int *x_length, 
 	if ((rc = c->utts.reserve(sizeof(UttDesc) * n_utt))) return rc;
 	if ((rc = c->cnt.reserve(sizeof(uint32_t) * total))) return rc;
 	if ((rc = c->uidx.reserve(sizeof(int) * total))) return rc;
+	if ((rc = c->rare.reserve(sizeof(int) * (total + 1)))) return rc;
 	if ((rc = c->off.reserve(sizeof(uint64_t) * total))) return rc;
 	if ((rc = c->endpos.reserve(sizeof(uint64_t) * n_utt))) return rc;
 	if ((rc = c->h_stage.reserve(sizeof(UttDesc) * n_utt + sizeof(uint64_t) * n_utt))) return rc;
@@ -956,7 +948,7 @@ int ct_prepare(wc_cheaptrick *c, hipStream_t s, int n_utt, const int *x_length, 
 	WC_HIP(hipMemcpyAsync(c->utts.p, c->h_stage.p, sizeof(UttDesc) * n_utt, hipMemcpyHostToDevice, s));
 	if ((rc = c->h_stage.mark(s))) return rc;
 	hipLaunchKernelGGL(ct_count_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_f0, total, c->fs,
-					   c->f0_floor, bins, c->cnt.as<uint32_t>(), c->utts.as<UttDesc>(), n_utt, c->uidx.as<int>());
+					   c->f0_floor, bins, c->cnt.as<uint32_t>(), c->utts.as<UttDesc>(), n_utt, c->uidx.as<int>(), c->rare.as<int>());
 	hipLaunchKernelGGL(utt_scan_kernel, dim3(n_utt), dim3(256), 0, s, c->cnt.as<uint32_t>(), c->utts.as<UttDesc>(),
 					   (const unsigned long long *)nullptr, c->off.as<unsigned long long>(), c->endpos.as<unsigned long long>());
 	WC_HIP(hipGetLastError());
@@ -975,47 +967,24 @@ int ct_frames(wc_cheaptrick *c, hipStream_t s, int n_utt, const double *d_x, con
 	a.rng_base = dev->rng_base; a.tw = dev->twiddle; a.sp = d_sp; a.total_frames = total; a.fs = c->fs;
 	a.q1 = c->q1; a.f0_floor = c->f0_floor; a.uidx = c->uidx.as<int>();
 	if ((rc = dev->time_begin("cheaptrick_frames", s))) return rc;
-	a.rare_only = 0;
+	a.rare_list = c->rare.as<int>();
+	const unsigned grid8 = (unsigned)(((total + 7) / 8) * 8);
 	switch (c->fft_size) {
 		case 512: launch_ct<512>(a, s); break;
 		case 1024:
 			if (c->wave) {
-				// one wavefront per frame at eight points per lane; the frames it leaves out (ct_wave_can<1024>) by the block kernel
-				// behind it on the same stream (none for a contour out of Harvest: no second launch)
-				hipLaunchKernelGGL(ct_wave8_kernel, dim3((unsigned)(((total + 7) / 8) * 8)), dim3(64), 0, s, a);
-				if (!(c->f0_bound > 0.0 && ct_wave_can<1024>(c->f0_bound, c->fs))) {
-					a.rare_only = 1;
-					hipLaunchKernelGGL((ct_frames_kernel<1024, 128, true>), dim3(256), dim3(128), 0, s, a);
-				}
+				// one wavefront per frame at eight points per lane; the frames it leaves out (ct_wave_can: none for a contour out of
+				// Harvest) are listed and done by a small grid of the block kernel behind it
+				hipLaunchKernelGGL(ct_wave8_kernel, dim3(grid8), dim3(64), 0, s, a);
+				hipLaunchKernelGGL((ct_frames_kernel<1024, 128, true>), dim3(64), dim3(128), 0, s, a);
 			} else {
 				launch_ct<1024>(a, s);
 			}
 			break;
 		case 2048:
 			if (c->wave) {
-				// one wavefront per frame; the frames it leaves out (F0 above ~2 kHz, ct_wave_can) are found and done by a
-				// small grid of the block kernel behind it
-				// small grid of the block kernel -- on a stream of its own: its workgroups (four wavefronts, 18 KB) wait long for a
-				// place while one-wavefront kernels fill the CUs, and nothing on the caller's stream needs its rows before the
-				// spectrogram is read.  rows_done: the caller makes the readers wait (NULL: this stream does, before returning).
-				if (c->f0_bound > 0.0 && ct_wave_can<2048>(c->f0_bound, c->fs)) {
-					// a contour out of Harvest (ceiling far below the limit) holds no such frame: no second launch at all
-					hipLaunchKernelGGL(ct_wave_kernel, dim3((unsigned)(((total + 7) / 8) * 8)), dim3(64), 0, s, a);
-				} else {
-					if (!c->side) {
-						WC_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-						WC_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-						WC_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-					}
-					WC_HIP(hipEventRecord(c->ev_fork, s));
-					WC_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
-					hipLaunchKernelGGL(ct_wave_kernel, dim3((unsigned)(((total + 7) / 8) * 8)), dim3(64), 0, s, a);
-					a.rare_only = 1;
-					hipLaunchKernelGGL((ct_frames_kernel<2048, WC_CT_THREADS, true>), dim3(256), dim3(WC_CT_THREADS), 0, c->side, a);
-					WC_HIP(hipEventRecord(c->ev_join, c->side));
-					if (rows_done) *rows_done = c->ev_join;
-					else WC_HIP(hipStreamWaitEvent(s, c->ev_join, 0));
-				}
+				hipLaunchKernelGGL(ct_wave_kernel, dim3(grid8), dim3(64), 0, s, a);
+				hipLaunchKernelGGL((ct_frames_kernel<2048, WC_CT_THREADS, true>), dim3(64), dim3(WC_CT_THREADS), 0, s, a);
 			} else {
 				launch_ct<2048>(a, s);
 			}
@@ -1093,13 +1062,10 @@ wc_cheaptrick *wc_cheaptrick_create(int fs, double q1, double f0_floor, int fft_
 void wc_cheaptrick_destroy(wc_cheaptrick *c) {
 	if (!c) return;
 	c->dev->quiesce();
-	c->utts.release(); c->cnt.release(); c->uidx.release(); c->off.release(); c->endpos.release();
+	c->utts.release(); c->cnt.release(); c->uidx.release(); c->rare.release(); c->off.release(); c->endpos.release();
 	c->d_x.release(); c->d_tpos.release(); c->d_f0.release(); c->d_sp.release();
 	c->h_stage.release();
 	c->h_rows.release();
-	if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
-	if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-	if (c->ev_join) (void)hipEventDestroy(c->ev_join);
 	delete c;
 }
 int wc_cheaptrick_get_fft_size(const wc_cheaptrick *c) { return c ? c->fft_size : WC_ERR_INVALID; }

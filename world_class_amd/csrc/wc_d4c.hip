@@ -52,7 +52,8 @@ struct D4cArgs {
 	long long sgd_stride;  // doubles per frame in sgd
 	int *long_list, *long_cnt;  // gated frames whose windows exceed 2048 samples: left by d4c2_frames_kernel<false>, done by <true>
 	const int *uidx;  // [total_frames] utterance of every frame (d4c_lt_count_kernel): the one-wavefront kernels read it instead of bisecting
-	int rare_only;  // d4c_frames_kernel behind d4c2_frames_kernel: only the frames that one leaves out (d4c2_can)
+	int rare_only;  // (unused)
+	int *rare_list;  // [0]: count, then the gated frames the one-wavefront kernels leave to the block kernel
 };
 
 // F0-adaptive window of reference src/d4c.cpp:246-303 for the calling block; each thread keeps its
@@ -200,10 +201,11 @@ __host__ __device__ __forceinline__ bool d4c2_can(double f0, int fs) {
 
 // number of draws of one frame's LoveTrain window / of its three D4C windows
 __global__ void d4c_lt_count_kernel(const double *__restrict__ f0, long long total, int fs, uint32_t *__restrict__ cnt,
-									const UttDesc *__restrict__ utts, int n_utt, int *__restrict__ uidx, int *__restrict__ long_cnt) {
+									const UttDesc *__restrict__ utts, int n_utt, int *__restrict__ uidx, int *__restrict__ long_cnt,
+									int *__restrict__ rare_cnt) {
 	long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 	if (g >= total) return;
-	if (g == 0) *long_cnt = 0;
+	if (g == 0) { *long_cnt = 0; *rare_cnt = 0; }
 	uidx[g] = find_utt(utts, n_utt, g);  // (looked up once here rather than by every frame's wavefront, a chain of dependent loads each)
 	double f = f0[g];
 	cnt[g] = (f == 0.0) ? 0u : (uint32_t)(2 * mround(3.0 * fs / fmax(f, 40.0) / 2.0) + 1);
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(T, T == 512 ? 6 : 1) void d4c_lovetrain_kernel(D4cA
 #define WC_D4C_FFTSYNC 1  // FFT flags; 0 (no barriers) and 3 (no twiddle loads) are timing ablations with wrong results
 #endif
 template <int N, int T, bool SPLIT>
-__global__ __launch_bounds__(T, T >= 1024 ? 4 : (2 * T) / 256) void d4c_frames_kernel(D4cArgs a) {
+__device__ __forceinline__ void d4c_frames_body(const D4cArgs &a, const long long g) {
 	constexpr int M = N / 2;
 	constexpr int EPT = N / T;
 	constexpr int KPT = (M + 1 + T - 1) / T;  // power-spectrum keys per thread
@@ -285,11 +287,8 @@ __global__ __launch_bounds__(T, T >= 1024 ? 4 : (2 * T) / 256) void d4c_frames_k
 
 	int tid = threadIdx.x;
 #define WC_FRESH_TID() WC_FRESH(tid)  // see wc_device.hpp
-	long long g = xcd_frame(blockIdx.x, a.total_frames);
-	if (g >= a.total_frames) return;
 	const double f0v = a.f0[g];
 	if (f0v == 0.0 || a.ap0[g] <= a.threshold) return;  // reference :147
-	if (a.rare_only && d4c2_can(fmax(47.0, f0v), a.fs)) return;
 	const int u = find_utt(a.utts, a.n_utt, g);
 	const UttDesc ud = a.utts[u];
 	const double *__restrict__ x = a.x + ud.x_off;
@@ -532,6 +531,23 @@ __global__ __launch_bounds__(T, T >= 1024 ? 4 : (2 * T) / 256) void d4c_frames_k
 }
 
 #undef WC_FRESH_TID
+// every frame (XCD-contiguous order), or -- rare_only, behind the one-wavefront kernels -- the frames those have listed
+// (two kernels: the loop over a list keeps what is invariant from frame to frame in registers, 147 - 190 of them instead of 124)
+template <int N, int T, bool SPLIT, bool RARE = false>
+__global__ __launch_bounds__(T, T >= 1024 ? 4 : (2 * T) / 256) void d4c_frames_kernel(D4cArgs a) {
+	if constexpr (RARE) {
+		const int n = a.rare_list[0];
+#pragma unroll 1
+		for (int i = blockIdx.x; i < n; i += gridDim.x) {
+			d4c_frames_body<N, T, SPLIT>(a, a.rare_list[1 + i]);
+			__syncthreads();
+		}
+	} else {
+		const long long g = xcd_frame(blockIdx.x, a.total_frames);
+		if (g >= a.total_frames) return;
+		d4c_frames_body<N, T, SPLIT>(a, g);
+	}
+}
 
 #ifndef WC_D4C_PRUNE
 #define WC_D4C_PRUNE 1
@@ -1038,7 +1054,10 @@ __device__ __forceinline__ void d4c2_frame(const D4cArgs &a, const long long g, 
 	if (f0v == 0.0 || a.ap0[g] <= a.threshold) return;  // reference :147
 	const int fs = a.fs;
 	const double f0 = uniform_d(fmax(47.0, f0v));
-	if (!d4c2_can(f0, fs)) return;
+	if (!d4c2_can(f0, fs)) {  // left for the block kernel behind this one
+		if (!LONG && lane == 0) a.rare_list[1 + atomicAdd(a.rare_list, 1)] = (int)g;
+		return;
+	}
 	const int wl = __builtin_amdgcn_readfirstlane(2 * mround(4.0 * fs / f0 / 2.0) + 1);
 	if constexpr (!LONG) {
 		if (wl > 2048) {  // left for the second launch (before anything else is fetched)
@@ -1410,6 +1429,378 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_D4C2_BAND
 	}
 }
 
+
+// ==== N = 2048 (16 / 22.05 / 24 kHz): the same kernels where a real transform is ONE 1024-point complex one ===================
+// d4c2_* without the even / odd split: every window fits the 2048 samples of the sixteen slots (4 fs / 47 <= 2043 at 24 kHz), a
+// transform is wf_r2c4096_half's even form on the unfolded input (the 2048-point real transform itself), slot 4 g + q holds bin
+// j_g + 256 q, bin 1024 travels beside them in lane 0.  No second launch for long windows, half the parked traffic.
+constexpr long long kD4Row1 = 3136;  // doubles per frame of the group-delay array: centroid | power | parked odd samples (+ pad)
+constexpr int kD4Lds1 = 2176;  // doubles: exchange buffer (1152) + the parked even samples (1024); the smoothings' 1025 + 2 b + 1 terms, b <= 120, fit its head
+__host__ __device__ __forceinline__ bool d4c1_can(double f0, int fs) {
+	const int v = (int)(f0 * 2048 / fs);
+	return v + 1 <= 120 && v + 2 <= 122;
+}
+struct D4Bins1 {
+	double v[16];
+	double vM;
+};
+// DCCorrection (reference src/world_common.cpp:61-80): only bins below upper - 1 <= 121 change: slot A_0 (bin lane) and C_0
+// (bin 64 + lane), from bins <= upper + 1 <= 123
+__device__ __forceinline__ void d4c1_dc_correction(D4Bins1 &s, double f0, int fs, double *L, int lane) {
+	constexpr int N = 2048;
+	WC_FRESH(lane);
+	const int upper = __builtin_amdgcn_readfirstlane(2 + (int)(f0 * N / fs));
+	const double dx = -(double)fs / N, rdx = 1.0 / dx;
+	L[lane] = s.v[0];
+	L[64 + lane] = s.v[8];
+	wf_fence();
+	auto rep = [&](int i) {
+		const double axis = (double)i * fs / N;
+		return interp1q_rcp(f0, dx, rdx, [&](int b) { return L[min(max(b, 0), 127)]; }, upper + 1, axis);
+	};
+	if (lane < upper - 1) s.v[0] += rep(lane);
+	if (upper - 1 > 64) {
+		if (64 + lane < upper - 1) s.v[8] += rep(64 + lane);
+	}
+	wf_fence();
+}
+// LinearSmoothing (reference src/world_common.cpp:27-52, :82-116), in place; the cumulative sum in the reference's own
+// sequential rounding, for non-negative terms (NONNEG) or terms of either sign (see d4c2_smooth)
+template <bool NONNEG>
+__device__ __forceinline__ void d4c1_smooth(D4Bins1 &s, double width, int fs, double *L, int lane) {
+	constexpr int N = 2048, M = 1024;
+	WC_FRESH(lane);
+	const int b = __builtin_amdgcn_readfirstlane((int)(width * N / fs) + 1);  // <= 120 (d4c1_can)
+	const int len = M + 2 * b + 1;
+	int jg[4];
+#pragma unroll
+	for (int gq = 0; gq < 4; ++gq) jg[gq] = wf_bin(lane, gq, 0);
+	// mirrored segment: position i holds bin b - i (i < b), bin i - b (b <= i < M + b), bin 2 M + b - i (M + b <= i <= M + 2 b).
+	// The low mirror comes from slots A_0 (bins 1 .. 63) and C_0 (bins 64 .. 127), the high one from B_3 (bins 1024 - lane) and
+	// D_3 (bins 960 - lane).
+#pragma unroll
+	for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+		for (int q = 0; q < 4; ++q) L[jg[gq] + 256 * q + b] = s.v[4 * gq + q] * fs / N;
+	if (lane == 0) L[M + b] = s.vM * fs / N;
+	if (lane >= 1 && lane <= b) {
+		L[b - lane] = s.v[0] * fs / N;
+		L[M + b + lane] = s.v[7] * fs / N;
+	}
+	if (64 + lane <= b) {
+		L[b - 64 - lane] = s.v[8] * fs / N;
+		L[M + b + 64 + lane] = s.v[15] * fs / N;
+	}
+	wf_fence();
+	if (NONNEG) seq_cumsum_nonneg_wave<20>(L, len, lane);
+	else seq_cumsum_signed_wave<20>(L, len, lane);
+	const double step = (double)fs / N;
+	const double origin_axis = -(b - 0.5) * fs / N;
+	const double rstep = 1.0 / step;
+	const double rwidth = uniform_d(1.0 / width);
+	auto at = [&](int k) {
+		const double lo_axis = (double)k / N * fs - width / 2.0, hi_axis = lo_axis + width;
+		return (wf_interp1q(origin_axis, step, rstep, L, len, hi_axis) - wf_interp1q(origin_axis, step, rstep, L, len, lo_axis)) * rwidth;
+	};
+#pragma unroll
+	for (int gq = 0; gq < 4; ++gq) {
+#pragma unroll
+		for (int q = 0; q < 4; ++q) s.v[4 * gq + q] = at(jg[gq] + 256 * q);
+		WF_SCHED_FENCE();  // (four bins at a time: interleaving all of them overflows the registers)
+	}
+	s.vM = at(M);
+	wf_fence();
+}
+
+#ifndef WC_D4C1_LT_OCC
+#define WC_D4C1_LT_OCC 3
+#endif
+#ifndef WC_D4C1_OCC
+#define WC_D4C1_OCC 2
+#endif
+#ifndef WC_D4C1_BAND_OCC
+#define WC_D4C1_BAND_OCC 3
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_D4C1_LT_OCC, WC_D4C1_LT_OCC))) void d4c1_lovetrain_kernel(D4cArgs a) {
+	constexpr int N = 2048, M = 1024;
+	__shared__ __attribute__((aligned(16))) double L[kWfLds];
+	const int lane = threadIdx.x;
+	const long long g = xcd_frame(blockIdx.x, a.total_frames);
+	if (g >= a.total_frames) return;
+	const int bins_out = a.fft_size_out / 2 + 1;
+	double *__restrict__ row = a.ap + g * (long long)bins_out;
+	const double f0v = a.f0[g];
+	const int fs = a.fs;
+	const double f0c = uniform_d(fmax(f0v, 40.0));
+	double ap0 = 0.0;
+	if (f0v != 0.0) {
+		const int u = a.uidx[g];
+		const UttDesc ud = a.utts[u];
+		// cumulative powers above 100 Hz up to 4000 Hz and 7900 Hz (reference :184-186, :226-235); a common factor (the
+		// unpacking's 2) does not matter to their ratio
+		const int b0 = (int)ceil(100.0 * N / fs);
+		const int b1 = (int)ceil(4000.0 * N / fs);
+		const int b2 = min((int)ceil(7900.0 * N / fs), M);
+		double p1 = 0.0, p2 = 0.0;
+		double re[16], im[16], unused, nyq;
+		const int wl = d4c2_windowed<16>(2, a.x + ud.x_off, ud.x_len - 1, fs, f0c, a.tpos[g], 3.0, a.rng_table + (a.rng_off[g] - a.rng_base), 0,
+										 false, re, im, unused, lane);
+		wf_r2c4096_half(re, im, nyq, d4c2_groups(wl), L, a.tw, lane, 0);
+#pragma unroll
+		for (int gq = 0; gq < 4; ++gq) {
+			const int j = wf_bin(lane, gq, 0);
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				const int k = j + 256 * q;
+				const double p = fma(re[4 * gq + q], re[4 * gq + q], im[4 * gq + q] * im[4 * gq + q]);
+				p2 += (k > b0 && k <= b2) ? p : 0.0;
+				p1 += (k > b0 && k <= min(b1, b2)) ? p : 0.0;
+			}
+		}
+		if (lane == 0 && b2 == M) {
+			p2 += nyq * nyq;
+			if (b1 >= M) p1 += nyq * nyq;
+		}
+		p1 = wave_sum_all(p1);
+		p2 = wave_sum_all(p2);
+		ap0 = p1 / p2;
+	}
+	const bool gate = !(f0v == 0.0 || ap0 <= a.threshold);  // reference :147
+	if (lane == 0) {
+		a.ap0[g] = ap0;
+		a.cnt[g] = gate ? (uint32_t)(3 * (2 * mround(4.0 * a.fs / fmax(47.0, f0v) / 2.0) + 1)) : 0u;
+	}
+	if (!gate) {
+		const double init_val = 1.0 - kSafe;
+		for (int k = lane; k < bins_out; k += 64) row[k] = init_val;
+	}
+}
+
+// gated frames up to the static group delay (reference :308-460), which the band kernel reads back (see d4c2_frame)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_D4C1_OCC, WC_D4C1_OCC))) void d4c1_frames_kernel(D4cArgs a) {
+	constexpr int M = 1024;
+	__shared__ __attribute__((aligned(16))) double L[kD4Lds1];
+	const int lane = threadIdx.x;
+	const long long g = xcd_frame(blockIdx.x, a.total_frames);
+	if (g >= a.total_frames) return;
+	const double f0v = a.f0[g];
+	if (f0v == 0.0 || a.ap0[g] <= a.threshold) return;  // reference :147
+	const int fs = a.fs;
+	const double f0 = uniform_d(fmax(47.0, f0v));
+	if (!d4c1_can(f0, fs)) {  // left for the block kernel behind this one
+		if (lane == 0) a.rare_list[1 + atomicAdd(a.rare_list, 1)] = (int)g;
+		return;
+	}
+	const int wl = __builtin_amdgcn_readfirstlane(2 * mround(4.0 * fs / f0 / 2.0) + 1);
+	const int u = a.uidx[g];
+	const UttDesc ud = a.utts[u];
+	const double *__restrict__ x = a.x + ud.x_off;
+	const int x_last = ud.x_len - 1;
+	const double pos = uniform_d(a.tpos[g]);
+	const uint32_t *__restrict__ rng = a.rng_table + (a.rng_off[g] - a.rng_base);
+	// the frame's own row of the group-delay array: [0, 1024) the centroid, [1024, 2048) the power spectrum, [2048, 3072) the
+	// parked odd samples of the current window; the row's head is written for good at the end
+	double *park = a.sgd + g * a.sgd_stride;
+	const D4Row row = d4_row(park);
+
+	// ---- static centroid (reference :339-405) at t -+ T0/4 and the power spectrum of the Hanning-windowed frame (:411-434):
+	// jobs 0, 1, 2 through one copy of the code ----
+	const int ng = d4c2_groups(wl);
+	double cenM = 0.0, spsM = 0.0;  // bin 1024 (lane 0)
+#pragma unroll 1
+	for (int job = 0; job < 3; ++job) {
+		int ln = lane;
+		WC_FRESH(ln);
+		const double p = (job == 0) ? pos - 0.25 / f0 : (job == 1) ? pos + 0.25 / f0 : pos;
+		double re[16], im[16], nyq1;
+		{
+			double sumsq;
+			d4c2_windowed<16>(job == 2 ? 1 : 2, x, x_last, fs, f0, p, 4.0, rng + (long long)job * wl, 0, false, re, im, sumsq, ln);
+			// (the reference divides every sample by the norm: an ulp apart); half of it: the transforms below then yield X, not
+			// 2 X.  The power spectrum's window is not normalised: its 2 X is put right by the 0.25 below.
+			const double pw = (job == 2) ? 1.0 : 0.5 * (1.0 / sqrt(sumsq));
+#pragma unroll
+			for (int q = 0; q < 16; ++q) {
+				re[q] *= pw;
+				im[q] *= pw;
+				if (job != 2 && q < 4 * ng) {  // the centroid's second transform reads the window again
+					L[kWfLds + 64 * q + ln] = re[q];
+					d4_st(row, 2048 + 64 * q + ln, im[q]);
+				}
+			}
+		}
+		wf_r2c4096_half(re, im, nyq1, ng, L, a.tw, ln, 0);
+		if (job == 2) {
+#pragma unroll
+			for (int s = 0; s < 16; ++s) d4_st(row, 1024 + 64 * s + ln, 0.25 * fma(re[s], re[s], im[s] * im[s]));
+			spsM = 0.25 * (nyq1 * nyq1);
+		} else {
+			double ar[16], ai[16], nyq2;
+			{
+				int l2 = lane;
+				WC_FRESH(l2);  // (the weights below must not be hoisted out of the loop over the jobs and spilled)
+#pragma unroll
+				for (int q = 0; q < 16; ++q) {
+					ar[q] = ai[q] = 0.0;
+					if (q < 4 * ng) {
+						ar[q] = L[kWfLds + 64 * q + l2];
+						ai[q] = d4_ld(row, 2048 + 64 * q + l2);
+					}
+				}
+				WF_SCHED_FENCE();
+#pragma unroll
+				for (int q = 0; q < 16; ++q) {
+					const int i0 = 2 * l2 + 128 * q;
+					ar[q] *= i0 + 1.0;
+					ai[q] *= i0 + 2.0;
+				}
+			}
+			wf_r2c4096_half(ar, ai, nyq2, ng, L, a.tw, ln, 0);
+			double acc[16];
+#pragma unroll
+			for (int s = 0; s < 16; ++s) acc[s] = fma(re[s], ar[s], im[s] * ai[s]);
+			if (job == 1) {
+				double prev[16];
+#pragma unroll
+				for (int s = 0; s < 16; ++s) prev[s] = d4_ld(row, 64 * s + ln);
+				WF_SCHED_FENCE();
+#pragma unroll
+				for (int s = 0; s < 16; ++s) acc[s] += prev[s];
+			}
+#pragma unroll
+			for (int s = 0; s < 16; ++s) d4_st(row, 64 * s + ln, acc[s]);
+			cenM += nyq1 * nyq2;
+		}
+	}
+	D4Bins1 cen, sps;
+#pragma unroll
+	for (int s = 0; s < 16; ++s) {
+		cen.v[s] = d4_ld(row, 64 * s + lane);
+		sps.v[s] = d4_ld(row, 1024 + 64 * s + lane);
+	}
+	cen.vM = cenM;
+	sps.vM = spsM;
+	d4c1_dc_correction(cen, f0, fs, L, lane);
+	d4c1_dc_correction(sps, f0, fs, L, lane);
+	d4c1_smooth<true>(sps, f0, fs, L, lane);
+	// ---- static group delay (reference :440-460) ----
+#pragma unroll
+	for (int s = 0; s < 16; ++s) cen.v[s] = cen.v[s] / sps.v[s];
+	cen.vM = cen.vM / sps.vM;
+	// smoothed over f0 / 2, minus that smoothed once more over f0 (one copy of the code, run twice)
+#pragma unroll 1
+	for (int it = 0; it < 2; ++it) {
+		d4c1_smooth<false>(cen, it ? f0 : f0 / 2.0, fs, L, lane);
+		if (it == 0) sps = cen;
+	}
+	// (sps: once smoothed; cen: twice)
+#pragma unroll
+	for (int gq = 0; gq < 4; ++gq) {
+		const int j = wf_bin(lane, gq, 0);
+#pragma unroll
+		for (int q = 0; q < 4; ++q) d4_st(row, j + 256 * q, sps.v[4 * gq + q] - cen.v[4 * gq + q]);
+	}
+	if (lane == 0) d4_st(row, M, sps.vM - cen.vM);
+}
+
+// one wavefront per (gated frame, band) (reference :466-503), see d4c2_band_kernel: one transform, 17 keys per lane
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_D4C1_BAND_OCC, WC_D4C1_BAND_OCC))) void d4c1_band_kernel(D4cArgs a) {
+	constexpr int N = 2048, M = 1024;
+	__shared__ __attribute__((aligned(16))) double L[kWfLds];
+	const int lane = threadIdx.x;
+	const int n_ap = a.n_ap;
+	const long long blk = xcd_frame(blockIdx.x, (long long)gridDim.x);
+	const long long g = blk / n_ap;
+	const int bnd = (int)(blk % n_ap);
+	if (g >= a.total_frames) return;
+	const double f0v = a.f0[g];
+	if (f0v == 0.0 || a.ap0[g] <= a.threshold) return;
+	const double f0 = fmax(47.0, f0v);
+	const int fs = a.fs;
+	const int wln = a.window_length, hwl = wln / 2;  // <= 1023 samples = 512 packed points: slots 0 .. 7
+	const int boundary = mround(N * 8.0 / wln);
+	const unsigned int K = (unsigned int)(M + 1 - boundary - 1);
+	const int center = (int)(3000.0 * (bnd + 1) * N / fs);
+	const double *__restrict__ src = a.sgd + g * a.sgd_stride + (center - hwl);
+	const int ng = wln > 512 ? 2 : 1;
+	double key[16], keyM = 0.0;
+	{
+		double re[16], im[16], nyq;
+		{
+			double sv[16], nv[16];
+#pragma unroll
+			for (int k = 0; k < 16; ++k) {
+				const int i = min(2 * lane + 128 * (k >> 1) + (k & 1), wln - 1);
+				sv[k] = src[i];
+				nv[k] = a.nuttall[i];
+			}
+			WF_SCHED_FENCE();
+#pragma unroll
+			for (int q = 0; q < 16; ++q) {
+				re[q] = im[q] = 0.0;
+				if (q < 8) {
+					const int i0 = 2 * lane + 128 * q;
+					re[q] = (i0 < wln) ? sv[2 * q] * nv[2 * q] : 0.0;
+					im[q] = (i0 + 1 < wln) ? sv[2 * q + 1] * nv[2 * q + 1] : 0.0;
+				}
+			}
+		}
+		wf_r2c4096_half(re, im, nyq, ng, L, a.tw, lane, 0);  // 2 X: a common factor of all powers
+#pragma unroll
+		for (int s = 0; s < 16; ++s) key[s] = fma(re[s], re[s], im[s] * im[s]);
+		keyM = nyq * nyq;  // lane 0
+	}
+	// largest key
+	double mx = (lane == 0) ? keyM : 0.0;
+#pragma unroll
+	for (int s = 0; s < 16; ++s) mx = fmax(mx, key[s]);
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_down(mx, o, 64));
+	mx = uniform_d(mx);
+	long long lo = -1, hi = __double_as_longlong(mx);
+	unsigned int c_lo = 0;
+	auto count_le = [&](long long t) {
+		unsigned int c = (unsigned int)__popcll(__ballot(lane == 0 && __double_as_longlong(keyM) <= t));
+#pragma unroll
+		for (int s = 0; s < 16; ++s) c += (unsigned int)__popcll(__ballot(__double_as_longlong(key[s]) <= t));
+		return c;
+	};
+#if WC_D4C2_BRACKET
+#pragma unroll 1
+	for (int tr = 0; tr < 2; ++tr) {
+		const long long cand = __double_as_longlong(mx * (tr == 0 ? WC_D4C2_BRACKET_FIRST : 0x1p-40));
+		const unsigned int c = count_le(cand);
+		if (c <= K && cand > 0) { lo = cand; c_lo = c; break; }
+		hi = cand > 0 && c >= K ? cand : hi;  // (more than K below: the K-th smallest is at or below cand)
+	}
+#endif
+	for (int it = 0; it < 64 && hi - lo > 1 && c_lo != K; ++it) {
+		const long long mid = lo + ((hi - lo) >> 1);
+		const unsigned int c = count_le(mid);
+		if (c >= K) hi = mid;
+		if (c <= K) { lo = mid; c_lo = c; }
+		if (c == K) break;
+	}
+	// sum of the K smallest = sum(keys <= lo) + (K - #{keys <= lo}) * (the key at hi), and the total
+	double low = 0.0, tot = 0.0;
+#pragma unroll
+	for (int s = 0; s < 16; ++s) {
+		tot += key[s];
+		low += (__double_as_longlong(key[s]) <= lo) ? key[s] : 0.0;
+	}
+	if (lane == 0) {
+		tot += keyM;
+		low += (__double_as_longlong(keyM) <= lo) ? keyM : 0.0;
+	}
+	low = wave_sum_all(low);
+	tot = wave_sum_all(tot);
+	if (lane == 0) {
+		const double part = low + (double)(K - c_lo) * __longlong_as_double(hi);
+		const double cv = 10 * log10(part / tot);
+		a.coarse[g * kMaxBands + bnd] = fmin(0.0, cv + (f0 - 100) / 50.0);  // reference :326-328
+	}
+}
+
 }  // namespace wc
 
 using namespace wc;
@@ -1420,8 +1811,8 @@ struct wc_d4c {
 	bool split;  // band loop and row output as separate kernels (default; WC_D4C_SPLIT=0: one fused kernel)
 	bool wave2;  // 4096-point transforms by two wavefronts per frame (d4c2_*; default where they apply, WC_D4C_IMPL=block: never)
 	Device *dev;
-	double f0_bound = 0.0;  // > 0: the caller vouches that no F0 of the contour exceeds it (the pipeline: Harvest's ceiling)
-	DevBuf nuttall, utts, cnt, uidx, long_list, off, endpos, endpos2, ap0, sgd, coarse, d_x, d_tpos, d_f0, d_ap;
+	double f0_bound = 0.0;  // (a caller's promise about the contour's highest F0: no longer relied on -- the frames the wavefront kernels leave out are listed on the device)
+	DevBuf nuttall, utts, cnt, uidx, long_list, rare_list, off, endpos, endpos2, ap0, sgd, coarse, d_x, d_tpos, d_f0, d_ap;
 	HostBuf h_stage, h_rows;
 };
 
@@ -1479,12 +1870,15 @@ int d4c_enqueue(wc_d4c *d, hipStream_t s, int n_utt, const double *d_x, const in
 	if ((rc = d->cnt.reserve(sizeof(uint32_t) * total))) return rc;
 	if ((rc = d->uidx.reserve(sizeof(int) * total))) return rc;
 	if ((rc = d->long_list.reserve(sizeof(int) * (total + 1)))) return rc;  // [0]: the count
+	if ((rc = d->rare_list.reserve(sizeof(int) * (total + 1)))) return rc;  // [0]: the count
 	if ((rc = d->off.reserve(sizeof(uint64_t) * total))) return rc;
 	if ((rc = d->ap0.reserve(sizeof(double) * total))) return rc;
 	const bool split = d->split;
+	// the one-wavefront kernels (d4c2_* at N = 4096, d4c1_* at N = 2048) park their intermediate results in the frame's row of the group-delay array
+	const bool main2 = d->wave2 && split && (d->fft_size_d4c == 4096 || d->fft_size_d4c == 2048) && d->window_length <= 1023;
+	const long long row2 = d->fft_size_d4c == 4096 ? kD4Row : kD4Row1;
 	if (split) {
-		const bool rows2 = d->wave2 && d->fft_size_d4c == 4096 && d->window_length <= 1023;
-		if ((rc = d->sgd.reserve(sizeof(double) * (size_t)total * (rows2 ? (size_t)kD4Row : (size_t)(d->fft_size_d4c / 2 + 1))))) return rc;
+		if ((rc = d->sgd.reserve(sizeof(double) * (size_t)total * (main2 ? (size_t)row2 : (size_t)(d->fft_size_d4c / 2 + 1))))) return rc;
 		if ((rc = d->coarse.reserve(sizeof(double) * (size_t)total * kMaxBands))) return rc;
 	}
 	if ((rc = d->endpos.reserve(sizeof(uint64_t) * n_utt))) return rc;
@@ -1495,7 +1889,7 @@ int d4c_enqueue(wc_d4c *d, hipStream_t s, int n_utt, const double *d_x, const in
 	if ((rc = d->h_stage.mark(s))) return rc;
 	const unsigned grid1 = (unsigned)((total + 255) / 256);
 	hipLaunchKernelGGL(d4c_lt_count_kernel, dim3(grid1), dim3(256), 0, s, d_f0, total, d->fs, d->cnt.as<uint32_t>(), d->utts.as<UttDesc>(), n_utt,
-					   d->uidx.as<int>(), d->long_list.as<int>());
+					   d->uidx.as<int>(), d->long_list.as<int>(), d->rare_list.as<int>());
 	hipLaunchKernelGGL(utt_scan_kernel, dim3(n_utt), dim3(256), 0, s, d->cnt.as<uint32_t>(), d->utts.as<UttDesc>(),
 					   d_start, d->off.as<unsigned long long>(), d->endpos.as<unsigned long long>());
 	D4cArgs a;
@@ -1506,14 +1900,15 @@ int d4c_enqueue(wc_d4c *d, hipStream_t s, int n_utt, const double *d_x, const in
 	a.nuttall = d->nuttall.as<double>(); a.total_frames = total; a.fs = d->fs; a.fft_size_out = fft_size;
 	a.n_ap = d->n_ap; a.window_length = d->window_length; a.threshold = d->threshold;
 	a.rare_only = 0;
-	a.sgd_stride = (d->wave2 && split && d->fft_size_d4c == 4096 && d->window_length <= 1023) ? kD4Row : (long long)(d->fft_size_d4c / 2 + 1);
+	a.rare_list = d->rare_list.as<int>();
+	a.sgd_stride = main2 ? row2 : (long long)(d->fft_size_d4c / 2 + 1);
 	const long long blocks8 = ((total + 7) / 8) * 8;
-	const bool lt2 = d->wave2 && d->fft_size_lt == 4096;
-	const bool main2 = d->wave2 && split && d->fft_size_d4c == 4096 && d->window_length <= 1023;
 	if ((rc = dev->time_begin("d4c_lovetrain", s))) return rc;
-	if (lt2) {
+	if (d->wave2 && d->fft_size_lt == 4096) {
 		hipLaunchKernelGGL(d4c2_lovetrain_kernel<false>, dim3((unsigned)blocks8), dim3(64), 0, s, a);
 		hipLaunchKernelGGL(d4c2_lovetrain_kernel<true>, dim3((unsigned)blocks8), dim3(64), 0, s, a);
+	} else if (d->wave2 && d->fft_size_lt == 2048) {
+		hipLaunchKernelGGL(d4c1_lovetrain_kernel, dim3((unsigned)blocks8), dim3(64), 0, s, a);
 	}
 	else switch (d->fft_size_lt) {
 		case 1024: launch_lt<1024>(a, s); break;
@@ -1531,16 +1926,23 @@ int d4c_enqueue(wc_d4c *d, hipStream_t s, int n_utt, const double *d_x, const in
 		const char *name = part == 0 ? "d4c_frames" : "d4c_bands";
 		if ((rc = dev->time_begin(name, s))) return rc;
 		if (main2 && part == 0) {
-			// one wavefront per frame; the frames it leaves out (F0 above ~1.4 kHz, d4c2_can) by the block kernel behind them
-			hipLaunchKernelGGL(d4c2_frames_kernel<false>, dim3((unsigned)blocks8), dim3(64), 0, s, a);
-			hipLaunchKernelGGL(d4c2_frames_kernel<true>, dim3((unsigned)std::min<long long>(blocks8, 4096)), dim3(64), 0, s, a);
-			if (!(d->f0_bound > 0.0 && d4c2_can(d->f0_bound, d->fs))) {  // (a contour out of Harvest cannot hold such frames: no launch)
-				a.rare_only = 1;
-				hipLaunchKernelGGL((d4c_frames_kernel<4096, 512, true>), dim3((unsigned)blocks8), dim3(512), 0, s, a);
-				a.rare_only = 0;
+			// one wavefront per frame; the frames it leaves out (F0 above ~1.4 kHz at 48 kHz, ~930 Hz at 16 kHz: d4c2_can / d4c1_can) are
+			// listed and done by a small grid of the block kernel behind it (a contour out of Harvest lists none: the grid leaves at once)
+			a.rare_only = 1;
+			if (d->fft_size_d4c == 4096) {
+				hipLaunchKernelGGL(d4c2_frames_kernel<false>, dim3((unsigned)blocks8), dim3(64), 0, s, a);
+				hipLaunchKernelGGL(d4c2_frames_kernel<true>, dim3((unsigned)std::min<long long>(blocks8, 4096)), dim3(64), 0, s, a);
+				hipLaunchKernelGGL((d4c_frames_kernel<4096, 512, true, true>), dim3(256), dim3(512), 0, s, a);
+			} else {
+				hipLaunchKernelGGL(d4c1_frames_kernel, dim3((unsigned)blocks8), dim3(64), 0, s, a);
+				hipLaunchKernelGGL((d4c_frames_kernel<2048, 256, true, true>), dim3(256), dim3(256), 0, s, a);
 			}
+			a.rare_only = 0;
 		} else if (main2 && part == 1) {
-			if (a.n_ap > 0) hipLaunchKernelGGL(d4c2_band_kernel, dim3((unsigned)(blocks8 * a.n_ap)), dim3(64), 0, s, a);
+			if (a.n_ap > 0) {
+				if (d->fft_size_d4c == 4096) hipLaunchKernelGGL(d4c2_band_kernel, dim3((unsigned)(blocks8 * a.n_ap)), dim3(64), 0, s, a);
+				else hipLaunchKernelGGL(d4c1_band_kernel, dim3((unsigned)(blocks8 * a.n_ap)), dim3(64), 0, s, a);
+			}
 			hipLaunchKernelGGL(d4c_rows_kernel, dim3((unsigned)a.total_frames), dim3(256), 0, s, a);
 		} else
 		switch (d->fft_size_d4c) {
@@ -1649,7 +2051,7 @@ wc_d4c *wc_d4c_create(int fs, double threshold) {
 void wc_d4c_destroy(wc_d4c *d) {
 	if (!d) return;
 	d->dev->quiesce();
-	d->nuttall.release(); d->utts.release(); d->cnt.release(); d->uidx.release(); d->long_list.release(); d->off.release(); d->endpos.release(); d->endpos2.release();
+	d->nuttall.release(); d->utts.release(); d->cnt.release(); d->uidx.release(); d->long_list.release(); d->rare_list.release(); d->off.release(); d->endpos.release(); d->endpos2.release();
 	d->ap0.release(); d->sgd.release(); d->coarse.release(); d->d_x.release(); d->d_tpos.release(); d->d_f0.release(); d->d_ap.release(); d->h_stage.release(); d->h_rows.release();
 	delete d;
 }
