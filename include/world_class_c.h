@@ -90,6 +90,13 @@ int wc_harvest_compute(wc_harvest *h, const double *x, int x_length, double *tem
                        double *f0);
 int wc_harvest_compute_device(wc_harvest *h, int n_utt, const double *d_x, const int *x_length,
                               double *d_tpos, double *d_f0);
+/* frames this handle returns for x_length samples (Harvest::getSamples with the handle's fs and frame period) */
+int wc_harvest_get_samples(const wc_harvest *h, int x_length);
+/* n_utt utterances held as separate HOST arrays in one call (the reference's calling convention, one compute() per utterance,
+ * include/harvest.hpp:37-39, batched: packed through page-locked staging, one trip over PCIe each way, one batch on the GPU).
+ * temporal_positions[u], f0[u]: wc_harvest_get_samples(h, x_length[u]) doubles each, the caller's. */
+int wc_harvest_compute_batch(wc_harvest *h, int n_utt, const double *const *x, const int *x_length,
+                             double *const *temporal_positions, double *const *f0);
 
 /* ---- CheapTrick: include/cheaptrick.hpp:14-38 --------------------------------------------------- */
 /* CheapTrickOption{q1,f0_floor,fft_size} (src/cheaptrick.cpp:22-45); fft_size 0 = automatic */
@@ -103,6 +110,12 @@ int wc_cheaptrick_compute(wc_cheaptrick *c, const double *x, int x_length,
 int wc_cheaptrick_compute_device(wc_cheaptrick *c, int n_utt, const double *d_x, const int *x_length,
                                  const double *d_tpos, const double *d_f0, const int *f0_length,
                                  double *d_sp, uint64_t *rng_pos);
+/* host arrays of n_utt utterances in one call; spectrogram[u][i]: row of frame i of utterance u (fft_size / 2 + 1 doubles, the
+ * caller's, as in include/cheaptrick.hpp:30-33).  rng_pos: per-utterance noise-stream positions in / out as in the device call,
+ * NULL = every utterance as in a fresh process. */
+int wc_cheaptrick_compute_batch(wc_cheaptrick *c, int n_utt, const double *const *x, const int *x_length,
+                                const double *const *temporal_positions, const double *const *f0, const int *f0_length,
+                                double *const *const *spectrogram, uint64_t *rng_pos);
 
 /* ---- D4C: include/d4c.hpp:16-36 ---------------------------------------------------------------- */
 wc_d4c *wc_d4c_create(int fs, double threshold);
@@ -113,6 +126,9 @@ int wc_d4c_compute(wc_d4c *d, const double *x, int x_length, const double *tempo
 int wc_d4c_compute_device(wc_d4c *d, int n_utt, const double *d_x, const int *x_length,
                           const double *d_tpos, const double *d_f0, const int *f0_length,
                           int fft_size, double *d_ap, uint64_t *rng_pos);
+int wc_d4c_compute_batch(wc_d4c *d, int n_utt, const double *const *x, const int *x_length, const double *const *temporal_positions,
+                         const double *const *f0, const int *f0_length, int fft_size, double *const *const *aperiodicity,
+                         uint64_t *rng_pos);
 
 /* ---- Synthesis: include/synthesis.hpp:29-51 ------------------------------------------------------ */
 wc_synthesis *wc_synthesis_create(int fs, int fft_size, double frame_period_ms);
@@ -124,6 +140,10 @@ int wc_synthesis_compute(wc_synthesis *s, const double *f0, int f0_length,
 int wc_synthesis_compute_device(wc_synthesis *s, int n_utt, const double *d_f0, const int *f0_length,
                                 const double *d_sp, const double *d_ap, const int *out_length,
                                 double *d_out, uint64_t *rng_pos);
+/* host arrays of n_utt utterances in one call; fft_size: that of the handle (the row length is fft_size / 2 + 1) */
+int wc_synthesis_compute_batch(wc_synthesis *s, int n_utt, const double *const *f0, const int *f0_length, int fft_size,
+                               const double *const *const *spectrogram, const double *const *const *aperiodicity,
+                               const int *out_length, double *const *out, uint64_t *rng_pos);
 
 /* ---- fused pipeline (extension): Harvest -> CheapTrick -> D4C -> Synthesis in the demo's order (reference
  * test/test.cpp:288-384) for a packed batch, everything device resident, the stages overlapped on several HIP

@@ -105,3 +105,34 @@ def test_cpp_dropin_headers_compile_with_plain_gxx(built_lib, tmp_path):
            "-L" + os.path.dirname(built_lib), "-lworldclass_hip", "-Wl,-rpath," + os.path.dirname(built_lib)]
     subprocess.run(cmd, check=True)
     assert exe.exists()
+
+
+def test_constant_and_macro_headers_of_the_reference_are_shipped(tmp_path):
+    """include/world_constantnumbers.hpp and include/macrodefinitions.hpp (reference include/world_constantnumbers.hpp:1-44,
+    include/macrodefinitions.hpp:1-144): a caller that includes either compiles against include/, as C++11 and -- the macro
+    header -- as C; the constants carry the reference's values."""
+    src = tmp_path / "consts.cpp"
+    src.write_text('''#include "macrodefinitions.hpp"
+#include "world_constantnumbers.hpp"
+#include "harvest.hpp"
+#include <cstdio>
+WORLD_BEGIN_C_DECLS
+WORLD_API int exported_by_a_caller(void) { return world::kHanning + world::kBlackman; }
+WORLD_END_C_DECLS
+static_assert(world::kFloorF0 == 71.0 && world::kCeilF0 == 800.0 && world::kDefaultF0 == 500.0, "F0 range");
+static_assert(world::kFrequencyInterval == 3000.0 && world::kUpperLimit == 15000.0 && world::kThreshold == 0.85 && world::kFloorF0D4C == 47.0, "D4C");
+static_assert(world::kM0 == 1127.01048 && world::kF0 == 700.0 && world::kFloorFrequency == 40.0 && world::kCeilFrequency == 20000.0, "codec");
+static_assert(world::kMySafeGuardMinimum == 1e-12 && world::kMaximumValue == 100000.0, "guards");
+int main() {
+    std::printf("%.20g %.20g %.20g %d\\n", world::kPi, world::kEps, world::kLog2, exported_by_a_caller());
+    return 0;
+}
+''')
+    exe = tmp_path / "consts"
+    subprocess.run(["g++", "-std=c++11", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], stdout=subprocess.PIPE, text=True, check=True).stdout.split()
+    assert float(out[0]) == 3.1415926535897932384 and float(out[1]) == 2.0 ** -52 and float(out[2]) == 0.69314718055994529 and out[3] == "3"
+    csrc = tmp_path / "m.c"
+    csrc.write_text('#include "macrodefinitions.hpp"\nWORLD_BEGIN_C_DECLS\nWORLD_API int f(void);\nWORLD_END_C_DECLS\nint f(void) { return 1; }\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-DWORLD_LIBRARIES_EXPORTS", "-DWORLD_SRC", "-I" + os.path.join(ROOT, "include"), "-c", str(csrc),
+                    "-o", str(tmp_path / "m.o")], check=True)

@@ -40,6 +40,11 @@ _SIGNATURES = {
     "wc_harvest_destroy": (None, [_vp]),
     "wc_harvest_compute": (C.c_int, [_vp, _dp, C.c_int, _dp, _dp]),
     "wc_harvest_compute_device": (C.c_int, [_vp, C.c_int, _vp, _ip, _vp, _vp]),
+    "wc_harvest_get_samples": (C.c_int, [_vp, C.c_int]),
+    "wc_harvest_compute_batch": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), _ip, C.POINTER(_vp), C.POINTER(_vp)]),
+    "wc_cheaptrick_compute_batch": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), _ip, C.POINTER(_vp), C.POINTER(_vp), _ip, C.POINTER(_vp), _u64p]),
+    "wc_d4c_compute_batch": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), _ip, C.POINTER(_vp), C.POINTER(_vp), _ip, C.c_int, C.POINTER(_vp), _u64p]),
+    "wc_synthesis_compute_batch": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), _ip, C.c_int, C.POINTER(_vp), C.POINTER(_vp), _ip, C.POINTER(_vp), _u64p]),
     "wc_cheaptrick_create": (_vp, [C.c_int, C.c_double, C.c_double, C.c_int]),
     "wc_cheaptrick_destroy": (None, [_vp]),
     "wc_cheaptrick_get_fft_size": (C.c_int, [_vp]),
@@ -120,6 +125,26 @@ def _c(a):
 
 def _p(a):
     return a.ctypes.data_as(_dp)
+
+
+def _out_matrix(out, rows, cols, what):
+    """a caller's result buffer: exactly (rows, cols) float64, C-contiguous -- anything else would be a heap overwrite in C"""
+    if out is None:
+        return np.empty((rows, cols))
+    if not isinstance(out, np.ndarray) or out.dtype != np.float64 or out.shape != (rows, cols) or not out.flags.c_contiguous:
+        raise ValueError(f"{what}: out must be a C-contiguous float64 array of shape ({rows}, {cols})")
+    return out
+
+
+def _row_tables(mats):
+    """(array of row-pointer tables, keep-alive list) for a list of 2-D float64 arrays: the reference's double** per utterance"""
+    tabs = [_rows(m) for m in mats]
+    arr = (_vp * len(mats))(*[C.cast(t, _vp) for t in tabs])
+    return arr, tabs
+
+
+def _ptr_array(arrs):
+    return (_vp * len(arrs))(*[a.ctypes.data for a in arrs])
 
 
 def _rows(mat):
@@ -221,7 +246,7 @@ class CheapTrick:
         """out: a (frames, bins) float64 array of an earlier call to be written again (the caller's buffer, as in the reference
         demo, which allocates its rows once: reference test/test.cpp:92-101)"""
         x, t, f = _c(x), _c(temporal_positions), _c(f0)
-        sp = out if out is not None else np.empty((len(f), self.bins))
+        sp = _out_matrix(out, len(f), self.bins, "CheapTrick.compute")
         _check(lib().wc_cheaptrick_compute(self._h, _p(x), len(x), _p(t), _p(f), len(f), _rows(sp)))
         return sp
 
@@ -233,19 +258,14 @@ class CheapTrick:
         return list(arr) if arr is not None else None
 
     def compute_batch(self, xs, tposs, f0s, rng_pos=None):
-        """Convenience: host lists in, host list of spectrograms out, one batched device call."""
-        d_x = DeviceArray.from_host(np.concatenate([_c(v) for v in xs]))
-        d_t = DeviceArray.from_host(np.concatenate([_c(v) for v in tposs]))
-        d_f = DeviceArray.from_host(np.concatenate([_c(v) for v in f0s]))
-        fl = [len(v) for v in f0s]
-        d_sp = DeviceArray(sum(fl) * self.bins)
-        pos = self.compute_device(d_x, [len(v) for v in xs], d_t, d_f, fl, d_sp, rng_pos)
-        sp = d_sp.to_host((sum(fl), self.bins))
-        out, o = [], 0
-        for n in fl:
-            out.append(sp[o:o + n])
-            o += n
-        return (out, pos) if rng_pos is not None else out
+        """host lists in, host list of spectrograms out: wc_cheaptrick_compute_batch (one trip over PCIe each way, one batch)"""
+        xs, ts, fs_ = [_c(v) for v in xs], [_c(v) for v in tposs], [_c(v) for v in f0s]
+        out = [np.empty((len(f), self.bins)) for f in fs_]
+        tabs, keep = _row_tables(out)
+        arr, arg = _rng_arg(rng_pos, len(xs))
+        _check(lib().wc_cheaptrick_compute_batch(self._h, len(xs), _ptr_array(xs), _ints([len(v) for v in xs]), _ptr_array(ts), _ptr_array(fs_),
+                                                 _ints([len(v) for v in fs_]), tabs, arg))
+        return (out, list(arr)) if rng_pos is not None else out
 
     def __del__(self):
         try:
@@ -265,7 +285,7 @@ class D4C:
 
     def compute(self, x, temporal_positions, f0, fft_size, out=None):
         x, t, f = _c(x), _c(temporal_positions), _c(f0)
-        ap = out if out is not None else np.empty((len(f), fft_size // 2 + 1))
+        ap = _out_matrix(out, len(f), fft_size // 2 + 1, "D4C.compute")
         _check(lib().wc_d4c_compute(self._h, _p(x), len(x), _p(t), _p(f), len(f), fft_size, _rows(ap)))
         return ap
 
@@ -277,19 +297,15 @@ class D4C:
         return list(arr) if arr is not None else None
 
     def compute_batch(self, xs, tposs, f0s, fft_size, rng_pos=None):
+        """host lists in, host list of aperiodicity matrices out: wc_d4c_compute_batch"""
         bins = fft_size // 2 + 1
-        d_x = DeviceArray.from_host(np.concatenate([_c(v) for v in xs]))
-        d_t = DeviceArray.from_host(np.concatenate([_c(v) for v in tposs]))
-        d_f = DeviceArray.from_host(np.concatenate([_c(v) for v in f0s]))
-        fl = [len(v) for v in f0s]
-        d_ap = DeviceArray(sum(fl) * bins)
-        pos = self.compute_device(d_x, [len(v) for v in xs], d_t, d_f, fl, fft_size, d_ap, rng_pos)
-        ap = d_ap.to_host((sum(fl), bins))
-        out, o = [], 0
-        for n in fl:
-            out.append(ap[o:o + n])
-            o += n
-        return (out, pos) if rng_pos is not None else out
+        xs, ts, fs_ = [_c(v) for v in xs], [_c(v) for v in tposs], [_c(v) for v in f0s]
+        out = [np.empty((len(f), bins)) for f in fs_]
+        tabs, keep = _row_tables(out)
+        arr, arg = _rng_arg(rng_pos, len(xs))
+        _check(lib().wc_d4c_compute_batch(self._h, len(xs), _ptr_array(xs), _ints([len(v) for v in xs]), _ptr_array(ts), _ptr_array(fs_),
+                                          _ints([len(v) for v in fs_]), fft_size, tabs, arg))
+        return (out, list(arr)) if rng_pos is not None else out
 
     def __del__(self):
         try:

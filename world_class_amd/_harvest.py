@@ -3,7 +3,7 @@ import ctypes as C
 
 import numpy as np
 
-from . import DeviceArray, _c, _check, _handle, _ints, _p, _ptr, get_samples, lib
+from . import _c, _check, _handle, _ints, _p, _ptr, _ptr_array, get_samples, lib
 
 
 class Harvest:
@@ -31,16 +31,12 @@ class Harvest:
                                                _ptr(d_f0)))
 
     def compute_batch(self, xs):
+        """host list in, list of (temporal positions, F0) out: wc_harvest_compute_batch (one trip over PCIe each way, one batch)"""
+        xs = [_c(v) for v in xs]
         fl = [self.get_samples(len(x)) for x in xs]
-        d_x = DeviceArray.from_host(np.concatenate([_c(v) for v in xs]))
-        d_t, d_f = DeviceArray(sum(fl)), DeviceArray(sum(fl))
-        self.compute_device(d_x, [len(x) for x in xs], d_t, d_f)
-        t, f = d_t.to_host(), d_f.to_host()
-        out, o = [], 0
-        for n in fl:
-            out.append((t[o:o + n], f[o:o + n]))
-            o += n
-        return out
+        ts, fs_ = [np.zeros(n) for n in fl], [np.zeros(n) for n in fl]
+        _check(lib().wc_harvest_compute_batch(self._h, len(xs), _ptr_array(xs), _ints([len(x) for x in xs]), _ptr_array(ts), _ptr_array(fs_)))
+        return list(zip(ts, fs_))
 
     def debug_fetch(self, name, utt=0):
         """Development hook: an intermediate of the most recent call (y, raw, cand0, cand1, score1, cand, score, base,

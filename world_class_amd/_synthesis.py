@@ -3,7 +3,7 @@ import ctypes as C
 
 import numpy as np
 
-from . import (DeviceArray, _c, _check, _handle, _ints, _p, _ptr, _rng_arg, _rows, lib,
+from . import (_c, _check, _handle, _ints, _p, _ptr, _ptr_array, _rng_arg, _row_tables, _rows, lib,
                synthesis_out_length)
 
 
@@ -21,9 +21,14 @@ class Synthesis:
     def compute(self, f0, spectrogram, aperiodicity, out_length=None, out=None):
         f = _c(f0)
         sp, ap = _c(spectrogram), _c(aperiodicity)
+        if sp.shape != (len(f), self.bins) or ap.shape != (len(f), self.bins):
+            raise ValueError(f"Synthesis.compute: spectrogram and aperiodicity must be ({len(f)}, {self.bins})")
         if out_length is None:
             out_length = self.out_length(len(f)) if out is None else len(out)
-        out = np.zeros(out_length) if out is None else out
+        if out is None:
+            out = np.zeros(out_length)
+        elif not isinstance(out, np.ndarray) or out.dtype != np.float64 or out.ndim != 1 or not out.flags.c_contiguous or len(out) < out_length:
+            raise ValueError(f"Synthesis.compute: out must be a contiguous float64 vector of at least {out_length} samples")
         _check(lib().wc_synthesis_compute(self._h, _p(f), len(f), _rows(sp), _rows(ap), out_length, _p(out)))
         return out
 
@@ -38,17 +43,14 @@ class Synthesis:
         fl = [len(v) for v in f0s]
         if out_lengths is None:
             out_lengths = [self.out_length(n) for n in fl]
-        d_f = DeviceArray.from_host(np.concatenate([_c(v) for v in f0s]))
-        d_sp = DeviceArray.from_host(np.concatenate([_c(v) for v in sps]))
-        d_ap = DeviceArray.from_host(np.concatenate([_c(v) for v in aps]))
-        d_y = DeviceArray(sum(out_lengths))
-        pos = self.compute_device(d_f, fl, d_sp, d_ap, out_lengths, d_y, rng_pos)
-        y = d_y.to_host()
-        out, o = [], 0
-        for n in out_lengths:
-            out.append(y[o:o + n])
-            o += n
-        return (out, pos) if rng_pos is not None else out
+        fs_, sps, aps = [_c(v) for v in f0s], [_c(v) for v in sps], [_c(v) for v in aps]
+        ys = [np.zeros(n) for n in out_lengths]
+        stab, keep1 = _row_tables(sps)
+        atab, keep2 = _row_tables(aps)
+        arr, arg = _rng_arg(rng_pos, len(fl))
+        _check(lib().wc_synthesis_compute_batch(self._h, len(fl), _ptr_array(fs_), _ints(fl), self.fft_size, stab, atab, _ints(out_lengths),
+                                                _ptr_array(ys), arg))
+        return (ys, list(arr)) if rng_pos is not None else ys
 
     def __del__(self):
         try:

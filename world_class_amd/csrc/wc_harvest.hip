@@ -2930,6 +2930,10 @@ wc_harvest *wc_harvest_create(int fs, double f0_floor, double f0_ceil, double fr
 	return h;
 }
 
+int wc_harvest_get_samples(const wc_harvest *h, int x_length) {
+	if (!h) return WC_ERR_INVALID;
+	return wc_get_samples(h->fs, x_length, h->frame_period);
+}
 void wc_harvest_destroy(wc_harvest *h) {
 	if (!h) return;
 	h->dev->quiesce();
