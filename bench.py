@@ -535,9 +535,27 @@ def main():
                 if flops:  # FP64 FLOP/s from SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 x 64 lanes (FMA counted twice)
                     rate = flops / (kern[dom] * 1e-3) / 1e12
                     fp64 = {"flops_per_step": flops, "tflops": rate, "peak_tflops": FP64_VECTOR_PEAK_TFLOPS, "frac": rate / FP64_VECTOR_PEAK_TFLOPS}
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # What binds: none of the full-grid kernels is limited by bytes (20 KB per frame against ~6 MFLOP of FP64); they compete
+            # for vector issue slots -- every VALU instruction, FP64 or integer, holds a SIMD for four cycles.  issue_frac = wave-level
+            # VALU instructions (SQ_INSTS_VALU of the counter pass) x 4 cycles / (1024 SIMDs x 2.4 GHz x the kernel's live time).
+            issue = {}
+            for k, n_valu in (pmc.get("_valu_insts_per_step") or {}).items():
+                if k in kern and kern[k] > 0:
+                    issue[k] = n_valu * 4.0 / (1024 * 2.4e9 * kern[k] * 1e-3)
+            # the kernels left out of `kernel`: sequential scans, one wavefront or workgroup per utterance, a few dozen of the chip's
+            # 8192 wave slots; they run underneath the full-grid kernels of the other half batch, and what of them is exposed is the
+            # step time minus the full-grid kernels' sum (the tail nothing hides, with launch gaps)
+            exposed = ms_per_step - sum(full_grid.values())
+            critical = {"kernels_ms": {k: kern[k] for k in SEQUENTIAL_SCANS if k in kern}, "full_grid_sum_ms": sum(full_grid.values()),
+                        "step_ms": ms_per_step, "exposed_ms": exposed, "exposed_share_of_step": exposed / ms_per_step,
+                        "note": "one wavefront / workgroup per utterance: latency-bound, hidden under the other half batch's full-grid kernels at "
+                                "64 utterances; they are what a single utterance (2.4 ms) mostly waits for"}
+            roofline = {"bound": "hbm", "binds": "fp64_issue", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                         "kernel_ms": kern[dom], "bytes_per_frame": STAGE_BYTES[stage],
+                        "issue_frac": issue.get(dom), "issue_frac_by_kernel": issue or None,
+                        "issue_frac_step": (sum((pmc.get("_valu_insts_per_step") or {}).values()) * 4.0 / (1024 * 2.4e9 * ms_per_step * 1e-3)) if pmc.get("_valu_insts_per_step") else None,
+                        "critical_path_ms": critical,
                         "fp64_vector": fp64, "all_kernels_ms": kern,
                         "pipeline": {"bytes_per_frame": 20248, "achieved": frames * 20248 / (ms_per_step * 1e-3) / 1e9,
                                      "frac": frames * 20248 / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}}

@@ -52,7 +52,8 @@ def stages(x, fs, fp, which, contour=None):
 
 def main():
     out = {"levels_db": LEVELS_DB, "builds": ["-O3 -mavx (the reference Makefile)", "-O3 -mavx2 -mfma -ffp-contract=fast"], "cases": {}}
-    cases = [(16000, 1.5, 5.0, s) for s in range(230000, 230020)] + [(48000, 1.0, 1.0, s) for s in (230101, 230104, 230108)]
+    cases = ([(16000, 1.5, 5.0, s) for s in range(230000, 230020)] + [(16000, 1.5, 5.0, s) for s in (230023, 230033, 230043, 230053)]  # (+ impulse trains)
+             + [(48000, 1.0, 1.0, s) for s in (230101, 230104, 230108, 230111, 230121, 230131)])  # (chirps x 4, duet, gaps)
     for fs, sec, fp, seed in cases:
         kind = SIGNAL_KINDS[seed % len(SIGNAL_KINDS)]
         x = make_signal(fs, sec, seed)

@@ -64,20 +64,41 @@ def test_other_signal_kinds_16k(wca, P):
         check(r, P.pipeline(x, fs), x, "seed %d (%s)" % (s, SIGNAL_KINDS[s % len(SIGNAL_KINDS)]), fs=fs, checker=P)
 
 
-def test_impulse_trains_agree_in_voicing_and_within_a_window_length_step(wca, P):
+def ref_self_spread(kind, fs, field):
+    """The real reference's largest deviation from ITSELF on the signals of one kind at one rate when only its floating-point
+    rounding changes (its own Makefile's flags against -mfma -ffp-contract=fast on the same sources: oracle/gen_golden_ref_spread.py,
+    tests/golden/ref_self_spread.json) -- the bound where two correct FP64 implementations cannot agree to the stated tolerance."""
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_self_spread.json")) as f:
+        cases = json.load(f)["cases"]
+    vals = [c[field] for c in cases.values() if c["kind"] == kind and c["fs"] == fs]
+    assert vals, (kind, fs)
+    return max(vals)
+
+
+def test_impulse_trains_agree_in_voicing_and_within_the_references_own_spread(wca, P):
     """A train whose period is a whole number of samples at the decimated rate puts 1.5 fs / f0 + 1 exactly on an integer
     (reference src/harvest.cpp:950): the refinement window is 45 or 46 samples long depending on the last bits of the raw
-    candidate, in any implementation -- the reference's own choice is made by the rounding of its FFT convolution.  The
-    contour then moves by a few mHz on those frames; voicing decisions must still agree."""
+    candidate, in any implementation -- the reference's own choice is made by the rounding of its FFT convolution, and two builds
+    of the reference itself part by 1.4e-3 Hz on such trains (ref_self_spread.json: two of six trains; the CPU restatement and
+    the reference by 1.3e-3 Hz on the same two).  Voicing decisions must agree; F0 within ten times what the reference allows
+    itself: which frames sit on the edge differs per implementation, the size of a step (0.06 Hz on a refined candidate) does
+    not, and the sliding-DFT band-pass rounds at 1e-14 of the signal where the reference's FFT convolution rounds at 1e-16, so
+    more of the edge frames of a train fall the other way (measured 7.8e-3 Hz)."""
     fs = 16000
     seeds = [230003, 230013, 230023, 230033]
     xs = [make_signal(fs, 1.5, s) for s in seeds]
     assert all(SIGNAL_KINDS[s % len(SIGNAL_KINDS)] == "impulses" for s in seeds)
+    tol = 10.0 * ref_self_spread("impulses", fs, "f0_abs")
+    assert 1e-6 < tol < 2e-2
     res = wca.Pipeline(fs).run_batch(xs)
+    worst = 0.0
     for s, x, r in zip(seeds, xs, res):
         o = P.pipeline(x, fs)
         assert np.array_equal(r["f0"] == 0, o["f0"] == 0), s
-        assert dev(r["f0"], o["f0"]) < 0.1, s
+        worst = max(worst, dev(r["f0"], o["f0"]))
+    print("impulse trains: worst F0 deviation %.3e Hz (bound %.3e)" % (worst, tol))
+    assert worst < tol
 
 
 def test_seeded_utterances_48k(wca, P):
@@ -96,12 +117,14 @@ def test_other_signal_kinds_48k_1ms_hop(wca, P):
     res = wca.Pipeline(fs, frame_period=1.0).run_batch(xs)
     for s, x, r in zip(seeds, xs, res):
         # A noise-free chirp at 48 kHz leaves D4C's static group delay -- a ratio of two smoothed spectra whose bands above the
-        # chirp hold rounding noise only -- ill-conditioned in every implementation (the reference itself returns NaN rows for some
-        # such signals).  Both of its cumulative sums run in the reference's order here (seq_cumsum_signed_wave,
-        # bit for bit in tests/test_gpu_blocks.py), which took this signal from 2.8e-7 to 2.1e-7; what is left is the rounding of
-        # the transforms themselves in bands that hold nothing else.  3e-7 stated for it; every other kind holds 1e-7.
+        # chirp hold rounding noise only -- ill-conditioned in every implementation: the reference returns four NaN rows for it, and
+        # two builds of the reference part by 5.9e-8 on the others (ref_self_spread.json).  Both of D4C's cumulative sums run in the
+        # reference's order here (seq_cumsum_signed_wave, bit for bit in tests/test_gpu_blocks.py); what is left is the rounding of
+        # the transforms themselves in bands that hold nothing else.  Bound for it: four times the reference's own spread; every
+        # other kind holds 1e-7.
         kind = SIGNAL_KINDS[s % len(SIGNAL_KINDS)]
-        check(r, P.pipeline(x, fs, frame_period=1.0), x, "seed %d (%s)" % (s, kind), ap_abs=3e-7 if kind == "chirp" else 1e-7)
+        ap_abs = max(1e-7, 4.0 * ref_self_spread("chirp", fs, "ap_abs")) if kind == "chirp" else 1e-7
+        check(r, P.pipeline(x, fs, frame_period=1.0), x, "seed %d (%s)" % (s, kind), ap_abs=ap_abs)
 
 
 def test_stages_on_arbitrary_contours(wca, P):

@@ -2455,6 +2455,7 @@ struct wc_harvest {
 	bool debug_small_caps;  // WC_DEBUG_SMALL_CAPS, read once at creation: tiny rate-bounded buffers, so that the overflow retry runs (tests)
 	bool tables_valid;  // the capacity tables on the device are those of (tables_ylen, tables_full, tables_tiles)
 	int tables_ylen, tables_full, tables_tiles;
+	hipStream_t tables_stream = nullptr;  // the stream those uploads were enqueued on
 	int sdft_lanes;  // WC_HARVEST_SDFT_LANES=1 / 8: lanes per (band, chunk) of the sliding band-pass (default 0: eight for small batches; A/B and the bit-identity test)
 	bool use_fir;  // WC_HARVEST_BANDPASS=fir: the direct FIR band-pass instead of the sliding DFT (A/B and tests)
 	bool use_cos_table;  // HarvestOption::use_cos_table
@@ -2635,15 +2636,19 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 		if (!resume) WC_HIP(hipMemcpyAsync(h->utts.p, hs, sizeof(HvUtt) * n_utt, hipMemcpyHostToDevice, s));
 		// the per-band capacity tables depend on the longest utterance and the retry flag only: a call like the one before (the usual
 		// case of a stream of equal-sized batches) finds them on the device already -- four copies less in front of the first kernel
-		const bool same_tables = h->tables_valid && h->tables_ylen == max_ylen && h->tables_full == (full ? 1 : 0) && h->tables_tiles == n_tiles;
+		// (on the SAME stream: the uploads are only ordered against kernels behind them on the stream they were enqueued on, and
+		// wc_set_stream / the pipeline may hand this handle another one from call to call)
+		const bool same_tables = h->tables_valid && h->tables_stream == s && h->tables_ylen == max_ylen && h->tables_full == (full ? 1 : 0) &&
+								 h->tables_tiles == n_tiles;
 		if (!same_tables && !resume) {
+			h->tables_valid = false;  // (valid again only once all four copies have been enqueued)
 			WC_HIP(hipMemcpyAsync(h->d_ev_band_off.p, hs + o1, sizeof(long long) * nb, hipMemcpyHostToDevice, s));
 			WC_HIP(hipMemcpyAsync(h->d_ev_cap.p, hs + o2, sizeof(int) * nb, hipMemcpyHostToDevice, s));
 			if (!h->use_fir) {
 				WC_HIP(hipMemcpyAsync(h->d_slot_off.p, hs + o3a, sizeof(long long) * nb, hipMemcpyHostToDevice, s));
 				WC_HIP(hipMemcpyAsync(h->d_slot_cap.p, hs + o4, sizeof(int) * nb, hipMemcpyHostToDevice, s));
 			}
-			h->tables_valid = true; h->tables_ylen = max_ylen; h->tables_full = full ? 1 : 0; h->tables_tiles = n_tiles;
+			h->tables_valid = true; h->tables_stream = s; h->tables_ylen = max_ylen; h->tables_full = full ? 1 : 0; h->tables_tiles = n_tiles;
 		}
 		if (!resume) {
 			if ((rc = h->h_stage.mark(s))) return rc;

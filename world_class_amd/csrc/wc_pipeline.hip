@@ -624,8 +624,12 @@ int wc_pipeline_run_batch_host(wc_pipeline *p, int n_utt, const void *const *x, 
 		}
 	}
 	if ((rc = pipeline_run(p, n_utt, p->b_x.as<double>(), x_length, p->b_t.as<double>(), p->b_f.as<double>(),
-						   p->b_sp.as<double>(), p->b_ap.as<double>(), p->b_y.as<double>(), rng_pos, &sink)))
+						   p->b_sp.as<double>(), p->b_ap.as<double>(), p->b_y.as<double>(), rng_pos, &sink))) {
+		// (a failed run may leave the second half's upload out of st_in, or row copies into the caller's page-locked buffers, in
+		// flight on the copy streams: nothing of this call may still be moving when the caller gets its buffers back)
+		(void)hipDeviceSynchronize();
 		return rc;
+	}
 	mark("pipeline_run returned");
 	if ((rc = p->st_in.mark(s))) return rc;  // (both uploads are long done: the run has been waited for)
 	if (total == 0) return WC_OK;
