@@ -2,9 +2,11 @@
 # stage-by-stage timings and the small-batch latency probe; outputs under gpurun_out/, copied into profiles/ by hand:  bash tools/evidence_round.sh TAG
 TAG=$1
 mkdir -p gpurun_out
-python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_gputest.log 2>&1; tail -3 gpurun_out/${TAG}_gputest.log
-python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_gputest.log 2>&1; grep -E 'passed|failed' gpurun_out/${TAG}_gputest.log | tail -3
+# (the counter passes first: bench.py reads profiles/pmc_traffic.json of THIS build for roofline.traffic / issue_frac and refuses another build's)
 bash tools/profile_round.sh $TAG > gpurun_out/${TAG}_profile.log 2>&1
+cp gpurun_out/$TAG/pmc_traffic.json profiles/pmc_traffic.json
+python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 python tools/microbench.py --utts 64 --iters 3 > gpurun_out/${TAG}_mb64.txt 2>&1
 python tools/microbench.py --utts 16 --iters 3 > gpurun_out/${TAG}_mb16.txt 2>&1
 python tools/microbench.py --utts 1 --iters 5 > gpurun_out/${TAG}_mb1.txt 2>&1

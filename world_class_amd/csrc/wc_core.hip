@@ -127,28 +127,61 @@ __global__ void rng_fill_kernel(const uint4 *__restrict__ seeds, uint32_t *__res
 	}
 }
 
+// The chunk seeds T^(256 c) s0 on the device: the host jumps from super-chunk to super-chunk (kRngSuper chunks each, one 128 x 128
+// bit-matrix product per jump) and every thread here walks its super-chunk's chunks with T^256 -- on the host alone the 124 k
+// products behind the table of one 48 kHz x 10 s D4C call were 35 of the 45 ms of a process's first compute().
+constexpr int kRngSuper = 64;
+__global__ void rng_seed_expand_kernel(const uint4 *__restrict__ super, const uint4 *__restrict__ step, uint4 *__restrict__ seeds, int n_chunks) {
+	__shared__ uint4 m[128];  // column j of T^256
+	for (int j = threadIdx.x; j < 128; j += blockDim.x) m[j] = step[j];
+	__syncthreads();
+	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if ((long long)t * kRngSuper >= n_chunks) return;
+	uint4 s = super[t];
+	for (int c = 0; c < kRngSuper; ++c) {
+		const int at = t * kRngSuper + c;
+		if (at >= n_chunks) break;
+		seeds[at] = s;
+		uint4 o = make_uint4(0u, 0u, 0u, 0u);
+		const uint32_t w[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll 4
+		for (int j = 0; j < 128; ++j) {
+			const uint32_t on = 0u - ((w[j >> 5] >> (j & 31)) & 1u);
+			const uint4 col = m[j];
+			o.x ^= col.x & on; o.y ^= col.y & on; o.z ^= col.z & on; o.w ^= col.w & on;
+		}
+		s = o;
+	}
+}
+
 int launch_rng_fill(Device *dev, uint32_t *table, uint64_t first, uint64_t count) {
 	// first and count are multiples of kRngChunk
 	int n_chunks = (int)(count / kRngChunk);
 	if (n_chunks == 0) return WC_OK;
-	std::vector<uint32_t> seeds((size_t)n_chunks * 4);
+	const int n_super = (n_chunks + kRngSuper - 1) / kRngSuper;
+	std::vector<uint32_t> host((size_t)n_super * 4 + 128 * 4);
 	uint32_t s[4], o[4];
 	rng_state_at(first, s);
-	const BitMat &step = jump()[8];  // T^256
-	for (int c = 0; c < n_chunks; ++c) {
-		std::memcpy(&seeds[(size_t)c * 4], s, sizeof(s));
-		matvec(step, s, o);
+	const BitMat &jump_super = jump()[14];  // T^(256 * 64)
+	static_assert(kRngChunk == 256 && kRngSuper == 64, "jump()[8] is T^256, jump()[14] is T^(256 * 64)");
+	for (int c = 0; c < n_super; ++c) {
+		std::memcpy(&host[(size_t)c * 4], s, sizeof(s));
+		matvec(jump_super, s, o);
 		std::memcpy(s, o, sizeof(o));
 	}
-	uint4 *d_seeds = nullptr;
-	WC_HIP(hipMalloc(&d_seeds, seeds.size() * sizeof(uint32_t)));
-	hipError_t e = hipMemcpyAsync(d_seeds, seeds.data(), seeds.size() * sizeof(uint32_t), hipMemcpyHostToDevice, dev->stream);
+	std::memcpy(&host[(size_t)n_super * 4], jump()[8].col, sizeof(uint32_t) * 128 * 4);
+	uint4 *d_host = nullptr, *d_seeds = nullptr;
+	WC_HIP(hipMalloc(&d_host, host.size() * sizeof(uint32_t)));
+	hipError_t e = hipMalloc(&d_seeds, (size_t)n_chunks * sizeof(uint4));
+	if (e == hipSuccess) e = hipMemcpyAsync(d_host, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice, dev->stream);
 	if (e == hipSuccess) {
+		hipLaunchKernelGGL(rng_seed_expand_kernel, dim3((n_super + 63) / 64), dim3(64), 0, dev->stream, d_host, d_host + n_super, d_seeds, n_chunks);
 		hipLaunchKernelGGL(rng_fill_kernel, dim3((n_chunks + 255) / 256), dim3(256), 0, dev->stream, d_seeds, table, n_chunks);
 		e = hipGetLastError();
 	}
-	if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);  // seeds vector must outlive the copy
-	(void)hipFree(d_seeds);
+	if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);  // the host vector must outlive the copy
+	(void)hipFree(d_host);
+	if (d_seeds) (void)hipFree(d_seeds);
 	if (e != hipSuccess) return fail(WC_ERR_DEVICE, std::string("rng_fill: ") + hipGetErrorString(e));
 	return WC_OK;
 }

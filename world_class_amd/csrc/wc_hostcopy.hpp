@@ -13,7 +13,7 @@ namespace wc {
 struct CopyJob { void *dst; const void *src; size_t bytes; };
 
 inline void parallel_copy(const std::vector<CopyJob> &jobs) {
-	constexpr size_t kPiece = 2u << 20;
+	constexpr size_t kPiece = 1u << 20;
 	struct Piece { char *dst; const char *src; size_t bytes; };
 	std::vector<Piece> pieces;
 	size_t total = 0;
@@ -23,7 +23,9 @@ inline void parallel_copy(const std::vector<CopyJob> &jobs) {
 			total += pieces.back().bytes;
 		}
 	unsigned hw = std::thread::hardware_concurrency();
-	size_t nt = std::min<size_t>({hw ? hw : 4u, 16u, total / (8u << 20) + 1, pieces.size()});
+	// (a thread moves 5 - 10 GB/s and costs ~50 us to start: one per 2 MB up to 16 -- with one per 8 MB the 16 MB of rows of a
+	// 10 s utterance went over three threads, 1 ms of the 2 ms of a host-pointer CheapTrick call)
+	size_t nt = std::min<size_t>({hw ? hw : 4u, 16u, total / (2u << 20) + 1, pieces.size()});
 	std::atomic<size_t> next{0};
 	auto work = [&]() {
 		for (size_t i = next.fetch_add(1); i < pieces.size(); i = next.fetch_add(1)) std::memcpy(pieces[i].dst, pieces[i].src, pieces[i].bytes);

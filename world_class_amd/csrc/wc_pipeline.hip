@@ -69,6 +69,7 @@ struct HostSink {
 	bool y_done = false;
 	hipEvent_t x_b = nullptr;  // the samples of the second half batch are on the device (their upload runs beside the first half's Harvest)
 	bool eager = false;        // the first half's CheapTrick / D4C do not wait for the second half's Harvest: their rows leave earlier
+	int split = 0;             // > 0: utterances of the first group (a run whose rows leave for the host takes a SMALL first group: below)
 };
 
 // true when p lies in page-locked host memory (hipHostMalloc / hipHostRegister; e.g. a pinned torch tensor)
@@ -291,6 +292,7 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 		p->grp[0].main = s0;  // chain A runs on the calling thread's stream (wc_set_stream) -- resolved per call, not at creation
 		p->grp[0].aux = (sink && sink->eager && p->s1_hi) ? p->s1_hi : p->s1;
 		bool full[2][2] = {{false, false}, {false, false}};
+		const int uA = (sink && sink->split > 0 && sink->split < n_utt) ? sink->split : n_utt / 2;  // utterances of the first group
 		for (int attempt = 0; attempt < 3; ++attempt) {
 			const int bins_ = p->fft_size / 2 + 1;
 			struct Slice { int u0, nu; long long xo, fo, yo; } sl[2];
@@ -298,8 +300,8 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 			{
 				long long xo = 0, fo = 0, yo = 0;
 				for (int g = 0; g < 2; ++g) {
-					sl[g].u0 = g == 0 ? 0 : n_utt / 2;
-					sl[g].nu = (g == 0 ? n_utt / 2 : n_utt) - sl[g].u0;
+					sl[g].u0 = g == 0 ? 0 : uA;
+					sl[g].nu = (g == 0 ? uA : n_utt) - sl[g].u0;
 					sl[g].xo = xo; sl[g].fo = fo; sl[g].yo = yo;
 					for (int u = sl[g].u0; u < sl[g].u0 + sl[g].nu; ++u) { xo += x_length[u]; fo += f_len[u]; yo += y_len[u]; }
 					fo_end[g] = fo;
@@ -435,7 +437,7 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 			bool again = false;
 			for (int g = 0; g < 2; ++g) {
 				PipeGroup &G = p->grp[g];
-				const int u0 = g == 0 ? 0 : n_utt / 2;
+				const int u0 = g == 0 ? 0 : uA;
 				bool o1 = false, o2 = false;
 				if ((rc = syn_finish(G.sy, G.main, rng_pos ? rng_pos + u0 : nullptr, &o2))) return rc;
 				pmark(g == 0 ? "half A finished" : "half B finished");
@@ -548,7 +550,19 @@ int wc_pipeline_run_batch_host(wc_pipeline *p, int n_utt, const void *const *x, 
 	HostSink sink;
 	{
 		const bool halves = p->mode == 1 && n_utt >= 2 && x_is_pcm16 == 0;
-		const int uB = halves ? n_utt / 2 : n_utt;
+		// A run whose spectrogram / aperiodicity rows leave for the host is bound by PCIe (2.1 GB per 64 x 10 s at 48 kHz: 37 ms at
+		// 57 GB/s against 28 ms of kernels): what counts is how early the FIRST rows are ready and that the copy engines never wait
+		// afterwards.  A first group of a third of the batch has its rows ready earlier, and they take about as long to copy as the
+		// rest of the batch needs to get its own ready (WC_PIPELINE_HOST_SPLIT: per cent of the utterances in the first group;
+		// measured on 64 x 10 s at 48 kHz, all five outputs: 50 % 59.0 ms, 35 % 55.9 ms, 25 % 57.3 ms, 12 % 60.8 ms).
+		int uA = n_utt / 2;
+		if (p->mode == 1 && n_utt >= 4 && (sp || ap)) {
+			const char *env = getenv("WC_PIPELINE_HOST_SPLIT");
+			const int pct = env ? atoi(env) : 35;
+			uA = std::min(n_utt - 1, std::max(1, (int)((long long)n_utt * pct / 100)));
+			sink.split = uA;
+		}
+		const int uB = halves ? uA : n_utt;
 		bool pinned_in = halves && !(getenv("WC_PIPELINE_DIRECT") && getenv("WC_PIPELINE_DIRECT")[0] == '0');
 		for (int u = 0; u < n_utt && pinned_in; ++u) pinned_in = is_pinned(x[u]);
 		char *dst = static_cast<char *>(p->st_in.p);
