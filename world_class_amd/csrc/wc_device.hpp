@@ -16,6 +16,7 @@
 namespace wc {
 
 constexpr double kPi = 3.1415926535897932384;
+constexpr int kTwiddleLog2 = 12;
 constexpr int kTwiddleN = 4096;  // table W[k] = e^{+2 pi i k / 4096}, k < 4096
 
 // reference src/world_matlabfunctions.cpp:212-214

@@ -1339,8 +1339,20 @@ __device__ __forceinline__ double group8_xor(double v) {
 // A candidate's refined F0 and score are the values the kernel above computes, bit for bit: the arithmetic of a group of eight
 // lanes never depended on what else ran in the wavefront, and candidates with equal keys got equal harmonics there as well.
 // 39 % fewer passes through the sample loop and 23 % fewer samples per frame on speech at 48 kHz.
-constexpr int RF_GROUP = 3;             // passes whose start phases are staged together (see phase 1 above)
+constexpr int RF_GROUP = 2;             // passes whose start phases are staged together (see phase 1 above); a frame's distinct keys rarely need a third pass
 // RF_NP: candidate positions of a frame the LDS is sized for (7 S <= RF_NP; 112 covers the reference's default 15 slots, 7 MAX_SLOTS everything)
+#ifndef WC_RF_EXP
+#define WC_RF_EXP 0  // timing experiments: 1 no sample loop, 2 no closing, 3 gather and de-duplication only
+#endif
+constexpr int RF_RED_PLANE = 144;       // doubles between the two planes of `red` (1152 bytes: the planes fall into different halves of the banks)
+constexpr int RF_RED = RF_RED_PLANE + 128;
+// lane i of a row of sixteen receives lane i + Q's value (a DPP row shift: VALU, no trip through the LDS crossbar)
+template <int Q>
+__device__ __forceinline__ double row_shl_d(double v) {
+	const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x100 + Q, 0xF, 0xF, true);
+	const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x100 + Q, 0xF, 0xF, true);
+	return __hiloint2double(hi, lo);
+}
 template <bool TABLE, int RF_NP>
 __global__ __launch_bounds__(64, RF_NP > 112 ? 2 : WC_REFINE_WAVES) void hv_refine_packed_kernel(RefArgs a) {  // (the LDS of the wide variant allows 11 wavefronts per CU anyway)
 	const int lane = threadIdx.x;
@@ -1365,6 +1377,7 @@ __global__ __launch_bounds__(64, RF_NP > 112 ? 2 : WC_REFINE_WAVES) void hv_refi
 	__shared__ unsigned long long key[RF_NP];   // half window length and harmonic bins
 	__shared__ double row_f[RF_NP], row_s[RF_NP], row_c[RF_NP];  // per position: the three sums over harmonics of :880-893
 	__shared__ double2 stage[RF_GROUP][64];     // start phases of a pass; the harmonics it found overwrite them
+	__shared__ __attribute__((aligned(16))) double red[RF_RED];  // the eight lanes' closing terms of one harmonic on their way to its sum
 	__shared__ int it_basic[RF_NP];             // first sample of the window (reference :762-771)
 	__shared__ unsigned char it_pos[RF_NP], it_u[RF_NP], it_rep[RF_NP], un_src[RF_NP], dup_of[RF_NP], it_nh[RF_NP], pos_nh[RF_NP];
 	const unsigned long long below = (1ull << lane) - 1ull;
@@ -1451,19 +1464,20 @@ __global__ __launch_bounds__(64, RF_NP > 112 ? 2 : WC_REFINE_WAVES) void hv_refi
 	// the sums over harmonics behind a candidate's refined F0 and score, from the harmonics in lanes 0..5 of its group (fixF0,
 	// reference :880-893); the quotients of :964-979 wait for the sweep over the row at the end
 	auto finish = [&](int ln, double inst, double amp, double fc, int nh, double &num, double &den, double &sc) {
+		// valid in lane 0 of every group of eight only (the lane that stores them).  Harmonics beyond nh enter as +0.0: the sums
+		// start from +0.0 and can never be -0.0, so adding +0.0 leaves their bits alone.
 		const int h = ln & 7;
-		const double e_num = amp * inst, e_den = amp * (h + 1.0), e_sc = fabs((inst / (h + 1.0) - fc) / fc);
-		num = 0.0; den = 0.0; sc = 0.0;
-#pragma unroll
-		for (int q = 0; q < 6; ++q) {  // the reference's summation order over harmonics
-			const double x1 = __shfl(e_num, (ln & 56) + q, 64);
-			const double x2 = __shfl(e_den, (ln & 56) + q, 64);
-			const double x3 = __shfl(e_sc, (ln & 56) + q, 64);
-			if (q < nh) { num += x1; den += x2; sc += x3; }
-		}
+		const bool on = h < nh;
+		const double e_num = on ? amp * inst : 0.0, e_den = on ? amp * (h + 1.0) : 0.0, e_sc = on ? fabs((inst / (h + 1.0) - fc) / fc) : 0.0;
+		num = 0.0 + e_num; den = 0.0 + e_den; sc = 0.0 + e_sc;  // the reference's summation order over harmonics
+		num += row_shl_d<1>(e_num); den += row_shl_d<1>(e_den); sc += row_shl_d<1>(e_sc);
+		num += row_shl_d<2>(e_num); den += row_shl_d<2>(e_den); sc += row_shl_d<2>(e_sc);
+		num += row_shl_d<3>(e_num); den += row_shl_d<3>(e_den); sc += row_shl_d<3>(e_sc);
+		num += row_shl_d<4>(e_num); den += row_shl_d<4>(e_den); sc += row_shl_d<4>(e_sc);
+		num += row_shl_d<5>(e_num); den += row_shl_d<5>(e_den); sc += row_shl_d<5>(e_sc);
 	};
 
-	const int npass = (nu + 7) >> 3;
+	const int npass = WC_RF_EXP == 3 ? 0 : (nu + 7) >> 3;
 	for (int c0 = 0; c0 < npass; c0 += RF_GROUP) {
 		const int cn = min(RF_GROUP, npass - c0);
 		// phase 1 (see the kernel above): window phases at every lane's first sample
@@ -1486,11 +1500,10 @@ __global__ __launch_bounds__(64, RF_NP > 112 ? 2 : WC_REFINE_WAVES) void hv_refi
 			const int t_own = live ? un_src[r] : 0;
 			const unsigned long long kk = key[t_own];
 			const int hw = (int)(kk & 2047ull);
-			const int bt = live ? 2 * hw + 1 : 0;
+			const int bt = (WC_RF_EXP == 1) ? 0 : (live ? 2 * hw + 1 : 0);
 			const double wlt = (2.0 * hw + 1.0) / fs;
 			const int fft_index = 2 + (31 - __clz(hw * 2 + 1));
 			const int N = 1 << fft_index;
-			const int tsh = kTwiddleN / N;
 			const int basic = it_basic[t_own];
 			auto bin_of = [&](int h) -> int {  // harmonic bins (reference :853-861) out of the key
 				const int b0 = (int)(kk >> 32);
@@ -1501,7 +1514,7 @@ __global__ __launch_bounds__(64, RF_NP > 112 ? 2 : WC_REFINE_WAVES) void hv_refi
 			const double k1 = 0.5 * r1.y, k2 = 0.16 * (2.0 * r1.y * r1.x);
 			double c2[6];
 #pragma unroll
-			for (int h = 0; h < 6; ++h) c2[h] = 2.0 * a.tw[((bin_of(h) * 8) & (N - 1)) * tsh].x;
+			for (int h = 0; h < 6; ++h) c2[h] = 2.0 * a.tw[((bin_of(h) * 8) & (N - 1)) << (kTwiddleLog2 - fft_index)].x;
 			double sa[12], sb[12];
 #pragma unroll
 			for (int k = 0; k < 12; ++k) { sa[k] = 0.0; sb[k] = 0.0; }
@@ -1575,6 +1588,15 @@ __global__ __launch_bounds__(64, RF_NP > 112 ? 2 : WC_REFINE_WAVES) void hv_refi
 				y0 = ny0;
 				y1 = ny1;
 			}
+#if WC_RF_EXP == 2
+			{
+				double acc = 0.0;
+#pragma unroll
+				for (int k = 0; k < 12; ++k) acc += sa[k] + sb[k];
+				if (acc == 123.456) row_f[lane] = acc;
+				continue;
+			}
+#endif
 			// Everything the closing arithmetic needs of the candidate is looked up again from an opaque copy of the lane index: the
 			// sample loop above holds 118 registers of recurrence state, and whatever stays live across it is spilled -- once per
 			// thread, which at 640 k wavefronts per batch is gigabytes of scratch writes.
@@ -1593,53 +1615,65 @@ __global__ __launch_bounds__(64, RF_NP > 112 ? 2 : WC_REFINE_WAVES) void hv_refi
 				const int b0 = (int)(kk_c >> 32);
 				idx[h] = h == 0 ? b0 : (h + 1) * b0 + (int)(((unsigned)kk_c >> (11 + 4 * (h - 1))) & 15u) - 8;
 			}
-			double v[16];
-			auto closing = [&](int h, double (&o)[4]) {
-				const double2 e1 = a.tw[((idx[h] * (sub_c + 8 * (Q - 1))) & (N_c - 1)) * tsh_c];
-				const double2 e2 = a.tw[((idx[h] * (sub_c + 8 * Q)) & (N_c - 1)) * tsh_c];
+			// The 24 closing terms of a lane (6 harmonics x {re, im} x {main, difference window}) are summed over the group's eight
+			// lanes through LDS, one harmonic at a time: every lane leaves its four terms of the harmonic in `red` (two planes of
+			// 16-byte slots, slot = 8 sub + a rotation of the group so that neither the writes nor the reads below conflict), lane
+			// (group, c) adds up term c of the eight lanes in the order of the halving butterfly this replaces --
+			// ((x0 + x4) + (x2 + x6)) + ((x1 + x5) + (x3 + x7)), additions commute -- and the four sums wait in this pass's dead
+			// start-phase entry (harmonics 0-3) or in registers (4, 5) for lane h to collect them.  ~110 instructions where the
+			// butterfly's 28 exchanges of selects and DPP moves took ~300.  A wavefront's LDS operations execute in order: no fences.
+			double *const res = reinterpret_cast<double *>(&stage[q][0]);  // [grp][h < 4][c]
+			const int jc = sub_c & 3;
+			const int wslot = sub_c * 8 + ((grp_c + 2 * (sub_c >> 1)) & 7);
+			int rbase[4];
+#pragma unroll
+			for (int m = 0; m < 4; ++m) rbase[m] = (jc >> 1) * RF_RED_PLANE + (jc & 1) + 2 * (16 * m + ((grp_c + 2 * m) & 7));
+			// the two closing twiddles of harmonic h (table indices are multiples of a power of two: shifts, not multiplications);
+			// a harmonic's pair is requested one round ahead of its use
+			const int tsl_c = __builtin_ctz((unsigned)tsh_c);
+			auto twiddles = [&](int h, double2 &e1, double2 &e2) {
+				const int i1 = (idx[h] * (sub_c + 8 * (Q - 1))) & (N_c - 1);
+				e1 = a.tw[i1 << tsl_c];
+				e2 = a.tw[((i1 + 8 * idx[h]) & (N_c - 1)) << tsl_c];
+			};
+			double2 e1n, e2n;
+			twiddles(0, e1n, e2n);
+			double r45[2] = {0.0, 0.0};
+#pragma unroll
+			for (int h = 0; h < 6; ++h) {
+				const double2 e1 = e1n, e2 = e2n;
+				if (h < 5) twiddles(h + 1, e1n, e2n);
+				double o[4];
 				o[0] = sa[2 * h] * e1.x - sb[2 * h] * e2.x;
 				o[1] = sb[2 * h] * e2.y - sa[2 * h] * e1.y;
 				o[2] = sa[2 * h + 1] * e1.x - sb[2 * h + 1] * e2.x;
 				o[3] = sb[2 * h + 1] * e2.y - sa[2 * h + 1] * e1.y;
-			};
+				*reinterpret_cast<double2 *>(&red[2 * wslot]) = make_double2(o[0], o[1]);
+				*reinterpret_cast<double2 *>(&red[RF_RED_PLANE + 2 * wslot]) = make_double2(o[2], o[3]);
+				double x[8];
 #pragma unroll
-			for (int p = 0; p < 4; ++p) {
-				double lo[4], hi[4] = {0.0, 0.0, 0.0, 0.0};
-				closing(p, lo);
-				if (p < 2) closing(p + 4, hi);
-				const bool up = (sub_c & 4) != 0;
-#pragma unroll
-				for (int c = 0; c < 4; ++c) {
-					const double send = up ? lo[c] : hi[c];
-					const double keep = up ? hi[c] : lo[c];
-					v[4 * p + c] = keep + group8_xor<4>(send);
+				for (int s_ = 0; s_ < 8; ++s_) x[s_] = red[rbase[s_ >> 1] + 16 * (s_ & 1)];
+				const double sum = ((x[0] + x[4]) + (x[2] + x[6])) + ((x[1] + x[5]) + (x[3] + x[7]));
+				if (h < 4) {
+					if (sub_c < 4) res[(grp_c * 4 + h) * 4 + jc] = sum;
+				} else {
+					r45[h - 4] = sum;
 				}
-#if WC_REFINE_FENCE
-				asm volatile("" ::: "memory");
-#endif
 			}
-#pragma unroll
-			for (int k = 0; k < 8; ++k) {
-				const bool up = (sub_c & 2) != 0;
-				const double send = up ? v[k] : v[8 + k];
-				const double keep = up ? v[8 + k] : v[k];
-				v[k] = keep + group8_xor<2>(send);
-			}
-#pragma unroll
-			for (int k = 0; k < 4; ++k) {
-				const bool up = (sub_c & 1) != 0;
-				const double send = up ? v[k] : v[4 + k];
-				const double keep = up ? v[4 + k] : v[k];
-				v[k] = keep + group8_xor<1>(send);
+			if (sub_c < 4) {
+				red[(grp_c * 2 + 0) * 4 + jc] = r45[0];
+				red[(grp_c * 2 + 1) * 4 + jc] = r45[1];
 			}
 			const int h = sub_c;
 			int myidx = 0;
 #pragma unroll
 			for (int q2 = 0; q2 < 6; ++q2) if (q2 == h) myidx = idx[q2];
-			const double mr = v[0], mi = v[1], dr = v[2], di = v[3];
+			const double *const mine4 = h < 4 ? &res[(grp_c * 4 + h) * 4] : &red[(grp_c * 2 + ((h - 4) & 1)) * 4];
+			const double2 m01 = *reinterpret_cast<const double2 *>(mine4), m23 = *reinterpret_cast<const double2 *>(mine4 + 2);
+			const double mr = m01.x, mi = m01.y, dr = m23.x, di = m23.y;
 			const double pw = mr * mr + mi * mi;
 			const double ni = mr * di - mi * dr;
-			const double inst = (pw == 0.0) ? 0.0 : (double)myidx * fs * (1.0 / N_c) + ni / pw * fs / 2.0 / kPi;  // (N is a power of two: the product is the quotient of :871)
+			const double inst = (pw == 0.0) ? 0.0 : ldexp((double)myidx * fs, -__builtin_ctz((unsigned)N_c)) + ni / pw * fs / 2.0 / kPi;  // (N is a power of two: scaling by its exponent is the quotient of :871)
 			const double amp = sqrt(pw);
 			if (sub_c < 6) stage[q][grp_c * 6 + sub_c] = make_double2(inst, amp);  // (every lane took its start phase from here long ago)
 			double num, den, sc;
