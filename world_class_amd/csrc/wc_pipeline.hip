@@ -36,12 +36,14 @@
 using namespace wc;
 
 // one independent chain (mode "groups"): its own stage handles and two streams
+constexpr int kMaxGroups = 6;  // two for a device-resident batch; up to six (of growing size) when the rows leave for the host
 struct PipeGroup {
 	wc_harvest *hv = nullptr;
 	wc_cheaptrick *ct = nullptr;
 	wc_d4c *d4 = nullptr;
 	wc_synthesis *sy = nullptr;
 	hipStream_t main = nullptr, aux = nullptr;
+	hipStream_t aux_hi = nullptr;  // group 0: the pipeline's high-priority stream s1_hi (runs whose rows leave for the host)
 	hipEvent_t e0 = nullptr, e_aux = nullptr, e_mid = nullptr, e_ct = nullptr;
 };
 
@@ -61,15 +63,16 @@ struct HostSink {
 	double *const *sp = nullptr, *const *ap = nullptr;  // the caller's per-utterance destinations
 	const int *f_len = nullptr;
 	int bins = 0;
-	bool overlapped[2] = {false, false};  // group g was copied and scattered during the run (first attempt only)
+	bool overlapped[kMaxGroups] = {};  // group g was copied and scattered during the run (first attempt only)
 	bool direct = false;  // every destination row lies in pinned host memory: the copy engine writes the rows where they belong
 	// the waveforms (float64) straight into the caller's page-locked rows, each half as soon as its pulses are summed
 	double *const *y = nullptr;
 	const int *y_len = nullptr;
 	bool y_done = false;
-	hipEvent_t x_b = nullptr;  // the samples of the second half batch are on the device (their upload runs beside the first half's Harvest)
-	bool eager = false;        // the first half's CheapTrick / D4C do not wait for the second half's Harvest: their rows leave earlier
-	int split = 0;             // > 0: utterances of the first group (a run whose rows leave for the host takes a SMALL first group: below)
+	hipEvent_t x_ev[kMaxGroups] = {};  // the samples of group g > 0 are on the device (their upload runs beside the first group's Harvest)
+	bool eager = false;        // a group's CheapTrick / D4C do not wait for the next group's Harvest: their rows leave earlier
+	int ng = 0;                // > 0: the run is cut into ng groups, group g = utterances [ub[g], ub[g + 1]) (a run whose rows leave for
+	int ub[kMaxGroups + 1] = {};  // the host takes SMALL first groups: below)
 };
 
 // true when p lies in page-locked host memory (hipHostMalloc / hipHostRegister; e.g. a pinned torch tensor)
@@ -84,7 +87,12 @@ static bool is_pinned(const void *p) {
 
 struct wc_pipeline {
 	int mode;  // 0: shared stages, Harvest split over streams; 1: independent staggered chains per utterance group
-	PipeGroup grp[2];
+	PipeGroup grp[kMaxGroups];
+	int n_grp;  // groups whose handles exist (2 at creation, the others when a run first asks for them)
+	double c_floor, c_ceil, c_q1, c_ct_floor, c_threshold;  // what the stage handles of a group are created with
+	int c_fft_size;
+	bool copy_prio;
+	int prio_hi;
 	int fs, fft_size;
 	double frame_period;
 	Device *dev;
@@ -96,12 +104,40 @@ struct wc_pipeline {
 	wc_d4c *d4;
 	wc_synthesis *sy;
 	hipStream_t s1, s1_hi, s2, s_copy, s_copy2;  // (s_copy2: the aperiodicity rows leave beside the spectrogram rows, on a DMA engine of their own)
-	hipEvent_t e_copy2[2];
-	hipEvent_t e0, e1, e2, e_copy[2], e_y[2], e_ycopy[2], e_xb, e_bp;
+	hipEvent_t e_copy2[kMaxGroups];
+	hipEvent_t e0, e1, e2, e_copy[kMaxGroups], e_y[kMaxGroups], e_ycopy[kMaxGroups], e_x[kMaxGroups], e_bp;
 	// host batch front-end (wc_pipeline_run_batch_host): device-resident batch + pinned staging, grow-only
 	DevBuf b_x, b_pcm, b_t, b_f, b_sp, b_ap, b_y, b_ypcm, b_coded;
 	HostBuf st_in, st_out;
 };
+
+// the stage handles, streams and events of groups [p->n_grp, ng)
+static int pipeline_ensure_groups(wc_pipeline *p, int ng) {
+	for (int g = p->n_grp; g < ng && g < kMaxGroups; ++g) {
+		PipeGroup &G = p->grp[g];
+		G.hv = wc_harvest_create(p->fs, p->c_floor, p->c_ceil, p->frame_period, 8000.0, 40.0, 0);
+		G.ct = G.hv ? wc_cheaptrick_create(p->fs, p->c_q1, p->c_ct_floor, p->c_fft_size) : nullptr;
+		G.d4 = G.ct ? wc_d4c_create(p->fs, p->c_threshold) : nullptr;
+		G.sy = G.d4 ? wc_synthesis_create(p->fs, p->fft_size, p->frame_period) : nullptr;
+		if (!G.sy) return WC_ERR_DEVICE;  // (the failed create has set the error text; wc_pipeline_destroy releases what exists)
+		// the contour these stages see comes out of Harvest: candidates outside [floor, ceil] are struck (reference
+		// src/harvest.cpp:974-979) and the smoothing filter overshoots by a few per cent at most
+		ct_set_f0_bound(G.ct, 1.25 * p->c_ceil);
+		d4c_set_f0_bound(G.d4, 1.25 * p->c_ceil);
+		if (g == 0) { G.main = p->dev->active(); G.aux = p->s1; G.aux_hi = p->s1_hi; }
+		else if (g == 1) { G.main = p->n_split > 1 ? p->hs[1] : p->s2; G.aux = p->s2; }
+		// (groups 2 .. 5 have no streams of their own: HIP multiplexes the streams of one priority onto four hardware queues, and a
+		// stream that shares a queue with one waiting for an event stands still with it -- measured: four groups on streams of
+		// their own 72 ms, with GPU_MAX_HW_QUEUES=8 54 ms.  They take turns on the two main streams and share the one
+		// high-priority stream, see pipeline_run.)
+		WC_HIP(hipEventCreateWithFlags(&G.e0, hipEventDisableTiming));
+		WC_HIP(hipEventCreateWithFlags(&G.e_aux, hipEventDisableTiming));
+		WC_HIP(hipEventCreateWithFlags(&G.e_mid, hipEventDisableTiming));
+		WC_HIP(hipEventCreateWithFlags(&G.e_ct, hipEventDisableTiming));
+		p->n_grp = g + 1;
+	}
+	return WC_OK;
+}
 
 extern "C" {
 
@@ -114,6 +150,8 @@ wc_pipeline *wc_pipeline_create(int fs, double frame_period, double harvest_f0_f
 	p->fs = fs;
 	p->frame_period = frame_period;
 	p->dev = dev;
+	p->c_floor = harvest_f0_floor; p->c_ceil = harvest_f0_ceil; p->c_q1 = q1; p->c_ct_floor = cheaptrick_f0_floor;
+	p->c_threshold = d4c_threshold; p->c_fft_size = fft_size;
 	{
 		const char *m = getenv("WC_PIPELINE_MODE");
 		p->mode = (m && std::string(m) == "shared") ? 0 : 1;  // default: two scheduled chains (measured 82 vs 90-96 ms per batch)
@@ -154,6 +192,8 @@ wc_pipeline *wc_pipeline_create(int fs, double frame_period, double harvest_f0_f
 	int prio_lo = 0, prio_hi = 0;
 	(void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
 	const bool copy_prio = !(getenv("WC_PIPELINE_COPY_PRIORITY") && getenv("WC_PIPELINE_COPY_PRIORITY")[0] == '0') && prio_hi != prio_lo;
+	p->copy_prio = copy_prio;
+	p->prio_hi = prio_hi;
 	auto copy_stream = [&](hipStream_t *st) {
 		return (copy_prio ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(st, hipStreamNonBlocking)) == hipSuccess;
 	};
@@ -166,41 +206,18 @@ wc_pipeline *wc_pipeline_create(int fs, double frame_period, double harvest_f0_f
 	{
 		const char *env = getenv("WC_PIPELINE_COPY_STREAMS");
 		if (ok && !(env && atoi(env) == 1)) {
-			ok = copy_stream(&p->s_copy2) &&
-				 hipEventCreateWithFlags(&p->e_copy2[0], hipEventDisableTiming) == hipSuccess &&
-				 hipEventCreateWithFlags(&p->e_copy2[1], hipEventDisableTiming) == hipSuccess;
+			ok = copy_stream(&p->s_copy2);
+			for (int g = 0; g < kMaxGroups; ++g) ok = ok && hipEventCreateWithFlags(&p->e_copy2[g], hipEventDisableTiming) == hipSuccess;
 		}
 	}
-	ok = ok && hipEventCreateWithFlags(&p->e_copy[0], hipEventDisableTiming) == hipSuccess;
-	ok = ok && hipEventCreateWithFlags(&p->e_copy[1], hipEventDisableTiming) == hipSuccess;
-	for (int g = 0; g < 2; ++g) {
+	for (int g = 0; g < kMaxGroups; ++g) {
+		ok = ok && hipEventCreateWithFlags(&p->e_copy[g], hipEventDisableTiming) == hipSuccess;
 		ok = ok && hipEventCreateWithFlags(&p->e_y[g], hipEventDisableTiming) == hipSuccess;
 		ok = ok && hipEventCreateWithFlags(&p->e_ycopy[g], hipEventDisableTiming) == hipSuccess;
+		ok = ok && hipEventCreateWithFlags(&p->e_x[g], hipEventDisableTiming) == hipSuccess;
 	}
-	ok = ok && hipEventCreateWithFlags(&p->e_xb, hipEventDisableTiming) == hipSuccess;
 	ok = ok && hipEventCreateWithFlags(&p->e_bp, hipEventDisableTiming) == hipSuccess;
-	if (ok && p->mode == 1) {
-		for (int g = 0; g < 2 && ok; ++g) {
-			PipeGroup &G = p->grp[g];
-			G.hv = wc_harvest_create(fs, harvest_f0_floor, harvest_f0_ceil, frame_period, 8000.0, 40.0, 0);
-			G.ct = G.hv ? wc_cheaptrick_create(fs, q1, cheaptrick_f0_floor, fft_size) : nullptr;
-			G.d4 = G.ct ? wc_d4c_create(fs, d4c_threshold) : nullptr;
-			G.sy = G.d4 ? wc_synthesis_create(fs, p->fft_size, frame_period) : nullptr;
-			ok = G.sy != nullptr;
-			if (ok) {
-				// the contour these stages see comes out of Harvest: candidates outside [floor, ceil] are struck (reference
-				// src/harvest.cpp:974-979) and the smoothing filter overshoots by a few per cent at most
-				ct_set_f0_bound(G.ct, 1.25 * harvest_f0_ceil);
-				d4c_set_f0_bound(G.d4, 1.25 * harvest_f0_ceil);
-			}
-			if (g == 0) { G.main = dev->active(); G.aux = p->s1; }
-			else { G.main = p->n_split > 1 ? p->hs[1] : p->s2; G.aux = p->s2; }
-			ok = ok && hipEventCreateWithFlags(&G.e0, hipEventDisableTiming) == hipSuccess;
-			ok = ok && hipEventCreateWithFlags(&G.e_aux, hipEventDisableTiming) == hipSuccess;
-			ok = ok && hipEventCreateWithFlags(&G.e_mid, hipEventDisableTiming) == hipSuccess;
-			ok = ok && hipEventCreateWithFlags(&G.e_ct, hipEventDisableTiming) == hipSuccess;
-		}
-	}
+	if (ok && p->mode == 1) ok = pipeline_ensure_groups(p, 2) == WC_OK;
 	if (!ok) {
 		std::string err = wc_last_error();
 		void wc_pipeline_destroy(wc_pipeline *);
@@ -225,13 +242,13 @@ void wc_pipeline_destroy(wc_pipeline *p) {
 	if (p->e2) (void)hipEventDestroy(p->e2);
 	if (p->s_copy) (void)hipStreamDestroy(p->s_copy);
 	if (p->s_copy2) (void)hipStreamDestroy(p->s_copy2);
-	for (int g = 0; g < 2; ++g) if (p->e_copy2[g]) (void)hipEventDestroy(p->e_copy2[g]);
-	for (int g = 0; g < 2; ++g) if (p->e_copy[g]) (void)hipEventDestroy(p->e_copy[g]);
-	for (int g = 0; g < 2; ++g) if (p->e_y[g]) (void)hipEventDestroy(p->e_y[g]);
-	for (int g = 0; g < 2; ++g) if (p->e_ycopy[g]) (void)hipEventDestroy(p->e_ycopy[g]);
-	if (p->e_xb) (void)hipEventDestroy(p->e_xb);
+	for (int g = 0; g < kMaxGroups; ++g) if (p->e_copy2[g]) (void)hipEventDestroy(p->e_copy2[g]);
+	for (int g = 0; g < kMaxGroups; ++g) if (p->e_copy[g]) (void)hipEventDestroy(p->e_copy[g]);
+	for (int g = 0; g < kMaxGroups; ++g) if (p->e_y[g]) (void)hipEventDestroy(p->e_y[g]);
+	for (int g = 0; g < kMaxGroups; ++g) if (p->e_ycopy[g]) (void)hipEventDestroy(p->e_ycopy[g]);
+	for (int g = 0; g < kMaxGroups; ++g) if (p->e_x[g]) (void)hipEventDestroy(p->e_x[g]);
 	if (p->e_bp) (void)hipEventDestroy(p->e_bp);
-	for (int g = 0; g < 2; ++g) {
+	for (int g = 0; g < kMaxGroups; ++g) {
 		PipeGroup &G = p->grp[g];
 		if (G.e0) (void)hipEventDestroy(G.e0);
 		if (G.e_aux) (void)hipEventDestroy(G.e_aux);
@@ -290,18 +307,36 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 		//   Harvest_A heavy | tail_A next to Harvest_B heavy | tail_B next to CheapTrick/D4C_A | pulses_A | D4C_B | pulses_B
 		// (tail = unreliable-candidate test, contour logic, smoothing; the Synthesis time bases hide the same way)
 		p->grp[0].main = s0;  // chain A runs on the calling thread's stream (wc_set_stream) -- resolved per call, not at creation
-		p->grp[0].aux = (sink && sink->eager && p->s1_hi) ? p->s1_hi : p->s1;
-		bool full[2][2] = {{false, false}, {false, false}};
-		const int uA = (sink && sink->split > 0 && sink->split < n_utt) ? sink->split : n_utt / 2;  // utterances of the first group
+		// A device-resident batch runs as two halves.  A run whose rows leave for the host may ask for up to six groups of growing
+		// size (HostSink::ng, ub): the same chain of chains -- group g's Harvest front behind group g - 1's refinement -- with every
+		// group's CheapTrick / D4C on a high-priority stream as soon as its own contour is there.
+		const int NG = (sink && sink->ng >= 2 && sink->ng <= kMaxGroups && sink->ub[sink->ng] == n_utt) ? sink->ng : 2;
+		if ((rc = pipeline_ensure_groups(p, NG))) return rc;
+		int ub[kMaxGroups + 1];
+		ub[0] = 0; ub[1] = n_utt / 2;
+		for (int g = 2; g <= kMaxGroups; ++g) ub[g] = n_utt;
+		if (NG > 2 || (sink && sink->ng == 2)) for (int g = 0; g <= NG; ++g) ub[g] = sink->ub[g];
+		const bool eager = sink && sink->eager;
+		// streams: two groups as ever (own main and aux streams; the first group's aux is the high-priority one when its rows are
+		// waited for).  More groups take turns on the two main streams -- group g + 2's Harvest sits behind group g's pulses there,
+		// by which time group g + 1's refinement, its own start signal, is about through -- and share the high-priority stream for
+		// CheapTrick / D4C, which run in group order anyway.
+		hipStream_t aux[kMaxGroups], mainS[kMaxGroups];
+		for (int g = 0; g < NG; ++g) {
+			mainS[g] = p->grp[g & 1].main;
+			if (NG == 2) aux[g] = (eager && g == 0 && p->grp[0].aux_hi) ? p->grp[0].aux_hi : p->grp[g].aux;
+			else aux[g] = p->grp[0].aux_hi ? p->grp[0].aux_hi : p->grp[0].aux;
+		}
+		bool full[kMaxGroups][2] = {};
 		for (int attempt = 0; attempt < 3; ++attempt) {
 			const int bins_ = p->fft_size / 2 + 1;
-			struct Slice { int u0, nu; long long xo, fo, yo; } sl[2];
-			long long fo_end[2];
+			struct Slice { int u0, nu; long long xo, fo, yo; } sl[kMaxGroups];
+			long long fo_end[kMaxGroups];
 			{
 				long long xo = 0, fo = 0, yo = 0;
-				for (int g = 0; g < 2; ++g) {
-					sl[g].u0 = g == 0 ? 0 : uA;
-					sl[g].nu = (g == 0 ? uA : n_utt) - sl[g].u0;
+				for (int g = 0; g < NG; ++g) {
+					sl[g].u0 = ub[g];
+					sl[g].nu = ub[g + 1] - ub[g];
 					sl[g].xo = xo; sl[g].fo = fo; sl[g].yo = yo;
 					for (int u = sl[g].u0; u < sl[g].u0 + sl[g].nu; ++u) { xo += x_length[u]; fo += f_len[u]; yo += y_len[u]; }
 					fo_end[g] = fo;
@@ -310,33 +345,40 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 			// 0. chain B's own stream starts behind whatever already sits on the caller's stream (an upload of the samples, the
 			//    caller's kernels): its decimation reads d_x right away.  (The aux streams follow their main streams through e0.)
 			WC_HIP(hipEventRecord(p->e1, s0));
-			WC_HIP(hipStreamWaitEvent(p->grp[1].main, p->e1, 0));
-			if (sink && sink->x_b) WC_HIP(hipStreamWaitEvent(p->grp[1].main, sink->x_b, 0));
+			WC_HIP(hipStreamWaitEvent(mainS[1], p->e1, 0));
+			// (a group's upload is waited for by its own Harvest, below: on a shared main stream the wait must not stand in front
+			// of the earlier group's kernels)
 			// 1. both Harvest chains; B's front starts when A's refinement kernel is done, A's tail runs beside it.
 			// (WC_PIPELINE_TAIL_AFTER_BP=1, measured and rejected: A's tail held back until B's band-pass is through -- that kernel is one
 			// round of long-lived wavefronts, 3040 on 3072 places at three per SIMD, and the places A's tail takes push some of them into
 			// a second round, 2.6 instead of 1.8 ms.  But the tail then shares the chip with B's issue-bound raw candidates and refinement,
 			// ends later and holds up A's CheapTrick: 29.2 against 28.6 ms per batch.  Enqueued front A, chain B, tail A in that case: an
 			// event must have been recorded by the time a stream is told to wait for it.)
-			static const bool tail_late = getenv("WC_PIPELINE_TAIL_AFTER_BP") && getenv("WC_PIPELINE_TAIL_AFTER_BP")[0] == '1';
-			for (int g = 0; g < 2; ++g) {
+			static const bool tail_late_env = getenv("WC_PIPELINE_TAIL_AFTER_BP") && getenv("WC_PIPELINE_TAIL_AFTER_BP")[0] == '1';
+			const bool tail_late = tail_late_env && NG == 2;
+			auto enqueue_harvest = [&](int g) -> int {
 				PipeGroup &G = p->grp[g];
 				dev->time_tag = g;
-				if ((rc = hv_enqueue(G.hv, G.main, sl[g].nu, d_x + sl[g].xo, x_length + sl[g].u0, d_tpos + sl[g].fo, d_f0 + sl[g].fo,
-									 full[g][0], G.e_mid, g == 1 ? p->grp[0].e_mid : nullptr, (g == 0 && tail_late) ? 1 : 3,
-									 g == 1 ? p->e_bp : nullptr, nullptr)))
-					return rc;
-			}
+				if (g >= 1 && sink && sink->x_ev[g]) WC_HIP(hipStreamWaitEvent(mainS[g], sink->x_ev[g], 0));
+				return hv_enqueue(G.hv, mainS[g], sl[g].nu, d_x + sl[g].xo, x_length + sl[g].u0, d_tpos + sl[g].fo, d_f0 + sl[g].fo,
+								  full[g][0], G.e_mid, g >= 1 ? p->grp[g - 1].e_mid : nullptr, (g == 0 && tail_late) ? 1 : 3,
+								  (g == 1 && tail_late) ? p->e_bp : nullptr, nullptr);
+			};
+			// (two groups: both Harvest chains first -- the first group's CheapTrick / D4C may wait for an event of the second's.
+			// More groups share streams: a group's whole chain is enqueued before the next group's Harvest lands on its stream.)
+			if (NG == 2) for (int g = 0; g < NG; ++g) if ((rc = enqueue_harvest(g))) return rc;
 			if (tail_late) {
 				PipeGroup &G = p->grp[0];
 				dev->time_tag = 0;
-				if ((rc = hv_enqueue(G.hv, G.main, sl[0].nu, d_x + sl[0].xo, x_length + sl[0].u0, d_tpos + sl[0].fo, d_f0 + sl[0].fo,
+				if ((rc = hv_enqueue(G.hv, mainS[0], sl[0].nu, d_x + sl[0].xo, x_length + sl[0].u0, d_tpos + sl[0].fo, d_f0 + sl[0].fo,
 									 full[0][0], nullptr, nullptr, 2, nullptr, p->e_bp)))
 					return rc;
 			}
 			// 2. the rest of each chain; A's CheapTrick/D4C wait for B's refinement as well
-			for (int g = 0; g < 2; ++g) {
+			for (int g = 0; g < NG; ++g) {
+				if (NG > 2 && (rc = enqueue_harvest(g))) return rc;
 				PipeGroup &G = p->grp[g];
+				const hipStream_t G_aux = aux[g];
 				dev->time_tag = g;
 				const int u0 = sl[g].u0, nu = sl[g].nu;
 				const double *gx = d_x + sl[g].xo;
@@ -345,20 +387,20 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 				const uint64_t *grp_rng = rng_start ? rng_start + u0 : nullptr;
 				long long total = 0;
 				uint64_t a0 = 0, a1 = 0;
-				if ((rc = ct_prepare(G.ct, G.main, nu, x_length + u0, gf, f_len.data() + u0, grp_rng, &total, &a0, &a1))) return rc;
-				WC_HIP(hipEventRecord(G.e0, G.main));
-				WC_HIP(hipStreamWaitEvent(G.aux, G.e0, 0));
+				if ((rc = ct_prepare(G.ct, mainS[g], nu, x_length + u0, gf, f_len.data() + u0, grp_rng, &total, &a0, &a1))) return rc;
+				WC_HIP(hipEventRecord(G.e0, mainS[g]));
+				WC_HIP(hipStreamWaitEvent(G_aux, G.e0, 0));
 				// (a run whose rows leave for the host is bound by PCIe, not by the kernels: there the first half's rows are wanted
 				// as early as they can be had, even if its CheapTrick / D4C then share the CUs with the second half's Harvest)
-				if (g == 0 && !(sink && sink->eager)) WC_HIP(hipStreamWaitEvent(G.aux, p->grp[1].e_mid, 0));
+				if (NG == 2 && g == 0 && !eager) WC_HIP(hipStreamWaitEvent(G_aux, p->grp[1].e_mid, 0));
 				hipEvent_t ct_rows = nullptr;  // CheapTrick's pass over the frames its one-wavefront kernel leaves out, on a stream of its own
-				if ((rc = ct_frames(G.ct, G.aux, nu, gx, gt, gf, gsp, total, &ct_rows))) return rc;
-				WC_HIP(hipEventRecord(G.e_ct, G.aux));
-				if ((rc = d4c_enqueue(G.d4, G.aux, nu, gx, x_length + u0, gt, gf, f_len.data() + u0, p->fft_size, gap, nullptr,
+				if ((rc = ct_frames(G.ct, G_aux, nu, gx, gt, gf, gsp, total, &ct_rows))) return rc;
+				WC_HIP(hipEventRecord(G.e_ct, G_aux));
+				if ((rc = d4c_enqueue(G.d4, G_aux, nu, gx, x_length + u0, gt, gf, f_len.data() + u0, p->fft_size, gap, nullptr,
 									  ct_end_positions(G.ct))))
 					return rc;
-				if (ct_rows) WC_HIP(hipStreamWaitEvent(G.aux, ct_rows, 0));  // (the pulses wait for e_aux)
-				WC_HIP(hipEventRecord(G.e_aux, G.aux));
+				if (ct_rows) WC_HIP(hipStreamWaitEvent(G_aux, ct_rows, 0));  // (the pulses wait for e_aux)
+				WC_HIP(hipEventRecord(G.e_aux, G_aux));
 				if (sink && attempt == 0 && (sink->stage_sp || sink->stage_ap)) {
 					const size_t off = sizeof(double) * (size_t)sl[g].fo * bins_, len = sizeof(double) * (size_t)(fo_end[g] - sl[g].fo) * bins_;
 					// the spectrogram rows leave as soon as CheapTrick is through, the aperiodicity rows behind D4C: PCIe is the longest
@@ -392,12 +434,12 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 					if (p->s_copy2) WC_HIP(hipEventRecord(p->e_copy2[g], p->s_copy2));
 					WC_HIP(hipEventRecord(p->e_copy[g], p->s_copy));
 				}
-				if ((rc = syn_prepare(G.sy, G.main, nu, gf, f_len.data() + u0, y_len.data() + u0, gy, nullptr, full[g][1]))) return rc;
-				WC_HIP(hipStreamWaitEvent(G.main, G.e_aux, 0));
-				if ((rc = syn_pulses(G.sy, G.main, gf, gsp, gap, gy, d4c_end_positions(G.d4)))) return rc;
+				if ((rc = syn_prepare(G.sy, mainS[g], nu, gf, f_len.data() + u0, y_len.data() + u0, gy, nullptr, full[g][1]))) return rc;
+				WC_HIP(hipStreamWaitEvent(mainS[g], G.e_aux, 0));
+				if ((rc = syn_pulses(G.sy, mainS[g], gf, gsp, gap, gy, d4c_end_positions(G.d4)))) return rc;
 				if (sink && sink->y) {
 					// (every attempt: a re-run after an overflow rewrites the waveform, and its copies land behind the first ones)
-					WC_HIP(hipEventRecord(p->e_y[g], G.main));
+					WC_HIP(hipEventRecord(p->e_y[g], mainS[g]));
 					WC_HIP(hipStreamWaitEvent(p->s_copy, p->e_y[g], 0));
 					if (p->s_copy2) WC_HIP(hipStreamWaitEvent(p->s_copy2, p->e_y[g], 0));
 					long long yo2 = 0;
@@ -417,10 +459,10 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 			pmark("both halves enqueued");
 			if (sink && attempt == 0 && (sink->stage_sp || sink->stage_ap)) {
 				// the rows of each half batch go to the caller's buffers as soon as their copy has landed: half A's while B computes
-				for (int g = 0; g < 2; ++g) {
+				for (int g = 0; g < NG; ++g) {
 					WC_HIP(hipEventSynchronize(p->e_copy[g]));
 					if (p->s_copy2) WC_HIP(hipEventSynchronize(p->e_copy2[g]));
-					pmark(g == 0 ? "rows of half A landed" : "rows of half B landed");
+					pmark(g == 0 ? "rows of group 0 landed" : g + 1 < NG ? "rows of a middle group landed" : "rows of the last group landed");
 					if (sink->direct) { sink->overlapped[g] = true; continue; }
 					std::vector<CopyJob> jobs;
 					long long fo = sl[g].fo;
@@ -435,20 +477,20 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 				}
 			}
 			bool again = false;
-			for (int g = 0; g < 2; ++g) {
+			for (int g = 0; g < NG; ++g) {
 				PipeGroup &G = p->grp[g];
-				const int u0 = g == 0 ? 0 : uA;
+				const int u0 = ub[g];
 				bool o1 = false, o2 = false;
-				if ((rc = syn_finish(G.sy, G.main, rng_pos ? rng_pos + u0 : nullptr, &o2))) return rc;
-				pmark(g == 0 ? "half A finished" : "half B finished");
-				if ((rc = hv_overflowed(G.hv, G.main, &o1))) return rc;
+				if ((rc = syn_finish(G.sy, mainS[g], rng_pos ? rng_pos + u0 : nullptr, &o2))) return rc;
+				pmark(g == 0 ? "group 0 finished" : g + 1 < NG ? "a middle group finished" : "the last group finished");
+				if ((rc = hv_overflowed(G.hv, mainS[g], &o1))) return rc;
 				full[g][0] = full[g][0] || o1;
 				full[g][1] = full[g][1] || o2;
 				again = again || o1 || o2;
 			}
-			if (again && sink) sink->overlapped[0] = sink->overlapped[1] = false;  // the re-run rewrites the rows
+			if (again && sink) for (int g = 0; g < kMaxGroups; ++g) sink->overlapped[g] = false;  // the re-run rewrites the rows
 			if (!again && sink && sink->y) {
-				for (int g = 0; g < 2; ++g) WC_HIP(hipEventSynchronize(p->e_ycopy[g]));
+				for (int g = 0; g < NG; ++g) WC_HIP(hipEventSynchronize(p->e_ycopy[g]));
 				sink->y_done = true;
 				pmark("waveforms landed");
 			}
@@ -544,31 +586,61 @@ int wc_pipeline_run_batch_host(wc_pipeline *p, int n_utt, const void *const *x, 
 	if ((rc = p->b_sp.reserve(sizeof(double) * nf * bins))) return rc;
 	if ((rc = p->b_ap.reserve(sizeof(double) * nf * bins))) return rc;
 	if ((rc = p->b_y.reserve(sizeof(double) * ny))) return rc;
-	// The samples go up half batch by half batch: the first half's Harvest starts behind its own upload while the second
-	// half's is still on the wire (copy stream).  Page-locked utterances are read by the copy engine where they lie; others
+	// The samples go up group by group: the first group's Harvest starts behind its own upload while the others'
+	// are still on the wire (copy stream).  Page-locked utterances are read by the copy engine where they lie; others
 	// are gathered into pinned staging by a few threads (245 MB of doubles take 40 ms on one).
 	HostSink sink;
 	{
-		const bool halves = p->mode == 1 && n_utt >= 2 && x_is_pcm16 == 0;
 		// A run whose spectrogram / aperiodicity rows leave for the host is bound by PCIe (2.1 GB per 64 x 10 s at 48 kHz: 37 ms at
 		// 57 GB/s against 28 ms of kernels): what counts is how early the FIRST rows are ready and that the copy engines never wait
 		// afterwards.  A first group of a third of the batch has its rows ready earlier, and they take about as long to copy as the
 		// rest of the batch needs to get its own ready (WC_PIPELINE_HOST_SPLIT: per cent of the utterances in the first group;
 		// measured on 64 x 10 s at 48 kHz, all five outputs: 50 % 59.0 ms, 35 % 55.9 ms, 25 % 57.3 ms, 12 % 60.8 ms).
-		int uA = n_utt / 2;
+		// Round 4: more groups of growing size do better still.  The kernels get an utterance ready in 0.44 ms, the link takes 0.64 ms
+		// for its rows: once the first group's rows are on the wire the copy engines never wait again as long as group g is no larger
+		// than the first group plus 0.45 of everything before it.  Measured (64 x 10 s at 48 kHz, all five outputs, this box): two groups
+		// 35 / 65 %: 55.2 ms; three 20 / 30 / 50: 51.3; four 12 / 20 / 30 / 38: 49.9; five 10 / 13 / 18 / 25 / 34: 49.6; six 6 / 8 / 11 / 15 / 21 / 39:
+		// 51.0 (41 ms for the bytes; the first rows cannot leave before ~7 ms whatever the first group's size: Harvest's tail and the
+		// first CheapTrick are latency, not work).  WC_PIPELINE_HOST_SPLITS: per cent of the utterances in every group but the last.
+		int ng = (p->mode == 1 && n_utt >= 2) ? 2 : 1;
+		int ub[kMaxGroups + 1];
+		ub[0] = 0; ub[1] = n_utt / 2;
+		for (int g = 2; g <= kMaxGroups; ++g) ub[g] = n_utt;
 		if (p->mode == 1 && n_utt >= 4 && (sp || ap)) {
-			const char *env = getenv("WC_PIPELINE_HOST_SPLIT");
-			const int pct = env ? atoi(env) : 35;
-			uA = std::min(n_utt - 1, std::max(1, (int)((long long)n_utt * pct / 100)));
-			sink.split = uA;
+			std::vector<int> pct;
+			if (const char *env = getenv("WC_PIPELINE_HOST_SPLITS")) {
+				for (const char *c = env; *c && (int)pct.size() < kMaxGroups - 1;) {
+					pct.push_back(atoi(c));
+					while (*c && *c != ',') ++c;
+					if (*c == ',') ++c;
+				}
+			} else if (const char *env1 = getenv("WC_PIPELINE_HOST_SPLIT")) {
+				pct.push_back(atoi(env1));
+			} else if (n_utt >= 20) {
+				pct = {10, 13, 18, 25};
+			} else if (n_utt >= 8) {
+				pct = {20, 30};
+			} else {
+				pct = {35};
+			}
+			ng = (int)pct.size() + 1;
+			int acc = 0;
+			for (int g = 0; g + 1 < ng; ++g) {
+				acc += pct[g];
+				// (every group gets at least one utterance)
+				ub[g + 1] = std::min(n_utt - (ng - 1 - g), std::max(ub[g] + 1, (int)((long long)n_utt * acc / 100)));
+			}
+			ub[ng] = n_utt;
+			sink.ng = ng;
+			for (int g = 0; g <= ng; ++g) sink.ub[g] = ub[g];
 		}
-		const int uB = halves ? uA : n_utt;
+		const bool halves = ng >= 2 && x_is_pcm16 == 0;
 		bool pinned_in = halves && !(getenv("WC_PIPELINE_DIRECT") && getenv("WC_PIPELINE_DIRECT")[0] == '0');
 		for (int u = 0; u < n_utt && pinned_in; ++u) pinned_in = is_pinned(x[u]);
 		char *dst = static_cast<char *>(p->st_in.p);
 		long long xo = 0;
-		for (int part = 0; part < (halves ? 2 : 1); ++part) {
-			const int u0 = part == 0 ? 0 : uB, u1 = part == 0 ? uB : n_utt;
+		for (int part = 0; part < (halves ? ng : 1); ++part) {
+			const int u0 = halves ? ub[part] : 0, u1 = halves ? ub[part + 1] : n_utt;
 			hipStream_t sc = part == 0 ? s : p->s_copy;
 			long long n_part = 0;
 			for (int u = u0; u < u1; ++u) n_part += x_length[u];
@@ -597,9 +669,9 @@ int wc_pipeline_run_batch_host(wc_pipeline *p, int n_utt, const void *const *x, 
 					WC_HIP(hipMemcpyAsync(p->b_x.as<double>() + xo, d0, sizeof(double) * (size_t)n_part, hipMemcpyHostToDevice, sc));
 				}
 			}
-			if (part == 1) {
-				WC_HIP(hipEventRecord(p->e_xb, sc));
-				sink.x_b = p->e_xb;
+			if (part >= 1) {
+				WC_HIP(hipEventRecord(p->e_x[part], sc));
+				sink.x_ev[part] = p->e_x[part];
 			}
 			xo += n_part;
 		}
@@ -647,7 +719,8 @@ int wc_pipeline_run_batch_host(wc_pipeline *p, int n_utt, const void *const *x, 
 	mark("pipeline_run returned");
 	if ((rc = p->st_in.mark(s))) return rc;  // (both uploads are long done: the run has been waited for)
 	if (total == 0) return WC_OK;
-	const bool rows_done = sink.overlapped[0] && sink.overlapped[1];
+	bool rows_done = true;
+	for (int g = 0; g < (sink.ng >= 2 ? sink.ng : 2); ++g) rows_done = rows_done && sink.overlapped[g];
 	if (tpos) WC_HIP(hipMemcpyAsync(out + off_t, p->b_t.p, sizeof(double) * nf, hipMemcpyDeviceToHost, s));
 	if (f0) WC_HIP(hipMemcpyAsync(out + off_f, p->b_f.p, sizeof(double) * nf, hipMemcpyDeviceToHost, s));
 	if (sp && !rows_done) WC_HIP(hipMemcpyAsync(out + off_sp, p->b_sp.p, sizeof(double) * nf * bins, hipMemcpyDeviceToHost, s));
