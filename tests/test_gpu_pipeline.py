@@ -198,6 +198,30 @@ def test_host_batch_front_end_pinned_rows_and_coded_outputs(wca):
         assert np.abs(c["y"] - b["y"]).max() < 1e-10
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("splits", ["10,13,18,25", "20,30", "6,8,11,15,21", "50"])
+def test_host_batch_front_end_in_more_than_two_groups(wca, splits, monkeypatch):
+    """wc_pipeline_run_batch_host cuts a batch whose rows leave for the host into up to six groups of growing size (round 4; groups
+    beyond the second share the two main streams and the high-priority stream): every grouping returns what the device-resident
+    batch gives, with the caller's rows page-locked (DMA into place, per-group uploads) and pageable (staging + host scatter)."""
+    fs = 16000
+    base = [make_utterance(fs, sec, seed) for sec, seed in ((0.4, 51), (0.65, 52), (0.3, 53), (0.5, 54), (0.8, 55))]
+    xs = [base[i % 5] for i in range(22)]
+    p = wca.Pipeline(fs)
+    ref = p.run_batch(xs)
+    monkeypatch.setenv("WC_PIPELINE_HOST_SPLITS", splits)
+    for pinned in (True, False):
+        out = p.host_buffers([len(x) for x in xs], pinned=pinned)
+        for g in out:
+            for v in g.values():
+                v.fill(-3.0)
+        p.run_batch_host(p.host_inputs(xs) if pinned else xs, out=out)
+        for r, g in zip(ref, out):
+            assert np.array_equal(g["tpos"], r["tpos"]) and np.array_equal(g["f0"], r["f0"])
+            assert np.array_equal(g["sp"], r["sp"]) and np.array_equal(g["ap"], r["ap"])
+            assert np.abs(g["y"] - r["y"]).max() < 1e-10
+
+
 def test_pipeline_at_96_khz_golden(wca):
     """96 kHz: decimation ratio 12, 4096-point CheapTrick / Synthesis, 8192-point D4C and LoveTrain (the unpacking twiddles of
     the 8192-point real transforms lie between the entries of the 4096-entry table and are computed) against the real

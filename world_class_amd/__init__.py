@@ -148,12 +148,10 @@ def _ptr_array(arrs):
 
 
 def _rows(mat):
-    ptrs = (_dp * mat.shape[0])()
-    base = mat.ctypes.data
-    stride = mat.strides[0]
-    for i in range(mat.shape[0]):
-        ptrs[i] = C.cast(base + i * stride, _dp)
-    return ptrs
+    """the reference's double** for a 2-D float64 array: a table of row addresses (built by numpy -- a Python loop of ctypes casts
+    over 2001 rows took 1 ms per call and 36 ms the first time, more than the stage's own work)"""
+    addr = np.uintp(mat.ctypes.data) + np.arange(mat.shape[0], dtype=np.uintp) * np.uintp(mat.strides[0])
+    return addr.ctypes.data_as(C.POINTER(_dp))  # (the pointer object keeps `addr` alive)
 
 
 # ---- size helpers ---------------------------------------------------------------------------

@@ -48,10 +48,8 @@ def _path(p):
 
 
 def _rows(mat):
-    arr = (_dp * mat.shape[0])()
-    for i in range(mat.shape[0]):
-        arr[i] = mat[i].ctypes.data_as(_dp)
-    return arr
+    from . import _rows as rows  # (a table of row addresses built by numpy, see world_class_amd/__init__.py)
+    return rows(mat)
 
 
 def wavwrite(x, fs, filename, nbit=16):
