@@ -867,8 +867,12 @@ __global__ __launch_bounds__(RAW_T) void hv_raw_kernel(RawArgs a) {
 	// the band-pass kernel recorded how many edges precede every tile, so the slice is bounded without searching: the running
 	// counts of the chunks around the block in one load (lane l: chunk q0 - 2 + l), requested before anything depends on them
 	const int i1 = min(i0 + RAW_T - 1, u.L1 - 1);
-	const int q0 = min(a.n_tiles, max(0, (int)((i0 * 1 / 1000.0) * a.fs_d) / a.tile_adv));
-	const int q1 = min(a.n_tiles, (int)((i1 * 1 / 1000.0) * a.fs_d) / a.tile_adv + 1);
+	// (the chunks the block's first and last frames fall into only bound the slice: a sample either way costs nothing -- four
+	// edges of margin on both sides, and a frame whose answer is not strictly inside the slice takes the whole list -- so no
+	// exact quotients here: two FP64 and two integer divisions per wavefront were an eighth of the kernel's instructions)
+	const int smp0 = (int)(i0 * (a.fs_d * 1e-3)), smp1 = (int)(i1 * (a.fs_d * 1e-3));
+	const int q0 = min(a.n_tiles, max(0, SLOTS ? smp0 / SD_CH : smp0 / a.tile_adv));
+	const int q1 = min(a.n_tiles, (SLOTS ? smp1 / SD_CH : smp1 / a.tile_adv) + 1);
 	const int tr_first = q0 - 2;
 	const int tr_mine = trun_b[min(max(tr_first + (lane & 7), 0), a.n_tiles) * 4 + ty_w];
 	// number of intervals = edges - 1 (0 when fewer than 2 edges); all four need more than 2 (reference :1101-1107)

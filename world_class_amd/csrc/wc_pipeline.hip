@@ -310,12 +310,20 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 		// A device-resident batch runs as two halves.  A run whose rows leave for the host may ask for up to six groups of growing
 		// size (HostSink::ng, ub): the same chain of chains -- group g's Harvest front behind group g - 1's refinement -- with every
 		// group's CheapTrick / D4C on a high-priority stream as soon as its own contour is there.
-		const int NG = (sink && sink->ng >= 2 && sink->ng <= kMaxGroups && sink->ub[sink->ng] == n_utt) ? sink->ng : 2;
-		if ((rc = pipeline_ensure_groups(p, NG))) return rc;
+		int NG = (sink && sink->ng >= 2 && sink->ng <= kMaxGroups && sink->ub[sink->ng] == n_utt) ? sink->ng : 2;
 		int ub[kMaxGroups + 1];
 		ub[0] = 0; ub[1] = n_utt / 2;
 		for (int g = 2; g <= kMaxGroups; ++g) ub[g] = n_utt;
 		if (NG > 2 || (sink && sink->ng == 2)) for (int g = 0; g <= NG; ++g) ub[g] = sink->ub[g];
+		if (!sink) {  // WC_PIPELINE_GROUPS: a device-resident batch in that many equal groups (experiment)
+			const char *env = getenv("WC_PIPELINE_GROUPS");
+			const int want = env ? atoi(env) : 2;
+			if (want > 2 && want <= kMaxGroups && n_utt >= want) {
+				NG = want;
+				for (int g = 0; g <= NG; ++g) ub[g] = (int)((long long)n_utt * g / NG);
+			}
+		}
+		if ((rc = pipeline_ensure_groups(p, NG))) return rc;
 		const bool eager = sink && sink->eager;
 		// streams: two groups as ever (own main and aux streams; the first group's aux is the high-priority one when its rows are
 		// waited for).  More groups take turns on the two main streams -- group g + 2's Harvest sits behind group g's pulses there,
