@@ -1,7 +1,7 @@
 """Kernels and copies of a host front-end run on one time line (development aid), from
     rocprofv3 --kernel-trace --memory-copy-trace -f csv -d DIR -o p -- python tools/host_frontend_probe.py
     python tools/trace_host_frontend.py DIR
-Runs of consecutive copies / blit kernels are merged; times in ms from the start of the last run's uploads."""
+Runs of consecutive copies / blit kernels are merged; times in ms from the start of the last run (the activity behind the last idle stretch)."""
 import csv, sys
 d = sys.argv[1]
 kt = list(csv.DictReader(open(d + '/p_kernel_trace.csv')))
@@ -10,8 +10,13 @@ ev = []
 for r in kt: ev.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), 'K q%s %s' % (r['Queue_Id'], r['Kernel_Name'].replace('void ', '').replace('wc::', '')[:40])))
 for r in mc: ev.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), 'C s%s %s' % (r['Stream_Id'], r['Direction'][12:])))
 ev.sort()
-h2d = [e for e in ev if e[2].startswith('C') and 'HOST_TO_DEVICE' in e[2] and e[1] - e[0] > 30000]
-t0 = h2d[-64][0]
+# the last run = everything behind the last idle stretch of 3 ms or more (the probe's runs are synchronous calls)
+t0 = ev[0][0]
+busy_until = ev[0][1]
+for s_, e_, n_ in ev:
+    if s_ - busy_until > 3000000:
+        t0 = s_
+    busy_until = max(busy_until, e_)
 # merge consecutive copies / blit kernels of the same name into runs
 runs = []
 for s, e, n in ev:

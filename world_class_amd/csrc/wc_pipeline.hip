@@ -352,6 +352,14 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 			}
 			// 0. chain B's own stream starts behind whatever already sits on the caller's stream (an upload of the samples, the
 			//    caller's kernels): its decimation reads d_x right away.  (The aux streams follow their main streams through e0.)
+			// WC_PIPELINE_TIMING: where every group stands on the device's own clock (events with time stamps, development aid)
+			static const bool gpu_marks = getenv("WC_PIPELINE_TIMING") != nullptr;
+			static hipEvent_t tm0 = nullptr, tm[kMaxGroups][4];
+			if (gpu_marks && !tm0) {
+				(void)hipEventCreate(&tm0);
+				for (int g = 0; g < kMaxGroups; ++g) for (int k = 0; k < 4; ++k) (void)hipEventCreate(&tm[g][k]);
+			}
+			if (gpu_marks) WC_HIP(hipEventRecord(tm0, s0));
 			WC_HIP(hipEventRecord(p->e1, s0));
 			WC_HIP(hipStreamWaitEvent(mainS[1], p->e1, 0));
 			// (a group's upload is waited for by its own Harvest, below: on a shared main stream the wait must not stand in front
@@ -364,12 +372,17 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 			// event must have been recorded by the time a stream is told to wait for it.)
 			static const bool tail_late_env = getenv("WC_PIPELINE_TAIL_AFTER_BP") && getenv("WC_PIPELINE_TAIL_AFTER_BP")[0] == '1';
 			const bool tail_late = tail_late_env && NG == 2;
+			// (WC_PIPELINE_CHAIN=0, measured and rejected: the Harvests of small neighbouring groups not held apart -- their full-grid
+			// kernels do not fill the chip, a 6-utterance band-pass is one round of 650 wavefronts on 3072 places -- 52-60 ms
+			// against 50: every group's contour arrives later)
+			static const bool chain_env = getenv("WC_PIPELINE_CHAIN") && getenv("WC_PIPELINE_CHAIN")[0] == '0';
+			const bool chain_harvest = NG == 2 || !chain_env;
 			auto enqueue_harvest = [&](int g) -> int {
 				PipeGroup &G = p->grp[g];
 				dev->time_tag = g;
 				if (g >= 1 && sink && sink->x_ev[g]) WC_HIP(hipStreamWaitEvent(mainS[g], sink->x_ev[g], 0));
 				return hv_enqueue(G.hv, mainS[g], sl[g].nu, d_x + sl[g].xo, x_length + sl[g].u0, d_tpos + sl[g].fo, d_f0 + sl[g].fo,
-								  full[g][0], G.e_mid, g >= 1 ? p->grp[g - 1].e_mid : nullptr, (g == 0 && tail_late) ? 1 : 3,
+								  full[g][0], G.e_mid, (g >= 1 && chain_harvest) ? p->grp[g - 1].e_mid : nullptr, (g == 0 && tail_late) ? 1 : 3,
 								  (g == 1 && tail_late) ? p->e_bp : nullptr, nullptr);
 			};
 			// (two groups: both Harvest chains first -- the first group's CheapTrick / D4C may wait for an event of the second's.
@@ -397,6 +410,7 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 				uint64_t a0 = 0, a1 = 0;
 				if ((rc = ct_prepare(G.ct, mainS[g], nu, x_length + u0, gf, f_len.data() + u0, grp_rng, &total, &a0, &a1))) return rc;
 				WC_HIP(hipEventRecord(G.e0, mainS[g]));
+				if (gpu_marks) WC_HIP(hipEventRecord(tm[g][0], mainS[g]));
 				WC_HIP(hipStreamWaitEvent(G_aux, G.e0, 0));
 				// (a run whose rows leave for the host is bound by PCIe, not by the kernels: there the first half's rows are wanted
 				// as early as they can be had, even if its CheapTrick / D4C then share the CUs with the second half's Harvest)
@@ -404,11 +418,13 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 				hipEvent_t ct_rows = nullptr;  // CheapTrick's pass over the frames its one-wavefront kernel leaves out, on a stream of its own
 				if ((rc = ct_frames(G.ct, G_aux, nu, gx, gt, gf, gsp, total, &ct_rows))) return rc;
 				WC_HIP(hipEventRecord(G.e_ct, G_aux));
+				if (gpu_marks) WC_HIP(hipEventRecord(tm[g][1], G_aux));
 				if ((rc = d4c_enqueue(G.d4, G_aux, nu, gx, x_length + u0, gt, gf, f_len.data() + u0, p->fft_size, gap, nullptr,
 									  ct_end_positions(G.ct))))
 					return rc;
 				if (ct_rows) WC_HIP(hipStreamWaitEvent(G_aux, ct_rows, 0));  // (the pulses wait for e_aux)
 				WC_HIP(hipEventRecord(G.e_aux, G_aux));
+				if (gpu_marks) WC_HIP(hipEventRecord(tm[g][2], G_aux));
 				if (sink && attempt == 0 && (sink->stage_sp || sink->stage_ap)) {
 					const size_t off = sizeof(double) * (size_t)sl[g].fo * bins_, len = sizeof(double) * (size_t)(fo_end[g] - sl[g].fo) * bins_;
 					// the spectrogram rows leave as soon as CheapTrick is through, the aperiodicity rows behind D4C: PCIe is the longest
@@ -445,6 +461,7 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 				if ((rc = syn_prepare(G.sy, mainS[g], nu, gf, f_len.data() + u0, y_len.data() + u0, gy, nullptr, full[g][1]))) return rc;
 				WC_HIP(hipStreamWaitEvent(mainS[g], G.e_aux, 0));
 				if ((rc = syn_pulses(G.sy, mainS[g], gf, gsp, gap, gy, d4c_end_positions(G.d4)))) return rc;
+				if (gpu_marks) WC_HIP(hipEventRecord(tm[g][3], mainS[g]));
 				if (sink && sink->y) {
 					// (every attempt: a re-run after an overflow rewrites the waveform, and its copies land behind the first ones)
 					WC_HIP(hipEventRecord(p->e_y[g], mainS[g]));
@@ -501,6 +518,15 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 				for (int g = 0; g < NG; ++g) WC_HIP(hipEventSynchronize(p->e_ycopy[g]));
 				sink->y_done = true;
 				pmark("waveforms landed");
+			}
+			if (gpu_marks) {
+				(void)hipDeviceSynchronize();
+				for (int g = 0; g < NG; ++g) {
+					float t[4] = {0, 0, 0, 0};
+					for (int k = 0; k < 4; ++k) (void)hipEventElapsedTime(&t[k], tm0, tm[g][k]);
+					std::fprintf(stderr, "  [pipeline] group %d (%d utterances) on the device: contour %.2f  CheapTrick %.2f  D4C %.2f  pulses %.2f ms\n",
+								 g, ub[g + 1] - ub[g], t[0], t[1], t[2], t[3]);
+				}
 			}
 			if (!again) return WC_OK;
 		}
