@@ -106,6 +106,7 @@ struct wc_pipeline {
 	hipStream_t s1, s1_hi, s2, s_copy, s_copy2;  // (s_copy2: the aperiodicity rows leave beside the spectrogram rows, on a DMA engine of their own)
 	hipEvent_t e_copy2[kMaxGroups];
 	hipEvent_t e0, e1, e2, e_copy[kMaxGroups], e_y[kMaxGroups], e_ycopy[kMaxGroups], e_x[kMaxGroups], e_bp;
+	hipEvent_t tm0, tm[kMaxGroups][4];  // WC_PIPELINE_TIMING: time-stamped marks of every group's progress (created on first use)
 	// host batch front-end (wc_pipeline_run_batch_host): device-resident batch + pinned staging, grow-only
 	DevBuf b_x, b_pcm, b_t, b_f, b_sp, b_ap, b_y, b_ypcm, b_coded;
 	HostBuf st_in, st_out;
@@ -248,6 +249,10 @@ void wc_pipeline_destroy(wc_pipeline *p) {
 	for (int g = 0; g < kMaxGroups; ++g) if (p->e_ycopy[g]) (void)hipEventDestroy(p->e_ycopy[g]);
 	for (int g = 0; g < kMaxGroups; ++g) if (p->e_x[g]) (void)hipEventDestroy(p->e_x[g]);
 	if (p->e_bp) (void)hipEventDestroy(p->e_bp);
+	if (p->tm0) {
+		(void)hipEventDestroy(p->tm0);
+		for (int g = 0; g < kMaxGroups; ++g) for (int k = 0; k < 4; ++k) if (p->tm[g][k]) (void)hipEventDestroy(p->tm[g][k]);
+	}
 	for (int g = 0; g < kMaxGroups; ++g) {
 		PipeGroup &G = p->grp[g];
 		if (G.e0) (void)hipEventDestroy(G.e0);
@@ -354,10 +359,11 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 			//    caller's kernels): its decimation reads d_x right away.  (The aux streams follow their main streams through e0.)
 			// WC_PIPELINE_TIMING: where every group stands on the device's own clock (events with time stamps, development aid)
 			static const bool gpu_marks = getenv("WC_PIPELINE_TIMING") != nullptr;
-			static hipEvent_t tm0 = nullptr, tm[kMaxGroups][4];
+			hipEvent_t &tm0 = p->tm0;
+			hipEvent_t (&tm)[kMaxGroups][4] = p->tm;
 			if (gpu_marks && !tm0) {
-				(void)hipEventCreate(&tm0);
-				for (int g = 0; g < kMaxGroups; ++g) for (int k = 0; k < 4; ++k) (void)hipEventCreate(&tm[g][k]);
+				WC_HIP(hipEventCreate(&tm0));
+				for (int g = 0; g < kMaxGroups; ++g) for (int k = 0; k < 4; ++k) WC_HIP(hipEventCreate(&tm[g][k]));
 			}
 			if (gpu_marks) WC_HIP(hipEventRecord(tm0, s0));
 			WC_HIP(hipEventRecord(p->e1, s0));
