@@ -24,7 +24,7 @@ def hooks():
         def fft(kind, x):
             x = np.ascontiguousarray(x, dtype=np.float64)
             n_in, n_out = {0: (2048, 2050), 1: (2050, 2048), 2: (2048, 2050), 3: (4096, 4098),
-                           4: (1024, 1026), 5: (1026, 1024), 6: (1024, 1026), 7: (1024, 1026)}[kind]
+                           4: (1024, 1026), 5: (1026, 1024), 6: (1024, 1026), 7: (1024, 1026), 8: (1025, 1025)}[kind]
             batch = x.size // n_in
             out = np.empty(batch * n_out)
             rc = L.wc_debug_wave_fft(kind, batch, x.ctypes.data_as(dp), out.ctypes.data_as(dp))
@@ -111,6 +111,24 @@ def test_eight_points_per_lane_transforms_batched_against_numpy(hooks):
         got = hooks.fft(kind, xz).reshape(batch, n // 2 + 1, 2)
         want = np.conj(np.fft.rfft(xz, axis=1))
         assert np.abs(got[..., 0] + 1j * got[..., 1] - want).max() < 1e-12
+
+
+def test_real_even_transform_at_half_cost(hooks):
+    """wf_even2048: the DFT of a real even sequence of 2048 points (CheapTrick's cepstral transforms, reference
+    src/cheaptrick.cpp:230-276; the first transform of MinimumPhaseAnalysis, src/world_common.cpp:196-205) through a 512-point
+    complex transform -- against numpy on log-spectrum-like and on random inputs"""
+    rng = np.random.default_rng(23)
+    batch = 29
+    k = np.arange(1025)
+    xs = [rng.standard_normal((batch, 1025)),
+          -12.0 + 4.0 * np.cos(2 * np.pi * k / 137.0)[None, :] + rng.standard_normal((batch, 1025)),   # a log spectrum: large mean
+          np.exp(-0.01 * k)[None, :] * rng.standard_normal((batch, 1025))]                                 # a cepstrum: decaying
+    for x in xs:
+        full = np.concatenate([x, x[:, -2:0:-1]], axis=1)
+        assert full.shape[1] == 2048
+        want = np.fft.fft(full, axis=1).real[:, :1025]
+        got = hooks.fft(8, x)
+        assert np.abs(got - want).max() < 2e-13 * np.abs(want).max()
 
 
 def test_two_wavefront_transform_of_4096_points(golden, hooks):

@@ -324,6 +324,9 @@ __global__ __launch_bounds__(T) void ct_frames_kernel(CtArgs a) {
 #ifndef WC_CT_PRELOAD
 #define WC_CT_PRELOAD 1
 #endif
+#ifndef WC_CT_EVEN
+#define WC_CT_EVEN 1  // the two cepstral transforms as real even transforms (wf_even2048); 0: 1024-point complex transforms (A/B)
+#endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_CT_WAVE_OCC, WC_CT_WAVE_OCC))) void ct_wave_kernel(CtArgs a) {
 	constexpr int N = 2048, M = 1024;
 	__shared__ __attribute__((aligned(16))) double L[kWfLds];
@@ -539,6 +542,61 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_CT_WAVE_O
 		}
 		wf_fence();
 	}
+#if WC_CT_EVEN
+	// ---- smoothing + recovery lifters in the cepstral domain (reference :230-276) ----
+	// Both transforms act on real even sequences -- the log spectrum, the liftered cepstrum -- and their results are real and
+	// even: wf_even2048 (a 512-point complex transform + O(N) passes) instead of a 1024-point complex transform with
+	// unpacking / packing each.  F[k] sits in the lane as k = t + 64 j and its partner 1024 - k.
+	double lo[8], hi[8], mid;
+	wf_even2048(P, L, a.tw, lane, lo, hi, mid);
+	{
+		// lifters at quefrency k / fs: sinc(f0 q) and 1 - 2 q1 + 2 q1 cos(2 pi q f0); with theta = pi f0 k / fs the cosine is
+		// 1 - 2 sin^2 theta.  (cos, sin) of theta_k by rotations of E_t by E_64; the partner's sine from E_1024 conj(E_k)
+		const double q1 = a.q1;
+		const double ralpha = 1.0 / (kPi * f0c / fs);
+		const double scale = 1.0 / N;  // the reference's / fft_size
+		double ec, es, c64, s64, c1024, s1024, c512, s512;
+		wf_sincospi(f0c / fs * lane, es, ec);
+		wf_sincospi(f0c / fs * 64.0, s64, c64);
+		wf_sincospi(f0c / fs * 1024.0, s1024, c1024);
+		wf_sincospi(f0c / fs * 512.0, s512, c512);
+		s64 = uniform_d(s64); c64 = uniform_d(c64);
+		s1024 = uniform_d(s1024); c1024 = uniform_d(c1024);
+		s512 = uniform_d(s512);
+		const double cl0 = 1.0 - 2.0 * q1, cl1 = 2.0 * q1;
+		auto lift = [&](double v, double sn, int k) {
+			const double sl = sn * (ralpha * tw_load_d(a.tw + kTwInvK, k));
+			const double cl = fma(cl1, fma(-2.0 * sn, sn, 1.0), cl0);
+			return v * sl * cl * scale;
+		};
+#pragma unroll
+		for (int j = 0; j < 8; ++j) {
+			const int k = lane + 64 * j;
+			const double sp = fma(s1024, ec, -(c1024 * es));
+			double vlo = lift(lo[j], es, k);
+			const double vhi = lift(hi[j], sp, 1024 - k);
+			if (j == 0) vlo = (lane == 0) ? lo[0] * (cl0 + cl1) * scale : vlo;  // k = 0: sinc = 1
+			P[k] = vlo;
+			P[1024 - k] = vhi;
+			const double cn = fma(ec, c64, -(es * s64));
+			es = fma(es, c64, ec * s64);
+			ec = cn;
+		}
+		const double vmid = lift(mid, s512, 512);
+		if (lane == 0) P[512] = vmid;
+	}
+	wf_fence();
+	wf_even2048(P, L, a.tw, lane, lo, hi, mid);
+	double *__restrict__ out = a.sp + g * (long long)(M + 1);
+#pragma unroll
+	for (int j = 0; j < 8; ++j) {
+		out[lane + 64 * j] = wf_exp_l(lo[j], T);
+		out[1024 - lane - 64 * j] = wf_exp_l(hi[j], T);
+	}
+	const double last = wf_exp_l(mid, T);
+	if (lane == 0) out[512] = last;
+}
+#else
 	// the mirrored log spectrum as the packed input of the second transform: sample n of slot q is 2 lane + 128 q (+ 1),
 	// samples beyond 1024 are the mirror images 2048 - n
 #pragma unroll
@@ -609,6 +667,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_CT_WAVE_O
 	const double last = wf_exp_l(re[8], T);
 	if (lane == 0) out[M] = last;
 }
+#endif
 
 
 // ---- one wavefront per frame at N = 1024 (16 / 22.05 / 24 kHz) ------------------------------------------------------------------

@@ -300,6 +300,11 @@ Device *current_device() {
 		for (int kb = 0; kb < 8; ++kb)
 			for (int t = 0; t < 64; ++t) tw[kTw8B + 64 * kb + t] = tw[(8 * (t & 7) * ((t >> 3) + 8 * kb)) % kTwiddleN];
 		for (int n = 0; n <= 512; ++n) tw[kTw8U + n] = tw[4 * n];
+		{
+			double *is = reinterpret_cast<double *>(&tw[kTwIS]);  // wf_even2048
+			is[0] = 0.0;
+			for (int k = 1; k < 512; ++k) is[k] = (double)(1.0L / (4.0L * sinl(2.0L * 3.14159265358979323846264338327950288L * k / 2048.0L)));
+		}
 		for (int i = 0; i < 128; ++i) {
 			const double c = 0.5 + (i + 0.5) / 256.0, invc = 1.0 / c;
 			tw[kTwLog + i] = make_double2(invc, (double)-logl((long double)invc));

@@ -178,6 +178,24 @@ __global__ __launch_bounds__(64) void hook_wave8_fft_kernel(const double *__rest
 		}
 	}
 }
+// the real even transform of 2048 points (wf_even2048): in x[0 .. 1024], out F[0 .. 1024]
+__global__ __launch_bounds__(64) void hook_even2048_kernel(const double *__restrict__ in, double *__restrict__ out, const double2 *__restrict__ tw) {
+	__shared__ __attribute__((aligned(16))) double L[kWfLds];
+	__shared__ __attribute__((aligned(16))) double X[1026];
+	const int lane = threadIdx.x;
+	const double *x = in + (size_t)blockIdx.x * 1025;
+	double *F = out + (size_t)blockIdx.x * 1025;
+	for (int i = lane; i <= 1024; i += 64) X[i] = x[i];
+	wf_fence();
+	double lo[8], hi[8], mid;
+	wf_even2048(X, L, tw, lane, lo, hi, mid);
+#pragma unroll
+	for (int j = 0; j < 8; ++j) {
+		F[lane + 64 * j] = lo[j];
+		F[1024 - lane - 64 * j] = hi[j];
+	}
+	if (lane == 0) F[512] = mid;
+}
 // 4096-point real transform by two wavefronts (one 128-thread workgroup): in 4096 doubles, out 2049 complex
 __global__ __launch_bounds__(128) void hook_wave2_r2c_kernel(const double *__restrict__ in, double *__restrict__ out,
 															 const double2 *__restrict__ tw) {
@@ -317,15 +335,16 @@ int wc_debug_seq_cumsum(const double *v, int n, int batch, int threads, double *
 // 2048-point real transforms by one wavefront each (wc_wavefft.hpp).  kind 0 r2c, 1 c2r, 2 r2c of an input whose last
 // three quarters are zero (pruned leading stage); host pointers; doubles in 2048 / 2050 / 2048, out 2050 / 2048 / 2050.
 int wc_debug_wave_fft(int kind, int batch, const double *in, double *out) {
-	if (kind < 0 || kind > 7 || batch <= 0 || !in || !out) return fail(WC_ERR_INVALID, "debug wave fft: bad argument");
+	if (kind < 0 || kind > 8 || batch <= 0 || !in || !out) return fail(WC_ERR_INVALID, "debug wave fft: bad argument");
 	Device *dev = current_device();
 	if (!dev) return WC_ERR_DEVICE;
 	DeviceLock lock(dev);
 	hipStream_t s = dev->active();
 	// (kind 3: the 4096-point r2c by two wavefronts, 4096 doubles in, 4098 out; kinds 4 .. 7: the 1024-point transforms at eight
 	// points per lane -- r2c, c2r, r2c pruned to a quarter / a half: 1024 / 1026 / 1024 / 1024 doubles in, 1026 / 1024 / 1026 / 1026 out)
-	const size_t n_in = (kind >= 4 ? (kind == 5 ? 1026 : 1024) : kind == 3 ? 4096 : kind == 1 ? 2050 : 2048) * (size_t)batch;
-	const size_t n_out = (kind >= 4 ? (kind == 5 ? 1024 : 1026) : kind == 3 ? 4098 : kind == 1 ? 2048 : 2050) * (size_t)batch;
+	// (kind 8: the real even transform of 2048 points, 1025 doubles in and out)
+	const size_t n_in = kind == 8 ? 1025 * (size_t)batch : (kind >= 4 ? (kind == 5 ? 1026 : 1024) : kind == 3 ? 4096 : kind == 1 ? 2050 : 2048) * (size_t)batch;
+	const size_t n_out = kind == 8 ? 1025 * (size_t)batch : (kind >= 4 ? (kind == 5 ? 1024 : 1026) : kind == 3 ? 4098 : kind == 1 ? 2048 : 2050) * (size_t)batch;
 	Scoped d_in, d_out;
 	WC_HIP(hipMalloc(&d_in.p, sizeof(double) * n_in));
 	WC_HIP(hipMalloc(&d_out.p, sizeof(double) * n_out));
@@ -339,7 +358,8 @@ int wc_debug_wave_fft(int kind, int batch, const double *in, double *out) {
 	else if (kind == 4) hipLaunchKernelGGL(hook_wave8_fft_kernel<0>, dim3(batch), dim3(64), 0, s, di, dout, dev->twiddle);
 	else if (kind == 5) hipLaunchKernelGGL(hook_wave8_fft_kernel<1>, dim3(batch), dim3(64), 0, s, di, dout, dev->twiddle);
 	else if (kind == 6) hipLaunchKernelGGL(hook_wave8_fft_kernel<2>, dim3(batch), dim3(64), 0, s, di, dout, dev->twiddle);
-	else hipLaunchKernelGGL(hook_wave8_fft_kernel<3>, dim3(batch), dim3(64), 0, s, di, dout, dev->twiddle);
+	else if (kind == 7) hipLaunchKernelGGL(hook_wave8_fft_kernel<3>, dim3(batch), dim3(64), 0, s, di, dout, dev->twiddle);
+	else hipLaunchKernelGGL(hook_even2048_kernel, dim3(batch), dim3(64), 0, s, di, dout, dev->twiddle);
 	WC_HIP(hipGetLastError());
 	WC_HIP(hipMemcpyAsync(out, d_out.p, sizeof(double) * n_out, hipMemcpyDeviceToHost, s));
 	WC_HIP(hipStreamSynchronize(s));

@@ -160,7 +160,8 @@ constexpr int kTwUo = kTwU + 1040;        // 1024 entries: W_4096^{2 j + 1} (unp
 constexpr int kTw8A = kTwUo + 1024;       // 64 entries: W_64^{n1 ka} at [8 n1 + ka] (second stage)
 constexpr int kTw8B = kTw8A + 64;         // 512 entries: W_512^{(t & 7) ((t >> 3) + 8 kb)} at [64 kb + t] (third stage)
 constexpr int kTw8U = kTw8B + 512;        // 528 entries: W_1024^n, n <= 512 (real-transform unpacking)
-constexpr int kTwTotal = kTw8U + 528;     // double2 entries of the whole table
+constexpr int kTwIS = kTw8U + 528;        // 256 entries = 512 doubles 1 / (4 sin(2 pi k / 2048)), k < 512 (k = 0: 0): wf_even2048
+constexpr int kTwTotal = kTwIS + 256;     // double2 entries of the whole table
 
 // Left alone, the scheduler puts every twiddle load right in front of its use (load, wait ~500 cycles, use, 15 times per
 // stage: measured, the transforms ran five times slower than their arithmetic).  The loads of a stage are therefore issued
@@ -1345,6 +1346,63 @@ __device__ __forceinline__ void wf8_c2r_pack_re(double (&re)[8], double (&im)[8]
 #pragma unroll
 		for (int q = 0; q < 4; ++q) wf_c2r_pair_re(re[q], im[q], re[7 - q], im[7 - q], wr[q], wi[q]);
 	}
+}
+
+// ======== real EVEN transform of 2048 points at half a real transform's cost ================================================
+// F[k] = sum_{n < 2048} x[n] cos(2 pi n k / 2048) for x[n] = x[2048 - n] -- the DFT of a real even sequence (CheapTrick's two
+// cepstral transforms, the first transform of a minimum-phase analysis), itself real and even.  With
+//     c[n] = x[2 n] + i (x[2 n + 1] - x[2 n - 1]),   n < 1024   (Hermitian: c[1024 - n] = conj c[n]),
+// C = DFT_1024(c) is real: C[k] = E[k] - 2 sin(theta_k) T[k], theta_k = 2 pi k / 2048, where E is the transform of the even
+// samples and T[k] = w^k O[k] the twiddled transform of the odd ones, F[k] = E[k] + T[k].  E[1024 - k] = E[k] and
+// T[1024 - k] = -T[k], so the pair (C[k], C[1024 - k]) gives E[k] = (C[k] + C[1024 - k]) / 2, T[k] = (C[1024 - k] - C[k]) / (4 sin
+// theta_k), hence F[k] and F[1024 - k]; T[0] is the plain sum of the odd samples.  C itself is a 1024-point real-output
+// transform of a Hermitian sequence: wf8_c2r_pack + the 512-point complex transform at eight points per lane.  About 700
+// instructions where the 1024-point complex transform + unpacking take 1250; the division by 4 sin theta amplifies the
+// rounding of C by at most 163 (k = 1): 1e-13 of the largest |C|.
+// In: x[0 .. 1024] in LDS (X, 16-byte aligned), natural order.  L: the exchange buffer (>= 1026 doubles, not X).
+// Out: lo[j] = F[t + 64 j], hi[j] = F[1024 - t - 64 j], j < 8 (lane 0, j = 0: F[0] and F[1024]); mid = F[512] (every lane).
+__device__ __forceinline__ void wf_even2048(const double *X, double *L, const double2 *__restrict__ tw_, int lane, double (&lo)[8],
+											 double (&hi)[8], double &mid) {
+	const double2 *__restrict__ tw = tw_fresh(tw_);
+	double cr[8], ci[8], so = 0.0;
+#pragma unroll
+	for (int g = 0; g < 2; ++g)
+#pragma unroll
+		for (int c = 0; c < 4; ++c) {
+			const int n = wf8_bin(lane, g, c);  // 0 .. 511
+			const double2 v = *reinterpret_cast<const double2 *>(&X[2 * n]);
+			const double m = X[n ? 2 * n - 1 : 1];
+			cr[4 * g + c] = v.x;
+			ci[4 * g + c] = v.y - m;
+			so += v.y;
+		}
+	const double nyq = X[1024];
+	wf_fence();
+	wf8_c2r_pack(cr, ci, nyq, tw, lane);
+	wf8_fft512_dif<-1>(cr, ci, L, tw, lane);
+	double is[8];
+#pragma unroll
+	for (int j = 0; j < 8; ++j) is[j] = tw_load_d(tw + kTwIS, lane + 64 * j);
+	WF_SCHED_FENCE();
+#pragma unroll
+	for (int q = 0; q < 8; ++q) *reinterpret_cast<double2 *>(&L[2 * (lane + 64 * q)]) = make_double2(cr[q], ci[q]);
+	wf_fence();
+	so = 2.0 * wave_sum_all(so);
+#pragma unroll
+	for (int j = 0; j < 8; ++j) {
+		const int k = lane + 64 * j;
+		const double a = L[k], b = L[(1024 - k) & 1023];
+		const double e = 0.5 * (a + b), t = (b - a) * is[j];
+		lo[j] = e + t;
+		hi[j] = e - t;
+	}
+	if (lane == 0) {
+		const double e0 = L[0];
+		lo[0] = e0 + so;
+		hi[0] = e0 - so;
+	}
+	mid = L[512];
+	wf_fence();
 }
 
 }  // namespace wc
