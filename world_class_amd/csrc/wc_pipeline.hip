@@ -663,6 +663,7 @@ int wc_pipeline_run_batch_host(wc_pipeline *p, int n_utt, const void *const *x, 
 			} else {
 				pct = {35};
 			}
+			if ((int)pct.size() > n_utt - 1) pct.resize(n_utt - 1);  // (every group gets at least one utterance)
 			ng = (int)pct.size() + 1;
 			int acc = 0;
 			for (int g = 0; g + 1 < ng; ++g) {
