@@ -2781,7 +2781,12 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 	}
 	// the ALU-bound part of this chain is enqueued: a staggered twin chain may start its own now, next to our
 	// latency-bound tail (contour logic, smoothing) and whatever the caller runs after us
-	if (mid_event && !resume) WC_HIP(hipEventRecord(mid_event, s));
+	// Round 4: the twin chain starts behind the candidate test (hv_unreliable) as well, not right behind the refinement: that
+	// full-grid kernel takes wavefront places of which the twin's band-pass -- one round of 3040 long-lived wavefronts on 3072
+	// places -- wants all (1.83 ms alone, 2.55 ms beside it): 27.8 -> 27.2 ms per 64 x 10 s.  Later still (behind the contour
+	// kernels, one wavefront per utterance or section) exposes their latency: 27.9 / 28.1 ms.  WC_HARVEST_MID_LATE=0..3 (A/B).
+	static const int mid_late = getenv("WC_HARVEST_MID_LATE") ? atoi(getenv("WC_HARVEST_MID_LATE")) : 1;
+	if (mid_event && !resume && !(mid_late && (phases & 2))) WC_HIP(hipEventRecord(mid_event, s));
 	if (!(phases & 2)) {
 		h->last_utts = utts;
 		return WC_OK;
@@ -2791,6 +2796,7 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 	const size_t unr_lds = sizeof(double) * (size_t)(3 * UNR_F + 2) * nc + sizeof(int) * (2 * UNR_F + 2) + (size_t)UNR_F * nc;
 	hipLaunchKernelGGL(hv_unreliable_kernel, dim3((unsigned)((max_L1 + UNR_F - 1) / UNR_F), n_utt), dim3(256), unr_lds, s, du, h->cand1.as<double>(),
 					   h->score1.as<double>(), h->cand2.as<double>(), h->score2.as<double>(), h->base.as<double>(), nc);
+	if (mid_event && !resume && mid_late == 1) WC_HIP(hipEventRecord(mid_event, s));
 	CtrArgs ca;
 	ca.utts = du; ca.cand = h->cand2.as<double>(); ca.score = h->score2.as<double>(); ca.base = h->base.as<double>();
 	ca.s1 = h->s1.as<double>(); ca.s2 = h->s2.as<double>(); ca.s3 = h->s3.as<double>(); ca.fixed = h->fixed.as<double>();
@@ -2798,7 +2804,9 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 	ca.ibuf = h->ibuf.as<int>();
 	ca.nsec = h->ibuf.as<int>() + 4ll * max_sec * n_utt;
 	hipLaunchKernelGGL(hv_contour_kernel<0>, dim3(n_utt), dim3(64), 0, s, ca);
+	if (mid_event && !resume && mid_late == 2) WC_HIP(hipEventRecord(mid_event, s));
 	hipLaunchKernelGGL(hv_contour_kernel<1>, dim3(96, n_utt), dim3(64), 0, s, ca);  // a 10 s utterance has 20-40 sections
+	if (mid_event && !resume && mid_late == 3) WC_HIP(hipEventRecord(mid_event, s));
 	hipLaunchKernelGGL(hv_contour_kernel<2>, dim3(n_utt), dim3(64), 0, s, ca);
 	SmArgs sa;
 	sa.utts = du; sa.fixed = h->fixed.as<double>(); sa.f0_1ms = h->f0_1ms.as<double>(); sa.sec = h->sec.as<int>();
