@@ -68,6 +68,10 @@ int wc_synchronize(void);
 const char *wc_build_hash(void);
 uint64_t wc_rng_get_position(void);
 void wc_rng_set_position(uint64_t position);
+/* The host-pointer batch calls (wc_*_compute_batch) keep their page-locked staging and its device twin on the device between
+ * calls (grown on demand; ~1 GB each per row matrix of a 64 x 10 s batch at 48 kHz).  They are released when the last stage
+ * handle on the device is destroyed, and by this call (on the calling thread's device); the next batch call allocates again. */
+int wc_release_scratch(void);
 
 /* ---- size helpers (pure host arithmetic) ------------------------------------------------------- */
 /* Harvest::getSamples, include/harvest.hpp:41-43, src/harvest.cpp:173-181 */
@@ -133,6 +137,7 @@ int wc_d4c_compute_batch(wc_d4c *d, int n_utt, const double *const *x, const int
 /* ---- Synthesis: include/synthesis.hpp:29-51 ------------------------------------------------------ */
 wc_synthesis *wc_synthesis_create(int fs, int fft_size, double frame_period_ms);
 void wc_synthesis_destroy(wc_synthesis *s);
+int wc_synthesis_get_fft_size(const wc_synthesis *s);
 /* Synthesis::compute, include/synthesis.hpp:45-49, src/synthesis.cpp:77-177 */
 int wc_synthesis_compute(wc_synthesis *s, const double *f0, int f0_length,
                          const double *const *spectrogram, const double *const *aperiodicity,
@@ -140,7 +145,8 @@ int wc_synthesis_compute(wc_synthesis *s, const double *f0, int f0_length,
 int wc_synthesis_compute_device(wc_synthesis *s, int n_utt, const double *d_f0, const int *f0_length,
                                 const double *d_sp, const double *d_ap, const int *out_length,
                                 double *d_out, uint64_t *rng_pos);
-/* host arrays of n_utt utterances in one call; fft_size: that of the handle (the row length is fft_size / 2 + 1) */
+/* host arrays of n_utt utterances in one call; fft_size: that of the handle (the row length is fft_size / 2 + 1; another value
+ * is refused with WC_ERR_INVALID -- the reference's Synthesis holds one fft_size per object too, include/synthesis.hpp:31-33) */
 int wc_synthesis_compute_batch(wc_synthesis *s, int n_utt, const double *const *f0, const int *f0_length, int fft_size,
                                const double *const *const *spectrogram, const double *const *const *aperiodicity,
                                const int *out_length, double *const *out, uint64_t *rng_pos);

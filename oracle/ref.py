@@ -212,6 +212,21 @@ class Ref:
         return dict(tpos=tpos, f0=f0, sp=sp, ap=ap, y=y)
 
 
+def _pipeline_timed(ref, xs, fs, harvest_floor=71.0, frame_period=5.0):
+    """bench.py's cpu_baseline leg: the demo-order pipeline over the utterances `xs` one after the other in THIS process; returns
+    (frames, wall-clock stamp before the first call, stamp after the last) -- stamps of time.time(), comparable across the
+    processes of one host, taken inside the process so that interpreter start-up and result pickling stay outside"""
+    import time
+    frames = 0
+    t0 = time.time()
+    for x in xs:
+        frames += len(ref.pipeline(x, fs, harvest_floor=harvest_floor, frame_period=frame_period)["f0"])
+    return frames, t0, time.time()
+
+
+Ref.pipeline_timed = _pipeline_timed
+
+
 def taps_available():
     return os.path.exists(os.path.join(_HERE, "_ref", "libworld_ref_taps.so"))
 

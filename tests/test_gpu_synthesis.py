@@ -180,3 +180,55 @@ def test_synthesis_wavefront_kernels_against_the_block_kernel_and_beyond_the_row
     wca.rng_set_position(4242)
     again = wca.Synthesis(fs, n, fp).compute(r["f0"], r["sp"], r["ap"])
     assert np.array_equal(again, ys[0])
+
+
+def test_stage_call_in_two_halves_equals_one_piece_and_retries_only_the_half_that_overflowed(wca, port, monkeypatch):
+    """a batch of 16 utterances and more runs as two halves with a twin handle (wc_synthesis.hip: syn_run_device): the same bits as
+    one piece (WC_SYN_HALVES=0), the noise-stream positions in and out per utterance, and -- F0 beyond the 960 Hz rate bound in the
+    second half only -- a hard-bound retry of that half alone that must leave the first half's waveforms and end positions as
+    they were (the retry read the positions the first attempt had already advanced)."""
+    fs, n = 16000, 1024
+    from oracle.gen_golden import synth_params
+    cases = [synth_params(fs, n, 24 + 3 * (i % 5), 700 + i) for i in range(18)]
+    start = [1000 * i + 7 for i in range(18)]
+    s = wca.Synthesis(fs, n, 5.0)
+    arg = lambda cs: ([c[0] for c in cs], [c[1] for c in cs], [c[2] for c in cs])
+    ys, pos = s.compute_batch(*arg(cases), rng_pos=start)
+    monkeypatch.setenv("WC_SYN_HALVES", "0")
+    ys1, pos1 = wca.Synthesis(fs, n, 5.0).compute_batch(*arg(cases), rng_pos=start)
+    monkeypatch.delenv("WC_SYN_HALVES")
+    assert pos == pos1
+    for a, b in zip(ys, ys1):
+        assert np.array_equal(a, b)
+    for u in (0, 8, 9, 17):
+        f0, sp, ap = cases[u]
+        port.rng_seek(start[u])
+        ref = port.synthesis(f0, sp, ap, fs, 5.0)
+        assert port.rng_position() == pos[u]
+        assert np.abs(ys[u] - ref).max() < Y_ABS
+    # the second half overflows its rate-bounded pulse buffers, the first half does not
+    hot = [(np.where(f0 > 0, 1500.0, 0.0), sp, ap) if u in (12, 15) else (f0, sp, ap) for u, (f0, sp, ap) in enumerate(cases)]
+    ys2, pos2 = s.compute_batch(*arg(hot), rng_pos=start)
+    for u in range(18):
+        if u not in (12, 15):
+            assert np.array_equal(ys2[u], ys[u]) and pos2[u] == pos[u]
+        f0, sp, ap = hot[u]
+        one, p1 = wca.Synthesis(fs, n, 5.0).compute_batch([f0], [sp], [ap], rng_pos=[start[u]])
+        assert p1[0] == pos2[u]
+        assert np.array_equal(one[0], ys2[u])
+    port.rng_seek(start[12])
+    assert np.abs(ys2[12] - port.synthesis(*hot[12], fs, 5.0)).max() < Y_ABS
+    assert port.rng_position() == pos2[12]
+    port.rng_reset()
+    # a row length other than the handle's is refused, in the mirror and behind it
+    with pytest.raises(ValueError):
+        s.compute_batch([cases[0][0]], [cases[0][1][:, :-1]], [cases[0][2][:, :-1]])
+    import ctypes as C
+    assert wca.lib().wc_synthesis_get_fft_size(s._h) == n
+    z = (C.c_void_p * 1)()
+    one = (C.c_int * 1)(2)
+    assert wca.lib().wc_synthesis_compute_batch(s._h, 1, z, one, 2 * n, z, z, one, z, None) == -1
+    assert "fft_size" in wca.last_error()
+    assert wca.lib().wc_release_scratch() == 0
+    ys3 = s.compute_batch(*arg(cases[:3]), rng_pos=start[:3])[0]  # (the staging comes back on the next call)
+    assert all(np.array_equal(a, b) for a, b in zip(ys3, ys[:3]))

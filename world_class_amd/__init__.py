@@ -32,6 +32,7 @@ _SIGNATURES = {
     "wc_synchronize": (C.c_int, []),
     "wc_rng_get_position": (C.c_uint64, []),
     "wc_rng_set_position": (None, [C.c_uint64]),
+    "wc_release_scratch": (C.c_int, []),
     "wc_get_samples": (C.c_int, [C.c_int, C.c_int, C.c_double]),
     "wc_cheaptrick_fft_size": (C.c_int, [C.c_int, C.c_double]),
     "wc_cheaptrick_f0_floor": (C.c_double, [C.c_int, C.c_int]),
@@ -56,6 +57,7 @@ _SIGNATURES = {
     "wc_d4c_compute_device": (C.c_int, [_vp, C.c_int, _vp, _ip, _vp, _vp, _ip, C.c_int, _vp, _u64p]),
     "wc_synthesis_create": (_vp, [C.c_int, C.c_int, C.c_double]),
     "wc_synthesis_destroy": (None, [_vp]),
+    "wc_synthesis_get_fft_size": (C.c_int, [_vp]),
     "wc_synthesis_compute": (C.c_int, [_vp, _dp, C.c_int, C.POINTER(_dp), C.POINTER(_dp), C.c_int, _dp]),
     "wc_synthesis_compute_device": (C.c_int, [_vp, C.c_int, _vp, _ip, _vp, _vp, _ip, _vp, _u64p]),
     "wc_pipeline_create": (_vp, [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_double]),
@@ -258,6 +260,7 @@ class CheapTrick:
     def compute_batch(self, xs, tposs, f0s, rng_pos=None):
         """host lists in, host list of spectrograms out: wc_cheaptrick_compute_batch (one trip over PCIe each way, one batch)"""
         xs, ts, fs_ = [_c(v) for v in xs], [_c(v) for v in tposs], [_c(v) for v in f0s]
+        _check_batch_shapes("CheapTrick.compute_batch", xs, ts, fs_)
         out = [np.empty((len(f), self.bins)) for f in fs_]
         tabs, keep = _row_tables(out)
         arr, arg = _rng_arg(rng_pos, len(xs))
@@ -272,6 +275,15 @@ class CheapTrick:
                 self._h = None
         except Exception:
             pass
+
+
+def _check_batch_shapes(who, xs, ts, fs_):
+    """the per-utterance lists of a host batch call must agree: the C side strides by the lengths it is given"""
+    if not (len(xs) == len(ts) == len(fs_)) or len(xs) == 0:
+        raise ValueError(f"{who}: xs, tposs and f0s must be non-empty lists of the same length")
+    for u, (x, t, f) in enumerate(zip(xs, ts, fs_)):
+        if x.ndim != 1 or t.ndim != 1 or f.ndim != 1 or len(t) != len(f):
+            raise ValueError(f"{who}: utterance {u}: x, temporal positions and f0 must be vectors, the last two of one length")
 
 
 class D4C:
@@ -298,6 +310,7 @@ class D4C:
         """host lists in, host list of aperiodicity matrices out: wc_d4c_compute_batch"""
         bins = fft_size // 2 + 1
         xs, ts, fs_ = [_c(v) for v in xs], [_c(v) for v in tposs], [_c(v) for v in f0s]
+        _check_batch_shapes("D4C.compute_batch", xs, ts, fs_)
         out = [np.empty((len(f), bins)) for f in fs_]
         tabs, keep = _row_tables(out)
         arr, arg = _rng_arg(rng_pos, len(xs))

@@ -44,6 +44,11 @@ class Synthesis:
         if out_lengths is None:
             out_lengths = [self.out_length(n) for n in fl]
         fs_, sps, aps = [_c(v) for v in f0s], [_c(v) for v in sps], [_c(v) for v in aps]
+        if not (len(fs_) == len(sps) == len(aps) == len(out_lengths)) or len(fs_) == 0:
+            raise ValueError("Synthesis.compute_batch: f0s, sps, aps (and out_lengths) must be non-empty lists of the same length")
+        for u, (f, sp, ap) in enumerate(zip(fs_, sps, aps)):
+            if sp.shape != (len(f), self.bins) or ap.shape != (len(f), self.bins):
+                raise ValueError(f"Synthesis.compute_batch: utterance {u}: spectrogram and aperiodicity must be ({len(f)}, {self.bins})")
         ys = [np.zeros(n) for n in out_lengths]
         stab, keep1 = _row_tables(sps)
         atab, keep2 = _row_tables(aps)

@@ -15,18 +15,12 @@ using namespace wc;
 
 namespace {
 
-struct Staging {
-	HostBuf h;
-	DevBuf d;
-};
-// per-thread staging, grown on demand and kept: steady-state calls allocate nothing
+// the device's staging (wc_internal.hpp: Device::batch), named; steady-state calls allocate nothing
 struct BatchScratch {
-	Staging x, t, f, a, b, y;
+	Staging &x, &t, &f, &a, &b, &y;
 };
-BatchScratch &scratch() {
-	// (never destroyed: a thread that ends after the HIP runtime has shut down must not free device memory)
-	static thread_local BatchScratch *s = new BatchScratch();
-	return *s;
+BatchScratch scratch(Device *dev) {
+	return BatchScratch{dev->batch[0], dev->batch[1], dev->batch[2], dev->batch[3], dev->batch[4], dev->batch[5]};
 }
 
 // host arrays -> one packed device array (through page-locked staging)
@@ -118,7 +112,7 @@ int wc_harvest_compute_batch(wc_harvest *h, int n_utt, const double *const *x, c
 	if (!dev) return WC_ERR_DEVICE;
 	DeviceLock lock(dev);
 	hipStream_t s = dev->active();
-	BatchScratch &sc = scratch();
+	BatchScratch sc = scratch(dev);
 	std::vector<int> fl(n_utt);
 	long long frames = 0, samples = 0;
 	for (int u = 0; u < n_utt; ++u) {
@@ -144,7 +138,7 @@ int wc_cheaptrick_compute_batch(wc_cheaptrick *c, int n_utt, const double *const
 	if (!dev) return WC_ERR_DEVICE;
 	DeviceLock lock(dev);
 	hipStream_t s = dev->active();
-	BatchScratch &sc = scratch();
+	BatchScratch sc = scratch(dev);
 	const int bins = wc_cheaptrick_get_fft_size(c) / 2 + 1;
 	long long samples = 0, frames = 0, frames2 = 0;
 	int rc;
@@ -167,7 +161,7 @@ int wc_d4c_compute_batch(wc_d4c *d, int n_utt, const double *const *x, const int
 	if (!dev) return WC_ERR_DEVICE;
 	DeviceLock lock(dev);
 	hipStream_t s = dev->active();
-	BatchScratch &sc = scratch();
+	BatchScratch sc = scratch(dev);
 	const int bins = fft_size / 2 + 1;
 	long long samples = 0, frames = 0, frames2 = 0;
 	int rc;
@@ -186,12 +180,13 @@ int wc_synthesis_compute_batch(wc_synthesis *sy, int n_utt, const double *const 
 							   double *const *out, uint64_t *rng_pos) {
 	if (!sy || n_utt <= 0 || !f0 || !f0_length || !spectrogram || !aperiodicity || !out_length || !out)
 		return fail(WC_ERR_INVALID, "synthesis batch: null argument");
-	if (fft_size < 2 || (fft_size & 1)) return fail(WC_ERR_INVALID, "synthesis batch: fft_size must be even and positive");
+	// (the rows are packed with the caller's fft_size and read by kernels that stride with the handle's: they must agree)
+	if (fft_size != wc_synthesis_get_fft_size(sy)) return fail(WC_ERR_INVALID, "synthesis batch: fft_size differs from the handle's");
 	Device *dev = current_device();
 	if (!dev) return WC_ERR_DEVICE;
 	DeviceLock lock(dev);
 	hipStream_t s = dev->active();
-	BatchScratch &sc = scratch();
+	BatchScratch sc = scratch(dev);
 	const int bins = fft_size / 2 + 1;
 	long long frames = 0, total_out = 0;
 	int rc;

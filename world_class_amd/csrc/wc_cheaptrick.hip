@@ -1116,11 +1116,13 @@ wc_cheaptrick *wc_cheaptrick_create(int fs, double q1, double f0_floor, int fft_
 		delete c;
 		return nullptr;
 	}
+	dev->handle_born();
 	return c;
 }
 void wc_cheaptrick_destroy(wc_cheaptrick *c) {
 	if (!c) return;
 	c->dev->quiesce();
+	c->dev->handle_gone();
 	c->utts.release(); c->cnt.release(); c->uidx.release(); c->rare.release(); c->off.release(); c->endpos.release();
 	c->d_x.release(); c->d_tpos.release(); c->d_f0.release(); c->d_sp.release();
 	c->h_stage.release();

@@ -251,6 +251,23 @@ void Device::quiesce() const {
 	if (cur >= 0 && cur != id) (void)hipSetDevice(cur);
 }
 
+void Device::release_batch_staging() {
+	std::lock_guard<std::recursive_mutex> lk(mu);
+	quiesce();  // (a copy out of the staging may still be in flight on a caller's stream)
+	for (Staging &st : batch) { st.h.release(); st.d.release(); }
+}
+void Device::handle_born() {
+	std::lock_guard<std::recursive_mutex> lk(mu);
+	++live_handles;
+}
+void Device::handle_gone() {
+	std::lock_guard<std::recursive_mutex> lk(mu);
+	if (--live_handles <= 0) {
+		live_handles = 0;
+		release_batch_staging();
+	}
+}
+
 Device *current_device() {
 	std::lock_guard<std::mutex> lk(g_mu);
 	int n = 0;
@@ -361,6 +378,14 @@ int wc_synchronize(void) {
 	Device *d = current_device();
 	if (!d) return WC_ERR_DEVICE;
 	WC_HIP(hipStreamSynchronize(d->active()));
+	return WC_OK;
+}
+// frees the staging the host-pointer batch calls keep on the calling thread's device (page-locked host memory and its device
+// twin; they come back on the next batch call)
+int wc_release_scratch(void) {
+	Device *d = current_device();
+	if (!d) return WC_ERR_DEVICE;
+	d->release_batch_staging();
 	return WC_OK;
 }
 uint64_t wc_rng_get_position(void) { return g_rng_position.load(); }

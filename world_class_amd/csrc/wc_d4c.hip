@@ -2046,11 +2046,13 @@ wc_d4c *wc_d4c_create(int fs, double threshold) {
 		delete d;
 		return nullptr;
 	}
+	dev->handle_born();
 	return d;
 }
 void wc_d4c_destroy(wc_d4c *d) {
 	if (!d) return;
 	d->dev->quiesce();
+	d->dev->handle_gone();
 	d->nuttall.release(); d->utts.release(); d->cnt.release(); d->uidx.release(); d->long_list.release(); d->rare_list.release(); d->off.release(); d->endpos.release(); d->endpos2.release();
 	d->ap0.release(); d->sgd.release(); d->coarse.release(); d->d_x.release(); d->d_tpos.release(); d->d_f0.release(); d->d_ap.release(); d->h_stage.release(); d->h_rows.release();
 	delete d;

@@ -2978,6 +2978,7 @@ wc_harvest *wc_harvest_create(int fs, double f0_floor, double f0_ceil, double fr
 		delete h;
 		return nullptr;
 	}
+	dev->handle_born();
 	return h;
 }
 
@@ -2988,6 +2989,7 @@ int wc_harvest_get_samples(const wc_harvest *h, int x_length) {
 void wc_harvest_destroy(wc_harvest *h) {
 	if (!h) return;
 	h->dev->quiesce();
+	h->dev->handle_gone();
 	for (DevBuf *b : {&h->d_cos_table, &h->d_sd_rot, &h->d_sd_p0, &h->d_slot_off, &h->d_slot_cap, &h->slots, &h->slot_count, &h->d_rot, &h->d_taps, &h->d_tap_off, &h->d_half_len, &h->d_band_f0, &h->d_ev_band_off, &h->d_ev_cap, &h->utts, &h->dec, &h->y,
 					  &h->events, &h->ev_count, &h->overflow, &h->tile_run, &h->raw, &h->cand0, &h->cand1, &h->score1, &h->cand2, &h->score2, &h->base,
 					  &h->s1, &h->s2, &h->s3, &h->fixed, &h->f0_1ms, &h->sec, &h->chan, &h->smooth, &h->ibuf, &h->d_x, &h->d_tpos, &h->d_f0})

@@ -43,6 +43,12 @@ struct HostBuf {
 	template <class T> T *as() const { return static_cast<T *>(p); }
 };
 
+// host arrays <-> one packed device array: page-locked staging and its device twin (wc_batch.hip)
+struct Staging {
+	HostBuf h;
+	DevBuf d;
+};
+
 // Per-device shared state.
 struct Device {
 	int id = 0;
@@ -67,6 +73,15 @@ struct Device {
 	std::map<std::string, std::pair<hipEvent_t, hipEvent_t>> events;
 	int time_begin(const char *name, hipStream_t s = nullptr);  // nullptr = active()
 	int time_end(const char *name, hipStream_t s = nullptr);
+	// Staging of the host-pointer batch calls (wc_*_compute_batch): samples, time axis, contour, two row matrices, waveform.
+	// Owned by the device, used under its call lock by whichever host thread calls, grown on demand and kept between calls
+	// (a 64 x 10 s batch at 48 kHz holds ~1 GB of device and ~1 GB of page-locked memory per row matrix).  Released when the
+	// last stage handle on the device is destroyed and by wc_release_scratch() -- never tied to a host thread's lifetime.
+	Staging batch[6];
+	int live_handles = 0;  // stage handles alive on this device (under mu)
+	void handle_born();
+	void handle_gone();  // the last one takes the batch staging with it
+	void release_batch_staging();
 };
 
 Device *current_device();  // creates the state on first use; nullptr + error on failure

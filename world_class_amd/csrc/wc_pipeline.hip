@@ -36,7 +36,7 @@
 using namespace wc;
 
 // one independent chain (mode "groups"): its own stage handles and two streams
-constexpr int kMaxGroups = 6;  // two for a device-resident batch; up to six (of growing size) when the rows leave for the host
+constexpr int kMaxGroups = 8;  // two for a device-resident batch; up to eight (of growing size) when the rows leave for the host
 struct PipeGroup {
 	wc_harvest *hv = nullptr;
 	wc_cheaptrick *ct = nullptr;
@@ -340,6 +340,16 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 			if (NG == 2) aux[g] = (eager && g == 0 && p->grp[0].aux_hi) ? p->grp[0].aux_hi : p->grp[g].aux;
 			else aux[g] = p->grp[0].aux_hi ? p->grp[0].aux_hi : p->grp[0].aux;
 		}
+		// Round 5: in a run of more than two groups the Synthesis of a group (time base, pulses) has a stream of its own -- the two
+		// plain aux streams, which such a run does not use otherwise, in turn.  On the group's main stream it stood between the
+		// Harvest of group g and that of group g + 2, which then could not start before group g's D4C was through and its pulses
+		// summed: the contours of the later groups -- what the rows on the wire wait for -- came late.  WC_PIPELINE_SYN_STREAMS=0: as before.
+		const bool syn_own = NG > 2 && p->grp[0].aux_hi && !(getenv("WC_PIPELINE_SYN_STREAMS") && getenv("WC_PIPELINE_SYN_STREAMS")[0] == '0');
+		hipStream_t synS[kMaxGroups];
+		for (int g = 0; g < NG; ++g) synS[g] = syn_own ? ((g & 1) ? p->s2 : p->s1) : mainS[g];
+		// WC_PIPELINE_CHAIN_MIN=n: a group's Harvest is not held behind that of a predecessor with fewer than n utterances (a group
+		// of two or three fills a few per cent of the chip: holding the next one back behind it is latency for nothing)
+		const int chain_min = getenv("WC_PIPELINE_CHAIN_MIN") ? atoi(getenv("WC_PIPELINE_CHAIN_MIN")) : 4;
 		bool full[kMaxGroups][2] = {};
 		for (int attempt = 0; attempt < 3; ++attempt) {
 			const int bins_ = p->fft_size / 2 + 1;
@@ -388,7 +398,7 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 				dev->time_tag = g;
 				if (g >= 1 && sink && sink->x_ev[g]) WC_HIP(hipStreamWaitEvent(mainS[g], sink->x_ev[g], 0));
 				return hv_enqueue(G.hv, mainS[g], sl[g].nu, d_x + sl[g].xo, x_length + sl[g].u0, d_tpos + sl[g].fo, d_f0 + sl[g].fo,
-								  full[g][0], G.e_mid, (g >= 1 && chain_harvest) ? p->grp[g - 1].e_mid : nullptr, (g == 0 && tail_late) ? 1 : 3,
+								  full[g][0], G.e_mid, (g >= 1 && chain_harvest && sl[g - 1].nu >= chain_min) ? p->grp[g - 1].e_mid : nullptr, (g == 0 && tail_late) ? 1 : 3,
 								  (g == 1 && tail_late) ? p->e_bp : nullptr, nullptr);
 			};
 			// (two groups: both Harvest chains first -- the first group's CheapTrick / D4C may wait for an event of the second's.
@@ -464,13 +474,14 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 					if (p->s_copy2) WC_HIP(hipEventRecord(p->e_copy2[g], p->s_copy2));
 					WC_HIP(hipEventRecord(p->e_copy[g], p->s_copy));
 				}
-				if ((rc = syn_prepare(G.sy, mainS[g], nu, gf, f_len.data() + u0, y_len.data() + u0, gy, nullptr, full[g][1]))) return rc;
-				WC_HIP(hipStreamWaitEvent(mainS[g], G.e_aux, 0));
-				if ((rc = syn_pulses(G.sy, mainS[g], gf, gsp, gap, gy, d4c_end_positions(G.d4)))) return rc;
-				if (gpu_marks) WC_HIP(hipEventRecord(tm[g][3], mainS[g]));
+				if (syn_own) WC_HIP(hipStreamWaitEvent(synS[g], G.e0, 0));  // (the contour; e0 stands behind ct_prepare on the main stream)
+				if ((rc = syn_prepare(G.sy, synS[g], nu, gf, f_len.data() + u0, y_len.data() + u0, gy, nullptr, full[g][1]))) return rc;
+				WC_HIP(hipStreamWaitEvent(synS[g], G.e_aux, 0));
+				if ((rc = syn_pulses(G.sy, synS[g], gf, gsp, gap, gy, d4c_end_positions(G.d4)))) return rc;
+				if (gpu_marks) WC_HIP(hipEventRecord(tm[g][3], synS[g]));
 				if (sink && sink->y) {
 					// (every attempt: a re-run after an overflow rewrites the waveform, and its copies land behind the first ones)
-					WC_HIP(hipEventRecord(p->e_y[g], mainS[g]));
+					WC_HIP(hipEventRecord(p->e_y[g], synS[g]));
 					WC_HIP(hipStreamWaitEvent(p->s_copy, p->e_y[g], 0));
 					if (p->s_copy2) WC_HIP(hipStreamWaitEvent(p->s_copy2, p->e_y[g], 0));
 					long long yo2 = 0;
@@ -512,7 +523,7 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 				PipeGroup &G = p->grp[g];
 				const int u0 = ub[g];
 				bool o1 = false, o2 = false;
-				if ((rc = syn_finish(G.sy, mainS[g], rng_pos ? rng_pos + u0 : nullptr, &o2))) return rc;
+				if ((rc = syn_finish(G.sy, synS[g], rng_pos ? rng_pos + u0 : nullptr, &o2))) return rc;
 				pmark(g == 0 ? "group 0 finished" : g + 1 < NG ? "a middle group finished" : "the last group finished");
 				if ((rc = hv_overflowed(G.hv, mainS[g], &o1))) return rc;
 				full[g][0] = full[g][0] || o1;
@@ -656,6 +667,8 @@ int wc_pipeline_run_batch_host(wc_pipeline *p, int n_utt, const void *const *x, 
 				}
 			} else if (const char *env1 = getenv("WC_PIPELINE_HOST_SPLIT")) {
 				pct.push_back(atoi(env1));
+			} else if (n_utt >= 32) {
+				pct = {5, 8, 12, 18, 25};  // round 5 (with Synthesis on streams of its own): 3 / 5 / 8 / 11 / 16 / 21 of 64 utterances
 			} else if (n_utt >= 20) {
 				pct = {10, 13, 18, 25};
 			} else if (n_utt >= 8) {

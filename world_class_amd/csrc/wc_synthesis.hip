@@ -2229,7 +2229,7 @@ static int syn_run_device(wc_synthesis *sy, int n_utt, const double *d_f0, const
 	// A large batch runs as two halves with a twin handle on a second stream (round 4): the second half's time base -- one
 	// wavefront or workgroup per utterance, ~1 ms of latency whatever the batch -- runs beside the first half's pulses instead of
 	// in front of everything (BASELINE config 4, 128 utterances: 10.4 -> 9.7 ms).  WC_SYN_HALVES=0: one piece.
-	static const bool halves_on = !(getenv("WC_SYN_HALVES") && getenv("WC_SYN_HALVES")[0] == '0');
+	const bool halves_on = !(getenv("WC_SYN_HALVES") && getenv("WC_SYN_HALVES")[0] == '0');  // (read per call: the tests switch it)
 	if (halves_on && n_utt >= 16 && !sy->is_twin) {
 		if (!sy->twin) {
 			sy->twin = wc_synthesis_create(sy->fs, sy->fft_size, sy->frame_period * 1000.0);
@@ -2244,25 +2244,42 @@ static int syn_run_device(wc_synthesis *sy, int n_utt, const double *d_f0, const
 		for (int u = 0; u < nA; ++u) { foA += f0_length[u]; yoA += out_length[u] > 0 ? out_length[u] : 0; }
 		wc_synthesis *syB = sy->twin;
 		hipStream_t sB = sy->s_twin;
-		bool fullA = false, fullB = false;
+		// The start positions are read from a private copy and the end positions collected in one: rng_pos is also the output, a
+		// half that overflowed is run again from the SAME start positions, and the caller's array is written once, when both halves
+		// are through (a half's end positions written early would be the other attempt's start positions: ADVICE round 4).
+		std::vector<uint64_t> rng_in, rng_end;
+		if (rng_pos) { rng_in.assign(rng_pos, rng_pos + n_utt); rng_end = rng_in; }
+		const uint64_t *startA = rng_pos ? rng_in.data() : nullptr, *startB = rng_pos ? rng_in.data() + nA : nullptr;
+		uint64_t *endA = rng_pos ? rng_end.data() : nullptr, *endB = rng_pos ? rng_end.data() + nA : nullptr;
+		// (an error between the enqueues leaves work on the twin's stream that still writes into the caller's d_out: nothing of
+		// this call may be moving when the caller gets its buffers back)
+		auto bail = [&](int code) { (void)hipStreamSynchronize(sB); (void)hipStreamSynchronize(s); dev->time_tag = -1; return code; };
+		bool fullA = false, fullB = false, runA = true, runB = true;
 		for (int attempt = 0; attempt < 2; ++attempt) {
 			WC_HIP(hipEventRecord(sy->e_twin, s));  // the twin's stream starts behind whatever precedes this call on the caller's
 			WC_HIP(hipStreamWaitEvent(sB, sy->e_twin, 0));
 			dev->time_tag = 0;  // (wc_last_kernel_ms sums the two halves' launches, as with the pipeline's groups)
-			if ((rc = syn_prepare(sy, s, nA, d_f0, f0_length, out_length, d_out, rng_pos, fullA))) return rc;
+			if (runA && (rc = syn_prepare(sy, s, nA, d_f0, f0_length, out_length, d_out, startA, fullA))) return bail(rc);
 			dev->time_tag = 1;
-			if ((rc = syn_prepare(syB, sB, nB, d_f0 + foA, f0_length + nA, out_length + nA, d_out + yoA, rng_pos ? rng_pos + nA : nullptr, fullB))) return rc;
+			if (runB && (rc = syn_prepare(syB, sB, nB, d_f0 + foA, f0_length + nA, out_length + nA, d_out + yoA, startB, fullB))) return bail(rc);
 			dev->time_tag = 0;
-			if ((rc = syn_pulses(sy, s, d_f0, d_sp, d_ap, d_out, nullptr))) return rc;
+			if (runA && (rc = syn_pulses(sy, s, d_f0, d_sp, d_ap, d_out, nullptr))) return bail(rc);
 			dev->time_tag = 1;
 			WC_HIP(hipEventRecord(sy->e_twin, s));  // the two halves' pulses one after the other: full-grid kernels gain nothing side by side
 			WC_HIP(hipStreamWaitEvent(sB, sy->e_twin, 0));
-			if ((rc = syn_pulses(syB, sB, d_f0 + foA, d_sp + foA * bins, d_ap + foA * bins, d_out + yoA, nullptr))) return rc;
+			if (runB && (rc = syn_pulses(syB, sB, d_f0 + foA, d_sp + foA * bins, d_ap + foA * bins, d_out + yoA, nullptr))) return bail(rc);
 			dev->time_tag = -1;
 			bool oA = false, oB = false;
-			if ((rc = syn_finish(sy, s, rng_pos, &oA))) return rc;
-			if ((rc = syn_finish(syB, sB, rng_pos ? rng_pos + nA : nullptr, &oB))) return rc;  // (synchronises the twin's stream)
-			if (!oA && !oB) return WC_OK;
+			if (runA && (rc = syn_finish(sy, s, endA, &oA))) return bail(rc);
+			if (runB && (rc = syn_finish(syB, sB, endB, &oB))) return bail(rc);  // (synchronises the twin's stream)
+			if (!runA) WC_HIP(hipStreamSynchronize(s));
+			if (!runB) WC_HIP(hipStreamSynchronize(sB));
+			if (!oA && !oB) {
+				if (rng_pos) std::copy(rng_end.begin(), rng_end.end(), rng_pos);
+				return WC_OK;
+			}
+			// only the half that overflowed runs again (with the hard bound); the other half's samples and end positions stand
+			runA = oA; runB = oB;
 			fullA = fullA || oA;
 			fullB = fullB || oB;
 		}
@@ -2321,11 +2338,13 @@ wc_synthesis *wc_synthesis_create(int fs, int fft_size, double frame_period_ms) 
 		delete s;
 		return nullptr;
 	}
+	dev->handle_born();
 	return s;
 }
 void wc_synthesis_destroy(wc_synthesis *s) {
 	if (!s) return;
 	s->dev->quiesce();
+	s->dev->handle_gone();
 	if (s->twin) wc_synthesis_destroy(s->twin);
 	if (s->s_twin) (void)hipStreamDestroy(s->s_twin);
 	if (s->e_twin) (void)hipEventDestroy(s->e_twin);
@@ -2333,6 +2352,8 @@ void wc_synthesis_destroy(wc_synthesis *s) {
 	s->d_f0.release(); s->d_sp.release(); s->d_ap.release(); s->d_out.release(); s->h_stage.release(); s->h_rows.release();
 	delete s;
 }
+
+int wc_synthesis_get_fft_size(const wc_synthesis *s) { return s ? s->fft_size : WC_ERR_INVALID; }
 
 int wc_synthesis_compute_device(wc_synthesis *s, int n_utt, const double *d_f0, const int *f0_length, const double *d_sp,
 								const double *d_ap, const int *out_length, double *d_out, uint64_t *rng_pos) {
