@@ -23,4 +23,8 @@ cp $G/${T}_mb64.txt $P/${T}_stage_by_stage_64utt.txt
 cp $G/${T}_mb16.txt $P/${T}_stage_by_stage_16utt.txt
 cp $G/${T}_mb1.txt $P/${T}_stage_by_stage_1utt.txt
 cp $G/${T}_latency.txt $P/${T}_latency_probe.txt
+cp $G/${T}_issue_rates.txt $P/${T}_issue_rates.txt
+cp $G/${T}_issue_rates.json $P/${T}_issue_rates.json
+cp $G/${T}_issue_rates.json $P/issue_rates.json
+grep -v "^run\|amdgpu.ids" $G/${T}_host_frontend_timing.txt | tail -40 > $P/${T}_host_frontend_timing.txt
 ls -la $P | grep $T

@@ -1,8 +1,8 @@
 // What does a vector instruction of each class cost on this MI355X?  (development aid; the numbers behind bench.py's
 // `issue_cycles_frac` and DESIGN.md section 3; successor of tools/fp64_issue_rate.hip, which timed one FP64 FMA stream)
 //   hipcc --offload-arch=gfx950 -O3 -o /tmp/issue_rate tools/issue_rate.hip && /tmp/issue_rate [out.json]
-// Every lane runs 8 independent chains of ONE instruction (inline asm, so the class is what is measured), 4096 x 8 instructions
-// per timed stretch, at 1, 2, 4 and 8 wavefronts per SIMD (256-thread workgroups, 256 x W of them).  Lane 0 of every wavefront
+// Every lane runs 8 independent chains of ONE instruction (inline asm, so the class is what is measured), 16384 x 8 instructions
+// per timed stretch, at 1, 2, 3, 4 and 8 wavefronts per SIMD (256-thread workgroups, 256 x W of them).  Lane 0 of every wavefront
 // reads the shader clock (s_memtime) and the 100 MHz wall clock around the stretch:
 //   cycles per instruction and SIMD = shader cycles of the stretch / (instructions of one wavefront x wavefronts on its SIMD)
 //   clock = shader cycles / wall time  (the chip clocks to its power budget: an FP64 stream runs well below 2.4 GHz)
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void burn(double *out, long long *clk, int ite
 typedef void (*KernelFn)(double *, long long *, int);
 
 int main(int argc, char **argv) {
-	const int threads = 256, iters = 4096;
+	const int threads = 256, iters = 16384;  // (1 - 5 ms per launch at 8 wavefronts per SIMD: the length of the product's kernels)
 	const int max_blocks = 256 * 8;
 	double *out;
 	long long *clk;
@@ -97,16 +97,26 @@ int main(int argc, char **argv) {
 	KernelFn fn[N_MODES] = {burn<FMA64>, burn<ADD64>, burn<MUL64>, burn<FMA32>, burn<ADD_U32>, burn<LSHL_ADD_U64>, burn<CNDMASK>, burn<MOV_B32>, burn<MOV_B64>,
 							burn<CVT_F64_I32>, burn<CVT_I32_F64>, burn<CMP_F64>, burn<MIX_FMA64_ADDU32>, burn<MIX_FMA64_CNDMASK>, burn<MIX_FMA64_MOV64>};
 	std::string json = "{\n";
-	std::printf("%-32s %5s  %9s %9s %9s %9s   clock at 8 waves\n", "stream", "", "1 w/SIMD", "2", "4", "8");
+	std::printf("%-32s %5s  %9s %9s %9s %9s %9s   clock at 8 waves\n", "stream", "", "1 w/SIMD", "2", "3", "4", "8");
+	const int Ws[5] = {1, 2, 3, 4, 8};
 	for (int md = 0; md < N_MODES; ++md) {
-		double cpi[4] = {0, 0, 0, 0}, mhz[4] = {0, 0, 0, 0};
-		for (int wi = 0; wi < 4; ++wi) {
-			const int W = 1 << wi, blocks = 256 * W, waves = blocks * 4;
+		double cpi[5] = {0, 0, 0, 0, 0}, mhz[5] = {0, 0, 0, 0, 0}, nspi[5] = {0, 0, 0, 0, 0};
+		hipEvent_t e0, e1;
+		CK(hipEventCreate(&e0));
+		CK(hipEventCreate(&e1));
+		for (int wi = 0; wi < 5; ++wi) {
+			const int W = Ws[wi], blocks = 256 * W, waves = blocks * 4;
 			std::vector<long long> h(2 * (size_t)waves);
+			float ms = 0;
 			for (int rep = 0; rep < 2; ++rep) {  // (the second run is the one that counts: clocks have settled)
+				CK(hipEventRecord(e0));
 				hipLaunchKernelGGL(fn[md], dim3(blocks), dim3(threads), 0, 0, out, clk, iters);
+				CK(hipEventRecord(e1));
 				CK(hipDeviceSynchronize());
+				CK(hipEventElapsedTime(&ms, e0, e1));
 			}
+			// the clock-free figure: nanoseconds of one SIMD per instruction, from the launch's duration on the host's events
+			nspi[wi] = (double)ms * 1e6 / ((double)iters * 8 * kPerChain[md] * W);
 			CK(hipMemcpy(h.data(), clk, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
 			double cyc = 0, wall = 0;
 			for (int v = 0; v < waves; ++v) { cyc += (double)h[2 * v]; wall += (double)h[2 * v + 1]; }
@@ -114,10 +124,11 @@ int main(int argc, char **argv) {
 			cpi[wi] = cyc / ((double)iters * 8 * kPerChain[md] * W);
 			mhz[wi] = cyc / wall * 100.0;
 		}
-		std::printf("%-32s cyc/inst/SIMD %9.2f %9.2f %9.2f %9.2f   %6.0f MHz\n", kNames[md], cpi[0], cpi[1], cpi[2], cpi[3], mhz[3]);
-		char buf[512];
-		std::snprintf(buf, sizeof buf, "  \"%s\": {\"cycles_per_inst_by_waves\": {\"1\": %.3f, \"2\": %.3f, \"4\": %.3f, \"8\": %.3f}, \"clock_mhz_at_8\": %.0f, \"clock_mhz_at_2\": %.0f}%s\n",
-					  kNames[md], cpi[0], cpi[1], cpi[2], cpi[3], mhz[3], mhz[1], md + 1 < N_MODES ? "," : "");
+		std::printf("%-32s cyc/inst/SIMD %9.2f %9.2f %9.2f %9.2f %9.2f   %6.0f MHz\n", kNames[md], cpi[0], cpi[1], cpi[2], cpi[3], cpi[4], mhz[4]);
+		std::printf("%-32s  ns/inst/SIMD %9.3f %9.3f %9.3f %9.3f %9.3f   (HIP events around the launch)\n", "", nspi[0], nspi[1], nspi[2], nspi[3], nspi[4]);
+		char buf[1024];
+		std::snprintf(buf, sizeof buf, "  \"%s\": {\"ns_per_inst_by_waves\": {\"1\": %.4f, \"2\": %.4f, \"3\": %.4f, \"4\": %.4f, \"8\": %.4f}, \"cycles_per_inst_by_waves\": {\"1\": %.3f, \"2\": %.3f, \"3\": %.3f, \"4\": %.3f, \"8\": %.3f}, \"clock_mhz_at_8\": %.0f, \"clock_mhz_at_2\": %.0f}%s\n",
+					  kNames[md], nspi[0], nspi[1], nspi[2], nspi[3], nspi[4], cpi[0], cpi[1], cpi[2], cpi[3], cpi[4], mhz[4], mhz[1], md + 1 < N_MODES ? "," : "");
 		json += buf;
 	}
 	json += "}\n";

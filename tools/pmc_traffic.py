@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--build-hash", default=None, help="source hash of the profiled library (wc_build_hash): bench.py refuses the file for any other build")
     ap.add_argument("--calib", default=None, help="FETCH_SIZE pass over tools/fetch_calibrate.py: measured bytes per counted KiB for 8- and 16-byte loads")
     ap.add_argument("--config3-f64-dir", default=None, help="F64 instruction-counter pass over `tools/microbench.py --stages c --utts 256 --iters 1` (2 launches)")
+    ap.add_argument("--config3-valu-dir", default=None, help="SQ_INSTS_VALU pass over the same config-3 command")
     ap.add_argument("-o", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json"))
     a = ap.parse_args()
     fetch, write = total_kib(a.fetch_dir, "FETCH_SIZE"), total_kib(a.write_dir, "WRITE_SIZE")
@@ -104,6 +105,9 @@ def main():
         g = lambda c: parts[c].get("cheaptrick_frames", 0.0)
         launches = 2.0  # microbench: one warm-up and one timed launch
         out["_config3_fp64_flops"] = 64.0 * (g("SQ_INSTS_VALU_ADD_F64") + g("SQ_INSTS_VALU_MUL_F64") + 2.0 * g("SQ_INSTS_VALU_FMA_F64") + g("SQ_INSTS_VALU_TRANS_F64")) / launches
+        out["_config3_fp64_insts"] = (g("SQ_INSTS_VALU_ADD_F64") + g("SQ_INSTS_VALU_MUL_F64") + g("SQ_INSTS_VALU_FMA_F64") + g("SQ_INSTS_VALU_TRANS_F64")) / launches
+    if a.config3_valu_dir:
+        out["_config3_valu_insts"] = total_kib(a.config3_valu_dir, "SQ_INSTS_VALU").get("cheaptrick_frames", 0.0) / 2.0  # (two launches)
     with open(a.o, "w") as fh:
         json.dump(out, fh, indent=1)
     print(json.dumps({k: v for k, v in out.items() if not k.startswith("_")}))

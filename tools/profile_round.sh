@@ -31,7 +31,7 @@ done
 ( cd $REPO && rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d "$OUT/pmc_calib" -o p -- python tools/fetch_calibrate.py > "$OUT/pmc_calib.txt" 2> "$OUT/pmc_calib.err" ) || true
 cd "$REPO"
 python tools/pmc_traffic.py "$OUT/pmc_fetch" "$OUT/pmc_write" --valu-dir "$OUT/pmc_valu" --f64-dir "$OUT/pmc_f64" --steps 3 --build-hash "$HASH" \
-  --calib "$OUT/pmc_calib" --config3-f64-dir "$OUT/pmc_c3f64" -o "$OUT/pmc_traffic.json" > "$OUT/pmc_traffic.log" 2>&1
+  --calib "$OUT/pmc_calib" --config3-f64-dir "$OUT/pmc_c3f64" --config3-valu-dir "$OUT/pmc_c3valu" -o "$OUT/pmc_traffic.json" > "$OUT/pmc_traffic.log" 2>&1
 python tools/pmc_traffic.py "$OUT/pmc_c3fetch" "$OUT/pmc_c3write" --steps 2 --calib "$OUT/pmc_calib" -o "$OUT/pmc_traffic_config3.json" > "$OUT/pmc_traffic_config3.log" 2>&1
 python tools/pmc_sq.py "$OUT/pmc_valu" > "$OUT/sq_counters.txt" 2>&1
 python tools/pmc_sq.py "$OUT/pmc_c3valu" > "$OUT/sq_counters_config3.txt" 2>&1

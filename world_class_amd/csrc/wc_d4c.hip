@@ -1074,7 +1074,11 @@ __device__ __forceinline__ void d4c2_frame(const D4cArgs &a, const long long g, 
 	// Each half's results (centroid, power spectrum) wait in the frame's own row of the group-delay array (kD4Row doubles: four
 	// blocks of 1024) until both halves are through: nothing but the running products stays in registers across the
 	// transforms.  Every lane reads back what it wrote itself; the row's head is written for good at the end.
+#ifdef WC_D4C2_PARK_ALIAS  // timing experiment only (results are garbage): all frames park in 2048 rows, which stay in the L2
+	double *park = a.sgd + (g & 2047) * a.sgd_stride;
+#else
 	double *park = a.sgd + g * a.sgd_stride;
+#endif
 	const D4Row row = d4_row(park);
 	D4_STAMP(0);
 

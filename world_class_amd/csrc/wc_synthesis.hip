@@ -1341,6 +1341,12 @@ __device__ __forceinline__ void minimum_phase_wave(double (&mr)[16], double (&mi
 #else
 #define SYN_STAMP(i) do { } while (0)
 #endif
+// ATOMIC (WC_SYN_OLA=atomic, an A/B variant): the response goes straight into y with FP64 atomics -- the periodic half as soon as it
+// exists, the aperiodic response and the DC term at the end -- instead of into a row that syn_overlap_add_kernel sums in pulse
+// order: no row written and read (32 KB per pulse), no parked periodic half (16 KB), no second kernel; the sums then carry the
+// order in which the atomics land (1e-16 of a sample, not the same bits on every run).  Only the noise spectrum's imaginary parts
+// still wait in global memory (a row of 1024 doubles per pulse).
+template <bool ATOMIC>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_SYN_WAVE_OCC, WC_SYN_WAVE_OCC))) void syn_pulse_wave_kernel(SynArgs a) {
 	constexpr int N = 2048, M = 1024;
 	__shared__ __attribute__((aligned(16))) double L[kWfLds];
@@ -1401,7 +1407,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_SYN_WAVE_
 	// fractional delay / the noise spectrum, back to the time domain ----
 	double dc = 0.0;
 	const double sq = sqrt((double)noise_size);
-	double *__restrict__ resp = a.resp + gp * N;
+#ifdef WC_SYN_RESP_ALIAS  // timing experiment only (results are garbage): all pulses share 2048 rows, which stay in the L2
+	double *__restrict__ resp = a.resp + (gp & 2047) * (ATOMIC ? M : N);
+#else
+	double *__restrict__ resp = a.resp + gp * (ATOMIC ? M : N);
+#endif
+	double *__restrict__ yout = a.out + ud.y_off;
+	const int ylen = ud.y_len;
+	auto add2 = [&](int o, double v0, double v1) {  // y[o] += v0, y[o + 1] += v1 where they exist (reference :118-139: y[index + 1 + j] += response[j])
+		if (o >= 0 && o < ylen) atomicAdd(yout + o, v0);
+		if (o + 1 >= 0 && o + 1 < ylen) atomicAdd(yout + o + 1, v1);
+	};
 	const bool has_periodic = !(vuv <= 0.5 || ar0 > 0.999);
 #pragma unroll 1
 	for (int part = has_periodic ? 0 : 1; part < 2; ++part) {
@@ -1545,8 +1561,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_SYN_WAVE_
 #pragma unroll
 			for (int q = 0; q < 8; ++q) {
 				dc += wr[q] + wi[q];
-				// (parked in the pulse's own row of the response buffer, unscaled; the mix below picks it up)
-				*reinterpret_cast<double2 *>(resp + M + 2 * ln + 128 * q) = make_double2(wr[q] * sq, wi[q] * sq);
+				if (ATOMIC) {
+					// row place M + n is output sample index - M + 1 + (M + n)
+					add2(pidx + 1 + 2 * ln + 128 * q, wr[q] * sq / N, wi[q] * sq / N);
+				} else {
+					// (parked in the pulse's own row of the response buffer, unscaled; the mix below picks it up)
+					*reinterpret_cast<double2 *>(resp + M + 2 * ln + 128 * q) = make_double2(wr[q] * sq, wi[q] * sq);
+				}
 			}
 			dc = wave_sum_all(dc);
 			SYN_STAMP(5);
@@ -1556,6 +1577,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_SYN_WAVE_
 			// order; syn_overlap_add_kernel sums the rows into y pulse after pulse, the reference's order (:118-139) -- no atomics,
 			// the same bits on every run.
 			const double dcs = has_periodic ? -dc * sq : 0.0;
+			if (ATOMIC) {
+#pragma unroll
+				for (int q0 = 0; q0 < 8; q0 += 4) {
+					double2 dr[4];
+#pragma unroll
+					for (int q = 0; q < 4; ++q) dr[q] = *reinterpret_cast<const double2 *>(a.dc_remover + 2 * ln + 128 * (q0 + q));
+					WF_SCHED_FENCE();
+#pragma unroll
+					for (int q = 0; q < 4; ++q) {
+						const int n = 2 * ln + 128 * (q0 + q);
+						add2(pidx + 1 + n, fma(dcs, dr[q].x, wr[q0 + q]) / N, fma(dcs, dr[q].y, wi[q0 + q]) / N);
+						add2(pidx + 1 - M + n, fma(dcs, dr[q].x, wr[q0 + q + 8]) / N, fma(dcs, dr[q].y, wi[q0 + q + 8]) / N);
+					}
+				}
+			} else
 #pragma unroll
 			for (int q0 = 0; q0 < 8; q0 += 4) {
 				double2 dr[4], pp[4];
@@ -1938,6 +1974,7 @@ struct wc_synthesis {
 	bool pulses_by_utterance;  // WC_SYN_PULSES=utterance: one workgroup walks an utterance's tiles (A/B and the bit-identity test)
 	bool wave;  // N = 2048 / 1024: one wavefront per pulse (default; WC_SYN_IMPL=block: the workgroup-per-pulse kernel)
 	bool rows = false;  // of the most recent syn_prepare: pulses through response rows + syn_overlap_add_kernel (else atomics into the output)
+	bool wave_atomic = false;  // WC_SYN_OLA=atomic: the one-wavefront kernel (N = 2048) adds into the output itself (A/B variant)
 	size_t rows_budget = 0;  // bytes the response rows may take (an eighth of the device's memory; WC_SYN_ROWS_BUDGET_MB)
 	bool phase_single;  // WC_SYN_PHASE=single: the phase sum by one workgroup per utterance (A/B and the bit-identity test)
 	bool serial_timebase;  // WC_SYN_TIMEBASE=serial: the one-wavefront sequential accumulation instead of the exact parallel one
@@ -2041,7 +2078,7 @@ int syn_prepare(wc_synthesis *sy, hipStream_t s, int n_utt, const double *d_f0, 
 	// atomics kernel takes over (into a cleared output) instead of an allocation that cannot succeed.
 	sy->rows = sy->wave && (sy->fft_size == 2048 || sy->fft_size == 1024) &&
 			   (double)co * sy->fft_size * sizeof(double) <= (double)sy->rows_budget;
-	if (!sy->rows) WC_HIP(hipMemsetAsync(d_out, 0, sizeof(double) * total_out, s));
+	if (!sy->rows || (sy->wave_atomic && sy->fft_size == 2048)) WC_HIP(hipMemsetAsync(d_out, 0, sizeof(double) * total_out, s));
 	if ((rc = sy->incs.reserve(sizeof(double) * inc_total))) return rc;
 	if (!sy->serial_timebase && (rc = sy->phase.reserve(sizeof(double) * inc_total))) return rc;
 	if ((rc = sy->pulses.reserve((size_t)co * (sizeof(int) * 3 + sizeof(double))))) return rc;
@@ -2147,7 +2184,8 @@ int syn_pulses(wc_synthesis *sy, hipStream_t s, const double *d_f0, const double
 	a.pulse_utt = nullptr;
 	if (sy->rows) {
 		// a response row per pulse slot of the rate bound (only the rows of real pulses are ever touched)
-		if ((rc = sy->resp.reserve(sizeof(double) * (size_t)sy->fft_size * (size_t)co))) return rc;
+		const bool atomic_rows = sy->wave_atomic && sy->fft_size == 2048;  // (only the parked noise half then: 1024 doubles per pulse)
+		if ((rc = sy->resp.reserve(sizeof(double) * (size_t)(atomic_rows ? sy->fft_size / 2 : sy->fft_size) * (size_t)co))) return rc;
 		a.resp = sy->resp.as<double>();
 		if ((rc = sy->pulse_utt.reserve(sizeof(int) * (size_t)co))) return rc;
 		a.pulse_utt = sy->pulse_utt.as<int>();
@@ -2173,8 +2211,12 @@ int syn_pulses(wc_synthesis *sy, hipStream_t s, const double *d_f0, const double
 			break;
 		case 2048:
 			if (sy->rows) {
-				hipLaunchKernelGGL(syn_pulse_wave_kernel, dim3((unsigned)(8 * ((a.total_pulses + 7) / 8))), dim3(64), 0, s, a);
-				hipLaunchKernelGGL(syn_overlap_add_kernel<2048>, dim3((unsigned)((sy->max_out + OA_TILE - 1) / OA_TILE), n_utt), dim3(OA_T), 0, s, a);
+				if (sy->wave_atomic) {
+					hipLaunchKernelGGL(syn_pulse_wave_kernel<true>, dim3((unsigned)(8 * ((a.total_pulses + 7) / 8))), dim3(64), 0, s, a);
+				} else {
+					hipLaunchKernelGGL(syn_pulse_wave_kernel<false>, dim3((unsigned)(8 * ((a.total_pulses + 7) / 8))), dim3(64), 0, s, a);
+					hipLaunchKernelGGL(syn_overlap_add_kernel<2048>, dim3((unsigned)((sy->max_out + OA_TILE - 1) / OA_TILE), n_utt), dim3(OA_T), 0, s, a);
+				}
 			} else {
 				launch_pulses<2048>(a, s);
 			}
@@ -2318,6 +2360,8 @@ wc_synthesis *wc_synthesis_create(int fs, int fft_size, double frame_period_ms) 
 		s->pulses_by_utterance = pu && std::string(pu) == "utterance";
 		const char *impl = getenv("WC_SYN_IMPL");
 		s->wave = !(impl && std::string(impl) == "block");
+		const char *ola = getenv("WC_SYN_OLA");
+		s->wave_atomic = ola && std::string(ola) == "atomic";
 		size_t free_b = 0, total_b = 0;
 		if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) total_b = (size_t)64 << 30;
 		s->rows_budget = total_b / 8;
