@@ -127,6 +127,8 @@ def cpu_baseline(xs, budget_s=24.0, min_utts=16, reps=3):
             per = max(1, -(-min_utts // procs))
             jobs = [([xs[(i * per + k) % len(xs)] for k in range(per)], threads) for i in range(procs)]
             rates = []
+            with ThreadPoolExecutor(procs) as ex:  # (one discarded pass of an utterance per process: page cache, core clocks)
+                list(ex.map(_ref_call, [([xs[i % len(xs)]], threads) for i in range(procs)]))
             for _ in range(reps):
                 with ThreadPoolExecutor(procs) as ex:
                     res = list(ex.map(_ref_call, jobs))
@@ -445,6 +447,10 @@ def main():
                          "exercises the sharded code path on a one-GPU box and reports n_gpus = 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the stages / with_transfers blocks (N = 1)")
+    ap.add_argument("--no-serialised", action="store_true",
+                    help="skip the serialised kernel pass (the counter passes of tools/profile_round.sh: every kernel launch of the process "
+                         "must belong to a pipeline step, the counters are divided by the number of steps); roofline.kernel_ms then comes "
+                         "from the overlapped step's events")
     a = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -594,7 +600,9 @@ def main():
             pass
     # ... and the same kernels one after the other, each alone on the chip, one launch for the whole batch: the times the roofline
     # figures are priced on (no schedule effects, no exclusion list)
-    kern = serialised_kernels(w, L, d_x, x_len, d_t, d_f, f_len, d_sp, d_ap, y_len, d_y, pipe.fft_size) if rank == 0 else {}
+    kern = {}
+    if rank == 0:
+        kern = dict(kern_overlapped) if a.no_serialised else serialised_kernels(w, L, d_x, x_len, d_t, d_f, f_len, d_sp, d_ap, y_len, d_y, pipe.fft_size)
 
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3

@@ -1,18 +1,15 @@
-mkdir -p gpurun_out/r05_p4
-O=gpurun_out/r05_p4
-hipcc --offload-arch=gfx950 -O3 -o /tmp/issue_rate tools/issue_rate.hip && /tmp/issue_rate $O/issue_rates.json > $O/issue_rates.txt 2>&1
-cat $O/issue_rates.txt
-python tools/microbench.py --utts 64 --iters 3 > $O/mb_base.txt 2>&1
-WC_SYN_OLA=atomic python tools/microbench.py --utts 64 --iters 3 > $O/mb_atomic.txt 2>&1
-WC_LIB_PATH=world_class_amd/_variants/alias.so python tools/microbench.py --utts 64 --iters 3 > $O/mb_alias.txt 2>&1
-WC_LIB_PATH=world_class_amd/_variants/alias.so WC_SYN_OLA=atomic python tools/microbench.py --utts 64 --iters 3 > $O/mb_alias_atomic.txt 2>&1
-tail -14 $O/mb_base.txt; grep -E "d4c_frames|synthesis_pulses|wall" $O/mb_atomic.txt $O/mb_alias.txt $O/mb_alias_atomic.txt
-WC_SYN_OLA=atomic python -m pytest tests/test_gpu_synthesis.py tests/test_gpu_pipeline.py -m gpu -q -k "golden or oracle or ragged" > $O/tests_atomic.log 2>&1; grep -E "passed|failed" $O/tests_atomic.log
-for ola in rows atomic; do
- WC_SYN_OLA=$ola python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $O/bench_$ola.json 2> $O/bench_$ola.err
- python -c "
-import json; d=json.load(open('$O/bench_$ola.json')); print('$ola', d['ms_per_step'], d['value'])"
+O=gpurun_out/r05_p6; mkdir -p $O
+for v in default bandpf0 bandpf192 bandpf768 synpf200 synpf60; do
+  if [ $v = default ]; then unset WC_LIB_PATH; else export WC_LIB_PATH=world_class_amd/_variants/$v.so; fi
+  python tools/microbench.py --utts 64 --iters 4 > $O/mb_$v.txt 2>&1
+  echo "$v: $(grep -E 'd4c_bands|synthesis_pulses' $O/mb_$v.txt | tr '\n' ' ')"
 done
-python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_full.json 2> $O/bench_full.err
-python -c "
-import json; d=json.load(open('$O/bench_full.json')); print(d['ms_per_step']); print({k:(round(v['ms'],1) if 'ms' in v else v) for k,v in d['with_transfers'].items()}); print({k:(round(v['ms'],2) if 'ms' in v else '') for k,v in d['stages'].items()})"
+unset WC_LIB_PATH
+python -m pytest tests/test_gpu_d4c.py tests/test_gpu_synthesis.py tests/test_gpu_pipeline.py -m gpu -x -q 2>&1 | grep -E "passed|failed"
+WC_LIB_PATH=world_class_amd/_variants/synpf200.so python -m pytest tests/test_gpu_synthesis.py -m gpu -x -q 2>&1 | grep -E "passed|failed"
+for v in default bandpf0; do
+  if [ $v = default ]; then unset WC_LIB_PATH; else export WC_LIB_PATH=world_class_amd/_variants/$v.so; fi
+  python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --no-serialised > $O/bench_$v.json 2>/dev/null
+  python -c "
+import json; d=json.load(open('$O/bench_$v.json')); print('$v', round(d['ms_per_step'],2), round(d['value']))"
+done

@@ -8,12 +8,12 @@ TAG=${1:-prof}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH_ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-extras"
+BENCH_ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-serialised"
 REPO=$PWD
 HASH=$(python -c "import world_class_amd as w; print(w.lib().wc_build_hash().decode())")
 cd /tmp
 # 1. kernel-trace statistics of the bench command and of BASELINE config 3 (CheapTrick alone)
-rocprofv3 --kernel-trace --stats -f csv -d "$OUT/stats" -o p -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > "$OUT/stats_bench.json" 2> "$OUT/stats.err" || true
+rocprofv3 --kernel-trace --stats -f csv -d "$OUT/stats" -o p -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --no-serialised > "$OUT/stats_bench.json" 2> "$OUT/stats.err" || true
 ( cd $REPO && rocprofv3 --kernel-trace --stats -f csv -d "$OUT/stats_config3" -o p -- python tools/microbench.py --stages c --utts 256 --iters 3 > "$OUT/stats_config3.txt" 2> "$OUT/stats_config3.err" ) || true
 # 2. counter passes over the bench command
 for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "valu SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT" "f64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64"; do

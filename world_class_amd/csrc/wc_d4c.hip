@@ -1314,6 +1314,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_D4C2_OCC,
 // of the K = bins - boundary - 1 smallest powers by bisecting the bit patterns (non-negative doubles order like integers):
 // per step one 64-bit compare per key and the count from ballots in scalar registers; it stops as soon as a threshold has
 // exactly K keys below it (after ~log2(2^62 / gap between the K-th and the next key) steps), or with the K-th key itself.
+// WC_D4C2_BAND_PF (round 5): a wavefront's first touch of its frame's group delay is an HBM round trip in front of everything it
+// does, and two wavefronts per SIMD do not hide it (the rows were written by another launch, a gigabyte ago).  Every wavefront
+// therefore also asks for the segment of the block that will run on ITS XCD about WC_D4C2_BAND_PF blocks later (xcd_frame:
+// block b runs on XCD b % 8 with local index b >> 3): one load per lane, a cache line each, whose result nothing waits for until
+// the wavefront ends -- by then that block finds its lines in the XCD's L2.  0: off.
+#ifndef WC_D4C2_BAND_PF
+#define WC_D4C2_BAND_PF 384
+#endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_D4C2_BAND_OCC, WC_D4C2_BAND_OCC))) void d4c2_band_kernel(D4cArgs a) {
 	constexpr int N = 4096, M = 2048;
 	__shared__ __attribute__((aligned(16))) double L[kWfLds];
@@ -1334,6 +1342,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_D4C2_BAND
 	const double *__restrict__ src = a.sgd + g * a.sgd_stride + (center - hwl);
 	const int ng = wln > 512 ? 2 : 1;
 	double key[2][16], keyM = 0.0;
+	double pf = 0.0;
 #pragma unroll
 	for (int odd = 0; odd < 2; ++odd) {
 		// the packed windowed group delay, elements lane + 64 q (read again for the second half rather than held across the first)
@@ -1346,6 +1355,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_D4C2_BAND
 				sv[k] = src[i];
 				nv[k] = a.nuttall[i];
 			}
+#if WC_D4C2_BAND_PF > 0
+			if (odd == 0) {
+				// (no branch around the load -- the tail of the grid asks for the last block's lines again --: behind a branch the
+				// compiler no longer knows how many loads are in flight and waits for all of them, this one included)
+				const long long b2 = min((long long)blockIdx.x + 8ll * WC_D4C2_BAND_PF, (long long)gridDim.x - 1);
+				const long long blk2 = xcd_frame(b2, (long long)gridDim.x);
+				const long long g2 = min(blk2 / n_ap, a.total_frames - 1);
+				const int center2 = (int)(3000.0 * ((int)(blk2 % n_ap) + 1) * N / fs);
+				pf = (a.sgd + g2 * a.sgd_stride + (center2 - hwl))[min(16 * lane, wln - 1)];  // (a line per lane)
+			}
+#endif
 			WF_SCHED_FENCE();
 #pragma unroll
 			for (int q = 0; q < 16; ++q) {
@@ -1431,6 +1451,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_D4C2_BAND
 		const double cv = 10 * log10(part / tot);
 		a.coarse[g * kMaxBands + bnd] = fmin(0.0, cv + (f0 - 100) / 50.0);  // reference :326-328
 	}
+#if WC_D4C2_BAND_PF > 0
+	// (the prefetched value is "used" only here, behind the wavefront's last store, so that the load is neither dropped nor waited
+	// for earlier: an empty statement that takes it in a register)
+	asm volatile("" ::"v"(pf));
+#endif
 }
 
 

@@ -1331,6 +1331,9 @@ __device__ __forceinline__ void minimum_phase_wave(double (&mr)[16], double (&mi
 #ifndef WC_SYN_PARK_NOISE
 #define WC_SYN_PARK_NOISE 1
 #endif
+#ifndef WC_SYN_ROW_PF
+#define WC_SYN_ROW_PF 0  // frames ahead whose spectrogram / aperiodicity rows a pulse asks for on behalf of later pulses (0: off)
+#endif
 // WC_SYN_TRACE (development builds only): lane 0 stamps the shader clock at the phase boundaries of every pulse;
 // WC_SYN_TRACE_FILE=<file> dumps them after the call (tools/syn_trace.py)
 #ifndef WC_SYN_TRACE
@@ -1399,6 +1402,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_SYN_WAVE_
 		blend(sf[0], sc[0], af[0], ac[0], env, ar0);
 		ar0 = uniform_d(ar0);
 	}
+#if WC_SYN_ROW_PF > 0
+	// (round 5) the rows of the frame WC_SYN_ROW_PF frames further on in this utterance -- pulses that will run on this XCD a few hundred
+	// pulses from now -- are asked for here, a cache line per lane, and looked at only when the wavefront ends (see d4c2_band_kernel)
+	double pf_s, pf_a;
+	{
+		const long long r2 = (ud.f_off + min(ce + WC_SYN_ROW_PF, Lf - 1)) * (long long)(M + 1) + 16 * lane;
+		pf_s = a.sp[r2];
+		pf_a = a.ap[r2];
+	}
+#endif
 	SYN_STAMP(0);
 	SYN_STAMP(1);
 
@@ -1613,7 +1626,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_SYN_WAVE_
 			SYN_STAMP(10);
 		}
 	}
-
+#if WC_SYN_ROW_PF > 0
+	asm volatile("" ::"v"(pf_s), "v"(pf_a));
+#endif
 }
 
 // ==== N = 1024 (16 / 22.05 / 24 kHz): one wavefront per pulse at eight points per lane ========================================
