@@ -1319,8 +1319,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_D4C2_OCC,
 // therefore also asks for the segment of the block that will run on ITS XCD about WC_D4C2_BAND_PF blocks later (xcd_frame:
 // block b runs on XCD b % 8 with local index b >> 3): one load per lane, a cache line each, whose result nothing waits for until
 // the wavefront ends -- by then that block finds its lines in the XCD's L2.  0: off.
+// Measured (profiles/r05_b_prefetch_ab.txt, 64 x 10 s): 3.52 ms without, 3.35 / 3.57 / 3.40 ms at distances 192 / 384 / 768 -- inside
+// the run-to-run spread of +-0.1 ms; the first touch is not what the kernel waits for.  Off by default.
 #ifndef WC_D4C2_BAND_PF
-#define WC_D4C2_BAND_PF 384
+#define WC_D4C2_BAND_PF 0
 #endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_D4C2_BAND_OCC, WC_D4C2_BAND_OCC))) void d4c2_band_kernel(D4cArgs a) {
 	constexpr int N = 4096, M = 2048;
