@@ -167,3 +167,43 @@ def test_cheaptrick_eight_points_per_lane_kernel_against_the_block_kernel_and_fr
     port.rng_reset()
     assert rel(a, b) < SP_REL
     assert rel(a, ref) < SP_REL
+
+
+def test_cheaptrick_split_kernel_against_the_sixteen_points_kernel(wca, port, monkeypatch):
+    """N = 2048 on eight points per lane (ct_wave_split_kernel, WC_CT_IMPL=split: the forward transform as two 512-point halves one
+    after the other, everything in one 9 KB buffer of LDS, three wavefronts per SIMD) against the default one-wavefront kernel and
+    the oracle: windows of every pruning class (F0 at the floor: 2029 samples; 150 Hz: 961; 400 Hz: 361; unvoiced: 289), the frames
+    either kernel leaves to the block kernel, and the bins lane 0 holds (multiples of 64)."""
+    fs = 48000
+    x = make_utterance(fs, 0.6, 398)
+    tpos, f0 = port.harvest(x, fs)
+    f0 = f0.copy()
+    n = len(f0)
+    f0[5:15] = 72.0       # just above CheapTrick's floor (70.4 Hz): the longest window
+    f0[20:30] = 150.0
+    f0[35:45] = 400.0
+    f0[50:54] = 1900.0    # just inside ct_wave_can<2048>
+    f0[60:66] = 2500.0    # left to the block kernel
+    f0[70:80] = 0.0
+    assert n > 100
+    wca.rng_set_position(4321)
+    a = wca.CheapTrick(fs).compute(x, tpos, f0)
+    end = wca.rng_get_position()
+    monkeypatch.setenv("WC_CT_IMPL", "split")
+    wca.rng_set_position(4321)
+    b = wca.CheapTrick(fs).compute(x, tpos, f0)
+    assert wca.rng_get_position() == end
+    monkeypatch.delenv("WC_CT_IMPL")
+    port.rng_seek(4321)
+    ref = port.cheaptrick(x, fs, tpos, f0)
+    port.rng_reset()
+    worst = np.abs(b / a - 1.0).max(axis=0)
+    assert rel(b, a) < 1e-10, "bins %s" % np.argsort(worst)[-5:]
+    assert rel(b, ref) < SP_REL
+    # through the fused pipeline too (the handle of a group reads the same switch)
+    monkeypatch.setenv("WC_CT_IMPL", "split")
+    r2 = wca.Pipeline(fs).run_batch([x, x[:20000]])
+    monkeypatch.delenv("WC_CT_IMPL")
+    r1 = wca.Pipeline(fs).run_batch([x, x[:20000]])
+    for u in range(2):
+        assert np.array_equal(r1[u]["f0"], r2[u]["f0"]) and rel(r2[u]["sp"], r1[u]["sp"]) < 1e-10

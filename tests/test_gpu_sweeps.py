@@ -80,29 +80,43 @@ def ref_self_spread(kind, fs, field):
     return max(vals)
 
 
-def test_impulse_trains_agree_in_voicing_and_within_the_references_own_spread(wca, P):
+def test_impulse_trains_agree_in_voicing_and_within_twice_the_references_own_spread(wca, P, monkeypatch):
     """A train whose period is a whole number of samples at the decimated rate puts 1.5 fs / f0 + 1 exactly on an integer
     (reference src/harvest.cpp:950): the refinement window is 45 or 46 samples long depending on the last bits of the raw
     candidate, in any implementation -- the reference's own choice is made by the rounding of its FFT convolution, and two builds
     of the reference itself part by 1.4e-3 Hz on such trains (ref_self_spread.json: two of six trains; the CPU restatement and
-    the reference by 1.3e-3 Hz on the same two).  Voicing decisions must agree; F0 within ten times what the reference allows
-    itself: which frames sit on the edge differs per implementation, the size of a step (0.06 Hz on a refined candidate) does
-    not, and the sliding-DFT band-pass rounds at 1e-14 of the signal where the reference's FFT convolution rounds at 1e-16, so
-    more of the edge frames of a train fall the other way (measured 7.8e-3 Hz)."""
+    the reference by 1.3e-3 Hz on the same two).  Round 5: (i) the two outputs on either side of a chunk border of the sliding
+    band-pass have ONE value (hv_seam_kernel: two lanes' estimates of a sample that is exactly zero made the same edge appear
+    twice -- NaN raw candidates around every border, three voicing flips on seed 1440023); (ii) a raw candidate within 2e-13 of
+    one of the refinement's integer cuts sends the batch through Harvest again with the band-pass as direct FIR sums
+    (hv_exact_twin; WC_HARVEST_TIES=ignore switches that off: 1.1e-2 Hz on seed 1340043 then, 1e-11 Hz with it).  Voicing
+    decisions must agree and F0 hold TWICE what the reference allows itself (measured: 2.6e-3 Hz), through the stage call and
+    through the fused pipeline."""
     fs = 16000
-    seeds = [230003, 230013, 230023, 230033]
-    xs = [make_signal(fs, 1.5, s) for s in seeds]
-    assert all(SIGNAL_KINDS[s % len(SIGNAL_KINDS)] == "impulses" for s in seeds)
-    tol = 10.0 * ref_self_spread("impulses", fs, "f0_abs")
-    assert 1e-6 < tol < 2e-2
+    cases = [(s, 1.5) for s in (230003, 230013, 230023, 230033)] + [(s, 3.0) for s in (1440023, 1440043, 1340043, 1340003)]
+    xs = [make_signal(fs, sec, s) for s, sec in cases]
+    assert all(SIGNAL_KINDS[s % len(SIGNAL_KINDS)] == "impulses" for s, _ in cases)
+    tol = 2.0 * ref_self_spread("impulses", fs, "f0_abs")
+    assert 1e-6 < tol < 3e-3
+    refs = [P.pipeline(x, fs) for x in xs]
     res = wca.Pipeline(fs).run_batch(xs)
+    hv = wca.Harvest(fs)
     worst = 0.0
-    for s, x, r in zip(seeds, xs, res):
-        o = P.pipeline(x, fs)
+    for (s, _), x, r, o in zip(cases, xs, res, refs):
         assert np.array_equal(r["f0"] == 0, o["f0"] == 0), s
         worst = max(worst, dev(r["f0"], o["f0"]))
+        f1 = hv.compute(x)[1]  # (the stage call has a retry of its own)
+        assert np.array_equal(f1 == 0, o["f0"] == 0), s
+        worst = max(worst, dev(f1, o["f0"]))
     print("impulse trains: worst F0 deviation %.3e Hz (bound %.3e)" % (worst, tol))
     assert worst < tol
+    # what the re-run buys: the same train without it
+    k = [s for s, _ in cases].index(1340043)
+    assert dev(wca.Harvest(fs).compute(xs[k])[1], refs[k]["f0"]) < 1e-9
+    monkeypatch.setenv("WC_HARVEST_TIES", "ignore")
+    f_ign = wca.Harvest(fs).compute(xs[k])[1]
+    monkeypatch.delenv("WC_HARVEST_TIES")
+    assert np.array_equal(f_ign == 0, refs[k]["f0"] == 0) and 1e-4 < dev(f_ign, refs[k]["f0"]) < 5e-2
 
 
 def test_seeded_utterances_48k(wca, P):

@@ -670,6 +670,334 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_CT_WAVE_O
 #endif
 
 
+// ---- one wavefront per frame at N = 2048 on EIGHT complex points per lane (round 5) ---------------------------------------------
+// ct_wave_kernel's frame with every transform on the 512-point transforms wf8_*: the two cepstral ones already are
+// (wf_even2048); the forward one -- a 1024-point complex transform of z[m] = x[2 m] + i x[2 m + 1] -- is split in time,
+//     Z[k] = E[k] + W_1024^k O[k],   Z[k + 512] = E[k] - W_1024^k O[k],   E = DFT_512(z[2 n]),   O = DFT_512(z[2 n + 1]),
+// the two halves one after the other by the same wavefront (E waits in sixteen registers while O is transformed).  In the
+// paired8 layout a lane holds bins k and 512 - k of both, which is all the real-transform unpacking of X[k], X[1024 - k],
+// X[512 - k], X[512 + k] needs: sixteen bins of the power spectrum per lane, nothing leaves the lane.  About 150 registers
+// instead of 233 and ONE 9 KB buffer of LDS for everything (exchanges, DC-correction staging, the smoothing's mirrored segment,
+// then the log spectrum and the cepstral transforms' exchanges in the same place; the log spectrum waits in registers until the
+// segment has been read): three wavefronts per SIMD instead of two -- by tools/issue_rate.hip's figures a 32-bit instruction
+// costs 1.06 instead of 1.56 ns there and an FP64 one 2.58 instead of 2.82.
+// Bins of a lane's sixteen values (s = 4 c + r, k = lane + 128 c): r = 0: k, 1: 1024 - k, 2: 512 - k, 3: 512 + k; lane 0 holds
+// k = 128 / 64 / 192 in rows 1 / 2 / 3 and bins 0, 512, 256, 768 in row 0; bin 1024 travels beside them (pwM, lane 0).
+#ifndef WC_CT_SPLIT_OCC
+#define WC_CT_SPLIT_OCC 3
+#endif
+__device__ __forceinline__ int ct_split_bin(int lane, int s) {
+	const int c = s >> 2, r = s & 3;
+	const int k = lane ? lane + 128 * c : (c == 1 ? 128 : c == 2 ? 64 : 192);
+	const int gen = r == 0 ? k : r == 1 ? 1024 - k : r == 2 ? 512 - k : 512 + k;
+	if (c == 0) return lane ? gen : (r == 0 ? 0 : r == 1 ? 512 : r == 2 ? 256 : 768);
+	return gen;
+}
+// E, O: paired8 outputs of wf8_fft512_dit<+1> on z[2 n] / z[2 n + 1].  Out: pw[s] = |2 X[bin s]|^2, pwM = |2 X[1024]|^2 (lane 0).
+__device__ __forceinline__ void ct_split_power(const double (&er)[8], const double (&ei)[8], const double (&orr)[8], const double (&oi)[8],
+												double (&pw)[16], double &pwM, const double2 *__restrict__ tw_, int lane) {
+	const double2 *__restrict__ tw = tw_fresh(tw_);
+	// one quartet: E[k], E[512 - k], O[k], O[512 - k], w1 = W_1024^k, w2 = W_2048^k  ->  powers of bins k, 1024 - k, 512 - k, 512 + k
+	auto quartet = [&](double ear, double eai, double ebr, double ebi, double oar, double oai, double obr, double obi, double w1r, double w1i,
+					   double w2r, double w2i, double &p0, double &p1, double &p2, double &p3) {
+		const double tr = fma(w1r, oar, -(w1i * oai)), ti = fma(w1r, oai, w1i * oar);       // W_1024^k O[k]
+		const double ur = -fma(w1r, obr, w1i * obi), ui = -fma(w1r, obi, -(w1i * obr));     // W_1024^(512 - k) O[512 - k] = -conj(w1) O[512 - k]
+		double zkr = ear + tr, zki = eai + ti, zk5r = ear - tr, zk5i = eai - ti;             // Z[k], Z[k + 512]
+		double zmr = ebr + ur, zmi = ebi + ui, zm5r = ebr - ur, zm5i = ebi - ui;             // Z[512 - k], Z[1024 - k]
+		wf_r2c_pair(zkr, zki, zm5r, zm5i, w2r, w2i);                                        // 2 X[k], 2 X[1024 - k]
+		wf_r2c_pair(zmr, zmi, zk5r, zk5i, w2i, w2r);                                        // 2 X[512 - k], 2 X[512 + k]: W_2048^(512 - k) = i conj(w2)
+		p0 = fma(zkr, zkr, zki * zki);
+		p1 = fma(zm5r, zm5r, zm5i * zm5i);
+		p2 = fma(zmr, zmr, zmi * zmi);
+		p3 = fma(zk5r, zk5r, zk5i * zk5i);
+	};
+	double w1r[4], w1i[4], w2r[4], w2i[4];
+#pragma unroll
+	for (int c = 0; c < 4; ++c) {
+		const double2 a = tw_load(tw + kTw8U + 128 * c, lane), b = tw_load(tw + kTwU + 128 * c, lane);
+		w1r[c] = a.x; w1i[c] = a.y;
+		w2r[c] = b.x; w2i[c] = b.y;
+	}
+	WF_SCHED_FENCE();
+	pwM = 0.0;
+	if (lane == 0) {
+		// slots: 0: k = 0, 1: 128, 2: 256, 3: 384, 4: 64, 5: 192, 6: 320, 7: 448
+		{
+			const double ar = er[0] + orr[0], ai = ei[0] + oi[0];     // Z[0]
+			const double br = er[0] - orr[0], bi = ei[0] - oi[0];     // Z[512] = X[512]
+			const double x0 = 2.0 * (ar + ai), xm = 2.0 * (ar - ai);
+			pw[0] = x0 * x0;
+			pwM = xm * xm;
+			pw[1] = 4.0 * fma(br, br, bi * bi);
+		}
+		{
+			// k = 256: W_1024^256 = i
+			double zr = er[2] - oi[2], zi = ei[2] + orr[2], yr = er[2] + oi[2], yi = ei[2] - orr[2];  // Z[256], Z[768]
+			wf_r2c_pair(zr, zi, yr, yi, kH, kH);
+			pw[2] = fma(zr, zr, zi * zi);
+			pw[3] = fma(yr, yr, yi * yi);
+		}
+		quartet(er[1], ei[1], er[3], ei[3], orr[1], oi[1], orr[3], oi[3], kH, kH, kC8, kS8, pw[4], pw[5], pw[6], pw[7]);
+		quartet(er[4], ei[4], er[7], ei[7], orr[4], oi[4], orr[7], oi[7], kC8, kS8, 0.98078528040323044913, 0.19509032201612826785,
+				pw[8], pw[9], pw[10], pw[11]);
+		quartet(er[5], ei[5], er[6], ei[6], orr[5], oi[5], orr[6], oi[6], kS8, kC8, 0.83146961230254523708, 0.55557023301960222474,
+				pw[12], pw[13], pw[14], pw[15]);
+	} else {
+#pragma unroll
+		for (int c = 0; c < 4; ++c)
+			quartet(er[c], ei[c], er[7 - c], ei[7 - c], orr[c], oi[c], orr[7 - c], oi[7 - c], w1r[c], w1i[c], w2r[c], w2i[c], pw[4 * c], pw[4 * c + 1],
+					pw[4 * c + 2], pw[4 * c + 3]);
+	}
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_CT_SPLIT_OCC, WC_CT_SPLIT_OCC))) void ct_wave_split_kernel(CtArgs a) {
+	constexpr int N = 2048, M = 1024;
+	__shared__ __attribute__((aligned(16))) double L[kWfLds];
+	__shared__ __attribute__((aligned(16))) double T[kWfTabLds];  // the tables of the lean log / exp
+	const int lane = threadIdx.x;
+	const long long g = xcd_frame(blockIdx.x, a.total_frames);
+	if (g >= a.total_frames) return;
+	const int fs = a.fs;
+	const double f0v = a.f0[g];
+	const double f0c = uniform_d((f0v <= a.f0_floor) ? 500.0 : f0v);  // reference :77
+	if (!ct_wave_can<N>(f0c, fs)) {  // left for the block kernel behind this one
+		if (lane == 0) a.rare_list[1 + atomicAdd(a.rare_list, 1)] = (int)g;
+		return;
+	}
+	const UttDesc ud = a.utts[a.uidx[g]];
+	const double *__restrict__ x = a.x + ud.x_off;
+	const int x_last = ud.x_len - 1;
+	const double pos = a.tpos[g];
+	const uint32_t *__restrict__ rng = a.rng_table + (a.rng_off[g] - a.rng_base);
+	wf_tables_to_lds(T, a.tw, lane);
+
+	// ---- F0-adaptive window (reference :137-196): window sample i of slot q is 4 lane + 256 q + r, r < 4; the packed halves'
+	// element lane + 64 q is (samples r = 0, 1) for E and (r = 2, 3) for O ----
+	const int hw = __builtin_amdgcn_readfirstlane(mround(1.5 * fs / f0c));
+	const int wl = 2 * hw + 1;
+	const int base = __builtin_amdgcn_readfirstlane(mround(pos * fs + 0.001)) - hw;  // signal index of window sample 0
+	double c0[4], s0[4], cd, sd;
+	{
+		const double kappa = f0c / 1.5 / fs;  // angle per sample in units of pi
+#pragma unroll
+		for (int r = 0; r < 4; ++r) wf_sincospi(kappa * (4 * lane + r - hw), s0[r], c0[r]);
+		wf_sincospi(kappa * 256.0, sd, cd);
+		sd = uniform_d(sd);
+		cd = uniform_d(cd);
+	}
+	// walks the live slots (two at a time: a uniform branch skips what lies beyond the window) with the raw window values of the
+	// slot's four samples, advanced by a rotation recurrence from the exact start phases; LOADS = 1: the pair's sixteen loads
+	// (signal and draws) are issued together and fenced off from their uses
+	auto walk = [&](auto loads_c, auto &&body) {
+		constexpr int LOADS = decltype(loads_c)::value;
+		double cc[4], ss[4];
+#pragma unroll
+		for (int r = 0; r < 4; ++r) { cc[r] = c0[r]; ss[r] = s0[r]; }
+#pragma unroll
+		for (int qg = 0; qg < 8; qg += 2) {
+			if (qg * 256 >= wl) break;
+			double xs[8];
+			uint32_t ns[8];
+			if (LOADS) {
+#pragma unroll
+				for (int k = 0; k < 8; ++k) {
+					const int i = 4 * lane + 256 * (qg + (k >> 2)) + (k & 3);
+					xs[k] = x[clampi(base + i, 0, x_last)];
+					ns[k] = rng[i < wl ? i : 0];
+				}
+				WF_SCHED_FENCE();
+			}
+#pragma unroll
+			for (int k = 0; k < 2; ++k) {
+				const int q = qg + k, i0 = 4 * lane + 256 * q;
+				double W[4];
+#pragma unroll
+				for (int r = 0; r < 4; ++r) W[r] = (i0 + r < wl) ? fma(0.5, cc[r], 0.5) : 0.0;
+				body(q, i0, W, LOADS ? &xs[4 * k] : nullptr, LOADS ? &ns[4 * k] : nullptr);
+#pragma unroll
+				for (int r = 0; r < 4; ++r) {
+					const double cn = fma(cc[r], cd, -(ss[r] * sd));
+					ss[r] = fma(ss[r], cd, cc[r] * sd);
+					cc[r] = cn;
+				}
+			}
+		}
+	};
+	double er[8], ei[8], orr[8], oi[8];
+#pragma unroll
+	for (int q = 0; q < 8; ++q) er[q] = ei[q] = orr[q] = oi[q] = 0.0;
+	double ssq = 0.0;
+	walk(std::integral_constant<int, 0>(), [&](int, int, const double (&W)[4], const double *, const uint32_t *) {
+#pragma unroll
+		for (int r = 0; r < 4; ++r) ssq = fma(W[r], W[r], ssq);
+	});
+	ssq = wave_sum_all(ssq);
+	const double hr = 0.5 * (1.0 / sqrt(ssq));  // half the window norm: the unpacking below then yields X, not 2 X
+	double s1 = 0.0, s2 = 0.0;
+	walk(std::integral_constant<int, 1>(), [&](int q, int i0, const double (&W)[4], const double *xs, const uint32_t *ns) {
+		double v[4];
+#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			const double w = W[r] * hr;
+			const double nz = (ns[r] / 268435456.0 - 6.0) * (0.5 * 0.000000000000001);
+			v[r] = (i0 + r < wl) ? fma(xs[r], w, nz) : 0.0;
+			s1 += v[r];
+			s2 += w;
+		}
+		er[q] = v[0]; ei[q] = v[1]; orr[q] = v[2]; oi[q] = v[3];
+	});
+	s1 = wave_sum_all(s1);
+	s2 = wave_sum_all(s2);
+	const double wc = s1 / s2;
+	walk(std::integral_constant<int, 0>(), [&](int q, int, const double (&W)[4], const double *, const uint32_t *) {
+		er[q] = fma(-(W[0] * hr), wc, er[q]);
+		ei[q] = fma(-(W[1] * hr), wc, ei[q]);
+		orr[q] = fma(-(W[2] * hr), wc, orr[q]);
+		oi[q] = fma(-(W[3] * hr), wc, oi[q]);
+	});
+
+	// ---- power spectrum (reference :198-218): the two half transforms, E first ----
+	if (wl <= 512) { wdft8p<+1, 1>(er, ei); wdft8p<+1, 1>(orr, oi); }
+	else if (wl <= 1024) { wdft8p<+1, 2>(er, ei); wdft8p<+1, 2>(orr, oi); }
+	else { wdft8p<+1, 4>(er, ei); wdft8p<+1, 4>(orr, oi); }
+	wf8_fft512_dit_rest<+1>(er, ei, L, a.tw, lane);
+	wf8_fft512_dit_rest<+1>(orr, oi, L, a.tw, lane);
+	double pw[16], pwM;
+	ct_split_power(er, ei, orr, oi, pw, pwM, a.tw, lane);
+	int bin[16];
+#pragma unroll
+	for (int s = 0; s < 16; ++s) bin[s] = ct_split_bin(lane, s);
+	// DC correction (reference src/world_common.cpp:61-80): bins below upper - 1 <= 119 change, from bins <= upper + 1: bin lane is
+	// value 0 of every lane, bin 128 - lane value 14 (lane 0: bin 64 is value 8)
+	{
+		const int upper = __builtin_amdgcn_readfirstlane(2 + (int)(f0c * N / fs));
+		const double dx = -(double)fs / N, rdx = 1.0 / dx;
+		L[lane] = pw[0];
+		if (lane) L[128 - lane] = pw[14];
+		else L[64] = pw[8];
+		wf_fence();
+		auto rep = [&](int i) {
+			const double axis = (double)i * fs / N;
+			return interp1q_rcp(f0c, dx, rdx, [&](int b) { return L[min(max(b, 0), 127)]; }, upper + 1, axis);
+		};
+		if (lane < upper - 1) pw[0] += rep(lane);
+		if (upper - 1 > 64) {
+			if (lane && 128 - lane < upper - 1) pw[14] += rep(128 - lane);
+			if (!lane && 64 < upper - 1) pw[8] += rep(64);
+		}
+		wf_fence();
+	}
+
+	// ---- linear smoothing, width 2 f0 / 3 (reference src/world_common.cpp:27-52, :82-116), infinitesimal noise, log ----
+	double lp[16], lpM;
+	{
+		const double width = f0c * 2.0 / 3.0;
+		const int b = __builtin_amdgcn_readfirstlane((int)(width * N / fs) + 1);  // <= 60 (ct_wave_can)
+		const int len = M + 2 * b + 1;
+		// mirrored segment (reference src/world_common.cpp:33-44): position i holds bin b - i (i < b), bin i - b (b <= i < M + b),
+		// bin 2 M + b - i (M + b <= i <= M + 2 b).  The low mirror comes from value 0 (bin lane of lanes 1 .. b), the high one from
+		// value 1 (bin 1024 - lane); bin 1024 itself sits at M + b.
+		const double sc = fs * (1.0 / N);
+#pragma unroll
+		for (int s = 0; s < 16; ++s) L[bin[s] + b] = pw[s] * sc;
+		if (lane == 0) L[M + b] = pwM * sc;
+		if (lane >= 1 && lane <= b) {
+			L[b - lane] = pw[0] * sc;
+			L[M + b + lane] = pw[1] * sc;
+		}
+		wf_fence();
+		seq_cumsum_nonneg_wave<18>(L, len, lane);
+		const double step = (double)fs / N;
+		const double origin_axis = -(b - 0.5) * fs / N;
+		const double rstep = 1.0 / step;
+		const double rwidth = 1.0 / width;
+		const uint32_t *__restrict__ rngb = rng + wl;
+		bool odd = false;  // a smoothed value that is not a positive finite number (the reference then takes log of it all the same)
+		auto smooth = [&](int k, bool slow) {
+			// (the two abscissae in the reference's own per-bin arithmetic: see ct_wave_kernel)
+			const double lo_axis = (double)k / N * fs - width / 2.0, hi_axis = lo_axis + width;
+			const double lo_v = wf_interp1q(origin_axis, step, rstep, L, len, lo_axis);
+			const double hi_v = wf_interp1q(origin_axis, step, rstep, L, len, hi_axis);
+			double sm = (hi_v - lo_v) * rwidth;
+			// infinitesimal noise (reference :220-228) then log (reference :251-252)
+			sm = fma(fabs(randn_at(rngb, k)), 0.00000000000000022204460492503131, sm);
+			if (slow) return wf_log_libm(sm);
+			odd = odd || !wf_log_ok(sm);
+			return wf_log_fast_l(sm, T);
+		};
+#pragma unroll
+		for (int c = 0; c < 4; ++c) {
+#pragma unroll
+			for (int r = 0; r < 4; ++r) lp[4 * c + r] = smooth(bin[4 * c + r], false);
+			WF_SCHED_FENCE();  // (four bins at a time)
+		}
+		lpM = smooth(M, false);
+		if (__any(odd)) {  // (never on signals with a noise floor)
+			int ln = lane, km = M;
+			WC_FRESH(ln);
+			WC_FRESH(km);
+#pragma unroll
+			for (int s = 0; s < 16; ++s) lp[s] = smooth(ct_split_bin(ln, s), true);
+			lpM = smooth(km, true);
+		}
+		wf_fence();
+	}
+	// the log spectrum, bins 0 .. 1024 in natural order, where the segment was (it has been read)
+#pragma unroll
+	for (int s = 0; s < 16; ++s) L[bin[s]] = lp[s];
+	if (lane == 0) L[M] = lpM;
+	wf_fence();
+
+	// ---- smoothing + recovery lifters in the cepstral domain (reference :230-276): see ct_wave_kernel; the real even transforms
+	// read their input into registers before their first exchange, so input, exchanges and output share the one buffer ----
+	double lo[8], hi[8], mid;
+	wf_even2048(L, L, a.tw, lane, lo, hi, mid);
+	{
+		const double q1 = a.q1;
+		const double ralpha = 1.0 / (kPi * f0c / fs);
+		const double scale = 1.0 / N;  // the reference's / fft_size
+		double ec, es, c64, s64, c1024, s1024, c512, s512;
+		wf_sincospi(f0c / fs * lane, es, ec);
+		wf_sincospi(f0c / fs * 64.0, s64, c64);
+		wf_sincospi(f0c / fs * 1024.0, s1024, c1024);
+		wf_sincospi(f0c / fs * 512.0, s512, c512);
+		s64 = uniform_d(s64); c64 = uniform_d(c64);
+		s1024 = uniform_d(s1024); c1024 = uniform_d(c1024);
+		s512 = uniform_d(s512);
+		const double cl0 = 1.0 - 2.0 * q1, cl1 = 2.0 * q1;
+		auto lift = [&](double v, double sn, int k) {
+			const double sl = sn * (ralpha * tw_load_d(a.tw + kTwInvK, k));
+			const double cl = fma(cl1, fma(-2.0 * sn, sn, 1.0), cl0);
+			return v * sl * cl * scale;
+		};
+#pragma unroll
+		for (int j = 0; j < 8; ++j) {
+			const int k = lane + 64 * j;
+			const double sp = fma(s1024, ec, -(c1024 * es));
+			double vlo = lift(lo[j], es, k);
+			const double vhi = lift(hi[j], sp, 1024 - k);
+			if (j == 0) vlo = (lane == 0) ? lo[0] * (cl0 + cl1) * scale : vlo;  // k = 0: sinc = 1
+			L[k] = vlo;
+			L[1024 - k] = vhi;
+			const double cn = fma(ec, c64, -(es * s64));
+			es = fma(es, c64, ec * s64);
+			ec = cn;
+		}
+		const double vmid = lift(mid, s512, 512);
+		if (lane == 0) L[512] = vmid;
+	}
+	wf_fence();
+	wf_even2048(L, L, a.tw, lane, lo, hi, mid);
+	double *__restrict__ out = a.sp + g * (long long)(M + 1);
+#pragma unroll
+	for (int j = 0; j < 8; ++j) {
+		out[lane + 64 * j] = wf_exp_l(lo[j], T);
+		out[1024 - lane - 64 * j] = wf_exp_l(hi[j], T);
+	}
+	const double last = wf_exp_l(mid, T);
+	if (lane == 0) out[512] = last;
+}
+
+
 // ---- one wavefront per frame at N = 1024 (16 / 22.05 / 24 kHz) ------------------------------------------------------------------
 // ct_wave_kernel at EIGHT complex points per lane on the 512-point transforms wf8_* (wc_wavefft.hpp): half the registers (four
 // wavefronts per SIMD instead of two), 7.7 KB of LDS.  The arithmetic is the wavefront kernel's, statement for statement; the
@@ -946,6 +1274,7 @@ using namespace wc;
 struct wc_cheaptrick {
 	int fs, fft_size;
 	bool wave;  // N = 2048 / 1024: one wavefront per frame (default; WC_CT_IMPL=block: the workgroup-per-frame kernel for every frame)
+	bool split = false;  // N = 2048: the wavefront kernel on eight points per lane (WC_CT_IMPL=split)
 	double q1, f0_floor_opt, f0_floor;
 	Device *dev;
 	DevBuf utts, cnt, uidx, rare, off, endpos, d_x, d_tpos, d_f0, d_sp;
@@ -1042,7 +1371,8 @@ int ct_frames(wc_cheaptrick *c, hipStream_t s, int n_utt, const double *d_x, con
 			break;
 		case 2048:
 			if (c->wave) {
-				hipLaunchKernelGGL(ct_wave_kernel, dim3(grid8), dim3(64), 0, s, a);
+				if (c->split) hipLaunchKernelGGL(ct_wave_split_kernel, dim3(grid8), dim3(64), 0, s, a);
+				else hipLaunchKernelGGL(ct_wave_kernel, dim3(grid8), dim3(64), 0, s, a);
 				hipLaunchKernelGGL((ct_frames_kernel<2048, WC_CT_THREADS, true>), dim3(64), dim3(WC_CT_THREADS), 0, s, a);
 			} else {
 				launch_ct<2048>(a, s);
@@ -1110,6 +1440,7 @@ wc_cheaptrick *wc_cheaptrick_create(int fs, double q1, double f0_floor, int fft_
 	{
 		const char *impl = getenv("WC_CT_IMPL");
 		c->wave = !(impl && std::strcmp(impl, "block") == 0);
+		c->split = impl && std::strcmp(impl, "split") == 0;  // N = 2048 on eight points per lane (ct_wave_split_kernel; A/B)
 	}
 	if (c->fft_size != 512 && c->fft_size != 1024 && c->fft_size != 2048 && c->fft_size != 4096) {
 		set_error("cheaptrick: fft_size must be 512, 1024, 2048 or 4096 (fs between 8 kHz and 96 kHz)");

@@ -1344,7 +1344,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_D4C2_BAND
 	const double *__restrict__ src = a.sgd + g * a.sgd_stride + (center - hwl);
 	const int ng = wln > 512 ? 2 : 1;
 	double key[2][16], keyM = 0.0;
-	double pf = 0.0;
+	[[maybe_unused]] double pf = 0.0;
 #pragma unroll
 	for (int odd = 0; odd < 2; ++odd) {
 		// the packed windowed group delay, elements lane + 64 q (read again for the second half rather than held across the first)

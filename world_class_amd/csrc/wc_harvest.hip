@@ -419,7 +419,48 @@ struct SdArgs {
 	double *slots;
 	int *slot_count;           // [utt][band][chunk][4]
 	int n_bands, n_chunks;
+	const double *taps;        // the filters themselves (per band, as the FIR band-pass reads them) ...
+	const int *tap_off;
+	double *seam;              // ... and what hv_seam_kernel makes of them: [utt][band][n_chunks + 1][2], the first two outputs of every chunk
 };
+
+// Seams (round 5).  A chunk's lane and its neighbour's both need the two outputs on either side of their common border -- each
+// detector looks two samples ahead -- and each would compute them with its own recurrence: two estimates of one sample, 1e-14 of
+// the signal apart.  Where the true value is zero (a train of impulses leaves exact zeros and exactly symmetric extrema between
+// its pulses) one lane then sees a crossing at the last sample of its chunk and the other one at the first sample of the next:
+// the same edge twice, an interval of nothing, a NaN in the raw candidates of 41 bands around every border
+// (profiles/r05_c_impulse_trains.txt: three voicing flips against the reference on one train in forty).  The first two outputs of
+// every chunk are therefore computed ONCE, here, as direct sums of the filter itself (1e-16, like the reference's FFT
+// convolution), and both lanes use these: every sample has one value again.  One thread per (band, chunk), the band's taps in
+// LDS; 0.02 ms per 64 x 10 s.
+__global__ __launch_bounds__(64) void hv_seam_kernel(SdArgs a) {
+	__shared__ double Tp[2 * HL_MAX + 16];
+	const int band = blockIdx.x;
+	const HvUtt u = a.utts[blockIdx.y];
+	const int hl = a.half_len[band], nt = 2 * hl + 1;
+	const double *__restrict__ taps = a.taps + a.tap_off[band];
+	for (int q = threadIdx.x; q < nt; q += 64) Tp[q] = taps[q];
+	__syncthreads();
+	const double *__restrict__ y = a.y + u.y_off;  // (zero margins of Y_PADL / Y_PADR samples)
+	double *__restrict__ out = a.seam + ((long long)blockIdx.y * a.n_bands + band) * (a.n_chunks + 1) * 2;
+	for (int c = threadIdx.x; c <= a.n_chunks; c += 64) {
+		const int i0 = c * SD_CH;
+		double f0 = 0.0, f1 = 0.0;
+		if (i0 < u.y_len) {
+			// output i is the filter centred on sample i + 1: sum_q tap[q] y[i + 1 - hl + q] (hv_bandpass_kernel)
+			const double *__restrict__ w = y + (i0 + 1 - hl);
+			double prev = w[0];
+			for (int q = 0; q < nt; ++q) {
+				const double next = w[q + 1];
+				f0 = fma(Tp[q], prev, f0);
+				f1 = fma(Tp[q], next, f1);
+				prev = next;
+			}
+		}
+		out[2 * c] = f0;
+		out[2 * c + 1] = f1;
+	}
+}
 
 #ifndef WC_SDFT_U
 #define WC_SDFT_U 4      // outputs per trip = depth of the sample prefetch
@@ -499,6 +540,10 @@ __global__ __launch_bounds__(64, WC_SDFT_WAVES) void hv_bandpass_sdft_kernel(SdA
 	double s0 = out();
 	slide(pn[0], po[0]);
 	double s1 = out();
+	// the chunk's first two outputs and its two outputs of lookahead (the next chunk's first two) from hv_seam_kernel: see there
+	const double *__restrict__ sm = a.seam + (((long long)blockIdx.y * a.n_bands + band) * (a.n_chunks + 1) + chunk) * 2;
+	if (live) { s0 = sm[0]; s1 = sm[1]; }
+	const double fn0 = live ? sm[2] : 0.0, fn1 = live ? sm[3] : 0.0;
 	const int cap = a.slot_cap[band];
 	double *__restrict__ slot = a.slots + blockIdx.y * a.slots_per_utt + a.slot_off[band] + (long long)chunk * 4 * cap;
 	int cnt[4] = {0, 0, 0, 0};
@@ -529,6 +574,7 @@ __global__ __launch_bounds__(64, WC_SDFT_WAVES) void hv_bandpass_sdft_kernel(SdA
 	for (int o = 32; o > 0; o >>= 1) steps = max(steps, __shfl_xor(steps, o, 64));
 	// four outputs per trip; the samples of a trip are requested one trip ahead of their use
 	constexpr int U = WC_SDFT_U;
+	static_assert(U >= 2 && SD_CH % U == 0, "the last trip of a whole chunk ends on the chunk's border");
 	double yn[U], yo[U];
 #pragma unroll
 	for (int k = 0; k < U; ++k) { yn[k] = pn[1 + k]; yo[k] = po[1 + k]; }
@@ -538,11 +584,14 @@ __global__ __launch_bounds__(64, WC_SDFT_WAVES) void hv_bandpass_sdft_kernel(SdA
 		for (int k = 0; k < U; ++k) { cn[k] = yn[k]; co[k] = yo[k]; }
 #pragma unroll
 		for (int k = 0; k < U; ++k) { yn[k] = pn[st + U + 1 + k]; yo[k] = po[st + U + 1 + k]; }
+		const bool last_trip = live && st + U == SD_CH;  // (a whole chunk's last trip: its outputs 2 and 3 are the next chunk's first two)
 #pragma unroll
 		for (int k = 0; k < U; ++k) {
 			const int i = i0 + st + k;
 			slide(cn[k], co[k]);
-			const double s2 = out();
+			double s2 = out();
+			if (k == U - 2) s2 = last_trip ? fn0 : s2;
+			if (k == U - 1) s2 = last_trip ? fn1 : s2;
 			// zeroCrossingEngine (reference :1179-1219) over the y_length samples (types 0, 1) and over the
 			// y_length - 1 first differences (types 2, 3); fine edge = edges[e] - sig[e-1] / (sig[e] - sig[e-1]) with
 			// edges = i + 1, the same for a signal and its negation
@@ -673,6 +722,10 @@ __global__ __launch_bounds__(64) void hv_bandpass_sdft8_kernel(SdArgs a) {
 	double s0 = out();
 	slide(pn[0], po[0]);
 	double s1 = out();
+	// the chunk's first two outputs and its two outputs of lookahead (the next chunk's first two) from hv_seam_kernel: see there
+	const double *__restrict__ sm = a.seam + (((long long)blockIdx.y * a.n_bands + band) * (a.n_chunks + 1) + chunk) * 2;
+	if (live) { s0 = sm[0]; s1 = sm[1]; }
+	const double fn0 = live ? sm[2] : 0.0, fn1 = live ? sm[3] : 0.0;
 	const int cap = a.slot_cap[band];
 	double *__restrict__ slot = a.slots + blockIdx.y * a.slots_per_utt + a.slot_off[band] + (long long)chunk * 4 * cap;
 	int cnt[4] = {0, 0, 0, 0};
@@ -681,6 +734,7 @@ __global__ __launch_bounds__(64) void hv_bandpass_sdft8_kernel(SdArgs a) {
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) steps = max(steps, __shfl_xor(steps, o, 64));
 	constexpr int U = WC_SDFT_U;
+	static_assert(U >= 2 && SD_CH % U == 0, "the last trip of a whole chunk ends on the chunk's border");
 	double yn[U], yo[U];
 #pragma unroll
 	for (int k = 0; k < U; ++k) { yn[k] = pn[1 + k]; yo[k] = po[1 + k]; }
@@ -701,6 +755,7 @@ __global__ __launch_bounds__(64) void hv_bandpass_sdft8_kernel(SdArgs a) {
 		double so[U];
 #pragma unroll
 		for (int k = 0; k < U; ++k) so[k] = out_of(sx[k]);
+		if (live && st + U == SD_CH) { so[U - 2] = fn0; so[U - 1] = fn1; }  // (the next chunk's first two outputs: hv_seam_kernel)
 #pragma unroll
 		for (int k = 0; k < U; ++k) {
 			const int i = i0 + st + k;
@@ -1042,6 +1097,7 @@ struct RefArgs {
 	double *cand1, *score1;
 	long long total_frames;
 	HvParams p;
+	int *flags;  // [0]: a rate-bounded buffer overflowed; [1]: a raw candidate sits on a tie of the refinement's integer decisions (below)
 };
 
 #ifndef WC_REFINE_WAVES
@@ -1419,6 +1475,24 @@ __global__ __launch_bounds__(64, RF_NP > 112 ? 2 : WC_REFINE_WAVES) void hv_refi
 			const int nh = min((int)(fs / 2.0 / f), 6);  // >= 1 below the Nyquist frequency
 			it_nh[at] = (unsigned char)nh;
 			pos_nh[j + S * blk] = (unsigned char)nh;
+			// Ties (round 5).  The window length, the six bins and the number of harmonics are integers cut out of the raw candidate: a
+			// candidate within the sliding band-pass's own rounding (1e-14 of it) of one of those cuts gets whichever side that
+			// rounding leaves it on -- a train of impulses whose period is a whole number of decimated samples puts 1.5 fs / f0 + 1
+			// EXACTLY on an integer in every voiced frame, and the reference's FFT convolution, rounding at 1e-16, decides otherwise
+			// than a sliding DFT (profiles/r05_c_impulse_trains.txt: 1.1e-2 Hz and three voicing flips against 1e-11 Hz with the direct
+			// FIR).  Such a candidate raises a flag (within 2e-13 relative of a cut: 20 x the rounding, one natural utterance in a
+			// thousand); the caller then runs the batch again with the band-pass as a direct FIR sum (hv_exact_twin).
+			{
+				const double tol = 2e-13;
+				const double v = 1.5 * fs / f + 1.0, v2 = fs / 2.0 / f;
+				bool tie = fabs(v - rint(v)) < tol * v || (v2 < 7.0 && fabs(v2 - rint(v2)) < tol * v2);
+#pragma unroll
+				for (int h = 0; h < 6; ++h) {
+					const double wv = bin_unit * (h + 1);
+					tie = tie || fabs(wv - floor(wv) - 0.5) < tol * wv;
+				}
+				if (tie) a.flags[1] = 1;
+			}
 		}
 		n += __popcll(m);
 	}
@@ -2489,7 +2563,7 @@ struct wc_harvest {
 	std::vector<double> band_f0;
 	std::vector<int> half_len, tap_off;
 	DevBuf d_taps, d_tap_off, d_half_len, d_band_f0, d_ev_band_off, d_ev_cap, d_rot;
-	DevBuf d_sd_rot, d_sd_p0, d_slot_off, d_slot_cap, slots, slot_count;
+	DevBuf d_sd_rot, d_sd_p0, d_slot_off, d_slot_cap, slots, slot_count, seam;
 	bool debug_small_caps;  // WC_DEBUG_SMALL_CAPS, read once at creation: tiny rate-bounded buffers, so that the overflow retry runs (tests)
 	bool tables_valid;  // the capacity tables on the device are those of (tables_ylen, tables_full, tables_tiles)
 	int tables_ylen, tables_full, tables_tiles;
@@ -2499,6 +2573,9 @@ struct wc_harvest {
 	bool use_cos_table;  // HarvestOption::use_cos_table
 	DevBuf d_cos_table;
 	int phases = 3;  // hv_set_phases: 1 = front (decimation .. refinement), 2 = tail (unreliable-candidate test .. output), 3 = both
+	bool ignore_ties = false;  // WC_HARVEST_TIES=ignore: the tie flag is not acted upon (A/B and tests)
+	wc_harvest *exact_twin = nullptr;  // the same options with the band-pass as a direct FIR sum: re-runs of batches that raised the tie flag (hv_exact_twin)
+	int use_cos_table_opt = 0;
 	bool raw_from_lists;    // WC_HARVEST_RAW=lists: the edges packed into per-band lists before hv_raw reads them (A/B and the bit-identity test)
 	long long slots_per_utt = 0;
 	bool refine_by_slots;   // WC_HARVEST_REFINE=slots: one wavefront per candidate slot instead of the packed passes (A/B and the bit-identity test)
@@ -2602,7 +2679,7 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 	// event capacities per band and type: a rate bound, or the hard bound when `full`
 	std::vector<long long> ev_band_off(nb);
 	std::vector<int> ev_cap(nb);
-	if ((rc = h->overflow.reserve(sizeof(int)))) return rc;
+	if ((rc = h->overflow.reserve(2 * sizeof(int)))) return rc;  // [0] overflow, [1] tie (RefArgs::flags)
 	if ((rc = h->utts.reserve(sizeof(HvUtt) * n_utt))) return rc;
 	if ((rc = h->y.reserve(sizeof(double) * yo))) return rc;
 	if (r != 1 && (rc = h->dec.reserve(sizeof(double) * deco))) return rc;
@@ -2656,6 +2733,7 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 		if (!h->use_fir) {
 			if ((rc = h->slots.reserve(sizeof(double) * slots_per_utt * n_utt))) return rc;
 			if ((rc = h->slot_count.reserve(sizeof(int) * 4ll * n_tiles * nb * n_utt))) return rc;
+			if ((rc = h->seam.reserve(sizeof(double) * 2ll * (n_tiles + 1) * nb * n_utt))) return rc;
 			if ((rc = h->d_slot_off.reserve(sizeof(long long) * nb))) return rc;
 			if ((rc = h->d_slot_cap.reserve(sizeof(int) * nb))) return rc;
 		}
@@ -2690,7 +2768,7 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 		}
 		if (!resume) {
 			if ((rc = h->h_stage.mark(s))) return rc;
-			WC_HIP(hipMemsetAsync(h->overflow.p, 0, sizeof(int), s));
+			WC_HIP(hipMemsetAsync(h->overflow.p, 0, 2 * sizeof(int), s));
 		}
 		const HvUtt *du = h->utts.as<HvUtt>();
 		if (phases & 1) {
@@ -2733,6 +2811,8 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 			sa.slots_per_utt = slots_per_utt; sa.slots = h->slots.as<double>(); sa.slot_count = h->slot_count.as<int>();
 			h->slots_per_utt = slots_per_utt;
 			sa.n_bands = nb; sa.n_chunks = n_tiles;
+			sa.taps = h->d_taps.as<double>(); sa.tap_off = h->d_tap_off.as<int>(); sa.seam = h->seam.as<double>();
+			hipLaunchKernelGGL(hv_seam_kernel, dim3(nb, n_utt), dim3(64), 0, s, sa);
 			// small batches leave most of the chip idle with a lane per (band, chunk): eight lanes each then (same bits)
 			const long long waves1 = (long long)((nb * n_tiles + 63) / 64) * n_utt;
 			if (h->sdft_lanes == 8 || (h->sdft_lanes == 0 && waves1 * 8 <= 3072))
@@ -2773,6 +2853,7 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 	fa.p.f0_floor = h->f0_floor; fa.p.f0_ceil = h->f0_ceil; fa.p.frame_period = h->frame_period;
 	if ((rc = dev->time_begin("harvest_refine", s))) return rc;
 	fa.cos_table = h->d_cos_table.as<double>();
+	fa.flags = h->overflow.as<int>();
 	launch_refine(fa, s, h->refine_by_slots, h->use_cos_table);
 	h->last_refine = fa;
 	h->last_refine_valid = true;
@@ -2834,13 +2915,27 @@ int hv_reserve_rows(wc_harvest *h, long long total_l1) {
 double *hv_candidate_rows(wc_harvest *h) { return h->cand1.as<double>(); }
 double *hv_score_rows(wc_harvest *h) { return h->score1.as<double>(); }
 
-// after hv_enqueue: synchronises the stream and reports whether the zero-crossing buffers overflowed
-int hv_overflowed(wc_harvest *h, hipStream_t s, bool *overflow) {
-	int ovf = 0;
-	WC_HIP(hipMemcpyAsync(&ovf, h->overflow.p, sizeof(int), hipMemcpyDeviceToHost, s));
+// after hv_enqueue: synchronises the stream and reports whether the zero-crossing buffers overflowed and (tie != NULL) whether a
+// raw candidate sat on a tie of the refinement's integer decisions (never reported by a handle whose band-pass is the FIR sum)
+int hv_overflowed(wc_harvest *h, hipStream_t s, bool *overflow, bool *tie) {
+	int fl[2] = {0, 0};
+	WC_HIP(hipMemcpyAsync(fl, h->overflow.p, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
 	WC_HIP(hipStreamSynchronize(s));
-	*overflow = ovf != 0;
+	*overflow = fl[0] != 0;
+	if (tie) *tie = fl[1] != 0 && !h->use_fir && !h->ignore_ties;
 	return WC_OK;
+}
+// the handle that re-runs a batch after the tie flag: the same options, band-pass by direct FIR sums (created on first use)
+wc_harvest *hv_exact_twin(wc_harvest *h) {
+	if (h->use_fir) return h;
+	if (!h->exact_twin) {
+		wc_harvest *t = wc_harvest_create(h->fs, h->f0_floor, h->f0_ceil, h->frame_period, h->target_fs, h->channels_in_octave, h->use_cos_table_opt);
+		if (!t) return nullptr;
+		t->use_fir = true;
+		t->phases = h->phases;
+		h->exact_twin = t;
+	}
+	return h->exact_twin;
 }
 
 static int hv_run_device(wc_harvest *h, int n_utt, const double *d_x, const int *x_length, double *d_tpos, double *d_f0) {
@@ -2848,8 +2943,20 @@ static int hv_run_device(wc_harvest *h, int n_utt, const double *d_x, const int 
 	int rc;
 	for (int attempt = 0; attempt < 2; ++attempt) {
 		if ((rc = hv_enqueue(h, s, n_utt, d_x, x_length, d_tpos, d_f0, attempt == 1, nullptr, nullptr, 3, nullptr, nullptr))) return rc;
-		bool overflow = false;
-		if ((rc = hv_overflowed(h, s, &overflow))) return rc;
+		bool overflow = false, tie = false;
+		if ((rc = hv_overflowed(h, s, &overflow, &tie))) return rc;
+		if (tie && h->phases == 3) {
+			// (a candidate on a tie: the whole batch once more with the band-pass as direct FIR sums, see hv_refine_packed_kernel)
+			wc_harvest *t = hv_exact_twin(h);
+			if (!t) return WC_ERR_DEVICE;
+			for (int at2 = 0; at2 < 2; ++at2) {
+				if ((rc = hv_enqueue(t, s, n_utt, d_x, x_length, d_tpos, d_f0, at2 == 1, nullptr, nullptr, 3, nullptr, nullptr))) return rc;
+				bool o2 = false;
+				if ((rc = hv_overflowed(t, s, &o2, nullptr))) return rc;
+				if (!o2) return WC_OK;
+			}
+			return fail(WC_ERR_DEVICE, "harvest: zero-crossing buffer overflow");
+		}
 		if (!overflow) return WC_OK;
 	}
 	return fail(WC_ERR_DEVICE, "harvest: zero-crossing buffer overflow");
@@ -2868,6 +2975,7 @@ wc_harvest *wc_harvest_create(int fs, double f0_floor, double f0_ceil, double fr
 	wc_harvest *h = new wc_harvest();
 	h->fs = fs; h->f0_floor = f0_floor; h->f0_ceil = f0_ceil; h->frame_period = frame_period; h->target_fs = target_fs;
 	h->channels_in_octave = channels_in_octave; h->dev = dev;
+	h->use_cos_table_opt = use_cos_table;
 	h->use_cos_table = use_cos_table != 0;
 	// reference src/harvest.cpp:82-84, :1388-1397, :1418-1419
 	h->decim = std::max(std::min(h_mround(fs / target_fs), 12), 1);
@@ -2939,6 +3047,8 @@ wc_harvest *wc_harvest_create(int fs, double f0_floor, double f0_ceil, double fr
 			 hipMemcpy(h->d_sd_p0.p, sd_p0.data(), sizeof(double2) * sd_p0.size(), hipMemcpyHostToDevice) == hipSuccess;
 		const char *bp = getenv("WC_HARVEST_BANDPASS");
 		h->use_fir = bp && std::strcmp(bp, "fir") == 0;
+		const char *ti = getenv("WC_HARVEST_TIES");
+		h->ignore_ties = ti && std::strcmp(ti, "ignore") == 0;
 		const char *sl = getenv("WC_HARVEST_SDFT_LANES");
 		h->sdft_lanes = sl ? atoi(sl) : 0;
 		h->tables_valid = false;
@@ -2989,8 +3099,9 @@ int wc_harvest_get_samples(const wc_harvest *h, int x_length) {
 void wc_harvest_destroy(wc_harvest *h) {
 	if (!h) return;
 	h->dev->quiesce();
+	if (h->exact_twin) wc_harvest_destroy(h->exact_twin);
 	h->dev->handle_gone();
-	for (DevBuf *b : {&h->d_cos_table, &h->d_sd_rot, &h->d_sd_p0, &h->d_slot_off, &h->d_slot_cap, &h->slots, &h->slot_count, &h->d_rot, &h->d_taps, &h->d_tap_off, &h->d_half_len, &h->d_band_f0, &h->d_ev_band_off, &h->d_ev_cap, &h->utts, &h->dec, &h->y,
+	for (DevBuf *b : {&h->d_cos_table, &h->d_sd_rot, &h->d_sd_p0, &h->d_slot_off, &h->d_slot_cap, &h->slots, &h->slot_count, &h->seam, &h->d_rot, &h->d_taps, &h->d_tap_off, &h->d_half_len, &h->d_band_f0, &h->d_ev_band_off, &h->d_ev_cap, &h->utts, &h->dec, &h->y,
 					  &h->events, &h->ev_count, &h->overflow, &h->tile_run, &h->raw, &h->cand0, &h->cand1, &h->score1, &h->cand2, &h->score2, &h->base,
 					  &h->s1, &h->s2, &h->s3, &h->fixed, &h->f0_1ms, &h->sec, &h->chan, &h->smooth, &h->ibuf, &h->d_x, &h->d_tpos, &h->d_f0})
 		b->release();

@@ -351,7 +351,8 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 		// of two or three fills a few per cent of the chip: holding the next one back behind it is latency for nothing)
 		const int chain_min = getenv("WC_PIPELINE_CHAIN_MIN") ? atoi(getenv("WC_PIPELINE_CHAIN_MIN")) : 4;
 		bool full[kMaxGroups][2] = {};
-		for (int attempt = 0; attempt < 3; ++attempt) {
+		bool exact[kMaxGroups] = {};  // the group's refinement met a candidate on a tie: its Harvest runs again on the FIR twin (hv_exact_twin)
+		for (int attempt = 0; attempt < 4; ++attempt) {
 			const int bins_ = p->fft_size / 2 + 1;
 			struct Slice { int u0, nu; long long xo, fo, yo; } sl[kMaxGroups];
 			long long fo_end[kMaxGroups];
@@ -397,7 +398,9 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 				PipeGroup &G = p->grp[g];
 				dev->time_tag = g;
 				if (g >= 1 && sink && sink->x_ev[g]) WC_HIP(hipStreamWaitEvent(mainS[g], sink->x_ev[g], 0));
-				return hv_enqueue(G.hv, mainS[g], sl[g].nu, d_x + sl[g].xo, x_length + sl[g].u0, d_tpos + sl[g].fo, d_f0 + sl[g].fo,
+				wc_harvest *hvg = exact[g] ? hv_exact_twin(G.hv) : G.hv;
+				if (!hvg) return WC_ERR_DEVICE;
+				return hv_enqueue(hvg, mainS[g], sl[g].nu, d_x + sl[g].xo, x_length + sl[g].u0, d_tpos + sl[g].fo, d_f0 + sl[g].fo,
 								  full[g][0], G.e_mid, (g >= 1 && chain_harvest && sl[g - 1].nu >= chain_min) ? p->grp[g - 1].e_mid : nullptr, (g == 0 && tail_late) ? 1 : 3,
 								  (g == 1 && tail_late) ? p->e_bp : nullptr, nullptr);
 			};
@@ -525,9 +528,11 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 				bool o1 = false, o2 = false;
 				if ((rc = syn_finish(G.sy, synS[g], rng_pos ? rng_pos + u0 : nullptr, &o2))) return rc;
 				pmark(g == 0 ? "group 0 finished" : g + 1 < NG ? "a middle group finished" : "the last group finished");
-				if ((rc = hv_overflowed(G.hv, mainS[g], &o1))) return rc;
+				bool tie = false;
+				if ((rc = hv_overflowed(exact[g] ? hv_exact_twin(G.hv) : G.hv, mainS[g], &o1, &tie))) return rc;
 				full[g][0] = full[g][0] || o1;
 				full[g][1] = full[g][1] || o2;
+				if (tie && !exact[g]) { exact[g] = true; again = true; }
 				again = again || o1 || o2;
 			}
 			if (again && sink) for (int g = 0; g < kMaxGroups; ++g) sink->overlapped[g] = false;  // the re-run rewrites the rows

@@ -8,7 +8,9 @@
 int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const int *x_length, double *d_tpos, double *d_f0,
 			   bool full, hipEvent_t mid_event, hipEvent_t start_after, int part = 3, hipEvent_t bp_done = nullptr,
 			   hipEvent_t tail_after = nullptr);
-int hv_overflowed(wc_harvest *h, hipStream_t s, bool *overflow);
+int hv_overflowed(wc_harvest *h, hipStream_t s, bool *overflow, bool *tie = nullptr);
+// a batch whose refinement raised the tie flag is run again on this handle: the same options, band-pass as direct FIR sums
+wc_harvest *hv_exact_twin(wc_harvest *h);
 // Harvest in two parts (incremental streams): phases 1 = front (decimation .. refinement), 2 = tail (unreliable .. output), 3 = both
 void hv_set_phases(wc_harvest *h, int mask);
 int hv_row_width(const wc_harvest *h);
