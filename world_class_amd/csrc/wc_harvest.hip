@@ -37,6 +37,8 @@
 #include <vector>
 
 #include "wc_argsort.hpp"
+#include <algorithm>
+
 #include "wc_device.hpp"
 #include "wc_internal.hpp"
 #include "wc_frames.hpp"
@@ -422,6 +424,9 @@ struct SdArgs {
 	const double *taps;        // the filters themselves (per band, as the FIR band-pass reads them) ...
 	const int *tap_off;
 	double *seam;              // ... and what hv_seam_kernel makes of them: [utt][band][n_chunks + 1][2], the first two outputs of every chunk
+	const int *quiet;          // [utt][n_chunks]: chunks the sliding sums leave to hv_bandpass_quiet_kernel (hv_quiet_kernel), then [utt]: any
+	const double *bmax;        // [utt][n_blk]: largest |y| of every 64 samples (hv_blockmax_kernel)
+	int n_blk, hl_max;
 };
 
 // Seams (round 5).  A chunk's lane and its neighbour's both need the two outputs on either side of their common border -- each
@@ -462,6 +467,166 @@ __global__ __launch_bounds__(64) void hv_seam_kernel(SdArgs a) {
 	}
 }
 
+// Quiet chunks (round 5).  A sliding sum carries the rounding of everything that has passed through it: 1e-14 of the LOUDEST
+// stretch since it was built.  Where the signal then falls silent -- digital silence behind an utterance, a gated segment; after
+// decimation the decimator's decaying tail -- the true output drops by hundreds of decibels and the sum keeps oscillating at
+// its own frequency with that stale amplitude: a perfectly periodic "signal" in every band, whose zero crossings make consistent
+// raw candidates at the band frequencies and pull the contour's ends (9 Hz on the last frames of a voiced segment in front of a
+// gated one, 24 / 96 kHz: profiles/r05_c_quiet_chunks.txt; the direct FIR sum and the reference's FFT convolution -- noise 1e-16 of
+// the global maximum, incoherent -- leave nothing of the kind).  hv_blockmax_kernel / hv_quiet_kernel mark every chunk in
+// whose span (build window included) the level of 64 samples falls below 1e-8 of what the span has seen before; the sliding
+// kernels skip those, and hv_bandpass_quiet_kernel does them as direct FIR sums into the same slots (four times the work per
+// chunk; none on signals with a noise floor, a chunk or two per pause on digitally silenced ones).
+constexpr double kQuietDrop = 1e-8;
+__global__ __launch_bounds__(256) void hv_blockmax_kernel(SdArgs a, double *__restrict__ bmax) {
+	const int lane = threadIdx.x & 63, blk = blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (blk >= a.n_blk) return;
+	const HvUtt u = a.utts[blockIdx.y];
+	const int i = blk * 64 + lane;
+	double v = i < u.y_len ? fabs(a.y[u.y_off + i]) : 0.0;
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+	if (lane == 0) bmax[(long long)blockIdx.y * a.n_blk + blk] = v;
+}
+__global__ __launch_bounds__(64) void hv_quiet_kernel(SdArgs a, int *__restrict__ quiet, int enable) {
+	const HvUtt u = a.utts[blockIdx.x];
+	const double *__restrict__ bm = a.bmax + (long long)blockIdx.x * a.n_blk;
+	int any = 0;
+	for (int c = threadIdx.x; c < a.n_chunks; c += 64) {
+		const int i0 = c * SD_CH;
+		int flag = 0;
+		if (enable && i0 < u.y_len) {
+			// the samples a lane of this chunk ever sees: its build window (2 hl + 1 samples in front of output i0) to its lookahead
+			const int b0 = max(0, (i0 - 2 * a.hl_max - 2) / 64), b1 = min(a.n_blk - 1, (i0 + SD_CH + a.hl_max + 4) / 64);
+			double m = 0.0;
+			for (int b = b0; b <= b1; ++b) {
+				const double v = bm[b];
+				if (v < kQuietDrop * m) flag = 1;
+				m = fmax(m, v);
+			}
+		}
+		quiet[(long long)blockIdx.x * a.n_chunks + c] = flag;
+		any |= flag;
+	}
+	any = __any(any);
+	if (threadIdx.x == 0) quiet[(long long)gridDim.x * a.n_chunks + blockIdx.x] = any;
+}
+// the marked chunks of one (band, utterance): hv_bandpass_kernel's tile -- direct sums of the filter, eight outputs per thread,
+// ordered compaction -- on whole chunks, edges into the chunk's slots, the chunk's first two outputs and its lookahead from
+// hv_seam_kernel like everywhere else
+__global__ __launch_bounds__(BP_T, 3) void hv_bandpass_quiet_kernel(SdArgs a) {
+	__shared__ double Ys[(BP_TILE + 2 * HL_MAX + 32) * 9 / 8 + 16];
+	__shared__ double Tp[2 * HL_MAX + 16];
+	double *Ss = Ys;
+	__shared__ unsigned long long scan_s[BP_T / 64];
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int band = blockIdx.x;
+	if (!a.quiet[(long long)gridDim.y * a.n_chunks + blockIdx.y]) return;  // (nothing marked in this utterance: the usual case)
+	const HvUtt u = a.utts[blockIdx.y];
+	const int hl = a.half_len[band];
+	const int nt8 = ((2 * hl + 1 + 7) / 8) * 8;
+	const double *__restrict__ y = a.y + u.y_off;
+	const double *__restrict__ taps = a.taps + a.tap_off[band];
+	for (int i = tid; i < nt8; i += BP_T) Tp[i] = taps[i];
+	const int cap = a.slot_cap[band];
+	const int t0 = tid * BP_R;
+	const int *__restrict__ qf = a.quiet + (long long)blockIdx.y * a.n_chunks;
+	for (int c = 0; c < a.n_chunks; ++c) {
+		if (!qf[c]) continue;  // (uniform)
+		const int ts = c * SD_CH;
+		double *__restrict__ slot = a.slots + blockIdx.y * a.slots_per_utt + a.slot_off[band] + (long long)c * 4 * cap;
+		const double *__restrict__ sm = a.seam + (((long long)blockIdx.y * a.n_bands + band) * (a.n_chunks + 1) + c) * 2;
+		// Ys[m] = y[ts + 1 - hl + m], m in [0, TILE + nt8 + 8)
+		__syncthreads();
+		for (int m = tid; m < BP_TILE + nt8 + 8; m += BP_T) {
+			int g = ts + 1 - hl + m;
+			Ys[padidx(m)] = (g >= 0 && g < u.y_len) ? y[g] : 0.0;
+		}
+		__syncthreads();
+		double acc[BP_R];
+#pragma unroll
+		for (int j = 0; j < BP_R; ++j) acc[j] = 0.0;
+		double w[16];
+#pragma unroll
+		for (int k = 0; k < 8; ++k) w[k] = Ys[padidx(t0 + k)];
+		for (int q0 = 0; q0 < nt8; q0 += 8) {
+			double tp[8];
+#pragma unroll
+			for (int k = 0; k < 8; ++k) { w[8 + k] = Ys[padidx(t0 + q0 + 8 + k)]; tp[k] = Tp[q0 + k]; }
+#pragma unroll
+			for (int qq = 0; qq < 8; ++qq)
+#pragma unroll
+				for (int j = 0; j < BP_R; ++j) acc[j] = fma(tp[qq], w[qq + j], acc[j]);
+#pragma unroll
+			for (int k = 0; k < 8; ++k) w[k] = w[8 + k];
+		}
+		__syncthreads();  // every thread is done reading the signal tile
+#pragma unroll
+		for (int j = 0; j < BP_R; ++j) Ss[padidx(t0 + j)] = acc[j];
+		if (tid == 0) {  // one value per sample at the borders (hv_seam_kernel)
+			Ss[padidx(0)] = sm[0];
+			Ss[padidx(1)] = sm[1];
+			Ss[padidx(BP_TILE)] = sm[2];
+			Ss[padidx(BP_TILE + 1)] = sm[3];
+		}
+		__syncthreads();
+		double sv[BP_R + 2];
+#pragma unroll
+		for (int j = 0; j < BP_R + 2; ++j) sv[j] = Ss[padidx(t0 + j)];
+		unsigned int mask[4] = {0, 0, 0, 0};
+#pragma unroll
+		for (int j = 0; j < BP_R; ++j) {
+			const int i = ts + t0 + j;
+			const double s0 = sv[j], s1 = sv[j + 1], s2 = sv[j + 2];
+			if (i + 1 < u.y_len) {
+				if (0.0 < s0 && s1 <= 0.0) mask[0] |= 1u << j;
+				if (0.0 < -s0 && -s1 <= 0.0) mask[1] |= 1u << j;
+			}
+			if (i + 2 < u.y_len) {
+				const double d0 = s1 - s0, d1 = s2 - s1;
+				if (0.0 < d0 && d1 <= 0.0) mask[2] |= 1u << j;
+				if (0.0 < -d0 && -d1 <= 0.0) mask[3] |= 1u << j;
+			}
+		}
+		unsigned long long packed = 0;
+#pragma unroll
+		for (int ty = 0; ty < 4; ++ty) packed |= (unsigned long long)__popc(mask[ty]) << (16 * ty);
+		unsigned long long inc = packed;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			unsigned long long t = __shfl_up(inc, o, 64);
+			if (lane >= o) inc += t;
+		}
+		if (lane == 63) scan_s[wv] = inc;
+		__syncthreads();
+		unsigned long long base = 0, total = 0;
+#pragma unroll
+		for (int k = 0; k < BP_T / 64; ++k) {
+			unsigned long long t = scan_s[k];
+			if (k < wv) base += t;
+			total += t;
+		}
+		const unsigned long long excl = base + inc - packed;
+#pragma unroll
+		for (int ty = 0; ty < 4; ++ty) {
+			int at = (int)((excl >> (16 * ty)) & 0xffffull);
+#pragma unroll
+			for (int j = 0; j < BP_R; ++j) {
+				if (mask[ty] & (1u << j)) {
+					const int i = ts + t0 + j;
+					double v0, v1;
+					if (ty < 2) { v0 = sv[j]; v1 = sv[j + 1]; }
+					else { v0 = sv[j + 1] - sv[j]; v1 = sv[j + 2] - sv[j + 1]; }
+					const double fine = (i + 1) - v0 / (v1 - v0);
+					if (at < cap) slot[(long long)ty * cap + at] = fine;
+					++at;
+				}
+			}
+		}
+		if (tid < 4) a.slot_count[(((long long)blockIdx.y * a.n_bands + band) * a.n_chunks + c) * 4 + tid] = (int)((total >> (16 * tid)) & 0xffffull);
+	}
+}
+
 #ifndef WC_SDFT_U
 #define WC_SDFT_U 4      // outputs per trip = depth of the sample prefetch
 #endif
@@ -479,9 +644,10 @@ __global__ __launch_bounds__(64, WC_SDFT_WAVES) void hv_bandpass_sdft_kernel(SdA
 	const int chunk = valid ? item / a.n_bands : 0;
 	const int band = valid ? item - chunk * a.n_bands : 0;
 	const int i0 = chunk * SD_CH;
-	const bool live = valid && i0 < u.y_len;
+	const bool skip = valid && a.quiet[(long long)blockIdx.y * a.n_chunks + chunk] != 0;  // (left to hv_bandpass_quiet_kernel, counts and all)
+	const bool live = valid && i0 < u.y_len && !skip;
 	if (__ballot(live) == 0ull) {
-		if (valid) {
+		if (valid && !skip) {
 			int *c = a.slot_count + (((long long)blockIdx.y * a.n_bands + band) * a.n_chunks + chunk) * 4;
 			c[0] = c[1] = c[2] = c[3] = 0;
 		}
@@ -629,7 +795,7 @@ __global__ __launch_bounds__(64, WC_SDFT_WAVES) void hv_bandpass_sdft_kernel(SdA
 		}
 	}
 #endif
-	if (valid) {
+	if (valid && !skip) {
 		int *c = a.slot_count + (((long long)blockIdx.y * a.n_bands + band) * a.n_chunks + chunk) * 4;
 #pragma unroll
 		for (int ty = 0; ty < 4; ++ty) c[ty] = cnt[ty];
@@ -665,10 +831,11 @@ __global__ __launch_bounds__(64) void hv_bandpass_sdft8_kernel(SdArgs a) {
 	const int chunk = valid ? item / a.n_bands : 0;
 	const int band = valid ? item - chunk * a.n_bands : 0;
 	const int i0 = chunk * SD_CH;
-	const bool live = valid && i0 < u.y_len;
+	const bool skip = valid && a.quiet[(long long)blockIdx.y * a.n_chunks + chunk] != 0;
+	const bool live = valid && i0 < u.y_len && !skip;
 	const bool head = sub == 0;
 	if (__ballot(live) == 0ull) {
-		if (valid && head) {
+		if (valid && head && !skip) {
 			int *c = a.slot_count + (((long long)blockIdx.y * a.n_bands + band) * a.n_chunks + chunk) * 4;
 			c[0] = c[1] = c[2] = c[3] = 0;
 		}
@@ -782,7 +949,7 @@ __global__ __launch_bounds__(64) void hv_bandpass_sdft8_kernel(SdArgs a) {
 			s1 = s2;
 		}
 	}
-	if (valid && head) {
+	if (valid && head && !skip) {
 		int *c = a.slot_count + (((long long)blockIdx.y * a.n_bands + band) * a.n_chunks + chunk) * 4;
 #pragma unroll
 		for (int ty = 0; ty < 4; ++ty) c[ty] = cnt[ty];
@@ -2563,7 +2730,7 @@ struct wc_harvest {
 	std::vector<double> band_f0;
 	std::vector<int> half_len, tap_off;
 	DevBuf d_taps, d_tap_off, d_half_len, d_band_f0, d_ev_band_off, d_ev_cap, d_rot;
-	DevBuf d_sd_rot, d_sd_p0, d_slot_off, d_slot_cap, slots, slot_count, seam;
+	DevBuf d_sd_rot, d_sd_p0, d_slot_off, d_slot_cap, slots, slot_count, seam, quiet, bmax;
 	bool debug_small_caps;  // WC_DEBUG_SMALL_CAPS, read once at creation: tiny rate-bounded buffers, so that the overflow retry runs (tests)
 	bool tables_valid;  // the capacity tables on the device are those of (tables_ylen, tables_full, tables_tiles)
 	int tables_ylen, tables_full, tables_tiles;
@@ -2573,6 +2740,7 @@ struct wc_harvest {
 	bool use_cos_table;  // HarvestOption::use_cos_table
 	DevBuf d_cos_table;
 	int phases = 3;  // hv_set_phases: 1 = front (decimation .. refinement), 2 = tail (unreliable-candidate test .. output), 3 = both
+	bool no_quiet = false;  // WC_HARVEST_QUIET=sliding: no chunk is left to the FIR sums (A/B and tests)
 	bool ignore_ties = false;  // WC_HARVEST_TIES=ignore: the tie flag is not acted upon (A/B and tests)
 	wc_harvest *exact_twin = nullptr;  // the same options with the band-pass as a direct FIR sum: re-runs of batches that raised the tie flag (hv_exact_twin)
 	int use_cos_table_opt = 0;
@@ -2734,6 +2902,8 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 			if ((rc = h->slots.reserve(sizeof(double) * slots_per_utt * n_utt))) return rc;
 			if ((rc = h->slot_count.reserve(sizeof(int) * 4ll * n_tiles * nb * n_utt))) return rc;
 			if ((rc = h->seam.reserve(sizeof(double) * 2ll * (n_tiles + 1) * nb * n_utt))) return rc;
+			if ((rc = h->quiet.reserve(sizeof(int) * ((long long)n_tiles + 1) * n_utt))) return rc;
+			if ((rc = h->bmax.reserve(sizeof(double) * (long long)((max_ylen + 63) / 64) * n_utt))) return rc;
 			if ((rc = h->d_slot_off.reserve(sizeof(long long) * nb))) return rc;
 			if ((rc = h->d_slot_cap.reserve(sizeof(int) * nb))) return rc;
 		}
@@ -2812,6 +2982,11 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 			h->slots_per_utt = slots_per_utt;
 			sa.n_bands = nb; sa.n_chunks = n_tiles;
 			sa.taps = h->d_taps.as<double>(); sa.tap_off = h->d_tap_off.as<int>(); sa.seam = h->seam.as<double>();
+			sa.n_blk = (max_ylen + 63) / 64;
+			sa.hl_max = *std::max_element(h->half_len.begin(), h->half_len.end());
+			sa.bmax = h->bmax.as<double>(); sa.quiet = h->quiet.as<int>();
+			hipLaunchKernelGGL(hv_blockmax_kernel, dim3((sa.n_blk + 3) / 4, n_utt), dim3(256), 0, s, sa, h->bmax.as<double>());
+			hipLaunchKernelGGL(hv_quiet_kernel, dim3(n_utt), dim3(64), 0, s, sa, h->quiet.as<int>(), h->no_quiet ? 0 : 1);
 			hipLaunchKernelGGL(hv_seam_kernel, dim3(nb, n_utt), dim3(64), 0, s, sa);
 			// small batches leave most of the chip idle with a lane per (band, chunk): eight lanes each then (same bits)
 			const long long waves1 = (long long)((nb * n_tiles + 63) / 64) * n_utt;
@@ -2819,6 +2994,7 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 				hipLaunchKernelGGL(hv_bandpass_sdft8_kernel, dim3((nb * n_tiles + 7) / 8, n_utt), dim3(64), 0, s, sa);
 			else
 				hipLaunchKernelGGL(hv_bandpass_sdft_kernel, dim3((nb * n_tiles + 63) / 64, n_utt), dim3(64), 0, s, sa);
+			if (!h->no_quiet) hipLaunchKernelGGL(hv_bandpass_quiet_kernel, dim3(nb, n_utt), dim3(BP_T), 0, s, sa);
 			CpArgs ca;
 			ca.utts = du; ca.slot_off = sa.slot_off; ca.slot_cap = sa.slot_cap; ca.slots_per_utt = slots_per_utt; ca.slots = sa.slots;
 			ca.slot_count = sa.slot_count; ca.ev_band_off = ba.ev_band_off; ca.ev_cap = ba.ev_cap; ca.events = ba.events;
@@ -3049,6 +3225,8 @@ wc_harvest *wc_harvest_create(int fs, double f0_floor, double f0_ceil, double fr
 		h->use_fir = bp && std::strcmp(bp, "fir") == 0;
 		const char *ti = getenv("WC_HARVEST_TIES");
 		h->ignore_ties = ti && std::strcmp(ti, "ignore") == 0;
+		const char *qu = getenv("WC_HARVEST_QUIET");
+		h->no_quiet = qu && std::strcmp(qu, "sliding") == 0;
 		const char *sl = getenv("WC_HARVEST_SDFT_LANES");
 		h->sdft_lanes = sl ? atoi(sl) : 0;
 		h->tables_valid = false;
@@ -3101,7 +3279,7 @@ void wc_harvest_destroy(wc_harvest *h) {
 	h->dev->quiesce();
 	if (h->exact_twin) wc_harvest_destroy(h->exact_twin);
 	h->dev->handle_gone();
-	for (DevBuf *b : {&h->d_cos_table, &h->d_sd_rot, &h->d_sd_p0, &h->d_slot_off, &h->d_slot_cap, &h->slots, &h->slot_count, &h->seam, &h->d_rot, &h->d_taps, &h->d_tap_off, &h->d_half_len, &h->d_band_f0, &h->d_ev_band_off, &h->d_ev_cap, &h->utts, &h->dec, &h->y,
+	for (DevBuf *b : {&h->d_cos_table, &h->d_sd_rot, &h->d_sd_p0, &h->d_slot_off, &h->d_slot_cap, &h->slots, &h->slot_count, &h->seam, &h->quiet, &h->bmax, &h->d_rot, &h->d_taps, &h->d_tap_off, &h->d_half_len, &h->d_band_f0, &h->d_ev_band_off, &h->d_ev_cap, &h->utts, &h->dec, &h->y,
 					  &h->events, &h->ev_count, &h->overflow, &h->tile_run, &h->raw, &h->cand0, &h->cand1, &h->score1, &h->cand2, &h->score2, &h->base,
 					  &h->s1, &h->s2, &h->s3, &h->fixed, &h->f0_1ms, &h->sec, &h->chan, &h->smooth, &h->ibuf, &h->d_x, &h->d_tpos, &h->d_f0})
 		b->release();
