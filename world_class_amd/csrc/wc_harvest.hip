@@ -497,7 +497,8 @@ __global__ __launch_bounds__(64) void hv_quiet_kernel(SdArgs a, int *__restrict_
 		int flag = 0;
 		if (enable && i0 < u.y_len) {
 			// the samples a lane of this chunk ever sees: its build window (2 hl + 1 samples in front of output i0) to its lookahead
-			const int b0 = max(0, (i0 - 2 * a.hl_max - 2) / 64), b1 = min(a.n_blk - 1, (i0 + SD_CH + a.hl_max + 4) / 64);
+			// (not beyond the utterance's own end: what a lane reads there is margin, and its outputs there are masked)
+			const int b0 = max(0, (i0 - 2 * a.hl_max - 2) / 64), b1 = min(min(a.n_blk - 1, (u.y_len - 1) / 64), (i0 + SD_CH + a.hl_max + 4) / 64);
 			double m = 0.0;
 			for (int b = b0; b <= b1; ++b) {
 				const double v = bm[b];
