@@ -8,7 +8,10 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import world_class_amd as w  # noqa: E402
 from oracle import port, ref  # noqa: E402
-from world_class_amd.synth import SIGNAL_KINDS, make_signal  # noqa: E402
+from world_class_amd.synth import SIGNAL_KINDS, SIGNAL_KINDS2, make_signal, make_signal2  # noqa: E402
+
+if os.environ.get("ZOO2"):  # the second set of kinds (tests/parity_sweep.py --zoo2)
+    SIGNAL_KINDS, make_signal = SIGNAL_KINDS2, make_signal2
 
 P = port.Port()
 args = sys.argv[1:]
@@ -25,8 +28,13 @@ for k in range(0, len(args), 4):
     f_port = P.harvest(x, fs, frame_period=fp)[1]
     f_ref = ref.run_fresh("harvest", x, fs, frame_period=fp)[1]
     out = {}
-    for mode in ("sdft", "fir"):
+    for mode in ("sdft", "fir", "acting_on_ties", "no_quiet_chunks"):
         os.environ["WC_HARVEST_TIES"] = "ignore"
+        os.environ.pop("WC_HARVEST_QUIET", None)
+        if mode == "acting_on_ties":
+            os.environ.pop("WC_HARVEST_TIES", None)
+        if mode == "no_quiet_chunks":
+            os.environ["WC_HARVEST_QUIET"] = "sliding"
         if mode == "fir":
             os.environ["WC_HARVEST_BANDPASS"] = "fir"
         else:
@@ -50,6 +58,8 @@ for k in range(0, len(args), 4):
     print("   gpu(sdft) vs ref flips %d max dev %.3e" % cmp(out["sdft"], f_ref))
     print("   gpu(fir)  vs ref flips %d max dev %.3e" % cmp(out["fir"], f_ref))
     print("   gpu(sdft) vs port flips %d max dev %.3e" % cmp(out["sdft"], f_port))
+    print("   gpu(sdft, acting on ties) vs ref flips %d max dev %.3e" % cmp(out["acting_on_ties"], f_ref))
+    print("   gpu(sdft, quiet chunks left to the sliding sums) vs ref flips %d max dev %.3e" % cmp(out["no_quiet_chunks"], f_ref))
     d = np.abs(out["sdft"] - f_ref)
     idx = np.nonzero(d > 1e-3)[0]
     print("   frames with |gpu - ref| > 1e-3:", idx[:12], "..." if len(idx) > 12 else "", "gpu", out["sdft"][idx[:6]], "ref", f_ref[idx[:6]], flush=True)

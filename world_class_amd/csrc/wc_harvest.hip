@@ -3122,15 +3122,26 @@ static int hv_run_device(wc_harvest *h, int n_utt, const double *d_x, const int 
 		if ((rc = hv_enqueue(h, s, n_utt, d_x, x_length, d_tpos, d_f0, attempt == 1, nullptr, nullptr, 3, nullptr, nullptr))) return rc;
 		bool overflow = false, tie = false;
 		if ((rc = hv_overflowed(h, s, &overflow, &tie))) return rc;
-		if (tie && h->phases == 3) {
-			// (a candidate on a tie: the whole batch once more with the band-pass as direct FIR sums, see hv_refine_packed_kernel)
+		if (tie && (h->phases & 1)) {
+			// (a candidate on a tie: the whole batch once more with the band-pass as direct FIR sums, see hv_refine_packed_kernel.
+			// A handle restricted to the front -- the incremental stream path -- gets the twin's candidate and score rows copied
+			// into its own: the caller reads them through hv_candidate_rows / hv_score_rows of THIS handle)
 			wc_harvest *t = hv_exact_twin(h);
 			if (!t) return WC_ERR_DEVICE;
+			t->phases = h->phases;
 			for (int at2 = 0; at2 < 2; ++at2) {
 				if ((rc = hv_enqueue(t, s, n_utt, d_x, x_length, d_tpos, d_f0, at2 == 1, nullptr, nullptr, 3, nullptr, nullptr))) return rc;
 				bool o2 = false;
 				if ((rc = hv_overflowed(t, s, &o2, nullptr))) return rc;
-				if (!o2) return WC_OK;
+				if (o2) continue;
+				if (h->phases == 1) {
+					long long total_l1 = 0;
+					for (int u = 0; u < n_utt; ++u) total_l1 += wc_get_samples(h->fs, x_length[u], 1);
+					const size_t bytes = sizeof(double) * (size_t)total_l1 * 7 * h->S;
+					WC_HIP(hipMemcpyAsync(h->cand1.p, t->cand1.p, bytes, hipMemcpyDeviceToDevice, s));
+					WC_HIP(hipMemcpyAsync(h->score1.p, t->score1.p, bytes, hipMemcpyDeviceToDevice, s));
+				}
+				return WC_OK;
 			}
 			return fail(WC_ERR_DEVICE, "harvest: zero-crossing buffer overflow");
 		}
