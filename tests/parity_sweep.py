@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--fs", type=int, default=48000)
     ap.add_argument("--first-seed", type=int, default=9000)
+    ap.add_argument("--seed-step", type=int, default=1, help="10 with --zoo / --zoo2: one kind only")
     ap.add_argument("--floor", type=float, default=71.0)
     ap.add_argument("--zoo", action="store_true", help="signals of other kinds (noise, chirps, impulse trains, ...) instead of utterances")
     ap.add_argument("--zoo2", action="store_true", help="the second set of kinds (speech-like, clipped, level stairs, quantised tones, ...)")
@@ -77,9 +78,9 @@ def main():
     dur = [a.seconds * (0.2 + 0.8 * ((i * 7) % 10) / 9) if a.ragged else a.seconds for i in range(a.n)]
     gen = zoo2_signal if a.zoo2 else zoo_signal if a.zoo else make_utterance
     kinds = ZOO2 if a.zoo2 else ZOO
-    xs = [gen(a.fs, dur[i], a.first_seed + i) for i in range(a.n)]
+    xs = [gen(a.fs, dur[i], (a.first_seed + i * a.seed_step)) for i in range(a.n)]
     if a.dither > 0:
-        xs = [x + a.dither * np.random.default_rng(a.first_seed + i + 10 ** 6).normal(size=len(x)) for i, x in enumerate(xs)]
+        xs = [x + a.dither * np.random.default_rng((a.first_seed + i * a.seed_step) + 10 ** 6).normal(size=len(x)) for i, x in enumerate(xs)]
     res = w.Pipeline(a.fs, frame_period=a.frame_period, harvest_f0_floor=a.floor).run_batch(xs)
     P = port.Port()
     P.set_threads(os.cpu_count() or 1)
@@ -97,7 +98,7 @@ def main():
                     hv = ref.run_fresh("harvest", x, a.fs, f0_floor=a.floor, frame_period=a.frame_period)
                 except Exception:  # (and its Harvest corrupts its heap on others)
                     crashed += 1
-                    print("seed", a.first_seed + i, kinds[(a.first_seed + i) % len(kinds)] if (a.zoo or a.zoo2) else "", "the reference's Harvest crashed: nothing to compare with;",
+                    print("seed", (a.first_seed + i * a.seed_step), kinds[((a.first_seed + i * a.seed_step)) % len(kinds)] if (a.zoo or a.zoo2) else "", "the reference's Harvest crashed: nothing to compare with;",
                           "ours: voiced %d of %d frames, all finite: %s" % (int((r["f0"] > 0).sum()), len(r["f0"]), bool(all(np.isfinite(r[k]).all() for k in ("f0", "sp", "ap", "y")))))
                     continue
                 o = dict(r, f0=hv[1])  # (the later stages then compare the kernels with themselves: only F0 is checked)
@@ -113,7 +114,7 @@ def main():
         for k in worst:
             worst[k] = max(worst[k], float(e[k]))
         if fl or e["f0"] > 1e-6 or e["sp"] > 1e-7 or e["ap"] > 1e-7 or e["y"] > 1e-8:
-            print("seed", a.first_seed + i, kinds[(a.first_seed + i) % len(kinds)] if (a.zoo or a.zoo2) else "", "V/UV flips", fl, {k: "%.2e" % v for k, v in e.items()})
+            print("seed", (a.first_seed + i * a.seed_step), kinds[((a.first_seed + i * a.seed_step)) % len(kinds)] if (a.zoo or a.zoo2) else "", "V/UV flips", fl, {k: "%.2e" % v for k, v in e.items()})
     print("fs", a.fs, "floor", a.floor, "hop", a.frame_period, "utterances", a.n, "V/UV flips", flips, "worst", {k: "%.2e" % v for k, v in worst.items()},
           ("; reference crashed on %d, its Synthesis on %d more (F0 only); non-finite aperiodicities from the checker: %d" % (crashed, harvest_only, nan_ref)) if a.checker == "ref" else "")
 

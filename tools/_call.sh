@@ -1,6 +1,3 @@
 mkdir -p gpurun_out
-{
-ZOO2=1 python tools/raw_diag.py 24000 1800012 3 2>&1 | grep -v amdgpu.ids
-
-} > gpurun_out/diag_stairs2.txt 2>&1
-grep -A40 "base frames" gpurun_out/diag_stairs2.txt
+python -m pytest tests/test_gpu_stream.py -m gpu -x -q -k ties 2>&1 | grep -E "^E|assert|passed|failed" | head -20 > gpurun_out/stream_ties.txt
+cat gpurun_out/stream_ties.txt
