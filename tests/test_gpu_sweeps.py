@@ -12,7 +12,7 @@ import pytest
 
 from parity_sweep import dev, sp_dev
 from stage_sweep import contour
-from world_class_amd.synth import SIGNAL_KINDS, make_signal, make_utterance
+from world_class_amd.synth import SIGNAL_KINDS, SIGNAL_KINDS2, make_signal, make_signal2, make_utterance
 
 pytestmark = pytest.mark.gpu
 
@@ -66,6 +66,33 @@ def test_other_signal_kinds_16k(wca, P):
     res = wca.Pipeline(fs).run_batch(xs)
     for s, x, r in zip(seeds, xs, res):
         check(r, P.pipeline(x, fs), x, "seed %d (%s)" % (s, SIGNAL_KINDS[s % len(SIGNAL_KINDS)]), fs=fs, checker=P)
+
+
+def test_second_set_of_signal_kinds_16k(wca, P):
+    """The second set (round 5, synth.make_signal2; profiles/r05_parity_sweep_fifth_second_zoo.txt: 420 such signals at eight rates
+    against the real reference).  Speech-like pulses through formants with jitter, shimmer and fricatives, flat-topped and coarsely
+    quantised waveforms, band-limited impulses with a fractional period, a soprano: every tolerance, end to end.  Level stairs
+    down to 1e-12, full amplitude modulation, a decay over twelve decades: noise-free -- the reference's D4C returns NaN on
+    their quiet frames (0 / 0) and its neighbours are ill-conditioned, class (i) -- so F0, voicing and the spectral envelope only.
+    A DC offset and a 42-70 Hz voice: the reference's Harvest corrupts its heap on these; the kernels must return finite values."""
+    fs = 16000
+    seeds = [1800000 + i for i in range(20)]
+    xs = [make_signal2(fs, 3.0, s) for s in seeds]  # (the very signals of the sweep's 16 kHz line)
+    res = wca.Pipeline(fs).run_batch(xs)
+    for s, x, r in zip(seeds, xs, res):
+        kind = SIGNAL_KINDS2[s % len(SIGNAL_KINDS2)]
+        what = "seed %d (%s)" % (s, kind)
+        if kind in ("dc", "bass"):
+            assert all(np.isfinite(r[k]).all() for k in ("f0", "sp", "ap", "y")), what
+            assert (r["f0"] > 0).mean() < 0.05, what
+            continue
+        o = P.pipeline(x, fs)
+        if kind in ("stairs", "am", "decay"):
+            assert np.array_equal(r["f0"] == 0, o["f0"] == 0), what + ": voiced/unvoiced decisions differ"
+            assert dev(r["f0"], o["f0"]) < 1e-6, what
+            assert sp_dev(r["sp"], o["sp"], o["f0"], fs) < 1e-7, what
+            continue
+        check(r, o, x, what, fs=fs, checker=P)
 
 
 def ref_self_spread(kind, fs, field):
