@@ -312,3 +312,28 @@ def test_raw_candidates_from_the_band_pass_slots_are_bit_identical(wca):
             assert np.array_equal(a.debug_fetch("raw", k), b.debug_fetch("raw", k)), (opts, env, k)
             assert np.array_equal(ra[k][1], rb[k][1])
         assert sum(int((a.debug_fetch("raw", k) != 0).sum()) for k in range(len(batch))) > 10000
+
+
+def test_helper_handles_are_created_on_the_handles_own_device(wca):
+    """A handle creates helper handles of its own on first use: Harvest the twin that re-runs a batch on ties with direct FIR
+    sums, Synthesis the twin of its second half, the pipeline its groups.  They belong on the HANDLE's device, whatever the calling
+    thread's wc_set_device says by then (thread-local; a host that drives several GPUs from a pool of threads).  Here the thread
+    points at a device this box does not have; before round 5's fix the twin's creation failed there."""
+    lib = wca.lib()
+    fs = 24000
+    x = np.zeros(int(1.0 * fs))
+    x[5::240] = 0.9  # 100 Hz: 80 samples at the internal rate, every raw candidate on a tie (DESIGN.md section 7 (ii))
+    want = wca.Harvest(fs).compute(x)[1]
+    h = wca.Harvest(fs)
+    sy = wca.Synthesis(16000, 1024, 5.0)
+    f0 = np.full(41, 150.0)
+    sp = np.full((41, 513), 1e-4)
+    ap = np.full((41, 513), 0.1)
+    assert lib.wc_set_device(97) == 0
+    try:
+        got = h.compute(x)[1]
+        ys = sy.compute_batch([f0] * 16, [sp] * 16, [ap] * 16)  # (16 utterances and more run as two halves on a twin)
+    finally:
+        assert lib.wc_set_device(0) == 0
+    assert np.array_equal(got, want) and (got > 0).mean() > 0.8
+    assert len(ys) == 16 and all(np.isfinite(y).all() for y in ys)

@@ -8,7 +8,7 @@
 #include <cstring>
 #include <vector>
 
-#include "wc_internal.hpp"
+#include "wc_stages.hpp"
 #include "wc_hostcopy.hpp"
 
 using namespace wc;
@@ -96,10 +96,6 @@ int unpack_rows_down(Staging &st, int n, double *const *const *rows, const int *
 	}
 	return WC_OK;
 }
-hipStream_t stream_now() {
-	Device *dev = current_device();
-	return dev ? dev->active() : nullptr;
-}
 
 }  // namespace
 
@@ -108,8 +104,8 @@ extern "C" {
 int wc_harvest_compute_batch(wc_harvest *h, int n_utt, const double *const *x, const int *x_length,
 							 double *const *temporal_positions, double *const *f0) {
 	if (!h || n_utt <= 0 || !x || !x_length || !temporal_positions || !f0) return fail(WC_ERR_INVALID, "harvest batch: null argument");
-	Device *dev = current_device();
-	if (!dev) return WC_ERR_DEVICE;
+	Device *dev = hv_device(h);  // (the handle's device, whatever the calling thread's wc_set_device says)
+	WC_HIP(hipSetDevice(dev->id));
 	DeviceLock lock(dev);
 	hipStream_t s = dev->active();
 	BatchScratch sc = scratch(dev);
@@ -134,8 +130,8 @@ int wc_cheaptrick_compute_batch(wc_cheaptrick *c, int n_utt, const double *const
 								double *const *const *spectrogram, uint64_t *rng_pos) {
 	if (!c || n_utt <= 0 || !x || !x_length || !temporal_positions || !f0 || !f0_length || !spectrogram)
 		return fail(WC_ERR_INVALID, "cheaptrick batch: null argument");
-	Device *dev = current_device();
-	if (!dev) return WC_ERR_DEVICE;
+	Device *dev = ct_device(c);  // (the handle's device, whatever the calling thread's wc_set_device says)
+	WC_HIP(hipSetDevice(dev->id));
 	DeviceLock lock(dev);
 	hipStream_t s = dev->active();
 	BatchScratch sc = scratch(dev);
@@ -157,8 +153,8 @@ int wc_d4c_compute_batch(wc_d4c *d, int n_utt, const double *const *x, const int
 	if (!d || n_utt <= 0 || !x || !x_length || !temporal_positions || !f0 || !f0_length || !aperiodicity)
 		return fail(WC_ERR_INVALID, "d4c batch: null argument");
 	if (fft_size < 2 || (fft_size & 1)) return fail(WC_ERR_INVALID, "d4c batch: fft_size must be even and positive");
-	Device *dev = current_device();
-	if (!dev) return WC_ERR_DEVICE;
+	Device *dev = d4c_device(d);  // (the handle's device, whatever the calling thread's wc_set_device says)
+	WC_HIP(hipSetDevice(dev->id));
 	DeviceLock lock(dev);
 	hipStream_t s = dev->active();
 	BatchScratch sc = scratch(dev);
@@ -182,8 +178,8 @@ int wc_synthesis_compute_batch(wc_synthesis *sy, int n_utt, const double *const 
 		return fail(WC_ERR_INVALID, "synthesis batch: null argument");
 	// (the rows are packed with the caller's fft_size and read by kernels that stride with the handle's: they must agree)
 	if (fft_size != wc_synthesis_get_fft_size(sy)) return fail(WC_ERR_INVALID, "synthesis batch: fft_size differs from the handle's");
-	Device *dev = current_device();
-	if (!dev) return WC_ERR_DEVICE;
+	Device *dev = syn_device(sy);  // (the handle's device, whatever the calling thread's wc_set_device says)
+	WC_HIP(hipSetDevice(dev->id));
 	DeviceLock lock(dev);
 	hipStream_t s = dev->active();
 	BatchScratch sc = scratch(dev);

@@ -1421,6 +1421,8 @@ static int ct_run_device(wc_cheaptrick *c, int n_utt, const double *d_x, const i
 	return WC_OK;
 }
 
+wc::Device *ct_device(const wc_cheaptrick *c) { return c->dev; }
+
 extern "C" {
 
 wc_cheaptrick *wc_cheaptrick_create(int fs, double q1, double f0_floor, int fft_size) {

@@ -268,6 +268,9 @@ void Device::handle_gone() {
 	}
 }
 
+OnDeviceOf::OnDeviceOf(const Device *d) : prev(g_device_id) { if (d) g_device_id = d->id; }
+OnDeviceOf::~OnDeviceOf() { g_device_id = prev; }
+
 Device *current_device() {
 	std::lock_guard<std::mutex> lk(g_mu);
 	int n = 0;

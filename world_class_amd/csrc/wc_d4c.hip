@@ -2037,6 +2037,8 @@ static int d4c_run_device(wc_d4c *d, int n_utt, const double *d_x, const int *x_
 	return WC_OK;
 }
 
+wc::Device *d4c_device(const wc_d4c *d) { return d->dev; }
+
 extern "C" {
 
 wc_d4c *wc_d4c_create(int fs, double threshold) {

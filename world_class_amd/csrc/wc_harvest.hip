@@ -3106,6 +3106,7 @@ int hv_overflowed(wc_harvest *h, hipStream_t s, bool *overflow, bool *tie) {
 wc_harvest *hv_exact_twin(wc_harvest *h) {
 	if (h->use_fir) return h;
 	if (!h->exact_twin) {
+		OnDeviceOf here(h->dev);
 		wc_harvest *t = wc_harvest_create(h->fs, h->f0_floor, h->f0_ceil, h->frame_period, h->target_fs, h->channels_in_octave, h->use_cos_table_opt);
 		if (!t) return nullptr;
 		t->use_fir = true;
@@ -3149,6 +3150,8 @@ static int hv_run_device(wc_harvest *h, int n_utt, const double *d_x, const int 
 	}
 	return fail(WC_ERR_DEVICE, "harvest: zero-crossing buffer overflow");
 }
+
+wc::Device *hv_device(const wc_harvest *h) { return h->dev; }
 
 extern "C" {
 

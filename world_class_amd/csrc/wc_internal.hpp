@@ -85,6 +85,13 @@ struct Device {
 };
 
 Device *current_device();  // creates the state on first use; nullptr + error on failure
+// RAII: a handle that creates a helper handle of its own on first use (a twin, a pipeline group) does so on ITS device, whatever the
+// calling thread's wc_set_device says (thread-local; the compute entry points run a handle on its own device anyway)
+struct OnDeviceOf {
+	int prev;
+	explicit OnDeviceOf(const Device *d);
+	~OnDeviceOf();
+};
 // process-wide noise-stream position of the host-pointer calls (atomic: handles on different devices share it)
 uint64_t global_rng_position();
 void set_global_rng_position(uint64_t position);

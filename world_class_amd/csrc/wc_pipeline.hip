@@ -114,6 +114,7 @@ struct wc_pipeline {
 
 // the stage handles, streams and events of groups [p->n_grp, ng)
 static int pipeline_ensure_groups(wc_pipeline *p, int ng) {
+	OnDeviceOf here(p->dev);  // (groups beyond the second are created by the first run that asks for them, on whichever thread that is)
 	for (int g = p->n_grp; g < ng && g < kMaxGroups; ++g) {
 		PipeGroup &G = p->grp[g];
 		G.hv = wc_harvest_create(p->fs, p->c_floor, p->c_ceil, p->frame_period, 8000.0, 40.0, 0);

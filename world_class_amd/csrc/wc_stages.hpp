@@ -38,3 +38,9 @@ int syn_prepare(wc_synthesis *sy, hipStream_t s, int n_utt, const double *d_f0, 
 int syn_pulses(wc_synthesis *sy, hipStream_t s, const double *d_f0, const double *d_sp, const double *d_ap, double *d_out,
 			   const unsigned long long *d_start);
 int syn_finish(wc_synthesis *sy, hipStream_t s, uint64_t *rng_pos_out, bool *overflow);
+
+// the device a handle lives on (the host-pointer batch entry points stage their buffers there, not on the calling thread's device)
+wc::Device *hv_device(const wc_harvest *h);
+wc::Device *ct_device(const wc_cheaptrick *c);
+wc::Device *d4c_device(const wc_d4c *d);
+wc::Device *syn_device(const wc_synthesis *sy);

@@ -233,6 +233,7 @@ int wc_stream_set_incremental(wc_stream *s, int context_ms) {
 	if (context_ms < 0 || context_ms % s->align_ms) return fail(WC_ERR_INVALID, "stream: context must be a multiple of lcm(8 ms, frame period)");
 	if (context_ms > s->ahead_ms) return fail(WC_ERR_INVALID, "stream: the context is part of the lookahead and cannot exceed it");
 	if (!s->hv_front) {
+		OnDeviceOf here(s->dev);
 		s->hv_front = wc_harvest_create(s->fs, s->hv_floor, s->hv_ceil, s->frame_period, 8000.0, 40.0, 0);
 		s->hv_tail = s->hv_front ? wc_harvest_create(s->fs, s->hv_floor, s->hv_ceil, s->frame_period, 8000.0, 40.0, 0) : nullptr;
 		if (!s->hv_tail) {  // (both or neither: a later call must not find a front without its tail)

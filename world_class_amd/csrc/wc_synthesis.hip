@@ -2289,6 +2289,7 @@ static int syn_run_device(wc_synthesis *sy, int n_utt, const double *d_f0, const
 	const bool halves_on = !(getenv("WC_SYN_HALVES") && getenv("WC_SYN_HALVES")[0] == '0');  // (read per call: the tests switch it)
 	if (halves_on && n_utt >= 16 && !sy->is_twin) {
 		if (!sy->twin) {
+			OnDeviceOf here(sy->dev);
 			sy->twin = wc_synthesis_create(sy->fs, sy->fft_size, sy->frame_period * 1000.0);
 			if (!sy->twin) return WC_ERR_DEVICE;
 			sy->twin->is_twin = true;
@@ -2351,6 +2352,8 @@ static int syn_run_device(wc_synthesis *sy, int n_utt, const double *d_f0, const
 	}
 	return fail(WC_ERR_DEVICE, "synthesis: pulse buffer overflow");
 }
+
+wc::Device *syn_device(const wc_synthesis *sy) { return sy->dev; }
 
 extern "C" {
 
