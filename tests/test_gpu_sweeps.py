@@ -140,6 +140,9 @@ def test_impulse_trains_agree_in_voicing_and_within_twice_the_references_own_spr
     # what the re-run buys: the same train without it
     k = [s for s, _ in cases].index(1340043)
     assert dev(wca.Harvest(fs).compute(xs[k])[1], refs[k]["f0"]) < 1e-9
+    # ... and a pipeline call on ONE utterance (the schedule without groups) acts on the flag as well
+    one = wca.Pipeline(fs).run_batch([xs[k]])[0]
+    assert np.array_equal(one["f0"] == 0, refs[k]["f0"] == 0) and dev(one["f0"], refs[k]["f0"]) < 1e-9
     monkeypatch.setenv("WC_HARVEST_TIES", "ignore")
     f_ign = wca.Harvest(fs).compute(xs[k])[1]
     monkeypatch.delenv("WC_HARVEST_TIES")

@@ -556,8 +556,9 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 		return fail(WC_ERR_DEVICE, "pipeline: buffer overflow");
 	}
 	bool hv_full = false, syn_full = false;
+	bool hv_exact[4] = {};  // the split's refinement met a candidate on a tie: its Harvest runs again on the FIR twin (hv_exact_twin)
 	const int ns = p->n_split < n_utt ? p->n_split : n_utt;
-	for (int attempt = 0; attempt < 3; ++attempt) {
+	for (int attempt = 0; attempt < 4; ++attempt) {
 		{
 			// group k = utterances [u0, u1); the packed layout makes every group a contiguous slice
 			long long xo = 0, fo = 0;
@@ -566,7 +567,9 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 				const int u0 = (int)((long long)n_utt * k / ns), u1 = (int)((long long)n_utt * (k + 1) / ns);
 				hipStream_t sk = k == 0 ? s0 : p->hs[k];
 				if (k > 0) WC_HIP(hipStreamWaitEvent(sk, p->e0, 0));
-				if ((rc = hv_enqueue(p->hv[k], sk, u1 - u0, d_x + xo, x_length + u0, d_tpos + fo, d_f0 + fo, hv_full, nullptr, nullptr))) return rc;
+				wc_harvest *hvk = hv_exact[k] ? hv_exact_twin(p->hv[k]) : p->hv[k];
+				if (!hvk) return WC_ERR_DEVICE;
+				if ((rc = hv_enqueue(hvk, sk, u1 - u0, d_x + xo, x_length + u0, d_tpos + fo, d_f0 + fo, hv_full, nullptr, nullptr))) return rc;
 				if (k > 0) WC_HIP(hipEventRecord(p->he[k], sk));
 				for (int u = u0; u < u1; ++u) { xo += x_length[u]; fo += f_len[u]; }
 			}
@@ -593,12 +596,14 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 		if ((rc = syn_pulses(p->sy, s0, d_f0, d_sp, d_ap, d_y, d4c_end_positions(p->d4)))) return rc;
 		bool o1 = false, o2 = false;
 		if ((rc = syn_finish(p->sy, s0, rng_pos, &o2))) return rc;  // synchronises s0 (and, through E1/E2, s1 and s2)
+		bool ties = false;
 		for (int k = 0; k < ns; ++k) {
-			bool ok = false;
-			if ((rc = hv_overflowed(p->hv[k], s0, &ok))) return rc;  // s0 is already idle; the flag copies are tiny
+			bool ok = false, tie = false;
+			if ((rc = hv_overflowed(hv_exact[k] ? hv_exact_twin(p->hv[k]) : p->hv[k], s0, &ok, &tie))) return rc;  // s0 is already idle; the flag copies are tiny
 			o1 = o1 || ok;
+			if (tie && !hv_exact[k]) { hv_exact[k] = true; ties = true; }  // (like the groups of the chained schedule above)
 		}
-		if (!o1 && !o2) return WC_OK;
+		if (!o1 && !o2 && !ties) return WC_OK;
 		hv_full = hv_full || o1;
 		syn_full = syn_full || o2;
 	}
