@@ -411,7 +411,7 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 			if (tail_late) {
 				PipeGroup &G = p->grp[0];
 				dev->time_tag = 0;
-				if ((rc = hv_enqueue(G.hv, mainS[0], sl[0].nu, d_x + sl[0].xo, x_length + sl[0].u0, d_tpos + sl[0].fo, d_f0 + sl[0].fo,
+				if ((rc = hv_enqueue(exact[0] ? hv_exact_twin(G.hv) : G.hv, mainS[0], sl[0].nu, d_x + sl[0].xo, x_length + sl[0].u0, d_tpos + sl[0].fo, d_f0 + sl[0].fo,
 									 full[0][0], nullptr, nullptr, 2, nullptr, p->e_bp)))
 					return rc;
 			}
