@@ -1,3 +1,3 @@
 mkdir -p gpurun_out
-python -m pytest tests/test_gpu_sweeps.py tests/test_gpu_pipeline.py -m gpu -x -q 2>&1 | grep -E "^E|assert|passed|failed" | head -20 > gpurun_out/t.txt
-cat gpurun_out/t.txt
+hipcc --offload-arch=gfx950 -O3 -o /tmp/cumask_probe tools/cumask_probe.hip && timeout 60 /tmp/cumask_probe > gpurun_out/cumask_probe.txt 2>&1
+cat gpurun_out/cumask_probe.txt
