@@ -1,3 +1,2 @@
-mkdir -p gpurun_out
-hipcc --offload-arch=gfx950 -O3 -o /tmp/cumask_probe tools/cumask_probe.hip && timeout 60 /tmp/cumask_probe > gpurun_out/cumask_probe.txt 2>&1
-cat gpurun_out/cumask_probe.txt
+bash tools/evidence_round.sh r05_d > gpurun_out/r05_d_evidence.log 2>&1
+tail -20 gpurun_out/r05_d_evidence.log
