@@ -1,3 +1,3 @@
 mkdir -p gpurun_out
-timeout 1500 python tools/long_utterance_probe.py 16000 300 48000 120 8000 240 2>&1 | grep -v amdgpu.ids > gpurun_out/long.txt
+timeout 1500 python tools/long_utterance_probe.py 16000 300 2>&1 | grep -v amdgpu.ids > gpurun_out/long.txt
 cat gpurun_out/long.txt

@@ -31,4 +31,11 @@ for k in range(0, len(args), 2):
         same = (r["f0"] == 0) == (o["f0"] == 0)
         print("fs %d  %-6s %7.1f s  %8d frames  V/UV flips %d  f0 %.2e  sp %.2e  ap %.2e  y %.2e" %
               (fs, name, len(sig) / fs, len(r["f0"]), fl, dev(r["f0"][same], o["f0"][same]), dev(r["sp"], o["sp"], rel=True), dev(r["ap"], o["ap"]), dev(r["y"], o["y"])), flush=True)
+        if name == "long":
+            # the waveform as a stage: the checker's Synthesis on the parameters the kernels produced, from the same place in the noise
+            # stream (an F0 that differs by 1e-9 Hz moves every later pulse: end to end the deviation grows with the length)
+            P.rng_seek(o["syn_start"])
+            y2 = P.synthesis(r["f0"], r["sp"], r["ap"], fs, 5.0)
+            P.rng_reset()
+            print("          Synthesis as a stage on the kernels' own parameters: y %.2e" % dev(r["y"], y2), flush=True)
     print("   (the batch took %.1f ms on the device side of the call)" % ((t1 - t0) * 1e3))
