@@ -258,6 +258,38 @@ def test_schedules_agree(wca):
         assert np.abs(ra["y"] - rb["y"]).max() < 1e-12
 
 
+def test_resident_batch_side_by_side_and_held_apart_agree(wca, monkeypatch):
+    """A device-resident batch of less than 500 s of signal runs its two groups' full-grid kernels side by side, a larger one holds
+    them apart by events (round 5: 16 x 10 s 10.2 -> 9.0 ms, wc_pipeline.hip).  Only the order of execution differs: the same bits,
+    whichever way a ragged batch is run (WC_PIPELINE_UNCHAIN_BELOW = 0 / a large number; read per call)."""
+    import torch
+    fs = 16000
+    dev = torch.device("cuda", 0)
+    xs = [make_utterance(fs, sec, 120 + i) for i, sec in enumerate((0.9, 0.4, 1.3, 0.7, 1.1, 0.5))]
+    p = wca.Pipeline(fs)
+    xl = [len(x) for x in xs]
+    fl, yl = p.lengths(xl)
+    d_x = torch.from_numpy(np.concatenate(xs)).to(dev)
+    outs = []
+    for knob in ("0", "100000", None):
+        if knob is None:
+            monkeypatch.delenv("WC_PIPELINE_UNCHAIN_BELOW", raising=False)
+        else:
+            monkeypatch.setenv("WC_PIPELINE_UNCHAIN_BELOW", knob)
+        d_t = torch.zeros(sum(fl), dtype=torch.float64, device=dev)
+        d_f = torch.zeros_like(d_t)
+        d_sp = torch.zeros(sum(fl) * p.bins, dtype=torch.float64, device=dev)
+        d_ap = torch.zeros_like(d_sp)
+        d_y = torch.zeros(sum(yl), dtype=torch.float64, device=dev)
+        p.run_device(d_x.data_ptr(), xl, d_t.data_ptr(), d_f.data_ptr(), d_sp.data_ptr(), d_ap.data_ptr(), d_y.data_ptr(), rng_pos=[0] * len(xs))
+        wca.lib().wc_synchronize()
+        outs.append([v.cpu().numpy() for v in (d_t, d_f, d_sp, d_ap, d_y)])
+    assert (outs[0][1] > 0).mean() > 0.3
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert np.array_equal(a, b)
+
+
 def test_user_stream_orders_our_kernels_with_the_callers_work(wca):
     """wc_set_stream (include/world_class_c.h): the calling thread's calls run on the caller's stream -- after the work
     already queued there -- without touching the library's own stream; results equal those on the library stream."""

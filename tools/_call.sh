@@ -1,3 +1,4 @@
 mkdir -p gpurun_out
-python tools/zoo_diag.py 16000 1940003 3 5 16000 1940053 3 5 2>&1 | grep -v amdgpu.ids > gpurun_out/diag_imp.txt
-cat gpurun_out/diag_imp.txt
+python -m pytest tests -m gpu -x -q 2>&1 | grep -E "^E|assert|passed|failed" | head -20 > gpurun_out/t.txt
+python tools/latency_probe.py 2>&1 | grep utterances >> gpurun_out/t.txt
+cat gpurun_out/t.txt

@@ -1,13 +1,13 @@
 """Wall time of one fused-pipeline call for small batches of 10 s / 48 kHz utterances (request latency rather than batch
 throughput): python tools/latency_probe.py"""
-import sys, time, numpy as np, torch
+import os, sys, time, numpy as np, torch
 sys.path.insert(0, '.')
 import world_class_amd as w
 from world_class_amd.synth import make_utterance
 L = w.lib(); L.wc_set_device(0)
 fs = 48000
 dev = torch.device("cuda", 0)
-for n in (1, 2, 4, 8, 16):
+for n in [int(v) for v in os.environ.get("LAT_N", "1,2,4,8,16").split(",")]:
     xs = [make_utterance(fs, 10.0, 2000 + u) for u in range(n)]
     p = w.Pipeline(fs)
     xl = [len(x) for x in xs]

@@ -37,6 +37,7 @@ using namespace wc;
 
 // one independent chain (mode "groups"): its own stage handles and two streams
 constexpr int kMaxGroups = 8;  // two for a device-resident batch; up to eight (of growing size) when the rows leave for the host
+constexpr double kUnchainBelowSeconds = 500.0;  // (see pipeline_run: WC_PIPELINE_UNCHAIN_BELOW)
 struct PipeGroup {
 	wc_harvest *hv = nullptr;
 	wc_cheaptrick *ct = nullptr;
@@ -394,7 +395,16 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 			// kernels do not fill the chip, a 6-utterance band-pass is one round of 650 wavefronts on 3072 places -- 52-60 ms
 			// against 50: every group's contour arrives later)
 			static const bool chain_env = getenv("WC_PIPELINE_CHAIN") && getenv("WC_PIPELINE_CHAIN")[0] == '0';
-			const bool chain_harvest = NG == 2 || !chain_env;
+			// Round 5: a device-resident batch of less than 500 s of signal runs its two groups' full-grid kernels SIDE BY SIDE -- neither
+			// group fills the chip (the sliding band-pass of 32 x 10 s is one round of 3040 wavefronts on 3072 places: two halves of a
+			// smaller batch fit that round together), and holding them apart is latency for nothing: 16 x 10 s 10.2 -> 9.0 ms,
+			// 32 x 10 s 15.2 -> 14.1, 48 x 10 s 22.9 -> 21.9; 52 / 56 / 64 x 10 s are faster held apart (23.2 / 24.4 / 27.3 against
+			// 23.7 / 25.0 / 28.0 ms; profiles/r05_d_small_batches_side_by_side.txt).  WC_PIPELINE_UNCHAIN_BELOW=seconds (0: never).
+			const double unchain_below = getenv("WC_PIPELINE_UNCHAIN_BELOW") ? atof(getenv("WC_PIPELINE_UNCHAIN_BELOW")) : kUnchainBelowSeconds;
+			double total_s = 0.0;
+			for (int u = 0; u < n_utt; ++u) total_s += (double)x_length[u] / p->fs;
+			const bool side_by_side = NG == 2 && !sink && total_s < unchain_below;
+			const bool chain_harvest = (NG == 2 && !side_by_side) || (NG > 2 && !chain_env);
 			auto enqueue_harvest = [&](int g) -> int {
 				PipeGroup &G = p->grp[g];
 				dev->time_tag = g;
@@ -434,7 +444,7 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 				WC_HIP(hipStreamWaitEvent(G_aux, G.e0, 0));
 				// (a run whose rows leave for the host is bound by PCIe, not by the kernels: there the first half's rows are wanted
 				// as early as they can be had, even if its CheapTrick / D4C then share the CUs with the second half's Harvest)
-				if (NG == 2 && g == 0 && !eager) WC_HIP(hipStreamWaitEvent(G_aux, p->grp[1].e_mid, 0));
+				if (NG == 2 && g == 0 && !eager && !side_by_side) WC_HIP(hipStreamWaitEvent(G_aux, p->grp[1].e_mid, 0));
 				hipEvent_t ct_rows = nullptr;  // CheapTrick's pass over the frames its one-wavefront kernel leaves out, on a stream of its own
 				if ((rc = ct_frames(G.ct, G_aux, nu, gx, gt, gf, gsp, total, &ct_rows))) return rc;
 				WC_HIP(hipEventRecord(G.e_ct, G_aux));
