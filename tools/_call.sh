@@ -1,4 +1,5 @@
 mkdir -p gpurun_out
-python -m pytest tests -m gpu -x -q 2>&1 | grep -E "^E|assert|passed|failed" | head -20 > gpurun_out/t.txt
-python tools/latency_probe.py 2>&1 | grep utterances >> gpurun_out/t.txt
-cat gpurun_out/t.txt
+{
+for v in x h c x h c; do echo "== WC_PIPELINE_SIDE=$v"; LAT_N=56,64 WC_PIPELINE_SIDE=$v python tools/latency_probe.py 2>&1 | grep utterances; done
+} > gpurun_out/side.txt 2>&1
+cat gpurun_out/side.txt

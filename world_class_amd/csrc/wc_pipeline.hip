@@ -404,7 +404,11 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 			double total_s = 0.0;
 			for (int u = 0; u < n_utt; ++u) total_s += (double)x_length[u] / p->fs;
 			const bool side_by_side = NG == 2 && !sink && total_s < unchain_below;
-			const bool chain_harvest = (NG == 2 && !side_by_side) || (NG > 2 && !chain_env);
+			// (experiment, WC_PIPELINE_SIDE=h / c: only the Harvests, or only the first group's CheapTrick / D4C and the second's Harvest, side by side)
+			const char *side_env = getenv("WC_PIPELINE_SIDE");
+			const bool side_h = side_by_side || (NG == 2 && !sink && side_env && side_env[0] == 'h');
+			const bool side_c = side_by_side || (NG == 2 && !sink && side_env && side_env[0] == 'c');
+			const bool chain_harvest = (NG == 2 && !side_h) || (NG > 2 && !chain_env);
 			auto enqueue_harvest = [&](int g) -> int {
 				PipeGroup &G = p->grp[g];
 				dev->time_tag = g;
@@ -444,7 +448,7 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 				WC_HIP(hipStreamWaitEvent(G_aux, G.e0, 0));
 				// (a run whose rows leave for the host is bound by PCIe, not by the kernels: there the first half's rows are wanted
 				// as early as they can be had, even if its CheapTrick / D4C then share the CUs with the second half's Harvest)
-				if (NG == 2 && g == 0 && !eager && !side_by_side) WC_HIP(hipStreamWaitEvent(G_aux, p->grp[1].e_mid, 0));
+				if (NG == 2 && g == 0 && !eager && !side_c) WC_HIP(hipStreamWaitEvent(G_aux, p->grp[1].e_mid, 0));
 				hipEvent_t ct_rows = nullptr;  // CheapTrick's pass over the frames its one-wavefront kernel leaves out, on a stream of its own
 				if ((rc = ct_frames(G.ct, G_aux, nu, gx, gt, gf, gsp, total, &ct_rows))) return rc;
 				WC_HIP(hipEventRecord(G.e_ct, G_aux));
