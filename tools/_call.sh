@@ -1,5 +1,2 @@
-mkdir -p gpurun_out
-{
-for v in x h c x h c; do echo "== WC_PIPELINE_SIDE=$v"; LAT_N=56,64 WC_PIPELINE_SIDE=$v python tools/latency_probe.py 2>&1 | grep utterances; done
-} > gpurun_out/side.txt 2>&1
-cat gpurun_out/side.txt
+bash tools/evidence_round.sh r05_e > gpurun_out/r05_e_evidence.log 2>&1
+tail -20 gpurun_out/r05_e_evidence.log
