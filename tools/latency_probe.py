@@ -5,7 +5,7 @@ sys.path.insert(0, '.')
 import world_class_amd as w
 from world_class_amd.synth import make_utterance
 L = w.lib(); L.wc_set_device(0)
-fs = 48000
+fs = int(os.environ.get("LAT_FS", "48000"))
 dev = torch.device("cuda", 0)
 for n in [int(v) for v in os.environ.get("LAT_N", "1,2,4,8,16").split(",")]:
     xs = [make_utterance(fs, 10.0, 2000 + u) for u in range(n)]
