@@ -1,7 +1,5 @@
 mkdir -p gpurun_out
 {
-for fs in 16000 24000; do
-for v in "WC_PIPELINE_UNCHAIN_BELOW=0" "A=1" "WC_PIPELINE_UNCHAIN_BELOW=0" "A=1"; do echo "== fs $fs $v"; env LAT_FS=$fs LAT_N=8,16,32,48 $v python tools/latency_probe.py 2>&1 | grep utterances; done
-done
-} > gpurun_out/side16b.txt 2>&1
-cat gpurun_out/side16b.txt
+for v in 50 35 40 45 55 60 50 40 45; do echo "== WC_PIPELINE_FIRST_SHARE=$v"; LAT_N=16,32,48,64 WC_PIPELINE_FIRST_SHARE=$v python tools/latency_probe.py 2>&1 | grep utterances | tr "\n" " "; echo; done
+} > gpurun_out/share.txt 2>&1
+cat gpurun_out/share.txt
