@@ -271,11 +271,16 @@ def test_resident_batch_side_by_side_and_held_apart_agree(wca, monkeypatch):
     fl, yl = p.lengths(xl)
     d_x = torch.from_numpy(np.concatenate(xs)).to(dev)
     outs = []
-    for knob in ("0", "100000", None):
+    for knob in ("0", "100000", None, "lanes"):
+        monkeypatch.delenv("WC_PIPELINE_SCHEDULE", raising=False)
         if knob is None:
             monkeypatch.delenv("WC_PIPELINE_UNCHAIN_BELOW", raising=False)
+        elif knob == "lanes":  # (held apart, two lanes: the default of batches that fill the chip)
+            monkeypatch.setenv("WC_PIPELINE_UNCHAIN_BELOW", "0")
+            monkeypatch.setenv("WC_PIPELINE_SCHEDULE", "lanes")  # (anything but "chains")
         else:
             monkeypatch.setenv("WC_PIPELINE_UNCHAIN_BELOW", knob)
+            monkeypatch.setenv("WC_PIPELINE_SCHEDULE", "chains")  # ("0": held apart as two chains on four streams, rounds 3-5)
         d_t = torch.zeros(sum(fl), dtype=torch.float64, device=dev)
         d_f = torch.zeros_like(d_t)
         d_sp = torch.zeros(sum(fl) * p.bins, dtype=torch.float64, device=dev)

@@ -7,7 +7,7 @@ from world_class_amd.synth import make_utterance
 L = w.lib(); L.wc_set_device(0)
 fs = 48000
 dev = torch.device("cuda", 0)
-xs = [make_utterance(fs, 10.0, 2000)]
+xs = [make_utterance(fs, 10.0, 2000 + (u % 8)) for u in range(int(os.environ.get("TRACE_N", "1")))]
 p = w.Pipeline(fs)
 xl = [len(x) for x in xs]
 fl, yl = p.lengths(xl)

@@ -421,6 +421,69 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 			};
 			// (two groups: both Harvest chains first -- the first group's CheapTrick / D4C may wait for an event of the second's.
 			// More groups share streams: a group's whole chain is enqueued before the next group's Harvest lands on its stream.)
+			// Round 5, the default for a device-resident batch that fills the chip (500 s of signal and more): TWO LANES instead of four
+			// streams.  Every full-grid kernel of the step on one stream (the caller's), in the order front_A, front_B, CheapTrick /
+			// D4C_A, pulses_A, CheapTrick / D4C_B, pulses_B -- none of them shares the chip with another one --; every latency-bound
+			// stretch (a group's candidate test, contour logic and smoothing, CheapTrick's frame counts, the Synthesis time base) on the
+			// other, behind the front it needs and in front of the kernels that need it.  The four-stream order below (two chains
+			// held apart by events) reaches the same 27.1-27.3 ms per 64 x 10 s on boxes whose queue scheduler happens to deal its
+			// streams well and 28.3-28.7 ms on others (a third of the round's boxes); this one measured 27.2-27.3 on both kinds
+			// (profiles/r05_e_two_lanes.txt).  Same bits.  WC_PIPELINE_SCHEDULE=chains: the four-stream order.
+			const bool lanes = NG == 2 && !sink && !side_by_side && !(getenv("WC_PIPELINE_SCHEDULE") && std::strcmp(getenv("WC_PIPELINE_SCHEDULE"), "chains") == 0);
+			if (lanes) {
+				// (measured and dropped: the small kernels on the high-priority stream, 27.7 against 27.3 ms; the second group's front on a
+				// stream of its own so that its decimation runs underneath the first front, 27.8-28.0)
+				const hipStream_t F = mainS[0], S = p->grp[0].aux;
+				WC_HIP(hipStreamWaitEvent(S, p->e1, 0));  // (behind whatever precedes this call on the caller's stream)
+				wc_harvest *hvg[2];
+				for (int g = 0; g < 2; ++g) {
+					hvg[g] = exact[g] ? hv_exact_twin(p->grp[g].hv) : p->grp[g].hv;
+					if (!hvg[g]) return WC_ERR_DEVICE;
+					dev->time_tag = g;
+					if ((rc = hv_enqueue(hvg[g], F, sl[g].nu, d_x + sl[g].xo, x_length + sl[g].u0, d_tpos + sl[g].fo, d_f0 + sl[g].fo, full[g][0],
+										 p->grp[g].e_mid, nullptr, 1, nullptr, nullptr)))
+						return rc;
+				}
+				for (int g = 0; g < 2; ++g) {
+					PipeGroup &G = p->grp[g];
+					dev->time_tag = g;
+					const int u0 = sl[g].u0, nu = sl[g].nu;
+					const double *gx = d_x + sl[g].xo;
+					double *gt = d_tpos + sl[g].fo, *gf = d_f0 + sl[g].fo, *gsp = d_sp + sl[g].fo * bins_, *gap = d_ap + sl[g].fo * bins_;
+					double *gy = d_y + sl[g].yo;
+					const uint64_t *grp_rng = rng_start ? rng_start + u0 : nullptr;
+					long long total = 0;
+					uint64_t a0 = 0, a1 = 0;
+					if ((rc = hv_enqueue(hvg[g], S, nu, gx, x_length + u0, gt, gf, full[g][0], nullptr, nullptr, 2, nullptr, G.e_mid))) return rc;
+					if ((rc = ct_prepare(G.ct, S, nu, x_length + u0, gf, f_len.data() + u0, grp_rng, &total, &a0, &a1))) return rc;
+					WC_HIP(hipEventRecord(G.e0, S));
+					if ((rc = syn_prepare(G.sy, S, nu, gf, f_len.data() + u0, y_len.data() + u0, gy, nullptr, full[g][1]))) return rc;
+					WC_HIP(hipEventRecord(G.e_ct, S));
+					WC_HIP(hipStreamWaitEvent(F, G.e0, 0));
+					hipEvent_t ct_rows = nullptr;
+					if ((rc = ct_frames(G.ct, F, nu, gx, gt, gf, gsp, total, &ct_rows))) return rc;
+					if ((rc = d4c_enqueue(G.d4, F, nu, gx, x_length + u0, gt, gf, f_len.data() + u0, p->fft_size, gap, nullptr, ct_end_positions(G.ct))))
+						return rc;
+					// (measured and dropped: the pulses on a stream of their own, the first group's beside the second group's CheapTrick /
+					// D4C as in the four-stream order: 27.2-27.3 ms either way, 42.0 against 40.5 ms at 96 x 10 s)
+					if (ct_rows) WC_HIP(hipStreamWaitEvent(F, ct_rows, 0));
+					WC_HIP(hipStreamWaitEvent(F, G.e_ct, 0));
+					if ((rc = syn_pulses(G.sy, F, gf, gsp, gap, gy, d4c_end_positions(G.d4)))) return rc;
+				}
+				dev->time_tag = -1;
+				bool again = false;
+				for (int g = 0; g < 2; ++g) {
+					bool o1 = false, o2 = false, tie = false;
+					if ((rc = syn_finish(p->grp[g].sy, F, rng_pos ? rng_pos + ub[g] : nullptr, &o2))) return rc;
+					if ((rc = hv_overflowed(hvg[g], F, &o1, &tie))) return rc;
+					full[g][0] = full[g][0] || o1;
+					full[g][1] = full[g][1] || o2;
+					if (tie && !exact[g]) { exact[g] = true; again = true; }
+					again = again || o1 || o2;
+				}
+				if (!again) return WC_OK;
+				continue;
+			}
 			if (NG == 2) for (int g = 0; g < NG; ++g) if ((rc = enqueue_harvest(g))) return rc;
 			if (tail_late) {
 				PipeGroup &G = p->grp[0];
