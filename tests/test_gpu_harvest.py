@@ -243,16 +243,17 @@ def test_packed_refinement_is_bit_identical(wca):
         a = wca.Harvest(fs_, **opts)
         ra = a.compute_batch(batch)
         got = [(a.debug_fetch("cand1", k), a.debug_fetch("score1", k)) for k in range(len(batch))]
-        os.environ["WC_HARVEST_REFINE"] = "slots"
-        try:
-            b = wca.Harvest(fs_, **opts)
-        finally:
-            del os.environ["WC_HARVEST_REFINE"]
-        rb = b.compute_batch(batch)
-        for k in range(len(batch)):
-            assert np.array_equal(got[k][0], b.debug_fetch("cand1", k)), (opts, k)
-            assert np.array_equal(got[k][1], b.debug_fetch("score1", k)), (opts, k)
-            assert np.array_equal(ra[k][1], rb[k][1])
+        for mode in ("slots", "packed"):  # (the default since round 6: neighbouring frames' keys dealt out together, hv_refine_group_kernel)
+            os.environ["WC_HARVEST_REFINE"] = mode
+            try:
+                b = wca.Harvest(fs_, **opts)
+            finally:
+                del os.environ["WC_HARVEST_REFINE"]
+            rb = b.compute_batch(batch)
+            for k in range(len(batch)):
+                assert np.array_equal(got[k][0], b.debug_fetch("cand1", k)), (opts, k, mode)
+                assert np.array_equal(got[k][1], b.debug_fetch("score1", k)), (opts, k, mode)
+                assert np.array_equal(ra[k][1], rb[k][1])
         assert sum(int((c != 0).sum()) for c, _ in got) > 500
 
 
@@ -278,6 +279,8 @@ def test_packed_refinement_with_more_candidates_than_the_detector_finds(wca):
             pa, sa = h.debug_refine(c0)
             pb, sb = h.debug_refine(c0, by_slots=True)
             assert np.array_equal(pa, pb) and np.array_equal(sa, sb), (opts, fill)
+            pc, sc = h.debug_refine(c0, by_slots=2)  # one wavefront per frame (round 5's default)
+            assert np.array_equal(pa, pc) and np.array_equal(sa, sc), (opts, fill)
             assert (pa != 0).sum(axis=1).max() > (64 if fill == 1.0 else 30)
 
 

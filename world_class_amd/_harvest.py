@@ -61,7 +61,7 @@ class Harvest:
         frames, S = cand0.shape
         c1 = np.zeros((frames, 7 * S))
         s1 = np.zeros((frames, 7 * S))
-        _check(fn(self._h, cand0.ctypes.data, 1 if by_slots else 0, c1.ctypes.data, s1.ctypes.data))
+        _check(fn(self._h, cand0.ctypes.data, int(by_slots), c1.ctypes.data, s1.ctypes.data))  # 0 default (frames in groups), 1 slots, 2 packed
         return c1, s1
 
     def __del__(self):

@@ -31,6 +31,7 @@
 //   hv_smooth_kernel     zero-lag Butterworth per voiced section, one lane per section (:639-703)
 //   hv_output_kernel     1 ms contour -> frame_period grid (:199-204)
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -1261,9 +1262,11 @@ struct RefArgs {
 	const double *cand0;
 	const double2 *tw;
 	const double2 *rot;  // per half window length hw: (cos, sin) of 2 pi / (2 hw + 1) and of 8 times that
+	const double2 *rot8; // per half window length hw: (cos, sin) of k 2 pi / (2 hw + 1), k = 0 .. 7
 	const double *cos_table;  // HarvestOption::use_cos_table: the reference's 8001-entry cosine table (src/harvest.cpp:152-170)
 	double *cand1, *score1;
 	long long total_frames;
+	int max_l1;  // frames of the longest utterance (grid of hv_refine_group_kernel)
 	HvParams p;
 	int *flags;  // [0]: a rate-bounded buffer overflowed; [1]: a raw candidate sits on a tie of the refinement's integer decisions (below)
 };
@@ -1277,6 +1280,22 @@ struct RefArgs {
 constexpr int RF_MAXHW = 1023;          // longest half window: 2 hw + 1 < 2048 keeps the transform size of reference :962 within the 4096-entry twiddle table
                                         // (f0 = 37.5 Hz at 8 kHz needs 321; 16 kHz after decimation and a 47 Hz candidate 511)
 constexpr int RF_MAXW = 2 * RF_MAXHW + 1;
+
+// The window phase at a lane's first sample n = sub (reference :762-788) is the phase at sample 0 -- the reference's expression, one
+// sincos per (frame, window) -- turned by sub steps of beta = 2 pi / (2 hw + 1) out of a table (round 6: the sincos of a key is
+// evaluated once per key instead of once per lane and pass; hv_refine_group_kernel does it in front of the passes.  All three
+// kernels form it this way, so they agree bit for bit)
+__device__ __forceinline__ double2 rf_phase0(int hw, int basic, double pos, double fs) {
+	const double wlt = (2.0 * hw + 1.0) / fs;
+	const double tmp = (basic - 1.0) / fs - pos;
+	const double tmp2 = 2.0 * kPi * tmp / wlt;
+	double c, s;
+	sincos(tmp2, &s, &c);
+	return make_double2(c, s);
+}
+__device__ __forceinline__ double2 rf_turn(double2 p, double2 r) {
+	return make_double2(fma(p.x, r.x, -(p.y * r.y)), fma(p.y, r.x, p.x * r.y));
+}
 
 // One workgroup per 1 ms frame; a wavefront handles candidate slot j of all 7 overlap blocks at once:
 // lanes 8 b .. 8 b + 7 work on block b (the same slot of frames i-3 .. i+3, so the windows have similar
@@ -1317,14 +1336,9 @@ __global__ __launch_bounds__(256, WC_REFINE_WAVES) void hv_refine_kernel(RefArgs
 		if (__ballot(f > 0.0) == 0ull) continue;  // an empty slot (most are) is skipped in phase 2 as well
 		const double fc = f > 0.0 ? f : 100.0;
 		const int hw = min((int)(1.5 * fs / fc + 1.0), RF_MAXHW);
-		const double wlt = (2.0 * hw + 1.0) / fs;
 		const double bt0 = (-hw) / fs;
 		const int basic = mround((pos + bt0) * fs + 0.001);
-		const double tmp = (basic + sub - 1.0) / fs - pos;
-		const double tmp2 = 2.0 * kPi * tmp / wlt;
-		double wc, ws;
-		sincos(tmp2, &ws, &wc);
-		start_phase[q][threadIdx.x] = make_double2(wc, ws);
+		start_phase[q][threadIdx.x] = rf_turn(rf_phase0(hw, basic, pos, fs), a.rot8[hw * 8 + sub]);
 	}
 	for (int j = wv, q = 0; j < S; j += 4, ++q) {
 		double f = 0.0;
@@ -1732,12 +1746,7 @@ __global__ __launch_bounds__(64, RF_NP > 112 ? 2 : WC_REFINE_WAVES) void hv_refi
 			const int t_own = r < nu ? un_src[r] : 0;  // (an idle group borrows candidate 0: any valid window will do)
 			const int hw = (int)(key[t_own] & 2047ull);
 			const int basic = it_basic[t_own];
-			const double wlt = (2.0 * hw + 1.0) / fs;
-			const double tmp = (basic + sub - 1.0) / fs - pos;
-			const double tmp2 = 2.0 * kPi * tmp / wlt;
-			double wc, ws;
-			sincos(tmp2, &ws, &wc);
-			stage[q][lane] = make_double2(wc, ws);
+			stage[q][lane] = rf_turn(rf_phase0(hw, basic, pos, fs), a.rot8[hw * 8 + sub]);
 		}
 		// phase 2
 		for (int q = 0; q < cn; ++q) {
@@ -1969,6 +1978,442 @@ __global__ __launch_bounds__(64, RF_NP > 112 ? 2 : WC_REFINE_WAVES) void hv_refi
 		a.cand1[g * a.p.n_cand + k] = rf;
 		a.score1[g * a.p.n_cand + k] = rs;
 	}
+}
+
+// orders a wavefront's own LDS writes before its later reads (its LDS operations execute in order: this only keeps the compiler from
+// moving them; no wait, no s_barrier)
+__device__ __forceinline__ void rq_fence() {
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// The packed refinement with the work of RQ_F neighbouring frames dealt out together (round 6, default; the kernel above is
+// WC_HARVEST_REFINE=packed).  A pass of the kernel above takes as long as the longest of its eight windows and a frame's last pass is
+// rarely full: counted on the headline signal a frame has 14.5 distinct keys with windows of 40 .. 340 samples -- 21.9 trips of the
+// sample loop per frame in 2.25 passes where eight lanes per key, perfectly packed, would need 13.8.  Here a workgroup of RQ_F
+// wavefronts takes RQ_F consecutive frames: each wavefront gathers and de-duplicates its own frame as above, the distinct keys of all
+// the frames are ranked by window length, and the passes are cut from that one list -- eight neighbours of it have windows within a
+// few samples of each other, and only the group's last pass is partly empty: 15.5 trips and 1.91 passes per frame at four frames.
+// Behind the ranking the wavefronts no longer wait for each other: each takes the next pass of the list when it is through with
+// its own (longest first, so they finish together), scores the key's candidate and every candidate of the same frame that shares
+// the key -- lane m of the group takes member m, summing the six harmonics in the reference's order -- and stores refined F0 and
+// score straight into the frame's rows (the positions without a candidate were zeroed by the frame's own wavefront).
+// The arithmetic of a key is that of the kernel above instruction for instruction (eight lanes, samples n = sub + 8 q, the same
+// closing sums): same bits, whatever group of whatever wavefront takes it.
+#ifndef WC_RQ_F
+#define WC_RQ_F 4
+#endif
+#ifndef WC_RQ_PROF
+#define WC_RQ_PROF 0  // development builds: shader-clock cycles of every wavefront by phase, summed over the launch (printed by launch_refine)
+#endif
+#if WC_RQ_PROF
+__device__ unsigned long long rq_prof[16];
+#define RQ_T(k) do { const long long now_ = clock64(); acc_[k] += now_ - last_; last_ = now_; } while (0)
+#define RQ_FLUSH() do { if (lane == 0 && (blockIdx.x & 63) == 0) for (int k_ = 0; k_ < 12; ++k_) atomicAdd(&rq_prof[k_], (unsigned long long)acc_[k_]); } while (0)
+#else
+#define RQ_T(k) do {} while (0)
+#define RQ_FLUSH() do {} while (0)
+#endif
+#ifndef WC_RQ_PC
+#define WC_RQ_PC 8   // passes whose start phases are staged together: 8 KB, one stretch for up to 64 keys
+#endif
+template <bool TABLE, int F>
+__global__ __launch_bounds__(64 * F, WC_REFINE_WAVES) void hv_refine_group_kernel(RefArgs a) {
+	constexpr int NP = 112;  // candidate positions per frame (7 S <= 112; wider rows take the kernel above)
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const int grp = lane >> 3, sub = lane & 7;
+	// a workgroup per F consecutive frames of ONE utterance (blockIdx.y), the groups of an utterance XCD by XCD (see above)
+	const HvUtt u = a.utts[blockIdx.y];
+	const int n_grp = (u.L1 + F - 1) / F, per = (n_grp + 7) / 8;
+	if ((int)(blockIdx.x >> 3) >= per) return;
+	const int G = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+	if (G >= n_grp) return;
+	const int i0 = G * F, i = i0 + wv;
+	const bool have = i < u.L1;
+	const long long g0 = u.l1_off + i0, g = g0 + wv;
+	const double fs = a.p.fs_d;
+	const int S = a.p.S;
+	const int NC = 7 * S;
+	const double *__restrict__ y = a.y + u.y_off;
+	const double *__restrict__ crow = a.cand0 + g * S;
+	__shared__ double it_f[F][NP];
+	__shared__ unsigned long long key[F][NP];
+	__shared__ __attribute__((aligned(16))) double red[F][RF_RED];  // (the de-duplication's hash table lives here before the first pass)
+	__shared__ double2 stage[F][64];  // a wavefront's closing sums on their way to the harmonics' lanes
+	__shared__ double2 it_ph[F][NP];  // window phase of a distinct key at its sample 0
+	__shared__ int it_basic[F][NP];
+	__shared__ unsigned char it_pos[F][NP], it_rep[F][NP], un_src[F][NP], dup_of[F][NP], it_nh[F][NP], un_at[F][NP];
+	__shared__ int hist[F][128];   // distinct keys per wavefront and window-length class (eight samples of half length to a class, longest first)
+	__shared__ int place[F][128];  // where a wavefront's keys of a class start in the group's list
+	__shared__ unsigned short w_item[F * NP];
+	__shared__ int fr_n[F], fr_nd[F];
+	__shared__ int next_pass;
+	const unsigned long long below = (1ull << lane) - 1ull;
+#if WC_RQ_PROF
+	long long acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+	long long last_ = clock64();
+#endif
+	hist[wv][lane] = 0;
+	hist[wv][64 + lane] = 0;
+
+	// 1. live candidates of the overlap (reference :987-1000), slot-major: position k = 7 j + block
+	int n = 0;
+	{
+		const double pos = i * 1 / 1000.0;
+		for (int base = 0; have && base < NC; base += 64) {
+			const int k = base + lane;
+			const int j = k / 7, blk = k - 7 * j;
+			const int src = (blk == 0) ? i : (blk <= 3 ? i - blk : i + (blk - 3));
+			double f = 0.0;
+			if (k < NC && src >= 0 && src < u.L1) f = crow[(src - i) * S + j];
+			const bool live = f > 0.0;
+			const unsigned long long m = __ballot(live);
+			if (k < NC && !live) {  // an empty position
+				a.cand1[g * a.p.n_cand + j + S * blk] = 0.0;
+				a.score1[g * a.p.n_cand + j + S * blk] = 0.0;
+			}
+			if (live) {
+				const int at = n + __popcll(m & below);
+				const int hw = min((int)(1.5 * fs / f + 1.0), RF_MAXHW);
+				const int N = 1 << (2 + (31 - __clz(hw * 2 + 1)));
+				const double bin_unit = f * N / fs;
+				const int b0 = mround(bin_unit);
+				unsigned long long kk = (unsigned long long)hw | ((unsigned long long)(unsigned)b0 << 32);  // (the key of the kernel above)
+#pragma unroll
+				for (int h = 1; h < 6; ++h) {
+					const int dlt = mround(bin_unit * (h + 1)) - (h + 1) * b0 + 8;
+					kk |= (unsigned long long)(dlt & 15) << (11 + 4 * (h - 1));
+				}
+				it_f[wv][at] = f;
+				it_pos[wv][at] = (unsigned char)(j + S * blk);
+				key[wv][at] = kk;
+				it_basic[wv][at] = mround((pos + (-hw) / fs) * fs + 0.001);
+				it_nh[wv][at] = (unsigned char)min((int)(fs / 2.0 / f), 6);
+				{  // ties: see the kernel above
+					const double tol = 2e-13;
+					const double v = 1.5 * fs / f + 1.0, v2 = fs / 2.0 / f;
+					bool tie = fabs(v - rint(v)) < tol * v || (v2 < 7.0 && fabs(v2 - rint(v2)) < tol * v2);
+#pragma unroll
+					for (int h = 0; h < 6; ++h) {
+						const double wv_ = bin_unit * (h + 1);
+						tie = tie || fabs(wv_ - floor(wv_) - 0.5) < tol * wv_;
+					}
+					if (tie) a.flags[1] = 1;
+				}
+			}
+			n += __popcll(m);
+		}
+	}
+	RQ_T(0);
+	// 2. the first candidate of every key (the hash table of the kernel above; a wavefront's LDS operations execute in order), and
+	//    the distinct keys counted by window-length class
+	int nu = 0, nd = 0;
+	if (n > 0) {
+		unsigned int *const tab = reinterpret_cast<unsigned int *>(&red[wv][0]);
+		auto slot_of = [](unsigned long long kk) { return (((unsigned)kk * 2654435761u) ^ ((unsigned)(kk >> 32) * 40503u * 65537u)) >> 24; };
+		for (int k = lane; k < 256; k += 64) tab[k] = 0xFFFFFFFFu;
+		rq_fence();
+		for (int t = lane; t < n; t += 64) atomicMin(&tab[slot_of(key[wv][t])], (unsigned)t);
+		rq_fence();
+		for (int t0 = 0; t0 < n; t0 += 64) {
+			const int t = t0 + lane;
+			int rep = t;
+			unsigned long long mine = 0;
+			if (t < n) {
+				mine = key[wv][t];
+				const int r = (int)tab[slot_of(mine)];
+				if (r != t && key[wv][r] == mine) rep = r;
+			}
+			const bool uniq = t < n && rep == t, dup = t < n && rep != t;
+			const unsigned long long mu = __ballot(uniq), md = __ballot(dup);
+			if (uniq) {
+				const int r = nu + __popcll(mu & below);
+				un_src[wv][r] = (unsigned char)t;
+				un_at[wv][r] = (unsigned char)atomicAdd(&hist[wv][127 - (int)((mine & 2047ull) >> 3)], 1);  // (its place among the wavefront's keys of the class)
+			}
+			if (dup) {
+				dup_of[wv][nd + __popcll(md & below)] = (unsigned char)t;
+				it_rep[wv][t] = (unsigned char)rep;
+			}
+			nu += __popcll(mu);
+			nd += __popcll(md);
+		}
+	}
+	// the window phase of every distinct key at sample 0: a lane per key here, where the kernels above spend a lane per (key, first
+	// sample) and pass
+	for (int r = lane; r < nu; r += 64) {
+		const int t = un_src[wv][r];
+		it_ph[wv][t] = rf_phase0((int)(key[wv][t] & 2047ull), it_basic[wv][t], i * 1 / 1000.0, fs);
+	}
+	if (lane == 0) { fr_n[wv] = nu; fr_nd[wv] = nd; }
+	if (threadIdx.x == 0) next_pass = 0;
+	RQ_T(1);
+	__syncthreads();
+	RQ_T(2);
+	// 3. one list of the group's distinct keys, longest windows first: a key's place is the number of keys in the classes before
+	//    its own, plus those of its class in the wavefronts before this one, plus its place among this wavefront's
+	int M = 0;
+#pragma unroll
+	for (int w = 0; w < F; ++w) M += fr_n[w];
+	if (M == 0) { RQ_FLUSH(); return; }
+	{
+		int tot2[2], mine2[2];  // classes 2 lane, 2 lane + 1: keys in all wavefronts / in the wavefronts before this one
+#pragma unroll
+		for (int c = 0; c < 2; ++c) {
+			tot2[c] = 0; mine2[c] = 0;
+#pragma unroll
+			for (int w = 0; w < F; ++w) {
+				const int hv_ = hist[w][2 * lane + c];
+				tot2[c] += hv_;
+				if (w < wv) mine2[c] += hv_;
+			}
+		}
+		int inc = tot2[0] + tot2[1];
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			const int t = __shfl_up(inc, o, 64);
+			if (lane >= o) inc += t;
+		}
+		const int ex = inc - tot2[0] - tot2[1];
+		place[wv][2 * lane] = ex + mine2[0];
+		place[wv][2 * lane + 1] = ex + tot2[0] + mine2[1];
+		rq_fence();
+	}
+	for (int r = lane; r < nu; r += 64) {
+		const int t = un_src[wv][r];
+		const int rk = place[wv][127 - (int)((key[wv][t] & 2047ull) >> 3)] + un_at[wv][r];
+		w_item[rk] = (unsigned short)((wv << 7) | t);
+	}
+	RQ_T(3);
+
+	auto finish = [&](int ln, double inst, double amp, double fc, int nh, double &num, double &den, double &sc) {  // (see the kernel above)
+		const int h = ln & 7;
+		const bool on = h < nh;
+		const double e_num = on ? amp * inst : 0.0, e_den = on ? amp * (h + 1.0) : 0.0, e_sc = on ? fabs((inst / (h + 1.0) - fc) / fc) : 0.0;
+		num = 0.0 + e_num; den = 0.0 + e_den; sc = 0.0 + e_sc;
+		num += row_shl_d<1>(e_num); den += row_shl_d<1>(e_den); sc += row_shl_d<1>(e_sc);
+		num += row_shl_d<2>(e_num); den += row_shl_d<2>(e_den); sc += row_shl_d<2>(e_sc);
+		num += row_shl_d<3>(e_num); den += row_shl_d<3>(e_den); sc += row_shl_d<3>(e_sc);
+		num += row_shl_d<4>(e_num); den += row_shl_d<4>(e_den); sc += row_shl_d<4>(e_sc);
+		num += row_shl_d<5>(e_num); den += row_shl_d<5>(e_den); sc += row_shl_d<5>(e_sc);
+	};
+	// refined F0 and score of candidate t of frame w from its three sums (reference :964-979), stored by the lane that holds them
+	auto store = [&](int w, int t, double num, double den, double sc) {
+		const int nh = it_nh[w][t];
+		double rf = num / (den + kSafeH);
+		double rs = 1.0 / (sc / nh + kSafeH);
+		if (rf < a.p.f0_floor || rf > a.p.f0_ceil || rs < 2.5) { rf = 0.0; rs = 0.0; }
+		const long long at = (g0 + w) * a.p.n_cand + it_pos[w][t];
+		a.cand1[at] = rf;
+		a.score1[at] = rs;
+	};
+
+	const int npass = (M + 7) >> 3;
+	constexpr int c0 = 0;
+	const int q_own = wv;  // (this wavefront's entry of `stage`)
+	__syncthreads();  // (the list is complete)
+	RQ_T(5);
+	{
+		// a wavefront takes the next pass of the list when it is through with its own
+		for (;;) {
+			int q = 0;
+			if (lane == 0) q = atomicAdd(&next_pass, 1);
+			q = __builtin_amdgcn_readfirstlane(q);
+			RQ_T(6);
+			if (q >= npass) break;
+			const int r = (c0 + q) * 8 + grp;
+			const bool live = r < M;
+			const int item = w_item[live ? r : 0];
+			const int ws = item >> 7, t_own = item & 127;
+			const unsigned long long kk = key[ws][t_own];
+			const int hw = (int)(kk & 2047ull);
+			const int bt = live ? 2 * hw + 1 : 0;
+			const double wlt = (2.0 * hw + 1.0) / fs;
+			const int fft_index = 2 + (31 - __clz(hw * 2 + 1));
+			const int N = 1 << fft_index;
+			const int basic = it_basic[ws][t_own];
+			const double pos = (i0 + ws) * 1 / 1000.0;
+			auto bin_of = [&](int h) -> int {
+				const int b0 = (int)(kk >> 32);
+				return h == 0 ? b0 : (h + 1) * b0 + (int)(((unsigned)kk >> (11 + 4 * (h - 1))) & 15u) - 8;
+			};
+			const double2 r1 = a.rot[2 * hw], r8 = a.rot[2 * hw + 1];
+			const double2 ph = rf_turn(it_ph[ws][t_own], a.rot8[hw * 8 + sub]);
+			double wc = ph.x, ws_ = ph.y;
+			const double k1 = 0.5 * r1.y, k2 = 0.16 * (2.0 * r1.y * r1.x);
+			double c2[6];
+#pragma unroll
+			for (int h = 0; h < 6; ++h) c2[h] = 2.0 * a.tw[((bin_of(h) * 8) & (N - 1)) << (kTwiddleLog2 - fft_index)].x;
+			double sa[12], sb[12];
+#pragma unroll
+			for (int k = 0; k < 12; ++k) { sa[k] = 0.0; sb[k] = 0.0; }
+			auto table_window = [&](int n_) -> double {  // reference :779-787, operation by operation
+				const double two_pi = 2.0 * kPi;
+				const double tmp = (basic + n_ - 1.0) / fs - pos;
+				const double tmp2 = two_pi * (tmp / wlt + 1);
+				const double dindex = fmod(tmp2, two_pi) / two_pi * 8000;
+				const double dindex2 = fmod(dindex * 2, 8000.0);
+				return 0.42 + 0.5 * a.cos_table[(int)round(dindex)] + 0.08 * a.cos_table[(int)round(dindex2)];
+			};
+			auto sample = [&](int n_, double yl, double &xm, double &xd) {
+				const double yv = (n_ < bt) ? yl : 0.0;
+				if (TABLE) {
+					double m = 0.0, d = 0.0;
+					if (n_ < bt) {
+						m = table_window(n_);
+						if (n_ == 0) d = -table_window(1) / 2.0;
+						else if (n_ == bt - 1) d = table_window(bt - 2) / 2.0;
+						else d = -(table_window(n_ + 1) - table_window(n_ - 1)) / 2.0;
+					}
+					xm = m * yv;
+					xd = d * yv;
+					return;
+				}
+				const double m = fma(wc, fma(0.16, wc, 0.5), 0.34);
+				const bool first = n_ == 0, last = n_ == bt - 1;
+				const double cnb = fma(wc, r1.x, first ? -(ws_ * r1.y) : ws_ * r1.y);
+				const double mnb = fma(cnb, fma(0.16, cnb, 0.5), 0.34);
+				double d = ws_ * fma(k2, wc, k1);
+				d = first ? -mnb / 2.0 : (last ? mnb / 2.0 : d);
+				xm = m * yv;
+				xd = d * yv;
+				const double nc_ = fma(wc, r8.x, -(ws_ * r8.y));
+				ws_ = fma(ws_, r8.x, wc * r8.y);
+				wc = nc_;
+			};
+			auto interior = [&](int n_, double yv, double &xm, double &xd) {
+				const double m = fma(wc, fma(0.16, wc, 0.5), 0.34);
+				const double d = ws_ * fma(k2, wc, k1);
+				xm = m * yv;
+				xd = d * yv;
+				const double nc_ = fma(wc, r8.x, -(ws_ * r8.y));
+				ws_ = fma(ws_, r8.x, wc * r8.y);
+				wc = nc_;
+			};
+			RQ_T(7);
+			auto sample_at = [&](int n_) { return y[clampi(basic + n_ - 1, 0, u.y_len - 1)]; };
+			double ya = sample_at(sub), yb = sample_at(sub + 8);
+			int Q = 0;
+			for (int n_ = sub; n_ < bt; n_ += 16) {
+				const double nya = sample_at(n_ + 16), nyb = sample_at(n_ + 24);
+				const bool ends = TABLE || n_ == sub || n_ + 9 >= bt;
+				const bool any_end = __ballot(ends) != 0ull;
+				double xm, xd;
+				if (any_end) sample(n_, ya, xm, xd);
+				else interior(n_, ya, xm, xd);
+#pragma unroll
+				for (int h = 0; h < 6; ++h) {
+					sb[2 * h] = fma(c2[h], sa[2 * h], xm) - sb[2 * h];
+					sb[2 * h + 1] = fma(c2[h], sa[2 * h + 1], xd) - sb[2 * h + 1];
+				}
+				if (any_end) sample(n_ + 8, yb, xm, xd);
+				else interior(n_ + 8, yb, xm, xd);
+#pragma unroll
+				for (int h = 0; h < 6; ++h) {
+					sa[2 * h] = fma(c2[h], sb[2 * h], xm) - sa[2 * h];
+					sa[2 * h + 1] = fma(c2[h], sb[2 * h + 1], xd) - sa[2 * h + 1];
+				}
+				Q += 2;
+				ya = nya;
+				yb = nyb;
+			}
+			RQ_T(8);
+			// (everything the closing needs is looked up again from an opaque copy of the lane index: see the kernel above)
+			int ln = lane;
+			asm volatile("" : "+v"(ln));
+			const int sub_c = ln & 7, grp_c = ln >> 3;
+			const int r_c = (c0 + q) * 8 + grp_c;
+			const bool live_c = r_c < M;
+			const int item_c = w_item[live_c ? r_c : 0];
+			const int ws_c = item_c >> 7, t_c = item_c & 127;
+			const unsigned long long kk_c = key[ws_c][t_c];
+			const int N_c = 1 << (2 + (31 - __clz((int)(kk_c & 2047ull) * 2 + 1)));
+			const int tsh_c = kTwiddleN / N_c;
+			int idx[6];
+#pragma unroll
+			for (int h = 0; h < 6; ++h) {
+				const int b0 = (int)(kk_c >> 32);
+				idx[h] = h == 0 ? b0 : (h + 1) * b0 + (int)(((unsigned)kk_c >> (11 + 4 * (h - 1))) & 15u) - 8;
+			}
+			double *const res = reinterpret_cast<double *>(&stage[q_own][0]);  // [grp][h < 4][c]
+			double *const redw = &red[wv][0];
+			const int jc = sub_c & 3;
+			const int wslot = sub_c * 8 + ((grp_c + 2 * (sub_c >> 1)) & 7);
+			int rbase[4];
+#pragma unroll
+			for (int m = 0; m < 4; ++m) rbase[m] = (jc >> 1) * RF_RED_PLANE + (jc & 1) + 2 * (16 * m + ((grp_c + 2 * m) & 7));
+			const int tsl_c = __builtin_ctz((unsigned)tsh_c);
+			// the closing twiddles of the six harmonics, all requested before the first is used
+			double2 e1a[6], e2a[6];
+#pragma unroll
+			for (int h = 0; h < 6; ++h) {
+				const int i1 = (idx[h] * (sub_c + 8 * (Q - 1))) & (N_c - 1);
+				e1a[h] = a.tw[i1 << tsl_c];
+				e2a[h] = a.tw[((i1 + 8 * idx[h]) & (N_c - 1)) << tsl_c];
+			}
+			double r45[2] = {0.0, 0.0};
+#pragma unroll
+			for (int h = 0; h < 6; ++h) {
+				const double2 e1 = e1a[h], e2 = e2a[h];
+				double o[4];
+				o[0] = sa[2 * h] * e1.x - sb[2 * h] * e2.x;
+				o[1] = sb[2 * h] * e2.y - sa[2 * h] * e1.y;
+				o[2] = sa[2 * h + 1] * e1.x - sb[2 * h + 1] * e2.x;
+				o[3] = sb[2 * h + 1] * e2.y - sa[2 * h + 1] * e1.y;
+				*reinterpret_cast<double2 *>(&redw[2 * wslot]) = make_double2(o[0], o[1]);
+				*reinterpret_cast<double2 *>(&redw[RF_RED_PLANE + 2 * wslot]) = make_double2(o[2], o[3]);
+				double x[8];
+#pragma unroll
+				for (int s_ = 0; s_ < 8; ++s_) x[s_] = redw[rbase[s_ >> 1] + 16 * (s_ & 1)];
+				const double sum = ((x[0] + x[4]) + (x[2] + x[6])) + ((x[1] + x[5]) + (x[3] + x[7]));
+				if (h < 4) {
+					if (sub_c < 4) res[(grp_c * 4 + h) * 4 + jc] = sum;
+				} else {
+					r45[h - 4] = sum;
+				}
+			}
+			if (sub_c < 4) {
+				redw[(grp_c * 2 + 0) * 4 + jc] = r45[0];
+				redw[(grp_c * 2 + 1) * 4 + jc] = r45[1];
+			}
+			const int h = sub_c;
+			int myidx = 0;
+#pragma unroll
+			for (int q2 = 0; q2 < 6; ++q2) if (q2 == h) myidx = idx[q2];
+			const double *const mine4 = h < 4 ? &res[(grp_c * 4 + h) * 4] : &redw[(grp_c * 2 + ((h - 4) & 1)) * 4];
+			const double2 m01 = *reinterpret_cast<const double2 *>(mine4), m23 = *reinterpret_cast<const double2 *>(mine4 + 2);
+			const double mr = m01.x, mi = m01.y, dr = m23.x, di = m23.y;
+			const double pw = mr * mr + mi * mi;
+			const double ni = mr * di - mi * dr;
+			const double inst = (pw == 0.0) ? 0.0 : ldexp((double)myidx * fs, -__builtin_ctz((unsigned)N_c)) + ni / pw * fs / 2.0 / kPi;
+			const double amp = sqrt(pw);
+			RQ_T(9);
+			// the key's own candidate, then -- a round for the first of every group, a round for the second, ... -- the candidates of
+			// the same frame that share the key: the same harmonics, their own frequency (fixF0, reference :880-893)
+			{
+				double num, den, sc;
+				finish(ln, inst, amp, it_f[ws_c][t_c], it_nh[ws_c][t_c], num, den, sc);
+				if (sub_c == 0 && live_c) store(ws_c, t_c, num, den, sc);
+			}
+			const int nd_c = live_c ? fr_nd[ws_c] : 0;
+			int k_c = 0;  // (where the group's walk through its frame's list of duplicates stands)
+			for (;;) {
+				int t_m = -1;
+				for (; k_c < nd_c && t_m < 0; ++k_c) {
+					const int t = dup_of[ws_c][k_c];
+					if (it_rep[ws_c][t] == t_c) t_m = t;
+				}
+				if (__ballot(t_m >= 0) == 0ull) break;
+				const int t_s = max(t_m, 0);
+				double num, den, sc;
+				finish(ln, inst, amp, it_f[ws_c][t_s], it_nh[ws_c][t_s], num, den, sc);
+				if (sub_c == 0 && t_m >= 0) store(ws_c, t_s, num, den, sc);
+			}
+			RQ_T(10);
+		}
+	}
+	RQ_FLUSH();
 }
 
 // reference :708-744.  One workgroup per UNR_F consecutive frames of an utterance: the rows of the UNR_F + 2 frames involved are
@@ -2730,7 +3175,7 @@ struct wc_harvest {
 	Device *dev;
 	std::vector<double> band_f0;
 	std::vector<int> half_len, tap_off;
-	DevBuf d_taps, d_tap_off, d_half_len, d_band_f0, d_ev_band_off, d_ev_cap, d_rot;
+	DevBuf d_taps, d_tap_off, d_half_len, d_band_f0, d_ev_band_off, d_ev_cap, d_rot, d_rot8;
 	DevBuf d_sd_rot, d_sd_p0, d_slot_off, d_slot_cap, slots, slot_count, seam, quiet, bmax;
 	bool debug_small_caps;  // WC_DEBUG_SMALL_CAPS, read once at creation: tiny rate-bounded buffers, so that the overflow retry runs (tests)
 	bool tables_valid;  // the capacity tables on the device are those of (tables_ylen, tables_full, tables_tiles)
@@ -2747,7 +3192,7 @@ struct wc_harvest {
 	int use_cos_table_opt = 0;
 	bool raw_from_lists;    // WC_HARVEST_RAW=lists: the edges packed into per-band lists before hv_raw reads them (A/B and the bit-identity test)
 	long long slots_per_utt = 0;
-	bool refine_by_slots;   // WC_HARVEST_REFINE=slots: one wavefront per candidate slot instead of the packed passes (A/B and the bit-identity test)
+	int refine_mode;        // WC_HARVEST_REFINE=slots: one wavefront per candidate slot (1); =packed: one wavefront per frame (2); default: frames in groups (0) (A/B and the bit-identity tests)
 	bool smooth_full_walk;  // WC_HARVEST_SMOOTH=full: the smoothing filter without the skipping of settled stretches (A/B and the bit-identity test)
 	bool direct_decimation;  // WC_HARVEST_DECIMATE=direct: every lane reads its own stream from memory (A/B and the bit-identity test)
 	DevBuf utts, dec, y, events, ev_count, overflow, tile_run, raw, cand0, cand1, score1, cand2, score2;
@@ -2796,13 +3241,35 @@ static inline int h_mround(double x) { return x > 0 ? static_cast<int>(x + 0.5) 
 // Enqueue-only (no host synchronisation), shared with the fused pipeline.  `full` selects the hard bound for the
 // zero-crossing buffers; with the rate bound an overflow is reported through h->overflow (device) and handled by
 // the caller (hv_overflowed) by re-running with full == true.
-static void launch_refine(const RefArgs &fa, hipStream_t s, bool by_slots, bool table) {
+// mode: 0 = frames in groups (hv_refine_group_kernel; rows wider than 112 positions take the packed kernel), 1 = slots, 2 = packed
+static void launch_refine(const RefArgs &fa, hipStream_t s, int mode, bool table) {
 	const unsigned frames = (unsigned)(8 * ((fa.total_frames + 7) / 8));  // (the packed kernel deals frames to the XCDs in eighths)
-	if (by_slots) {
+	const bool small = 7 * fa.p.S <= 112;
+	if (mode == 1) {
 		if (table) hipLaunchKernelGGL(hv_refine_kernel<true>, dim3(frames), dim3(256), 0, s, fa);
 		else hipLaunchKernelGGL(hv_refine_kernel<false>, dim3(frames), dim3(256), 0, s, fa);
+	} else if (mode == 0 && small) {
+		const int n_grp = (fa.max_l1 + WC_RQ_F - 1) / WC_RQ_F;
+		const dim3 blocks((unsigned)(8 * ((n_grp + 7) / 8)), (unsigned)fa.n_utt);
+		if (table) hipLaunchKernelGGL((hv_refine_group_kernel<true, WC_RQ_F>), blocks, dim3(64 * WC_RQ_F), 0, s, fa);
+		else hipLaunchKernelGGL((hv_refine_group_kernel<false, WC_RQ_F>), blocks, dim3(64 * WC_RQ_F), 0, s, fa);
+#if WC_RQ_PROF
+		{
+			unsigned long long h_[16];
+			hipStreamSynchronize(s);
+			hipMemcpyFromSymbol(h_, HIP_SYMBOL(rq_prof), sizeof(h_));
+			static const char *nm[12] = {"gather", "dedupe", "barrier1", "rank+2 barriers", "phase1", "barrier4", "grab", "pass setup", "sample loop", "closing", "members", "-"};
+			unsigned long long tot = 0;
+			for (int k = 0; k < 11; ++k) tot += h_[k];
+			for (int k = 0; k < 11; ++k) fprintf(stderr, "rq_prof %-16s %8.1f Mcycles %5.1f %%\n", nm[k], h_[k] / 1e6, 100.0 * h_[k] / tot);
+			unsigned long long z_[16] = {0};
+			hipMemcpyToSymbol(HIP_SYMBOL(rq_prof), z_, sizeof(z_));
+		}
+#endif
+	} else if (mode == 3 && small && !table) {  // (A/B: two frames per workgroup)
+		const int n_grp = (fa.max_l1 + 1) / 2;
+		hipLaunchKernelGGL((hv_refine_group_kernel<false, 2>), dim3((unsigned)(8 * ((n_grp + 7) / 8)), (unsigned)fa.n_utt), dim3(128), 0, s, fa);
 	} else {
-		const bool small = 7 * fa.p.S <= 112;
 		if (table) {
 			if (small) hipLaunchKernelGGL((hv_refine_packed_kernel<true, 112>), dim3(frames), dim3(64), 0, s, fa);
 			else hipLaunchKernelGGL((hv_refine_packed_kernel<true, 7 * MAX_SLOTS>), dim3(frames), dim3(64), 0, s, fa);
@@ -3025,13 +3492,14 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 	if ((rc = dev->time_end("harvest_raw", s))) return rc;
 	RefArgs fa;
 	fa.utts = du; fa.n_utt = n_utt; fa.y = h->y.as<double>(); fa.cand0 = h->cand0.as<double>(); fa.tw = dev->twiddle; fa.rot = h->d_rot.as<double2>();
-	fa.cand1 = h->cand1.as<double>(); fa.score1 = h->score1.as<double>(); fa.total_frames = total_l1;
+	fa.rot8 = h->d_rot8.as<double2>();
+	fa.cand1 = h->cand1.as<double>(); fa.score1 = h->score1.as<double>(); fa.total_frames = total_l1; fa.max_l1 = max_L1;
 	fa.p.fs = h->fs; fa.p.decim = r; fa.p.n_bands = nb; fa.p.S = S; fa.p.n_cand = nc; fa.p.fs_d = h->fs_d;
 	fa.p.f0_floor = h->f0_floor; fa.p.f0_ceil = h->f0_ceil; fa.p.frame_period = h->frame_period;
 	if ((rc = dev->time_begin("harvest_refine", s))) return rc;
 	fa.cos_table = h->d_cos_table.as<double>();
 	fa.flags = h->overflow.as<int>();
-	launch_refine(fa, s, h->refine_by_slots, h->use_cos_table);
+	launch_refine(fa, s, h->refine_mode, h->use_cos_table);
 	h->last_refine = fa;
 	h->last_refine_valid = true;
 	WC_HIP(hipGetLastError());
@@ -3251,7 +3719,7 @@ wc_harvest *wc_harvest_create(int fs, double f0_floor, double f0_ceil, double fr
 		const char *sm = getenv("WC_HARVEST_SMOOTH");
 		h->smooth_full_walk = sm && std::strcmp(sm, "full") == 0;
 		const char *rfm = getenv("WC_HARVEST_REFINE");
-		h->refine_by_slots = rfm && std::strcmp(rfm, "slots") == 0;
+		h->refine_mode = !rfm ? 0 : std::strcmp(rfm, "slots") == 0 ? 1 : std::strcmp(rfm, "packed") == 0 ? 2 : std::strcmp(rfm, "group2") == 0 ? 3 : 0;
 		const char *rw = getenv("WC_HARVEST_RAW");
 		h->raw_from_lists = rw && std::strcmp(rw, "lists") == 0;
 	}
@@ -3264,6 +3732,15 @@ wc_harvest *wc_harvest_create(int fs, double f0_floor, double f0_ceil, double fr
 		}
 		ok = ok && h->d_rot.reserve(sizeof(double2) * rot.size()) == 0 &&
 			 hipMemcpy(h->d_rot.p, rot.data(), sizeof(double2) * rot.size(), hipMemcpyHostToDevice) == hipSuccess;
+		std::vector<double2> rot8(8 * (RF_MAXHW + 1));
+		const long double lpi = 3.14159265358979323846264338327950288L;
+		for (int hw = 0; hw <= RF_MAXHW; ++hw)
+			for (int k = 0; k < 8; ++k) {
+				const long double ang = 2.0L * lpi * k / (2 * hw + 1);
+				rot8[8 * hw + k] = make_double2((double)cosl(ang), (double)sinl(ang));
+			}
+		ok = ok && h->d_rot8.reserve(sizeof(double2) * rot8.size()) == 0 &&
+			 hipMemcpy(h->d_rot8.p, rot8.data(), sizeof(double2) * rot8.size(), hipMemcpyHostToDevice) == hipSuccess;
 	}
 	if (h->use_cos_table) {  // get_cos_table (reference src/harvest.cpp:152-170): one period from the first quarter, 8001 entries
 		const int n = 2000;
@@ -3294,7 +3771,7 @@ void wc_harvest_destroy(wc_harvest *h) {
 	h->dev->quiesce();
 	if (h->exact_twin) wc_harvest_destroy(h->exact_twin);
 	h->dev->handle_gone();
-	for (DevBuf *b : {&h->d_cos_table, &h->d_sd_rot, &h->d_sd_p0, &h->d_slot_off, &h->d_slot_cap, &h->slots, &h->slot_count, &h->seam, &h->quiet, &h->bmax, &h->d_rot, &h->d_taps, &h->d_tap_off, &h->d_half_len, &h->d_band_f0, &h->d_ev_band_off, &h->d_ev_cap, &h->utts, &h->dec, &h->y,
+	for (DevBuf *b : {&h->d_cos_table, &h->d_sd_rot, &h->d_sd_p0, &h->d_slot_off, &h->d_slot_cap, &h->slots, &h->slot_count, &h->seam, &h->quiet, &h->bmax, &h->d_rot, &h->d_rot8, &h->d_taps, &h->d_tap_off, &h->d_half_len, &h->d_band_f0, &h->d_ev_band_off, &h->d_ev_cap, &h->utts, &h->dec, &h->y,
 					  &h->events, &h->ev_count, &h->overflow, &h->tile_run, &h->raw, &h->cand0, &h->cand1, &h->score1, &h->cand2, &h->score2, &h->base,
 					  &h->s1, &h->s2, &h->s3, &h->fixed, &h->f0_1ms, &h->sec, &h->chan, &h->smooth, &h->ibuf, &h->d_x, &h->d_tpos, &h->d_f0})
 		b->release();
@@ -3370,7 +3847,7 @@ int wc_harvest_debug_refine(wc_harvest *h, const double *cand0, int by_slots, do
 	const RefArgs fa = h->last_refine;
 	const size_t n_in = (size_t)fa.total_frames * fa.p.S, n_out = (size_t)fa.total_frames * fa.p.n_cand;
 	WC_HIP(hipMemcpyAsync(const_cast<double *>(fa.cand0), cand0, sizeof(double) * n_in, hipMemcpyHostToDevice, s));
-	launch_refine(fa, s, by_slots != 0, h->use_cos_table);
+	launch_refine(fa, s, by_slots == 1 ? 1 : by_slots == 2 ? 2 : 0, h->use_cos_table);  // (by_slots: 0 default, 1 slots, 2 packed)
 	WC_HIP(hipGetLastError());
 	WC_HIP(hipMemcpyAsync(cand1, fa.cand1, sizeof(double) * n_out, hipMemcpyDeviceToHost, s));
 	WC_HIP(hipMemcpyAsync(score1, fa.score1, sizeof(double) * n_out, hipMemcpyDeviceToHost, s));
