@@ -180,3 +180,28 @@ def test_signed_cumulative_sum_of_many_random_group_delays(hooks):
     assert np.array_equal(got, sequential(v))
     tree = np.cumsum(v.astype(np.longdouble), axis=1).astype(np.float64)
     assert not np.array_equal(tree, sequential(v))
+
+
+@pytest.mark.parametrize("c", [8000.0, 1000.0, 7350.0, 11025.0, 16000.0, 4000.0, 12000.0, 5512.5, 9600.0])
+def test_division_by_a_known_divisor_is_the_ieee_quotient_bit_for_bit(c):
+    """div_const (wc_device.hpp): x / c as a product with the correctly rounded reciprocal, the exact remainder and one correction --
+    what hv_raw's interval midpoints (reference src/harvest.cpp:1210-1213: (e[k] + e[k + 1]) / 2 / fs) and frame times (i / 1000.0)
+    are divided with since round 6.  Held to the IEEE quotient on 2^24 numerators per divisor: random significands over thirty
+    binades, the integers the frame times are made of, half-integers like the edge sums, significands next to a power of two."""
+    import world_class_amd as w
+    L = w.lib()
+    dp = C.POINTER(C.c_double)
+    L.wc_debug_div_const.restype = C.c_int
+    L.wc_debug_div_const.argtypes = [C.c_longlong, dp, C.c_double, dp]
+    rng = np.random.default_rng(int(c))
+    n = 1 << 22
+    parts = [rng.uniform(1.0, 2.0, n) * 2.0 ** rng.integers(-6, 24, n),
+             np.arange(n, dtype=np.float64),
+             rng.integers(0, 1 << 30, n) / 2.0 + rng.integers(0, 2, n) * 2.0 ** -20,
+             (1.0 + rng.integers(-8, 9, n) * 2.0 ** -52) * 2.0 ** rng.integers(0, 20, n) * rng.choice([1.0, c, c / 3.0, 1000.0], n)]
+    x = np.ascontiguousarray(np.concatenate(parts))
+    out = np.empty_like(x)
+    assert L.wc_debug_div_const(x.size, x.ctypes.data_as(dp), c, out.ctypes.data_as(dp)) == 0
+    want = x / c
+    bad = np.flatnonzero(out.view(np.int64) != want.view(np.int64))
+    assert bad.size == 0, (bad.size, x[bad[:5]], out[bad[:5]], want[bad[:5]])

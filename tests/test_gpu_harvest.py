@@ -315,6 +315,21 @@ def test_raw_candidates_from_the_band_pass_slots_are_bit_identical(wca):
             assert np.array_equal(a.debug_fetch("raw", k), b.debug_fetch("raw", k)), (opts, env, k)
             assert np.array_equal(ra[k][1], rb[k][1])
         assert sum(int((a.debug_fetch("raw", k) != 0).sum()) for k in range(len(batch))) > 10000
+        # round 6: the blocks' slices come from hv_rawdesc_kernel (a thread per (utterance, band, block, type)) and the frames' interval
+        # counts from a running maximum instead of a bisection; WC_HARVEST_RAW=blocks lets every block work its slice out itself
+        for mode in ("blocks",):
+            os.environ.update(env)
+            os.environ["WC_HARVEST_RAW"] = mode
+            try:
+                c = wca.Harvest(fs, **opts)
+            finally:
+                del os.environ["WC_HARVEST_RAW"]
+                for k in env:
+                    del os.environ[k]
+            rc = c.compute_batch(batch)
+            for k in range(len(batch)):
+                assert np.array_equal(a.debug_fetch("raw", k), c.debug_fetch("raw", k)), (opts, env, k, mode)
+                assert np.array_equal(ra[k][1], rc[k][1])
 
 
 def test_helper_handles_are_created_on_the_handles_own_device(wca):

@@ -22,6 +22,15 @@ constexpr int kTwiddleN = 4096;  // table W[k] = e^{+2 pi i k / 4096}, k < 4096
 // reference src/world_matlabfunctions.cpp:212-214
 __device__ __forceinline__ int mround(double x) { return x > 0 ? (int)(x + 0.5) : (int)(x - 0.5); }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return max(lo, min(hi, v)); }
+// x / c for a divisor known in advance, with rc = 1 / c correctly rounded (an IEEE division on the host): a product, the exact
+// remainder, one correction -- three instructions where the division's scale / reciprocal / refine / fix-up sequence takes eleven.
+// The quotient is the correctly rounded one (Markstein's theorem for a correctly rounded reciprocal; held to the hardware's
+// division bit for bit on 2^24 values per divisor in tests/test_gpu_blocks.py), for finite x away from the over- / underflow range.
+__device__ __forceinline__ double div_const(double x, double c, double rc) {
+	const double q0 = x * rc;
+	const double r = fma(-q0, c, x);
+	return fma(r, rc, q0);
+}
 
 // reference src/world_matlabfunctions.cpp:220-241 for one abscissa (y indexed by a functor so the
 // table may live in LDS or be a mirrored view)

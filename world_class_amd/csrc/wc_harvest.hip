@@ -58,6 +58,26 @@ constexpr int FIR_ADV = BP_TILE - 2; // tile advance of the FIR band-pass: its d
 constexpr int Y_PADL = 2 * HL_MAX + 16, Y_PADR = SD_CH + 2 * HL_MAX + 16;
 constexpr int MAX_SLOTS = 32;     // candidates per frame before overlap (reference: round(bands/10))
 
+// orders a wavefront's own LDS writes before its later reads (its LDS operations execute in order: this only keeps the compiler from
+// moving them; no wait, no s_barrier)
+__device__ __forceinline__ void rq_fence() {
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+#ifndef WC_RQ_PROF
+#define WC_RQ_PROF 0  // development builds: shader-clock cycles of every wavefront by phase, summed over the launch (printed by launch_refine)
+#endif
+#if WC_RQ_PROF
+__device__ unsigned long long rq_prof[16];
+#define RQ_T(k) do { const long long now_ = clock64(); acc_[k] += now_ - last_; last_ = now_; } while (0)
+#define RQ_FLUSH() do { if (lane == 0 && ((blockIdx.x + 7 * blockIdx.y) & 63) == 0) for (int k_ = 0; k_ < 12; ++k_) atomicAdd(&rq_prof[k_], (unsigned long long)acc_[k_]); } while (0)
+#else
+#define RQ_T(k) do {} while (0)
+#define RQ_FLUSH() do {} while (0)
+#endif
+
 struct HvUtt {
 	long long x_off;     // samples
 	long long dec_off;   // scratch of the decimator (x_len + 2 lag + 18 per utterance)
@@ -1027,6 +1047,9 @@ struct RawArgs {
 	double *raw;  // [utt: l1_off * n_bands][band][L1]
 	int n_bands;
 	double fs_d, f0_floor, f0_ceil;
+	double r_fs_d;  // 1 / fs_d (div_const)
+	const int4 *desc = nullptr;  // [utt][band][block of frames][type][2]: {base, end, first chunk, mode}, {running counts of that chunk and the three behind it} (hv_rawdesc_kernel)
+	int desc_blocks = 0;
 };
 
 // c = #{k < n : loc[k] <= t} for the interval midpoints loc[k] = (e[k] + e[k+1]) / 2 / fs, searched in [lo, hi)
@@ -1048,7 +1071,10 @@ __device__ __forceinline__ int hv_count_le(E e, int lo, int hi, double fs, doubl
 }
 
 constexpr int RAW_T = 256;      // frames per workgroup
-constexpr int RAW_LDS = 304;    // staged intervals per type: 256 ms of a 968 Hz band hold 248 (+ 8 of margin); 19.5 KB per workgroup, 7 per CU (512: 4 per CU)
+#ifndef WC_RAW_LDS
+#define WC_RAW_LDS 304
+#endif
+constexpr int RAW_LDS = WC_RAW_LDS;    // staged intervals per type: 256 ms of a 968 Hz band hold 248 (+ 8 of margin); 19.5 KB per workgroup, 7 per CU (512: 4 per CU)
 
 // One workgroup per (utterance, band, 256 consecutive 1 ms frames).  The fine edges that can matter for these
 // frames form a short contiguous slice of each of the four event lists; wave `ty` locates the slice of type `ty`
@@ -1061,11 +1087,94 @@ constexpr int RAW_LDS = 304;    // staged intervals per type: 256 ms of a 968 Hz
 // reaches further than four chunks -- silence -- goes through a copy in LDS; single edges for the fallback are found by bisecting
 // tile_run).  hv_compact_kernel then only forms the running counts: 0.33 -> 0.02 ms per half batch and 1.6 GB less traffic per
 // step, for 0.13 ms more in this kernel.  <false>: per-band lists, as the FIR band-pass writes them and WC_HARVEST_RAW=lists packs them.
-template <bool SLOTS>
+// How many staged intervals lie at or before frame i of the block (X[j] <= i / 1000.0)?  Every frame used to bisect X for it, eight
+// dependent look-ups per type.  Round 6: interval j marks the FIRST frame at or behind its midpoint with j + 1 and a running
+// maximum over the block's 256 frames gives every frame its count -- the same comparison, made once per interval.  One wavefront.
+__device__ __forceinline__ void raw_frame_counts(const double *__restrict__ Xs, unsigned short *__restrict__ lo_, int len, int i0, int lane) {
+	*reinterpret_cast<uint2 *>(&lo_[4 * lane]) = make_uint2(0u, 0u);
+	rq_fence();
+	for (int j0 = 0; j0 < len; j0 += 64) {
+		const int j = j0 + lane;
+		int rel = RAW_T;
+		if (j < len) {
+			const double x = Xs[j];
+			int f = (int)ceil(x * 1000.0);
+			while (f > 0 && div_const((double)(f - 1), 1000.0, 1.0 / 1000.0) >= x) --f;   // the first frame with f / 1000.0 >= x, exactly
+			while (div_const((double)f, 1000.0, 1.0 / 1000.0) < x) ++f;
+			rel = max(f - i0, 0);
+		}
+		// (two midpoints less than a millisecond apart may mark one frame: the later interval must win, whatever the order the
+		// hardware serves the lanes of a store in)
+		bool pending = rel < RAW_T;
+		while (__ballot(pending) != 0ull) {
+			if (pending) lo_[rel] = (unsigned short)(j + 1);
+			rq_fence();
+			pending = pending && lo_[rel] < j + 1;
+		}
+	}
+	rq_fence();
+	const uint2 w2 = *reinterpret_cast<const uint2 *>(&lo_[4 * lane]);
+	int m0 = (int)(w2.x & 0xFFFFu), m1 = (int)(w2.x >> 16), m2 = (int)(w2.y & 0xFFFFu), m3 = (int)(w2.y >> 16);
+	m1 = max(m1, m0); m2 = max(m2, m1); m3 = max(m3, m2);
+	int inc = m3;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const int t = __shfl_up(inc, o, 64);
+		if (lane >= o) inc = max(inc, t);
+	}
+	int ex = __shfl_up(inc, 1, 64);
+	if (lane == 0) ex = 0;
+	m0 = max(m0, ex); m1 = max(m1, ex); m2 = max(m2, ex); m3 = max(m3, ex);
+	*reinterpret_cast<uint2 *>(&lo_[4 * lane]) = make_uint2((unsigned)m0 | ((unsigned)m1 << 16), (unsigned)m2 | ((unsigned)m3 << 16));
+}
+
+// The slice of edges a block of 256 frames needs of each of the four lists (see hv_raw_kernel), worked out once per (utterance,
+// band, block, type) by a thread of its own (round 6): {first edge, one past the last, the chunk that holds the first, mode} and the
+// running counts of that chunk and the three behind it.  mode 0: the slice lies within those four chunks (the usual case);
+// 1: too long to stage; 2: it reaches further (silence) -- the block goes through the running counts itself.
+__global__ __launch_bounds__(256) void hv_rawdesc_kernel(RawArgs a, int4 *__restrict__ desc, int nblk, int n_utt) {
+	const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+	const long long total = 4ll * nblk * a.n_bands * n_utt;
+	if (gid >= total) return;
+	const int ty = (int)(gid & 3);
+	const int b = (int)((gid >> 2) % nblk);
+	const long long ub = (gid >> 2) / nblk;  // utterance * n_bands + band
+	const HvUtt u = a.utts[ub / a.n_bands];
+	int4 d0 = make_int4(0, 0, 0, 1), d1 = make_int4(0, 0, 0, 0);
+	const int i0 = b * RAW_T;
+	if (i0 < u.L1) {
+		const int *__restrict__ trun = a.tile_run + ub * (a.n_tiles + 1) * 4;
+		const int cnt_ty = a.ev_count[ub * 4 + ty];
+		const int ce = (cnt_ty < 2 ? 0 : cnt_ty - 1) + 1;  // edges in the list (as hv_raw_kernel counts them)
+		const int i1 = min(i0 + RAW_T - 1, u.L1 - 1);
+		const int smp0 = (int)(i0 * (a.fs_d * 1e-3)), smp1 = (int)(i1 * (a.fs_d * 1e-3));
+		const int q0 = min(a.n_tiles, max(0, smp0 / SD_CH));
+		const int q1 = min(a.n_tiles, smp1 / SD_CH + 1);
+		auto T = [&](int c) { return trun[c * 4 + ty]; };
+		const int base = max(0, min(T(q0), ce) - 4);
+		const int end = min(ce, min(T(q1), ce) + 4);
+		int c = q0;
+		while (c > 0 && T(c) > base) --c;  // first chunk that holds an edge of the slice
+		const int t0 = T(c), t1 = T(min(c + 1, a.n_tiles)), t2 = T(min(c + 2, a.n_tiles)), t3 = T(min(c + 3, a.n_tiles)),
+				  t4 = T(min(c + 4, a.n_tiles));
+		const int mode = (end - base - 1 > RAW_LDS) ? 1 : ((end <= t4 || c + 4 >= a.n_tiles) ? 0 : 2);
+		d0 = make_int4(base, end, c, mode);
+		d1 = make_int4(t0, t1, t2, t3);
+	}
+	desc[2 * gid] = d0;
+	desc[2 * gid + 1] = d1;
+}
+
+template <bool SLOTS, bool DESC>
 __global__ __launch_bounds__(RAW_T) void hv_raw_kernel(RawArgs a) {
 	__shared__ double X[4][RAW_LDS], Y[4][RAW_LDS + 1];  // (Y holds the slice's edges first: interval j replaces edge j once both of its edges are read)
 	__shared__ int s_base[4], s_len[4];
+	__shared__ __attribute__((aligned(8))) unsigned short LO[4][RAW_T];  // per type and frame of the block: how many staged intervals lie at or before the frame
 	const int tid = threadIdx.x, lane = tid & 63, ty_w = tid >> 6;
+#if WC_RQ_PROF
+	long long acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+	long long last_ = clock64();
+#endif
 	const int band = blockIdx.y;
 	const HvUtt u = a.utts[blockIdx.z];
 	const int i0 = blockIdx.x * RAW_T;
@@ -1098,7 +1207,7 @@ __global__ __launch_bounds__(RAW_T) void hv_raw_kernel(RawArgs a) {
 	const int q0 = min(a.n_tiles, max(0, SLOTS ? smp0 / SD_CH : smp0 / a.tile_adv));
 	const int q1 = min(a.n_tiles, (SLOTS ? smp1 / SD_CH : smp1 / a.tile_adv) + 1);
 	const int tr_first = q0 - 2;
-	const int tr_mine = trun_b[min(max(tr_first + (lane & 7), 0), a.n_tiles) * 4 + ty_w];
+	const int tr_mine = DESC ? 0 : trun_b[min(max(tr_first + (lane & 7), 0), a.n_tiles) * 4 + ty_w];
 	// number of intervals = edges - 1 (0 when fewer than 2 edges); all four need more than 2 (reference :1101-1107)
 	int n[4];
 	bool ok = true;
@@ -1113,7 +1222,48 @@ __global__ __launch_bounds__(RAW_T) void hv_raw_kernel(RawArgs a) {
 		return;
 	}
 	const double fs = a.fs_d;
-	{
+	RQ_T(0);
+	if (DESC) {
+		// the slice as hv_rawdesc_kernel left it: scalar loads, nothing to work out in front of the edges' own loads
+		const int ty = __builtin_amdgcn_readfirstlane(ty_w);
+		const int4 *__restrict__ dp = a.desc + ((((long long)blockIdx.z * a.n_bands + band) * a.desc_blocks + blockIdx.x) * 4 + ty) * 2;
+		const int4 d0 = dp[0], d1 = dp[1];
+		const int base = d0.x, end = d0.y, c0 = d0.z, mode = d0.w;
+		const int len = end - base - 1;
+		RQ_T(1);
+		if (lane == 0) { s_base[ty] = (mode != 1) ? base : -1; s_len[ty] = len; }
+		if (mode != 1) {
+			double *__restrict__ E = Y[ty];
+			if (mode == 0) {
+				const int t0 = d1.x, t1 = d1.y, t2 = d1.z, t3 = d1.w;
+				const double *__restrict__ sl0 = slot + ((long long)c0 * 4 + ty) * scap;  // (the four chunks' slots lie 4 scap apart)
+				for (int j = lane; j <= len; j += 64) {  // the slice's edges, then interval j over edge j once both of its edges are read
+					const int q = base + j;
+					const int kq = (q >= t1 ? 1 : 0) + (q >= t2 ? 1 : 0) + (q >= t3 ? 1 : 0);
+					const int tk = kq == 0 ? t0 : (kq == 1 ? t1 : (kq == 2 ? t2 : t3));
+					E[j] = sl0[kq * 4 * scap + min(q - tk, scap - 1)];
+				}
+			} else {
+				for (int c = c0; c < a.n_tiles && trun_b[c * 4 + ty] < end; ++c) {
+					const int tc = trun_b[c * 4 + ty];
+					const int lo = max(base, tc), hi = min(end, trun_b[(c + 1) * 4 + ty]);
+					const double *__restrict__ src = slot + ((long long)c * 4 + ty) * scap;
+					for (int q = lo + lane; q < hi; q += 64) E[q - base] = src[min(q - tc, scap - 1)];
+				}
+			}
+			rq_fence();
+			for (int j0 = 0; j0 < len; j0 += 64) {  // (one wavefront per type: the reads of a trip precede its writes)
+				const int j = j0 + lane;
+				double ea = 0.0, eb = 1.0;
+				if (j < len) { ea = E[j]; eb = E[j + 1]; }
+				if (j < len) {
+					X[ty][j] = div_const((ea + eb) / 2.0, fs, a.r_fs_d);
+					Y[ty][j] = fs / (eb - ea);
+				}
+			}
+			raw_frame_counts(X[ty], LO[ty], len, i0, lane);
+		}
+	} else {
 		const int ty = ty_w;
 		const int *__restrict__ trun = trun_b;
 		const int ce = n[ty] + 1;  // edges in the list
@@ -1124,6 +1274,7 @@ __global__ __launch_bounds__(RAW_T) void hv_raw_kernel(RawArgs a) {
 		const int base = max(0, min(T(q0), ce) - 4);
 		const int end = min(ce, min(T(q1), ce) + 4);
 		const int len = end - base - 1;  // staged intervals base .. base + len - 1
+		RQ_T(1);
 		if (lane == 0) { s_base[ty] = (len <= RAW_LDS) ? base : -1; s_len[ty] = len; }
 		if (len <= RAW_LDS) {
 			double *__restrict__ E = Y[ty];  // edges base .. end - 1 (general path)
@@ -1143,7 +1294,7 @@ __global__ __launch_bounds__(RAW_T) void hv_raw_kernel(RawArgs a) {
 					};
 					for (int j = lane; j < len; j += 64) {
 						const double ea = at(base + j), eb = at(base + j + 1);
-						X[ty][j] = (ea + eb) / 2.0 / fs;
+						X[ty][j] = div_const((ea + eb) / 2.0, fs, a.r_fs_d);
 						Y[ty][j] = fs / (eb - ea);
 					}
 					done = true;
@@ -1159,7 +1310,7 @@ __global__ __launch_bounds__(RAW_T) void hv_raw_kernel(RawArgs a) {
 				const double *__restrict__ e = ev + (long long)ty * cap;
 				for (int j = lane; j < len; j += 64) {
 					const double ea = e[base + j], eb = e[base + j + 1];
-					X[ty][j] = (ea + eb) / 2.0 / fs;
+					X[ty][j] = div_const((ea + eb) / 2.0, fs, a.r_fs_d);
 					Y[ty][j] = fs / (eb - ea);
 				}
 				done = true;
@@ -1170,15 +1321,18 @@ __global__ __launch_bounds__(RAW_T) void hv_raw_kernel(RawArgs a) {
 					double ea = 0.0, eb = 1.0;
 					if (j < len) { ea = E[j]; eb = E[j + 1]; }
 					if (j < len) {
-						X[ty][j] = (ea + eb) / 2.0 / fs;
+						X[ty][j] = div_const((ea + eb) / 2.0, fs, a.r_fs_d);
 						Y[ty][j] = fs / (eb - ea);
 					}
 				}
+			raw_frame_counts(X[ty], LO[ty], len, i0, lane);
 		}
 	}
+	RQ_T(2);
 	__syncthreads();
+	RQ_T(3);
 	if (i >= u.L1) return;
-	const double t = i * 1 / 1000.0;
+	const double t = div_const((double)(i * 1), 1000.0, 1.0 / 1000.0);  // i * 1 / 1000.0
 	double s = 0.0;
 #pragma unroll
 	for (int ty = 0; ty < 4; ++ty) {  // (a + b + c + d) in the reference's order: negative-going, positive-going, peaks, dips
@@ -1190,11 +1344,7 @@ __global__ __launch_bounds__(RAW_T) void hv_raw_kernel(RawArgs a) {
 			// (otherwise the true boundary may lie outside: fall back to the whole list)
 			const double *xs = X[ty];
 			const int len = s_len[ty];
-			int lo = 0, hi = len;
-			while (lo < hi) {
-				const int mid = (lo + hi) >> 1;
-				if (xs[mid] <= t) lo = mid + 1; else hi = mid;
-			}
+			const int lo = LO[ty][tid];  // #{j < len : X[j] <= t}
 			const int c = base + lo;
 			if ((lo > 0 || base == 0) && (lo < len || base + len == n[ty])) {
 				const int k = min(max(c, 1), n[ty] - 1) - base;  // interp1 between intervals k - 1 and k
@@ -1210,7 +1360,7 @@ __global__ __launch_bounds__(RAW_T) void hv_raw_kernel(RawArgs a) {
 			const int c = hv_count_le(eg, 0, n[ty], fs, t);
 			const int k = min(max(c, 1), n[ty] - 1);
 			const double e0 = eg(k - 1), e1 = eg(k), e2 = eg(k + 1);
-			x0 = (e0 + e1) / 2.0 / fs; x1 = (e1 + e2) / 2.0 / fs;
+			x0 = div_const((e0 + e1) / 2.0, fs, a.r_fs_d); x1 = div_const((e1 + e2) / 2.0, fs, a.r_fs_d);
 			y0 = fs / (e1 - e0); y1 = fs / (e2 - e1);
 		}
 		// interp1 (reference src/world_matlabfunctions.cpp:157-182) of the intervals fs / (e[k+1] - e[k]) located
@@ -1219,10 +1369,13 @@ __global__ __launch_bounds__(RAW_T) void hv_raw_kernel(RawArgs a) {
 		const double v = y0 + sl * (y1 - y0);
 		s = (ty == 0) ? v : s + v;
 	}
+	RQ_T(4);
 	double v = s / 4.0;
 	const double fb = a.band_f0[band];
 	if (v > fb * 1.1 || v < fb * 0.9 || v > a.f0_ceil || v < a.f0_floor) v = 0.0;
 	out[i] = v;
+	RQ_T(5);
+	RQ_FLUSH();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1980,13 +2133,6 @@ __global__ __launch_bounds__(64, RF_NP > 112 ? 2 : WC_REFINE_WAVES) void hv_refi
 	}
 }
 
-// orders a wavefront's own LDS writes before its later reads (its LDS operations execute in order: this only keeps the compiler from
-// moving them; no wait, no s_barrier)
-__device__ __forceinline__ void rq_fence() {
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-	__builtin_amdgcn_wave_barrier();
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // The packed refinement with the work of RQ_F neighbouring frames dealt out together (round 6, default; the kernel above is
 // WC_HARVEST_REFINE=packed).  A pass of the kernel above takes as long as the longest of its eight windows and a frame's last pass is
@@ -2003,17 +2149,6 @@ __device__ __forceinline__ void rq_fence() {
 // closing sums): same bits, whatever group of whatever wavefront takes it.
 #ifndef WC_RQ_F
 #define WC_RQ_F 4
-#endif
-#ifndef WC_RQ_PROF
-#define WC_RQ_PROF 0  // development builds: shader-clock cycles of every wavefront by phase, summed over the launch (printed by launch_refine)
-#endif
-#if WC_RQ_PROF
-__device__ unsigned long long rq_prof[16];
-#define RQ_T(k) do { const long long now_ = clock64(); acc_[k] += now_ - last_; last_ = now_; } while (0)
-#define RQ_FLUSH() do { if (lane == 0 && (blockIdx.x & 63) == 0) for (int k_ = 0; k_ < 12; ++k_) atomicAdd(&rq_prof[k_], (unsigned long long)acc_[k_]); } while (0)
-#else
-#define RQ_T(k) do {} while (0)
-#define RQ_FLUSH() do {} while (0)
 #endif
 #ifndef WC_RQ_PC
 #define WC_RQ_PC 8   // passes whose start phases are staged together: 8 KB, one stretch for up to 64 keys
@@ -2043,11 +2178,12 @@ __global__ __launch_bounds__(64 * F, WC_REFINE_WAVES) void hv_refine_group_kerne
 	__shared__ double2 stage[F][64];  // a wavefront's closing sums on their way to the harmonics' lanes
 	__shared__ double2 it_ph[F][NP];  // window phase of a distinct key at its sample 0
 	__shared__ int it_basic[F][NP];
-	__shared__ unsigned char it_pos[F][NP], it_rep[F][NP], un_src[F][NP], dup_of[F][NP], it_nh[F][NP], un_at[F][NP];
+	__shared__ unsigned char it_pos[F][NP], un_src[F][NP], it_nh[F][NP], un_at[F][NP], dup_next[F][NP];
+	__shared__ int dup_head[F][NP];  // the candidates of a frame that share the key of candidate t: dup_head[t], dup_next[that], ... (>= NP: none)
 	__shared__ int hist[F][128];   // distinct keys per wavefront and window-length class (eight samples of half length to a class, longest first)
 	__shared__ int place[F][128];  // where a wavefront's keys of a class start in the group's list
 	__shared__ unsigned short w_item[F * NP];
-	__shared__ int fr_n[F], fr_nd[F];
+	__shared__ int fr_n[F];
 	__shared__ int next_pass;
 	const unsigned long long below = (1ull << lane) - 1ull;
 #if WC_RQ_PROF
@@ -2057,21 +2193,30 @@ __global__ __launch_bounds__(64 * F, WC_REFINE_WAVES) void hv_refine_group_kerne
 	hist[wv][lane] = 0;
 	hist[wv][64 + lane] = 0;
 
-	// 1. live candidates of the overlap (reference :987-1000), slot-major: position k = 7 j + block
+	// 1. live candidates of the overlap (reference :987-1000) in the order of the frame's row: position p = S block + j (the order
+	//    decides nothing but which of several candidates with one key stands for it).  Both rounds' rows are requested up front.
 	int n = 0;
 	{
 		const double pos = i * 1 / 1000.0;
-		for (int base = 0; have && base < NC; base += 64) {
-			const int k = base + lane;
-			const int j = k / 7, blk = k - 7 * j;
+		double fv[2] = {0.0, 0.0};
+		const float r_S = 1.0f / (float)S;
+#pragma unroll
+		for (int rd = 0; rd < 2; ++rd) {
+			const int p_ = rd * 64 + lane;
+			const int blk = (int)((p_ + 0.5f) * r_S), j = p_ - blk * S;  // (p_ / S: exact for these small integers)
 			const int src = (blk == 0) ? i : (blk <= 3 ? i - blk : i + (blk - 3));
-			double f = 0.0;
-			if (k < NC && src >= 0 && src < u.L1) f = crow[(src - i) * S + j];
+			if (have && p_ < NC && src >= 0 && src < u.L1) fv[rd] = crow[(src - i) * S + j];
+		}
+#pragma unroll
+		for (int rd = 0; rd < 2; ++rd) {
+			const int p_ = rd * 64 + lane;
+			if (!have || rd * 64 >= NC) break;
+			const double f = fv[rd];
 			const bool live = f > 0.0;
 			const unsigned long long m = __ballot(live);
-			if (k < NC && !live) {  // an empty position
-				a.cand1[g * a.p.n_cand + j + S * blk] = 0.0;
-				a.score1[g * a.p.n_cand + j + S * blk] = 0.0;
+			if (p_ < NC && !live) {  // an empty position
+				a.cand1[g * a.p.n_cand + p_] = 0.0;
+				a.score1[g * a.p.n_cand + p_] = 0.0;
 			}
 			if (live) {
 				const int at = n + __popcll(m & below);
@@ -2086,7 +2231,7 @@ __global__ __launch_bounds__(64 * F, WC_REFINE_WAVES) void hv_refine_group_kerne
 					kk |= (unsigned long long)(dlt & 15) << (11 + 4 * (h - 1));
 				}
 				it_f[wv][at] = f;
-				it_pos[wv][at] = (unsigned char)(j + S * blk);
+				it_pos[wv][at] = (unsigned char)p_;
 				key[wv][at] = kk;
 				it_basic[wv][at] = mround((pos + (-hw) / fs) * fs + 0.001);
 				it_nh[wv][at] = (unsigned char)min((int)(fs / 2.0 / f), 6);
@@ -2108,7 +2253,7 @@ __global__ __launch_bounds__(64 * F, WC_REFINE_WAVES) void hv_refine_group_kerne
 	RQ_T(0);
 	// 2. the first candidate of every key (the hash table of the kernel above; a wavefront's LDS operations execute in order), and
 	//    the distinct keys counted by window-length class
-	int nu = 0, nd = 0;
+	int nu = 0;
 	if (n > 0) {
 		unsigned int *const tab = reinterpret_cast<unsigned int *>(&red[wv][0]);
 		auto slot_of = [](unsigned long long kk) { return (((unsigned)kk * 2654435761u) ^ ((unsigned)(kk >> 32) * 40503u * 65537u)) >> 24; };
@@ -2126,18 +2271,15 @@ __global__ __launch_bounds__(64 * F, WC_REFINE_WAVES) void hv_refine_group_kerne
 				if (r != t && key[wv][r] == mine) rep = r;
 			}
 			const bool uniq = t < n && rep == t, dup = t < n && rep != t;
-			const unsigned long long mu = __ballot(uniq), md = __ballot(dup);
+			const unsigned long long mu = __ballot(uniq);
 			if (uniq) {
 				const int r = nu + __popcll(mu & below);
 				un_src[wv][r] = (unsigned char)t;
 				un_at[wv][r] = (unsigned char)atomicAdd(&hist[wv][127 - (int)((mine & 2047ull) >> 3)], 1);  // (its place among the wavefront's keys of the class)
 			}
-			if (dup) {
-				dup_of[wv][nd + __popcll(md & below)] = (unsigned char)t;
-				it_rep[wv][t] = (unsigned char)rep;
-			}
+			if (uniq) dup_head[wv][t] = 255;
+			if (dup) dup_next[wv][t] = (unsigned char)atomicExch(&dup_head[wv][rep], t);  // (rep < t: its head has been set, in this round by the line above)
 			nu += __popcll(mu);
-			nd += __popcll(md);
 		}
 	}
 	// the window phase of every distinct key at sample 0: a lane per key here, where the kernels above spend a lane per (key, first
@@ -2146,7 +2288,7 @@ __global__ __launch_bounds__(64 * F, WC_REFINE_WAVES) void hv_refine_group_kerne
 		const int t = un_src[wv][r];
 		it_ph[wv][t] = rf_phase0((int)(key[wv][t] & 2047ull), it_basic[wv][t], i * 1 / 1000.0, fs);
 	}
-	if (lane == 0) { fr_n[wv] = nu; fr_nd[wv] = nd; }
+	if (lane == 0) fr_n[wv] = nu;
 	if (threadIdx.x == 0) next_pass = 0;
 	RQ_T(1);
 	__syncthreads();
@@ -2396,19 +2538,13 @@ __global__ __launch_bounds__(64 * F, WC_REFINE_WAVES) void hv_refine_group_kerne
 				finish(ln, inst, amp, it_f[ws_c][t_c], it_nh[ws_c][t_c], num, den, sc);
 				if (sub_c == 0 && live_c) store(ws_c, t_c, num, den, sc);
 			}
-			const int nd_c = live_c ? fr_nd[ws_c] : 0;
-			int k_c = 0;  // (where the group's walk through its frame's list of duplicates stands)
-			for (;;) {
-				int t_m = -1;
-				for (; k_c < nd_c && t_m < 0; ++k_c) {
-					const int t = dup_of[ws_c][k_c];
-					if (it_rep[ws_c][t] == t_c) t_m = t;
-				}
-				if (__ballot(t_m >= 0) == 0ull) break;
-				const int t_s = max(t_m, 0);
+			int t_m = live_c ? dup_head[ws_c][t_c] : 255;
+			while (__ballot(t_m < NP) != 0ull) {
+				const int t_s = t_m < NP ? t_m : t_c;
 				double num, den, sc;
 				finish(ln, inst, amp, it_f[ws_c][t_s], it_nh[ws_c][t_s], num, den, sc);
-				if (sub_c == 0 && t_m >= 0) store(ws_c, t_s, num, den, sc);
+				if (sub_c == 0 && t_m < NP) store(ws_c, t_s, num, den, sc);
+				t_m = t_m < NP ? dup_next[ws_c][t_s] : 255;
 			}
 			RQ_T(10);
 		}
@@ -3190,13 +3326,14 @@ struct wc_harvest {
 	bool ignore_ties = false;  // WC_HARVEST_TIES=ignore: the tie flag is not acted upon (A/B and tests)
 	wc_harvest *exact_twin = nullptr;  // the same options with the band-pass as a direct FIR sum: re-runs of batches that raised the tie flag (hv_exact_twin)
 	int use_cos_table_opt = 0;
+	int raw_mode = 0;       // WC_HARVEST_RAW=blocks: every block of frames works out its own slice (1, round 5); default 0: slices from hv_rawdesc_kernel
 	bool raw_from_lists;    // WC_HARVEST_RAW=lists: the edges packed into per-band lists before hv_raw reads them (A/B and the bit-identity test)
 	long long slots_per_utt = 0;
 	int refine_mode;        // WC_HARVEST_REFINE=slots: one wavefront per candidate slot (1); =packed: one wavefront per frame (2); default: frames in groups (0) (A/B and the bit-identity tests)
 	bool smooth_full_walk;  // WC_HARVEST_SMOOTH=full: the smoothing filter without the skipping of settled stretches (A/B and the bit-identity test)
 	bool direct_decimation;  // WC_HARVEST_DECIMATE=direct: every lane reads its own stream from memory (A/B and the bit-identity test)
 	DevBuf utts, dec, y, events, ev_count, overflow, tile_run, raw, cand0, cand1, score1, cand2, score2;
-	DevBuf base, s1, s2, s3, fixed, f0_1ms, sec, chan, smooth, ibuf;
+	DevBuf base, s1, s2, s3, fixed, f0_1ms, sec, chan, smooth, ibuf, rawdesc;
 	DevBuf d_x, d_tpos, d_f0;
 	HostBuf h_stage;
 	std::vector<HvUtt> last_utts;
@@ -3481,12 +3618,36 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 	ra.utts = du; ra.events = h->events.as<double>(); ra.ev_band_off = h->d_ev_band_off.as<long long>(); ra.ev_cap = h->d_ev_cap.as<int>();
 	ra.ev_count = h->ev_count.as<int>(); ra.band_f0 = h->d_band_f0.as<double>(); ra.raw = h->raw.as<double>(); ra.n_bands = nb;
 	ra.tile_run = h->tile_run.as<int>(); ra.n_tiles = n_tiles; ra.tile_adv = tile_adv;
-	ra.fs_d = h->fs_d; ra.f0_floor = h->f0_floor; ra.f0_ceil = h->f0_ceil;
+	ra.fs_d = h->fs_d; ra.f0_floor = h->f0_floor; ra.f0_ceil = h->f0_ceil; ra.r_fs_d = 1.0 / h->fs_d;
 	if ((rc = dev->time_begin("harvest_raw", s))) return rc;
 	ra.slots = h->slots.as<double>(); ra.slot_off = h->d_slot_off.as<long long>(); ra.slot_cap = h->d_slot_cap.as<int>();
 	ra.slots_per_utt = h->slots_per_utt;
-	if (h->use_fir || h->raw_from_lists) hipLaunchKernelGGL(hv_raw_kernel<false>, dim3((max_L1 + 255) / 256, nb, n_utt), dim3(256), 0, s, ra);
-	else hipLaunchKernelGGL(hv_raw_kernel<true>, dim3((max_L1 + 255) / 256, nb, n_utt), dim3(256), 0, s, ra);
+	if (h->use_fir || h->raw_from_lists) hipLaunchKernelGGL((hv_raw_kernel<false, false>), dim3((max_L1 + 255) / 256, nb, n_utt), dim3(256), 0, s, ra);
+	else if (h->raw_mode == 1) hipLaunchKernelGGL((hv_raw_kernel<true, false>), dim3((max_L1 + 255) / 256, nb, n_utt), dim3(256), 0, s, ra);
+	else {
+		// the slice of every (utterance, band, block of frames, type) worked out once, a thread each, instead of by every lane of
+		// the block's wavefront behind three dependent look-ups
+		const int nblk = (max_L1 + RAW_T - 1) / RAW_T;
+		if ((rc = h->rawdesc.reserve(sizeof(int4) * 2ll * 4 * nblk * nb * n_utt))) return rc;
+		ra.desc = h->rawdesc.as<int4>();
+		ra.desc_blocks = nblk;
+		const long long nd = 4ll * nblk * nb * n_utt;
+		hipLaunchKernelGGL(hv_rawdesc_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, s, ra, h->rawdesc.as<int4>(), nblk, n_utt);
+		hipLaunchKernelGGL((hv_raw_kernel<true, true>), dim3(nblk, nb, n_utt), dim3(256), 0, s, ra);
+	}
+#if WC_RQ_PROF
+	{
+		unsigned long long h_[16];
+		hipStreamSynchronize(s);
+		hipMemcpyFromSymbol(h_, HIP_SYMBOL(rq_prof), sizeof(h_));
+		static const char *nm[6] = {"set-up", "slice bounds", "staging", "barrier", "frames", "store"};
+		unsigned long long tot = 0;
+		for (int k = 0; k < 6; ++k) tot += h_[k];
+		for (int k = 0; k < 6; ++k) fprintf(stderr, "raw_prof %-16s %8.1f Mcycles %5.1f %%\n", nm[k], h_[k] / 1e6, 100.0 * h_[k] / tot);
+		unsigned long long z_[16] = {0};
+		hipMemcpyToSymbol(HIP_SYMBOL(rq_prof), z_, sizeof(z_));
+	}
+#endif
 	hipLaunchKernelGGL(hv_detect_kernel, dim3((max_L1 + 255) / 256, n_utt), dim3(256), 0, s, du, h->raw.as<double>(), h->cand0.as<double>(), nb, S);
 	WC_HIP(hipGetLastError());
 	if ((rc = dev->time_end("harvest_raw", s))) return rc;
@@ -3722,6 +3883,7 @@ wc_harvest *wc_harvest_create(int fs, double f0_floor, double f0_ceil, double fr
 		h->refine_mode = !rfm ? 0 : std::strcmp(rfm, "slots") == 0 ? 1 : std::strcmp(rfm, "packed") == 0 ? 2 : std::strcmp(rfm, "group2") == 0 ? 3 : 0;
 		const char *rw = getenv("WC_HARVEST_RAW");
 		h->raw_from_lists = rw && std::strcmp(rw, "lists") == 0;
+		h->raw_mode = rw && std::strcmp(rw, "blocks") == 0 ? 1 : 0;
 	}
 	{
 		std::vector<double2> rot(2 * (RF_MAXHW + 1));
@@ -3773,7 +3935,7 @@ void wc_harvest_destroy(wc_harvest *h) {
 	h->dev->handle_gone();
 	for (DevBuf *b : {&h->d_cos_table, &h->d_sd_rot, &h->d_sd_p0, &h->d_slot_off, &h->d_slot_cap, &h->slots, &h->slot_count, &h->seam, &h->quiet, &h->bmax, &h->d_rot, &h->d_rot8, &h->d_taps, &h->d_tap_off, &h->d_half_len, &h->d_band_f0, &h->d_ev_band_off, &h->d_ev_cap, &h->utts, &h->dec, &h->y,
 					  &h->events, &h->ev_count, &h->overflow, &h->tile_run, &h->raw, &h->cand0, &h->cand1, &h->score1, &h->cand2, &h->score2, &h->base,
-					  &h->s1, &h->s2, &h->s3, &h->fixed, &h->f0_1ms, &h->sec, &h->chan, &h->smooth, &h->ibuf, &h->d_x, &h->d_tpos, &h->d_f0})
+					  &h->s1, &h->s2, &h->s3, &h->fixed, &h->f0_1ms, &h->sec, &h->chan, &h->smooth, &h->ibuf, &h->rawdesc, &h->d_x, &h->d_tpos, &h->d_f0})
 		b->release();
 	h->h_stage.release();
 	delete h;

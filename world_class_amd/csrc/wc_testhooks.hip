@@ -259,6 +259,11 @@ void launch_complex(int sign, int batch, const double2 *in, double2 *out, const 
 }
 }  // namespace
 
+__global__ void hook_div_const_kernel(const double *__restrict__ in, double *__restrict__ out, long long n, double c, double rc) {
+	const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) out[i] = div_const(in[i], c, rc);
+}
+
 extern "C" {
 
 // kind 0 r2c, 1 c2r, 2 c2c forward (e^{+i}), 3 c2c backward; host pointers; `batch` transforms back to back.
@@ -378,6 +383,25 @@ int wc_debug_logexp(int kind, long long n, const double *in, double *out) {
 	WC_HIP(hipMemcpyAsync(d_in.p, in, sizeof(double) * n, hipMemcpyHostToDevice, s));
 	hipLaunchKernelGGL(hook_logexp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, kind, static_cast<const double *>(d_in.p),
 					   static_cast<double *>(d_out.p), n, dev->twiddle);
+	WC_HIP(hipGetLastError());
+	WC_HIP(hipMemcpyAsync(out, d_out.p, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+	WC_HIP(hipStreamSynchronize(s));
+	return WC_OK;
+}
+
+// div_const of wc_device.hpp on n host values: out[i] = in[i] / c by reciprocal, remainder and correction
+int wc_debug_div_const(long long n, const double *in, double c, double *out) {
+	if (n <= 0 || !in || !out || c == 0.0) return fail(WC_ERR_INVALID, "debug div_const: bad argument");
+	Device *dev = current_device();
+	if (!dev) return WC_ERR_DEVICE;
+	DeviceLock lock(dev);
+	hipStream_t s = dev->active();
+	Scoped d_in, d_out;
+	WC_HIP(hipMalloc(&d_in.p, sizeof(double) * n));
+	WC_HIP(hipMalloc(&d_out.p, sizeof(double) * n));
+	WC_HIP(hipMemcpyAsync(d_in.p, in, sizeof(double) * n, hipMemcpyHostToDevice, s));
+	hipLaunchKernelGGL(hook_div_const_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, static_cast<const double *>(d_in.p),
+					   static_cast<double *>(d_out.p), n, c, 1.0 / c);
 	WC_HIP(hipGetLastError());
 	WC_HIP(hipMemcpyAsync(out, d_out.p, sizeof(double) * n, hipMemcpyDeviceToHost, s));
 	WC_HIP(hipStreamSynchronize(s));
