@@ -373,7 +373,7 @@ def with_transfers(w, pipe, xs, frames, iters=3):
 
 
 # wavefronts per SIMD the full-grid kernels of the 48 kHz step run at (registers / LDS: profiles/r05_*_kernel_resources.txt)
-WAVES_PER_SIMD = {"harvest_bandpass": 3, "harvest_raw": 8, "harvest_refine": 4, "cheaptrick_frames": 2, "d4c_lovetrain": 2, "d4c_frames": 2,
+WAVES_PER_SIMD = {"harvest_bandpass": 3, "harvest_raw": 7, "harvest_refine": 4, "cheaptrick_frames": 2, "d4c_lovetrain": 2, "d4c_frames": 2,
                   "d4c_bands": 2, "synthesis_pulses": 2}
 
 
@@ -730,6 +730,17 @@ def main():
                         c3["issue_floor_" + tag] = {"ms": t_iss * 1e3, "hbm_frac": byt / t_iss / (HBM_PEAK_GBS * 1e9)}
                     c3["issue_frac"] = c3["issue_floor_at_2_waves_per_simd"]["ms"] / c3["kernel_ms"]
             out["stages"] = st
+            # the figures beside `value` that SURVEY.md section 8(d) and BASELINE.json's north star name, repeated under keys the
+            # driver's record keeps whole (`config`, `roofline`): the transfer-inclusive headline and the batched-CheapTrick stage
+            wt = (host_first.get("with_transfers") or {}).get("f64_in_all_five_out") or {}
+            c2, c4 = st.get("config2_16k_full_pipeline") or {}, st.get("config4_synthesis_only_share") or {}
+            also = {"value_with_transfers": host_first.get("value_with_transfers"), "with_transfers_ms": wt.get("ms"),
+                    "cheaptrick_config3_ms": c3.get("ms"), "cheaptrick_config3_hbm_frac": c3.get("hbm_frac"),
+                    "cheaptrick_config3_target_hbm_frac": c3.get("target_hbm_frac"),
+                    "config2_ms": c2.get("ms"), "config4_ms": c4.get("ms")}
+            out["config"]["also_measured"] = also
+            if out["roofline"] is not None:
+                out["roofline"]["also_measured"] = also
         if world == 1 and not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(list(cache.values()))

@@ -161,6 +161,11 @@ wc_pipeline *wc_pipeline_create(int fs, double frame_period, double harvest_f0_f
                                 double cheaptrick_f0_floor, int fft_size, double d4c_threshold);
 void wc_pipeline_destroy(wc_pipeline *p);
 int wc_pipeline_get_fft_size(const wc_pipeline *p);
+/* A schedule knob of this handle (development / A-B switches; value NULL or "" = the default).  The WC_PIPELINE_* environment
+ * variables of the same names are read once, when the handle is created; a run reads none.  Names: "unchain_below" (seconds),
+ * "schedule" ("chains"), "side" ("h" / "c"), "syn_streams", "chain_min", "groups", "tail_after_bp", "chain", "direct", "eager",
+ * "host_splits" ("5,8,12"), "force_tie" (test hook).  Not for use beside a run of the same handle. */
+int wc_pipeline_set_option(wc_pipeline *p, const char *name, const char *value);
 int wc_pipeline_run_device(wc_pipeline *p, int n_utt, const double *d_x, const int *x_length, double *d_tpos, double *d_f0,
                            double *d_sp, double *d_ap, double *d_y, uint64_t *rng_pos);
 

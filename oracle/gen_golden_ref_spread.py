@@ -98,6 +98,16 @@ def main():
                              "sum_times_fs_over_N": float(sp_r[fr].sum() * fs / ((sp_r.shape[1] - 1) * 2))}
             c["restatement_vs_reference"] = dict(worst, voiced_frame_trials=trials, trials_beyond_1e_7=bad)
             print("   restatement vs reference:", c["restatement_vs_reference"])
+        if kind == "chirp" and fs == 48000:
+            # ... and the CPU restatement against the REAL reference on the chirps, D4C as a stage on the reference's own contour: a
+            # second sample of how far two correct FP64 implementations of this quotient part (the builds above differ in contraction
+            # only, the restatement in its transform) -- the bound of tests/test_gpu_sweeps.py's chirp case takes both
+            from oracle import port
+            P = port.Port()
+            ap_o = P.d4c(x, fs, a["tpos"], a["f0"], (a["sp"].shape[1] - 1) * 2)
+            P.rng_reset()
+            fin2 = np.isfinite(a["ap"]) & np.isfinite(ap_o)
+            c["restatement_vs_reference_ap_abs"] = float(np.abs(ap_o - a["ap"])[fin2].max())
         out["cases"]["%d_%d" % (fs, seed)] = c
         print(seed, kind, fs, {k: (("%.2e" % v) if isinstance(v, float) else v) for k, v in c.items() if k not in ("fs", "seconds", "frame_period", "kind")})
     path = os.path.join(_ROOT, "tests", "golden", "ref_self_spread.json")

@@ -212,6 +212,28 @@ class Ref:
         return dict(tpos=tpos, f0=f0, sp=sp, ap=ap, y=y)
 
 
+def _synthesis_behind_analysis(ref, x, fs, tpos, f0_own, f0, sp, ap, frame_period=5.0):
+    """Synthesis of given parameters from where the noise stream stands behind CheapTrick and D4C on (x, tpos, f0_own) -- the place
+    the reference's own pipeline reaches its Synthesis at (tests: a stage check that an upstream rounding cannot cascade into)"""
+    sp_own = ref.cheaptrick(x, fs, tpos, f0_own)
+    ref.d4c(x, fs, tpos, f0_own, (sp_own.shape[1] - 1) * 2)
+    return ref.synthesis(f0, sp, ap, fs, frame_period)
+
+
+def _at(ref, start, method, *args, **kwargs):
+    """Ref().<method> with the process-global noise stream `start` draws from its seed state"""
+    done = 0
+    while done < start:
+        n = min(1 << 20, start - done)
+        ref.randn(n)
+        done += n
+    return getattr(ref, method)(*args, **kwargs)
+
+
+Ref.synthesis_behind_analysis = _synthesis_behind_analysis
+Ref.at = _at
+
+
 def _pipeline_timed(ref, xs, fs, harvest_floor=71.0, frame_period=5.0):
     """bench.py's cpu_baseline leg: the demo-order pipeline over the utterances `xs` one after the other in THIS process; returns
     (frames, wall-clock stamp before the first call, stamp after the last) -- stamps of time.time(), comparable across the

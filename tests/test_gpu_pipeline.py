@@ -209,7 +209,7 @@ def test_host_batch_front_end_in_more_than_two_groups(wca, splits, monkeypatch):
     xs = [base[i % 5] for i in range(22)]
     p = wca.Pipeline(fs)
     ref = p.run_batch(xs)
-    monkeypatch.setenv("WC_PIPELINE_HOST_SPLITS", splits)
+    p.set_option("host_splits", splits)  # (WC_PIPELINE_HOST_SPLITS is read when a handle is created; a run reads no environment)
     for pinned in (True, False):
         out = p.host_buffers([len(x) for x in xs], pinned=pinned)
         for g in out:
@@ -261,7 +261,8 @@ def test_schedules_agree(wca):
 def test_resident_batch_side_by_side_and_held_apart_agree(wca, monkeypatch):
     """A device-resident batch of less than 500 s of signal runs its two groups' full-grid kernels side by side, a larger one holds
     them apart by events (round 5: 16 x 10 s 10.2 -> 9.0 ms, wc_pipeline.hip).  Only the order of execution differs: the same bits,
-    whichever way a ragged batch is run (WC_PIPELINE_UNCHAIN_BELOW = 0 / a large number; read per call)."""
+    whichever way a ragged batch is run (options "unchain_below" = 0 / a large number and "schedule" of the handle; the WC_PIPELINE_*
+    variables of those names are read once, at creation)."""
     import torch
     fs = 16000
     dev = torch.device("cuda", 0)
@@ -272,15 +273,15 @@ def test_resident_batch_side_by_side_and_held_apart_agree(wca, monkeypatch):
     d_x = torch.from_numpy(np.concatenate(xs)).to(dev)
     outs = []
     for knob in ("0", "100000", None, "lanes"):
-        monkeypatch.delenv("WC_PIPELINE_SCHEDULE", raising=False)
+        p.set_option("schedule", None)
         if knob is None:
-            monkeypatch.delenv("WC_PIPELINE_UNCHAIN_BELOW", raising=False)
+            p.set_option("unchain_below", None)
         elif knob == "lanes":  # (held apart, two lanes: the default of batches that fill the chip)
-            monkeypatch.setenv("WC_PIPELINE_UNCHAIN_BELOW", "0")
-            monkeypatch.setenv("WC_PIPELINE_SCHEDULE", "lanes")  # (anything but "chains")
+            p.set_option("unchain_below", "0")
+            p.set_option("schedule", "lanes")  # (anything but "chains")
         else:
-            monkeypatch.setenv("WC_PIPELINE_UNCHAIN_BELOW", knob)
-            monkeypatch.setenv("WC_PIPELINE_SCHEDULE", "chains")  # ("0": held apart as two chains on four streams, rounds 3-5)
+            p.set_option("unchain_below", knob)
+            p.set_option("schedule", "chains")  # ("0": held apart as two chains on four streams, rounds 3-5)
         d_t = torch.zeros(sum(fl), dtype=torch.float64, device=dev)
         d_f = torch.zeros_like(d_t)
         d_sp = torch.zeros(sum(fl) * p.bins, dtype=torch.float64, device=dev)
@@ -408,3 +409,67 @@ def test_c_abi_gather_over_rccl(wca):
         assert wca.lib().wc_gather_to_root_device(comm, 1, 0, 2, out[4].data_ptr(), counts, d_root.data_ptr()) != 0  # root outside the group
     finally:
         rccl.ncclCommDestroy(comm)
+
+
+def test_only_the_utterances_on_a_tie_are_run_again(wca, monkeypatch):
+    """Round 6 (verdict item 3).  A raw candidate within 2e-13 of one of the refinement's integer cuts raises a flag PER UTTERANCE
+    (hv_refine_packed_kernel / hv_refine_group_kernel); the flagged utterances -- and only those -- go through the path once more
+    with the band-pass as direct FIR sums (hv_exact_twin), into their own slices of the outputs.  Until round 5 one flagged
+    utterance re-ran the whole batch (the Harvest stage call) or every stage of every group (the pipeline).  Sixteen utterances:
+    number 11 is an impulse train that raises the flag by itself (and whose contour depends on it: 1e-2 Hz), number 3 is
+    forced onto it (WC_HARVEST_FORCE_TIE / option "force_tie", test hooks) -- two separate stretches to run again.  The other
+    fourteen keep the bits of a run that ignores ties in every output; the flagged ones have the values a FIR band-pass gives
+    them -- through the stage call, the two-lane schedule, the chains, the side-by-side schedule, the plain schedule
+    (WC_PIPELINE_MODE=shared) and the host front-end."""
+    from world_class_amd.synth import SIGNAL_KINDS, make_signal
+    fs = 16000
+    xs = [make_utterance(fs, 0.5 + 0.07 * (i % 5), 8100 + i) for i in range(16)]
+    k, j = 11, 3
+    assert SIGNAL_KINDS[1340043 % len(SIGNAL_KINDS)] == "impulses"
+    xs[k] = make_signal(fs, 3.0, 1340043)
+    # what a flagged utterance must come out as: the FIR band-pass from the start; what the others must: a run that ignores ties
+    monkeypatch.setenv("WC_HARVEST_BANDPASS", "fir")
+    fir = wca.Pipeline(fs).run_batch(xs, rng_pos=[0] * 16)[0]
+    hv_fir = wca.Harvest(fs).compute_batch(xs)
+    monkeypatch.delenv("WC_HARVEST_BANDPASS")
+    monkeypatch.setenv("WC_HARVEST_TIES", "ignore")
+    ign = wca.Pipeline(fs).run_batch(xs, rng_pos=[0] * 16)[0]
+    hv_ign = wca.Harvest(fs).compute_batch(xs)
+    monkeypatch.delenv("WC_HARVEST_TIES")
+    assert 1e-4 < np.abs(ign[k]["f0"] - fir[k]["f0"]).max() < 1.0, "the tie no longer shows on the train: is the test still about it?"
+
+    def same(a, b):
+        return all(np.array_equal(a[n], b[n]) for n in ("tpos", "f0", "sp", "ap", "y"))
+
+    # the stage call
+    monkeypatch.setenv("WC_HARVEST_FORCE_TIE", str(j))
+    hv = wca.Harvest(fs).compute_batch(xs)
+    monkeypatch.delenv("WC_HARVEST_FORCE_TIE")
+    hv_nat = wca.Harvest(fs).compute_batch(xs)  # (only the train's own flag)
+    for u in range(16):
+        assert np.array_equal(hv_nat[u][1], (hv_fir if u == k else hv_ign)[u][1]), ("stage call", u)
+        assert np.array_equal(hv[u][1], (hv_fir if u in (k, j) else hv_ign)[u][1]), ("stage call, one forced", u)
+    # the pipeline's schedules
+    for name, opts, env in (("two lanes", {"unchain_below": "0"}, {}), ("chains", {"unchain_below": "0", "schedule": "chains"}, {}),
+                            ("side by side", {}, {}), ("plain", {}, {"WC_PIPELINE_MODE": "shared"})):
+        for n, v in env.items():
+            monkeypatch.setenv(n, v)
+        p = wca.Pipeline(fs)
+        for n in env:
+            monkeypatch.delenv(n)
+        for n, v in opts.items():
+            p.set_option(n, v)
+        p.set_option("force_tie", str(j))
+        got = p.run_batch(xs, rng_pos=[0] * 16)[0]
+        for u in range(16):
+            assert same(got[u], fir[u] if u in (k, j) else ign[u]), (name, u)
+    # the host front-end (rows that have left for the host are sent again for the flagged utterances only)
+    p = wca.Pipeline(fs)
+    p.set_option("force_tie", str(j))
+    for pinned in (True, False):
+        out = p.host_buffers([len(x) for x in xs], pinned=pinned)
+        p.run_batch_host(p.host_inputs(xs) if pinned else xs, out=out, rng_pos=[0] * 16)
+        for u in range(16):
+            want = fir[u] if u in (k, j) else ign[u]
+            assert all(np.array_equal(out[u][n], want[n]) for n in ("tpos", "f0", "sp", "ap")), ("host front-end", pinned, u)
+            assert np.abs(out[u]["y"] - want["y"]).max() < 1e-10

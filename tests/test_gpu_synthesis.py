@@ -28,6 +28,32 @@ def test_synthesis_only_golden(golden, wca):
     assert np.abs(y - golden["synth_only/y"]).max() < Y_ABS
 
 
+def test_synthesis_only_golden_48k_sixteen_utterances(wca):
+    """SURVEY section 8(c) golden (3) at BASELINE config 4's size: Synthesis ALONE from given {f0, spectrogram, aperiodicity},
+    sixteen utterances of 48 kHz x 10 s against the real reference's waveforms (tests/golden/synth_only_48k_10s.npz,
+    oracle/gen_golden_synth48k.py: reference src/synthesis.cpp:77-177, every utterance in a process of its own).  Sixteen in one
+    stage call: the two-halves path of the Synthesis stage (n_utt >= 16), through the batch entry point, noise positions given."""
+    import os
+    from oracle.gen_golden import synth_params
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "synth_only_48k_10s.npz"))
+    fs, fft, frames, fp, n_utt, first_seed, block, win = [int(v) for v in z["meta"]]
+    params = [synth_params(fs, fft, frames, first_seed + u) for u in range(n_utt)]
+    for u, (f0, sp, ap) in enumerate(params):  # (the regenerated parameters are the ones the fixture was made from)
+        assert np.allclose([f0.sum(), sp.sum(), ap.sum()], z["u%d/param_sums" % u], rtol=1e-12, atol=0)
+    s = wca.Synthesis(fs, fft, float(fp))
+    ys = s.compute_batch([p[0] for p in params], [p[1] for p in params], [p[2] for p in params], rng_pos=[0] * n_utt)
+    ys = ys[0] if isinstance(ys, tuple) else ys
+    worst = 0.0
+    for u, y in enumerate(ys):
+        k = "u%d/" % u
+        assert len(y) == int(z[k + "y_len"][0])
+        for st, w in zip(z[k + "y_win_start"], z[k + "y_win"]):
+            worst = max(worst, float(np.abs(y[st:st + win] - w).max()))
+        nb = len(y) // block
+        assert np.abs(y[:nb * block].reshape(nb, block).sum(1) - z[k + "y_blocksum"]).max() < Y_ABS * block
+    assert worst < Y_ABS, worst
+
+
 @pytest.mark.parametrize("fs,sec,seed,fp", [(16000, 1.0, 41, 5.0), (48000, 0.6, 42, 5.0), (24000, 0.5, 5006, 1.0),
                                            (8000, 0.5, 43, 5.0)])
 def test_synthesis_vs_oracle(wca, port, fs, sec, seed, fp):

@@ -14,6 +14,15 @@ class Pipeline:
         self.fft_size = lib().wc_pipeline_get_fft_size(self._h)
         self.bins = self.fft_size // 2 + 1
 
+    def set_option(self, name, value=None):
+        """wc_pipeline_set_option: a schedule knob of this handle ("unchain_below", "schedule", "host_splits", "force_tie", ...;
+        None = the default).  The WC_PIPELINE_* environment variables are read once, when the handle is created."""
+        import ctypes as C
+        fn = lib().wc_pipeline_set_option
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+        _check(fn(self._h, name.encode(), None if value is None else str(value).encode()))
+
     def lengths(self, x_lengths):
         fl = [get_samples(self.fs, n, self.frame_period) for n in x_lengths]
         yl = [synthesis_out_length(n, self.frame_period, self.fs) for n in fl]

@@ -30,6 +30,7 @@
 //                        the extension walks (<1>), which get a wavefront per (voiced section, direction)
 //   hv_smooth_kernel     zero-lag Butterworth per voiced section, one lane per section (:639-703)
 //   hv_output_kernel     1 ms contour -> frame_period grid (:199-204)
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1182,6 +1183,7 @@ __global__ __launch_bounds__(RAW_T) void hv_raw_kernel(RawArgs a) {
 	const int i = i0 + tid;
 	const int *cnt = a.ev_count + ((long long)blockIdx.z * a.n_bands + band) * 4;
 	const int cap = a.ev_cap[band];
+	const double fb = a.band_f0[band];  // (asked for up front: behind the frames it was a round trip of its own)
 	const double *__restrict__ ev = SLOTS ? nullptr : a.events + u.ev_off + a.ev_band_off[band];
 	const int scap = SLOTS ? a.slot_cap[band] : 0;
 	const double *__restrict__ slot = SLOTS ? a.slots + blockIdx.z * a.slots_per_utt + a.slot_off[band] : nullptr;
@@ -1371,7 +1373,6 @@ __global__ __launch_bounds__(RAW_T) void hv_raw_kernel(RawArgs a) {
 	}
 	RQ_T(4);
 	double v = s / 4.0;
-	const double fb = a.band_f0[band];
 	if (v > fb * 1.1 || v < fb * 0.9 || v > a.f0_ceil || v < a.f0_floor) v = 0.0;
 	out[i] = v;
 	RQ_T(5);
@@ -1421,7 +1422,7 @@ struct RefArgs {
 	long long total_frames;
 	int max_l1;  // frames of the longest utterance (grid of hv_refine_group_kernel)
 	HvParams p;
-	int *flags;  // [0]: a rate-bounded buffer overflowed; [1]: a raw candidate sits on a tie of the refinement's integer decisions (below)
+	int *flags;  // [0]: a rate-bounded buffer overflowed; [1]: a raw candidate sits on a tie of the refinement's integer decisions (below); [2 + u]: ... in utterance u
 };
 
 #ifndef WC_REFINE_WAVES
@@ -1826,7 +1827,7 @@ __global__ __launch_bounds__(64, RF_NP > 112 ? 2 : WC_REFINE_WAVES) void hv_refi
 					const double wv = bin_unit * (h + 1);
 					tie = tie || fabs(wv - floor(wv) - 0.5) < tol * wv;
 				}
-				if (tie) a.flags[1] = 1;
+				if (tie) { a.flags[1] = 1; a.flags[2 + ui] = 1; }  // (per utterance since round 6: only the utterances on a tie are run again)
 			}
 		}
 		n += __popcll(m);
@@ -2244,7 +2245,7 @@ __global__ __launch_bounds__(64 * F, WC_REFINE_WAVES) void hv_refine_group_kerne
 						const double wv_ = bin_unit * (h + 1);
 						tie = tie || fabs(wv_ - floor(wv_) - 0.5) < tol * wv_;
 					}
-					if (tie) a.flags[1] = 1;
+					if (tie) { a.flags[1] = 1; a.flags[2 + blockIdx.y] = 1; }
 				}
 			}
 			n += __popcll(m);
@@ -3324,6 +3325,7 @@ struct wc_harvest {
 	int phases = 3;  // hv_set_phases: 1 = front (decimation .. refinement), 2 = tail (unreliable-candidate test .. output), 3 = both
 	bool no_quiet = false;  // WC_HARVEST_QUIET=sliding: no chunk is left to the FIR sums (A/B and tests)
 	bool ignore_ties = false;  // WC_HARVEST_TIES=ignore: the tie flag is not acted upon (A/B and tests)
+	int force_tie = -1;        // WC_HARVEST_FORCE_TIE=u (test hook, read at creation): utterance u of every stage call counts as flagged
 	wc_harvest *exact_twin = nullptr;  // the same options with the band-pass as a direct FIR sum: re-runs of batches that raised the tie flag (hv_exact_twin)
 	int use_cos_table_opt = 0;
 	int raw_mode = 0;       // WC_HARVEST_RAW=blocks: every block of frames works out its own slice (1, round 5); default 0: slices from hv_rawdesc_kernel
@@ -3452,7 +3454,7 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 	// event capacities per band and type: a rate bound, or the hard bound when `full`
 	std::vector<long long> ev_band_off(nb);
 	std::vector<int> ev_cap(nb);
-	if ((rc = h->overflow.reserve(2 * sizeof(int)))) return rc;  // [0] overflow, [1] tie (RefArgs::flags)
+	if ((rc = h->overflow.reserve((2 + (size_t)n_utt) * sizeof(int)))) return rc;  // [0] overflow, [1] tie, [2 + u] tie in utterance u (RefArgs::flags)
 	if ((rc = h->utts.reserve(sizeof(HvUtt) * n_utt))) return rc;
 	if ((rc = h->y.reserve(sizeof(double) * yo))) return rc;
 	if (r != 1 && (rc = h->dec.reserve(sizeof(double) * deco))) return rc;
@@ -3543,7 +3545,7 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 		}
 		if (!resume) {
 			if ((rc = h->h_stage.mark(s))) return rc;
-			WC_HIP(hipMemsetAsync(h->overflow.p, 0, 2 * sizeof(int), s));
+			WC_HIP(hipMemsetAsync(h->overflow.p, 0, (2 + (size_t)n_utt) * sizeof(int), s));
 		}
 		const HvUtt *du = h->utts.as<HvUtt>();
 		if (phases & 1) {
@@ -3721,14 +3723,30 @@ int hv_reserve_rows(wc_harvest *h, long long total_l1) {
 double *hv_candidate_rows(wc_harvest *h) { return h->cand1.as<double>(); }
 double *hv_score_rows(wc_harvest *h) { return h->score1.as<double>(); }
 
+// tie statistics of the process (development / bench): utterances that went through a refinement, utterances flagged
+static std::atomic<unsigned long long> g_tie_seen{0}, g_tie_flagged{0};
+
 // after hv_enqueue: synchronises the stream and reports whether the zero-crossing buffers overflowed and (tie != NULL) whether a
-// raw candidate sat on a tie of the refinement's integer decisions (never reported by a handle whose band-pass is the FIR sum)
-int hv_overflowed(wc_harvest *h, hipStream_t s, bool *overflow, bool *tie) {
-	int fl[2] = {0, 0};
-	WC_HIP(hipMemcpyAsync(fl, h->overflow.p, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+// raw candidate sat on a tie of the refinement's integer decisions (never reported by a handle whose band-pass is the FIR sum);
+// tie_utts: the utterances of the call in which one did (round 6: only those are run again)
+int hv_overflowed(wc_harvest *h, hipStream_t s, bool *overflow, bool *tie, std::vector<int> *tie_utts) {
+	const int n = (int)h->last_utts.size();
+	std::vector<int> fl(2 + (size_t)n, 0);
+	WC_HIP(hipMemcpyAsync(fl.data(), h->overflow.p, (tie_utts ? fl.size() : 2) * sizeof(int), hipMemcpyDeviceToHost, s));
 	WC_HIP(hipStreamSynchronize(s));
 	*overflow = fl[0] != 0;
-	if (tie) *tie = fl[1] != 0 && !h->use_fir && !h->ignore_ties;
+	const bool acts = !h->use_fir && !h->ignore_ties;
+	if (tie) *tie = fl[1] != 0 && acts;
+	if (tie_utts) {
+		tie_utts->clear();
+		for (int u = 0; u < n && acts; ++u)
+			if (fl[2 + u] != 0) tie_utts->push_back(u);
+		if (!h->use_fir) {
+			g_tie_seen += (unsigned long long)n;
+			g_tie_flagged += (unsigned long long)tie_utts->size();
+		}
+		if (tie) *tie = !tie_utts->empty();
+	}
 	return WC_OK;
 }
 // the handle that re-runs a batch after the tie flag: the same options, band-pass by direct FIR sums (created on first use)
@@ -3745,37 +3763,58 @@ wc_harvest *hv_exact_twin(wc_harvest *h) {
 	return h->exact_twin;
 }
 
+// stretches [u0, u1) of consecutive utterances out of a sorted list
+std::vector<std::pair<int, int>> hv_runs_of(const std::vector<int> &us) {
+	std::vector<std::pair<int, int>> r;
+	for (size_t k = 0; k < us.size(); ++k) {
+		if (!r.empty() && r.back().second == us[k]) r.back().second = us[k] + 1;
+		else r.push_back({us[k], us[k] + 1});
+	}
+	return r;
+}
+
 static int hv_run_device(wc_harvest *h, int n_utt, const double *d_x, const int *x_length, double *d_tpos, double *d_f0) {
 	hipStream_t s = h->dev->active();
 	int rc;
 	for (int attempt = 0; attempt < 2; ++attempt) {
 		if ((rc = hv_enqueue(h, s, n_utt, d_x, x_length, d_tpos, d_f0, attempt == 1, nullptr, nullptr, 3, nullptr, nullptr))) return rc;
 		bool overflow = false, tie = false;
-		if ((rc = hv_overflowed(h, s, &overflow, &tie))) return rc;
-		if (tie && (h->phases & 1)) {
-			// (a candidate on a tie: the whole batch once more with the band-pass as direct FIR sums, see hv_refine_packed_kernel.
-			// A handle restricted to the front -- the incremental stream path -- gets the twin's candidate and score rows copied
-			// into its own: the caller reads them through hv_candidate_rows / hv_score_rows of THIS handle)
-			wc_harvest *t = hv_exact_twin(h);
-			if (!t) return WC_ERR_DEVICE;
-			t->phases = h->phases;
-			for (int at2 = 0; at2 < 2; ++at2) {
-				if ((rc = hv_enqueue(t, s, n_utt, d_x, x_length, d_tpos, d_f0, at2 == 1, nullptr, nullptr, 3, nullptr, nullptr))) return rc;
-				bool o2 = false;
-				if ((rc = hv_overflowed(t, s, &o2, nullptr))) return rc;
-				if (o2) continue;
-				if (h->phases == 1) {
-					long long total_l1 = 0;
-					for (int u = 0; u < n_utt; ++u) total_l1 += wc_get_samples(h->fs, x_length[u], 1);
-					const size_t bytes = sizeof(double) * (size_t)total_l1 * 7 * h->S;
-					WC_HIP(hipMemcpyAsync(h->cand1.p, t->cand1.p, bytes, hipMemcpyDeviceToDevice, s));
-					WC_HIP(hipMemcpyAsync(h->score1.p, t->score1.p, bytes, hipMemcpyDeviceToDevice, s));
-				}
-				return WC_OK;
-			}
-			return fail(WC_ERR_DEVICE, "harvest: zero-crossing buffer overflow");
+		std::vector<int> tied;
+		if ((rc = hv_overflowed(h, s, &overflow, &tie, &tied))) return rc;
+		if (overflow) continue;
+		if (h->force_tie >= 0 && h->force_tie < n_utt && !h->use_fir && !h->ignore_ties && tied.empty()) tied.push_back(h->force_tie);  // (test hook)
+		if (tied.empty() || !(h->phases & 1)) return WC_OK;
+		// Candidates on a tie (see hv_refine_packed_kernel): the utterances that hold one -- and only those, round 6 -- once more with
+		// the band-pass as direct FIR sums, stretch of consecutive utterances by stretch, straight into their places in the outputs
+		// (the batch is packed: a stretch of utterances is a slice of every array).  A handle restricted to the front -- the
+		// incremental stream path -- gets the twin's candidate and score rows copied into its own: the caller reads them through
+		// hv_candidate_rows / hv_score_rows of THIS handle.
+		wc_harvest *t = hv_exact_twin(h);
+		if (!t) return WC_ERR_DEVICE;
+		t->phases = h->phases;
+		std::vector<long long> xo(n_utt + 1, 0), fo(n_utt + 1, 0), lo(n_utt + 1, 0);
+		for (int u = 0; u < n_utt; ++u) {
+			xo[u + 1] = xo[u] + x_length[u];
+			fo[u + 1] = fo[u] + ((h->frame_period == 1.0) ? wc_get_samples(h->fs, x_length[u], 1) : wc_get_samples(h->fs, x_length[u], h->frame_period));
+			lo[u + 1] = lo[u] + wc_get_samples(h->fs, x_length[u], 1);
 		}
-		if (!overflow) return WC_OK;
+		for (const auto &r : hv_runs_of(tied)) {
+			const int u0 = r.first, nu = r.second - r.first;
+			bool done = false;
+			for (int at2 = 0; at2 < 2 && !done; ++at2) {
+				if ((rc = hv_enqueue(t, s, nu, d_x + xo[u0], x_length + u0, d_tpos + fo[u0], d_f0 + fo[u0], at2 == 1, nullptr, nullptr, 3, nullptr, nullptr))) return rc;
+				bool o2 = false;
+				if ((rc = hv_overflowed(t, s, &o2, nullptr, nullptr))) return rc;
+				done = !o2;
+			}
+			if (!done) return fail(WC_ERR_DEVICE, "harvest: zero-crossing buffer overflow");
+			if (h->phases == 1) {
+				const size_t row = sizeof(double) * 7 * (size_t)h->S;
+				WC_HIP(hipMemcpyAsync(h->cand1.as<char>() + row * lo[u0], t->cand1.p, row * (size_t)(lo[u0 + nu] - lo[u0]), hipMemcpyDeviceToDevice, s));
+				WC_HIP(hipMemcpyAsync(h->score1.as<char>() + row * lo[u0], t->score1.p, row * (size_t)(lo[u0 + nu] - lo[u0]), hipMemcpyDeviceToDevice, s));
+			}
+		}
+		return WC_OK;
 	}
 	return fail(WC_ERR_DEVICE, "harvest: zero-crossing buffer overflow");
 }
@@ -3783,6 +3822,13 @@ static int hv_run_device(wc_harvest *h, int n_utt, const double *d_x, const int 
 wc::Device *hv_device(const wc_harvest *h) { return h->dev; }
 
 extern "C" {
+
+// Development hook: utterances that went through a refinement / that were flagged for a tie since the last reset (process-wide)
+void wc_harvest_tie_counts(unsigned long long *seen, unsigned long long *flagged, int reset) {
+	if (seen) *seen = g_tie_seen.load();
+	if (flagged) *flagged = g_tie_flagged.load();
+	if (reset) { g_tie_seen = 0; g_tie_flagged = 0; }
+}
 
 wc_harvest *wc_harvest_create(int fs, double f0_floor, double f0_ceil, double frame_period, double target_fs,
 							  double channels_in_octave, int use_cos_table) {
@@ -3869,6 +3915,7 @@ wc_harvest *wc_harvest_create(int fs, double f0_floor, double f0_ceil, double fr
 		h->use_fir = bp && std::strcmp(bp, "fir") == 0;
 		const char *ti = getenv("WC_HARVEST_TIES");
 		h->ignore_ties = ti && std::strcmp(ti, "ignore") == 0;
+		h->force_tie = getenv("WC_HARVEST_FORCE_TIE") ? atoi(getenv("WC_HARVEST_FORCE_TIE")) : -1;
 		const char *qu = getenv("WC_HARVEST_QUIET");
 		h->no_quiet = qu && std::strcmp(qu, "sliding") == 0;
 		const char *sl = getenv("WC_HARVEST_SDFT_LANES");

@@ -86,8 +86,52 @@ static bool is_pinned(const void *p) {
 	return at.type == hipMemoryTypeHost;
 }
 
+// Schedule knobs (development / A-B switches).  Read from the environment ONCE, when the handle is created, and changed afterwards
+// through wc_pipeline_set_option only: a run reads no environment variable (round-5 advice: getenv beside another thread's
+// setenv is a data race, and a run made several such reads per attempt).
+struct PipeKnobs {
+	double unchain_below = kUnchainBelowSeconds;  // WC_PIPELINE_UNCHAIN_BELOW / "unchain_below": seconds of signal below which the two groups run side by side
+	int schedule_chains = 0;   // WC_PIPELINE_SCHEDULE=chains / "schedule": the four-stream order instead of two lanes
+	int side = 0;              // WC_PIPELINE_SIDE=h / c ('h', 'c') / "side"
+	int syn_streams = 1;       // WC_PIPELINE_SYN_STREAMS / "syn_streams"
+	int chain_min = 4;         // WC_PIPELINE_CHAIN_MIN / "chain_min"
+	int groups = 2;            // WC_PIPELINE_GROUPS / "groups"
+	int tail_after_bp = 0;     // WC_PIPELINE_TAIL_AFTER_BP / "tail_after_bp"
+	int chain = 1;             // WC_PIPELINE_CHAIN / "chain"
+	int direct = 1;            // WC_PIPELINE_DIRECT / "direct"
+	int eager = 1;             // WC_PIPELINE_EAGER / "eager"
+	int force_tie = -1;        // WC_PIPELINE_FORCE_TIE / "force_tie" (test hook): this utterance of every run counts as flagged for a tie
+	std::vector<int> host_splits;  // WC_PIPELINE_HOST_SPLITS "a,b,c" / WC_PIPELINE_HOST_SPLIT "a" / "host_splits": per cent of the utterances per group but the last
+	bool host_splits_set = false;
+};
+
+static void knob_set(PipeKnobs &k, const std::string &name, const char *v) {
+	const std::string val = v ? v : "";
+	if (name == "unchain_below") k.unchain_below = v ? atof(v) : kUnchainBelowSeconds;
+	else if (name == "schedule") k.schedule_chains = val == "chains" ? 1 : 0;
+	else if (name == "side") k.side = val.empty() ? 0 : val[0];
+	else if (name == "syn_streams") k.syn_streams = val.empty() ? 1 : atoi(v);
+	else if (name == "chain_min") k.chain_min = val.empty() ? 4 : atoi(v);
+	else if (name == "groups") k.groups = val.empty() ? 2 : atoi(v);
+	else if (name == "tail_after_bp") k.tail_after_bp = val.empty() ? 0 : atoi(v);
+	else if (name == "chain") k.chain = val.empty() ? 1 : atoi(v);
+	else if (name == "direct") k.direct = val.empty() ? 1 : atoi(v);
+	else if (name == "eager") k.eager = val.empty() ? 1 : atoi(v);
+	else if (name == "force_tie") k.force_tie = val.empty() ? -1 : atoi(v);
+	else if (name == "host_splits") {
+		k.host_splits.clear();
+		k.host_splits_set = !val.empty();
+		for (const char *c = val.c_str(); *c && (int)k.host_splits.size() < kMaxGroups - 1;) {
+			k.host_splits.push_back(atoi(c));
+			while (*c && *c != ',') ++c;
+			if (*c == ',') ++c;
+		}
+	}
+}
+
 struct wc_pipeline {
 	int mode;  // 0: shared stages, Harvest split over streams; 1: independent staggered chains per utterance group
+	PipeKnobs *knobs;
 	PipeGroup grp[kMaxGroups];
 	int n_grp;  // groups whose handles exist (2 at creation, the others when a run first asks for them)
 	double c_floor, c_ceil, c_q1, c_ct_floor, c_threshold;  // what the stage handles of a group are created with
@@ -155,6 +199,15 @@ wc_pipeline *wc_pipeline_create(int fs, double frame_period, double harvest_f0_f
 	p->dev = dev;
 	p->c_floor = harvest_f0_floor; p->c_ceil = harvest_f0_ceil; p->c_q1 = q1; p->c_ct_floor = cheaptrick_f0_floor;
 	p->c_threshold = d4c_threshold; p->c_fft_size = fft_size;
+	p->knobs = new PipeKnobs();
+	for (const char *nm : {"UNCHAIN_BELOW", "SCHEDULE", "SIDE", "SYN_STREAMS", "CHAIN_MIN", "GROUPS", "TAIL_AFTER_BP", "CHAIN", "DIRECT", "EAGER", "FORCE_TIE", "HOST_SPLITS"}) {
+		const std::string env = std::string("WC_PIPELINE_") + nm;
+		std::string low(nm);
+		for (char &c : low) c = (char)tolower(c);
+		if (const char *v = getenv(env.c_str())) knob_set(*p->knobs, low, v);
+	}
+	if (!p->knobs->host_splits_set)
+		if (const char *v = getenv("WC_PIPELINE_HOST_SPLIT")) knob_set(*p->knobs, "host_splits", v);
 	{
 		const char *m = getenv("WC_PIPELINE_MODE");
 		p->mode = (m && std::string(m) == "shared") ? 0 : 1;  // default: two scheduled chains (measured 82 vs 90-96 ms per batch)
@@ -221,6 +274,9 @@ wc_pipeline *wc_pipeline_create(int fs, double frame_period, double harvest_f0_f
 	}
 	ok = ok && hipEventCreateWithFlags(&p->e_bp, hipEventDisableTiming) == hipSuccess;
 	if (ok && p->mode == 1) ok = pipeline_ensure_groups(p, 2) == WC_OK;
+	// (the handle that re-runs utterances on a tie, created here rather than inside the first run that meets one: building its tables
+	// is a few milliseconds of host work and synchronous uploads; its workspaces grow when it is first used)
+	if (ok) ok = hv_exact_twin(p->hv[0]) != nullptr;
 	if (!ok) {
 		std::string err = wc_last_error();
 		void wc_pipeline_destroy(wc_pipeline *);
@@ -274,7 +330,22 @@ void wc_pipeline_destroy(wc_pipeline *p) {
 		if (p->he[k]) (void)hipEventDestroy(p->he[k]);
 		wc_harvest_destroy(p->hv[k]);
 	}
+	delete p->knobs;
 	delete p;
+}
+
+// A schedule knob of this handle (see PipeKnobs; value NULL or "" = the default): "unchain_below", "schedule", "side", "syn_streams",
+// "chain_min", "groups", "tail_after_bp", "chain", "direct", "eager", "host_splits", "force_tie".  Not for use beside a run of the same handle.
+int wc_pipeline_set_option(wc_pipeline *p, const char *name, const char *value) {
+	if (!p || !name) return fail(WC_ERR_INVALID, "pipeline option: null argument");
+	static const char *known[] = {"unchain_below", "schedule", "side", "syn_streams", "chain_min", "groups", "tail_after_bp", "chain", "direct", "eager",
+								  "host_splits", "force_tie"};
+	bool ok = false;
+	for (const char *k : known) ok = ok || std::strcmp(k, name) == 0;
+	if (!ok) return fail(WC_ERR_INVALID, "pipeline option: unknown name");
+	DeviceLock lock(p->dev);
+	knob_set(*p->knobs, name, value);
+	return WC_OK;
 }
 
 int wc_pipeline_get_fft_size(const wc_pipeline *p) { return p ? p->fft_size : WC_ERR_INVALID; }
@@ -307,6 +378,64 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 	std::vector<uint64_t> rng_in;
 	if (rng_pos) rng_in.assign(rng_pos, rng_pos + n_utt);
 	const uint64_t *rng_start = rng_pos ? rng_in.data() : nullptr;
+	// Round 6: utterances in whose refinement a raw candidate sat on a tie of the window length or a harmonic's bin (hv_refine_packed_kernel)
+	// go through the path once more BY THEMSELVES, the band-pass as direct FIR sums: stretch of consecutive utterances by stretch,
+	// on the caller's stream and the handle's own plain stage handles, straight into their slices of the outputs -- everything the
+	// other utterances produced stands (an utterance's noise positions are its own).  Until round 5 one flagged utterance sent
+	// every stage of every group through a second attempt.
+	auto fix_up = [&](std::vector<int> tied) -> int {
+		if (p->knobs->force_tie >= 0 && p->knobs->force_tie < n_utt && tied.empty()) tied.push_back(p->knobs->force_tie);  // (test hook)
+		if (tied.empty()) return WC_OK;
+		wc_harvest *t = hv_exact_twin(p->hv[0]);
+		if (!t) return WC_ERR_DEVICE;
+		std::vector<long long> xo(n_utt + 1, 0), fo(n_utt + 1, 0), yo(n_utt + 1, 0);
+		for (int u = 0; u < n_utt; ++u) { xo[u + 1] = xo[u] + x_length[u]; fo[u + 1] = fo[u] + f_len[u]; yo[u + 1] = yo[u] + y_len[u]; }
+		for (const auto &r : hv_runs_of(tied)) {
+			const int u0 = r.first, nu = r.second - r.first;
+			const double *gx = d_x + xo[u0];
+			double *gt = d_tpos + fo[u0], *gf = d_f0 + fo[u0], *gsp = d_sp + fo[u0] * bins, *gap = d_ap + fo[u0] * bins, *gy = d_y + yo[u0];
+			bool hv_full = false, syn_full = false, done = false;
+			for (int attempt = 0; attempt < 3 && !done; ++attempt) {
+				int rc2;
+				long long total = 0;
+				uint64_t a0 = 0, a1 = 0;
+				if ((rc2 = hv_enqueue(t, s0, nu, gx, x_length + u0, gt, gf, hv_full, nullptr, nullptr))) return rc2;
+				if ((rc2 = ct_prepare(p->ct, s0, nu, x_length + u0, gf, f_len.data() + u0, rng_start ? rng_start + u0 : nullptr, &total, &a0, &a1))) return rc2;
+				if ((rc2 = ct_frames(p->ct, s0, nu, gx, gt, gf, gsp, total, nullptr))) return rc2;
+				if ((rc2 = d4c_enqueue(p->d4, s0, nu, gx, x_length + u0, gt, gf, f_len.data() + u0, p->fft_size, gap, nullptr, ct_end_positions(p->ct)))) return rc2;
+				if ((rc2 = syn_prepare(p->sy, s0, nu, gf, f_len.data() + u0, y_len.data() + u0, gy, nullptr, syn_full))) return rc2;
+				if ((rc2 = syn_pulses(p->sy, s0, gf, gsp, gap, gy, d4c_end_positions(p->d4)))) return rc2;
+				bool o1 = false, o2 = false;
+				if ((rc2 = syn_finish(p->sy, s0, rng_pos ? rng_pos + u0 : nullptr, &o2))) return rc2;
+				if ((rc2 = hv_overflowed(t, s0, &o1, nullptr))) return rc2;
+				hv_full = hv_full || o1;
+				syn_full = syn_full || o2;
+				done = !o1 && !o2;
+			}
+			if (!done) return fail(WC_ERR_DEVICE, "pipeline: buffer overflow");
+			if (sink) {  // rows (and waveforms) that left for the host during the run: these utterances' once more
+				std::vector<CopyJob> jobs;
+				for (int u = u0; u < u0 + nu; ++u) {
+					const size_t ulen = sizeof(double) * (size_t)f_len[u] * bins, off = sizeof(double) * (size_t)fo[u] * bins;
+					for (int which = 0; which < 2; ++which) {
+						char *stage = which == 0 ? sink->stage_sp : sink->stage_ap;
+						double *const *rows = which == 0 ? sink->sp : sink->ap;
+						const double *src = (which == 0 ? d_sp : d_ap) + fo[u] * bins;
+						if (!stage || !rows || !rows[u]) continue;
+						if (sink->direct) WC_HIP(hipMemcpyAsync(rows[u], src, ulen, hipMemcpyDeviceToHost, s0));
+						else {
+							WC_HIP(hipMemcpyAsync(stage + off, src, ulen, hipMemcpyDeviceToHost, s0));
+							jobs.push_back({rows[u], stage + off, ulen});
+						}
+					}
+					if (sink->y && sink->y[u]) WC_HIP(hipMemcpyAsync(sink->y[u], d_y + yo[u], sizeof(double) * (size_t)y_len[u], hipMemcpyDeviceToHost, s0));
+				}
+				WC_HIP(hipStreamSynchronize(s0));
+				parallel_copy(jobs);
+			}
+		}
+		return WC_OK;
+	};
 	if (p->mode == 1 && n_utt >= 2) {
 		// Two chains over the two halves of the batch, scheduled so that ALU-bound kernels never compete with each
 		// other (measured: Harvest refinement and D4C merely time-share a CU) while every latency-bound stretch
@@ -323,8 +452,7 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 		for (int g = 2; g <= kMaxGroups; ++g) ub[g] = n_utt;
 		if (NG > 2 || (sink && sink->ng == 2)) for (int g = 0; g <= NG; ++g) ub[g] = sink->ub[g];
 		if (!sink) {  // WC_PIPELINE_GROUPS: a device-resident batch in that many equal groups (experiment)
-			const char *env = getenv("WC_PIPELINE_GROUPS");
-			const int want = env ? atoi(env) : 2;
+			const int want = p->knobs->groups;
 			if (want > 2 && want <= kMaxGroups && n_utt >= want) {
 				NG = want;
 				for (int g = 0; g <= NG; ++g) ub[g] = (int)((long long)n_utt * g / NG);
@@ -346,14 +474,15 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 		// plain aux streams, which such a run does not use otherwise, in turn.  On the group's main stream it stood between the
 		// Harvest of group g and that of group g + 2, which then could not start before group g's D4C was through and its pulses
 		// summed: the contours of the later groups -- what the rows on the wire wait for -- came late.  WC_PIPELINE_SYN_STREAMS=0: as before.
-		const bool syn_own = NG > 2 && p->grp[0].aux_hi && !(getenv("WC_PIPELINE_SYN_STREAMS") && getenv("WC_PIPELINE_SYN_STREAMS")[0] == '0');
+		const bool syn_own = NG > 2 && p->grp[0].aux_hi && p->knobs->syn_streams != 0;
 		hipStream_t synS[kMaxGroups];
 		for (int g = 0; g < NG; ++g) synS[g] = syn_own ? ((g & 1) ? p->s2 : p->s1) : mainS[g];
 		// WC_PIPELINE_CHAIN_MIN=n: a group's Harvest is not held behind that of a predecessor with fewer than n utterances (a group
 		// of two or three fills a few per cent of the chip: holding the next one back behind it is latency for nothing)
-		const int chain_min = getenv("WC_PIPELINE_CHAIN_MIN") ? atoi(getenv("WC_PIPELINE_CHAIN_MIN")) : 4;
+		const int chain_min = p->knobs->chain_min;
 		bool full[kMaxGroups][2] = {};
-		bool exact[kMaxGroups] = {};  // the group's refinement met a candidate on a tie: its Harvest runs again on the FIR twin (hv_exact_twin)
+		double total_s = 0.0;
+		for (int u = 0; u < n_utt; ++u) total_s += (double)x_length[u] / p->fs;
 		for (int attempt = 0; attempt < 4; ++attempt) {
 			const int bins_ = p->fft_size / 2 + 1;
 			struct Slice { int u0, nu; long long xo, fo, yo; } sl[kMaxGroups];
@@ -389,32 +518,28 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 			// a second round, 2.6 instead of 1.8 ms.  But the tail then shares the chip with B's issue-bound raw candidates and refinement,
 			// ends later and holds up A's CheapTrick: 29.2 against 28.6 ms per batch.  Enqueued front A, chain B, tail A in that case: an
 			// event must have been recorded by the time a stream is told to wait for it.)
-			static const bool tail_late_env = getenv("WC_PIPELINE_TAIL_AFTER_BP") && getenv("WC_PIPELINE_TAIL_AFTER_BP")[0] == '1';
+			const bool tail_late_env = p->knobs->tail_after_bp == 1;
 			const bool tail_late = tail_late_env && NG == 2;
 			// (WC_PIPELINE_CHAIN=0, measured and rejected: the Harvests of small neighbouring groups not held apart -- their full-grid
 			// kernels do not fill the chip, a 6-utterance band-pass is one round of 650 wavefronts on 3072 places -- 52-60 ms
 			// against 50: every group's contour arrives later)
-			static const bool chain_env = getenv("WC_PIPELINE_CHAIN") && getenv("WC_PIPELINE_CHAIN")[0] == '0';
+			const bool chain_env = p->knobs->chain == 0;
 			// Round 5: a device-resident batch of less than 500 s of signal runs its two groups' full-grid kernels SIDE BY SIDE -- neither
 			// group fills the chip (the sliding band-pass of 32 x 10 s is one round of 3040 wavefronts on 3072 places: two halves of a
 			// smaller batch fit that round together), and holding them apart is latency for nothing: 16 x 10 s 10.2 -> 9.0 ms,
 			// 32 x 10 s 15.2 -> 14.1, 48 x 10 s 22.9 -> 21.9; 52 / 56 / 64 x 10 s are faster held apart (23.2 / 24.4 / 27.3 against
 			// 23.7 / 25.0 / 28.0 ms; profiles/r05_d_small_batches_side_by_side.txt).  WC_PIPELINE_UNCHAIN_BELOW=seconds (0: never).
-			const double unchain_below = getenv("WC_PIPELINE_UNCHAIN_BELOW") ? atof(getenv("WC_PIPELINE_UNCHAIN_BELOW")) : kUnchainBelowSeconds;
-			double total_s = 0.0;
-			for (int u = 0; u < n_utt; ++u) total_s += (double)x_length[u] / p->fs;
+			const double unchain_below = p->knobs->unchain_below;
 			const bool side_by_side = NG == 2 && !sink && total_s < unchain_below;
 			// (experiment, WC_PIPELINE_SIDE=h / c: only the Harvests, or only the first group's CheapTrick / D4C and the second's Harvest, side by side)
-			const char *side_env = getenv("WC_PIPELINE_SIDE");
-			const bool side_h = side_by_side || (NG == 2 && !sink && side_env && side_env[0] == 'h');
-			const bool side_c = side_by_side || (NG == 2 && !sink && side_env && side_env[0] == 'c');
+			const bool side_h = side_by_side || (NG == 2 && !sink && p->knobs->side == 'h');
+			const bool side_c = side_by_side || (NG == 2 && !sink && p->knobs->side == 'c');
 			const bool chain_harvest = (NG == 2 && !side_h) || (NG > 2 && !chain_env);
 			auto enqueue_harvest = [&](int g) -> int {
 				PipeGroup &G = p->grp[g];
 				dev->time_tag = g;
 				if (g >= 1 && sink && sink->x_ev[g]) WC_HIP(hipStreamWaitEvent(mainS[g], sink->x_ev[g], 0));
-				wc_harvest *hvg = exact[g] ? hv_exact_twin(G.hv) : G.hv;
-				if (!hvg) return WC_ERR_DEVICE;
+				wc_harvest *hvg = G.hv;
 				return hv_enqueue(hvg, mainS[g], sl[g].nu, d_x + sl[g].xo, x_length + sl[g].u0, d_tpos + sl[g].fo, d_f0 + sl[g].fo,
 								  full[g][0], G.e_mid, (g >= 1 && chain_harvest && sl[g - 1].nu >= chain_min) ? p->grp[g - 1].e_mid : nullptr, (g == 0 && tail_late) ? 1 : 3,
 								  (g == 1 && tail_late) ? p->e_bp : nullptr, nullptr);
@@ -428,8 +553,9 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 			// other, behind the front it needs and in front of the kernels that need it.  The four-stream order below (two chains
 			// held apart by events) reaches the same 27.1-27.3 ms per 64 x 10 s on boxes whose queue scheduler happens to deal its
 			// streams well and 28.3-28.7 ms on others (a third of the round's boxes); this one measured 27.2-27.3 on both kinds
-			// (profiles/r05_e_two_lanes.txt).  Same bits.  WC_PIPELINE_SCHEDULE=chains: the four-stream order.
-			const bool lanes = NG == 2 && !sink && !side_by_side && !(getenv("WC_PIPELINE_SCHEDULE") && std::strcmp(getenv("WC_PIPELINE_SCHEDULE"), "chains") == 0);
+			// (profiles/r05_e_two_lanes.txt).  Same bits.  WC_PIPELINE_SCHEDULE=chains / option "schedule": the four-stream order
+			// (WC_PIPELINE_TIMING's device marks are recorded by that order only).
+			const bool lanes = NG == 2 && !sink && !side_by_side && !p->knobs->schedule_chains;
 			if (lanes) {
 				// (measured and dropped: the small kernels on the high-priority stream, 27.7 against 27.3 ms; the second group's front on a
 				// stream of its own so that its decimation runs underneath the first front, 27.8-28.0)
@@ -437,8 +563,7 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 				WC_HIP(hipStreamWaitEvent(S, p->e1, 0));  // (behind whatever precedes this call on the caller's stream)
 				wc_harvest *hvg[2];
 				for (int g = 0; g < 2; ++g) {
-					hvg[g] = exact[g] ? hv_exact_twin(p->grp[g].hv) : p->grp[g].hv;
-					if (!hvg[g]) return WC_ERR_DEVICE;
+					hvg[g] = p->grp[g].hv;
 					dev->time_tag = g;
 					if ((rc = hv_enqueue(hvg[g], F, sl[g].nu, d_x + sl[g].xo, x_length + sl[g].u0, d_tpos + sl[g].fo, d_f0 + sl[g].fo, full[g][0],
 										 p->grp[g].e_mid, nullptr, 1, nullptr, nullptr)))
@@ -472,23 +597,25 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 				}
 				dev->time_tag = -1;
 				bool again = false;
+				std::vector<int> tied;
 				for (int g = 0; g < 2; ++g) {
 					bool o1 = false, o2 = false, tie = false;
+					std::vector<int> tg;
 					if ((rc = syn_finish(p->grp[g].sy, F, rng_pos ? rng_pos + ub[g] : nullptr, &o2))) return rc;
-					if ((rc = hv_overflowed(hvg[g], F, &o1, &tie))) return rc;
+					if ((rc = hv_overflowed(hvg[g], F, &o1, &tie, &tg))) return rc;
 					full[g][0] = full[g][0] || o1;
 					full[g][1] = full[g][1] || o2;
-					if (tie && !exact[g]) { exact[g] = true; again = true; }
+					for (int u : tg) tied.push_back(ub[g] + u);
 					again = again || o1 || o2;
 				}
-				if (!again) return WC_OK;
+				if (!again) return fix_up(tied);
 				continue;
 			}
 			if (NG == 2) for (int g = 0; g < NG; ++g) if ((rc = enqueue_harvest(g))) return rc;
 			if (tail_late) {
 				PipeGroup &G = p->grp[0];
 				dev->time_tag = 0;
-				if ((rc = hv_enqueue(exact[0] ? hv_exact_twin(G.hv) : G.hv, mainS[0], sl[0].nu, d_x + sl[0].xo, x_length + sl[0].u0, d_tpos + sl[0].fo, d_f0 + sl[0].fo,
+				if ((rc = hv_enqueue(G.hv, mainS[0], sl[0].nu, d_x + sl[0].xo, x_length + sl[0].u0, d_tpos + sl[0].fo, d_f0 + sl[0].fo,
 									 full[0][0], nullptr, nullptr, 2, nullptr, p->e_bp)))
 					return rc;
 			}
@@ -600,6 +727,7 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 				}
 			}
 			bool again = false;
+			std::vector<int> tied;
 			for (int g = 0; g < NG; ++g) {
 				PipeGroup &G = p->grp[g];
 				const int u0 = ub[g];
@@ -607,10 +735,11 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 				if ((rc = syn_finish(G.sy, synS[g], rng_pos ? rng_pos + u0 : nullptr, &o2))) return rc;
 				pmark(g == 0 ? "group 0 finished" : g + 1 < NG ? "a middle group finished" : "the last group finished");
 				bool tie = false;
-				if ((rc = hv_overflowed(exact[g] ? hv_exact_twin(G.hv) : G.hv, mainS[g], &o1, &tie))) return rc;
+				std::vector<int> tg;
+				if ((rc = hv_overflowed(G.hv, mainS[g], &o1, &tie, &tg))) return rc;
 				full[g][0] = full[g][0] || o1;
 				full[g][1] = full[g][1] || o2;
-				if (tie && !exact[g]) { exact[g] = true; again = true; }
+				for (int u : tg) tied.push_back(u0 + u);
 				again = again || o1 || o2;
 			}
 			if (again && sink) for (int g = 0; g < kMaxGroups; ++g) sink->overlapped[g] = false;  // the re-run rewrites the rows
@@ -628,12 +757,11 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 								 g, ub[g + 1] - ub[g], t[0], t[1], t[2], t[3]);
 				}
 			}
-			if (!again) return WC_OK;
+			if (!again) return fix_up(tied);
 		}
 		return fail(WC_ERR_DEVICE, "pipeline: buffer overflow");
 	}
 	bool hv_full = false, syn_full = false;
-	bool hv_exact[4] = {};  // the split's refinement met a candidate on a tie: its Harvest runs again on the FIR twin (hv_exact_twin)
 	const int ns = p->n_split < n_utt ? p->n_split : n_utt;
 	for (int attempt = 0; attempt < 4; ++attempt) {
 		{
@@ -644,8 +772,7 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 				const int u0 = (int)((long long)n_utt * k / ns), u1 = (int)((long long)n_utt * (k + 1) / ns);
 				hipStream_t sk = k == 0 ? s0 : p->hs[k];
 				if (k > 0) WC_HIP(hipStreamWaitEvent(sk, p->e0, 0));
-				wc_harvest *hvk = hv_exact[k] ? hv_exact_twin(p->hv[k]) : p->hv[k];
-				if (!hvk) return WC_ERR_DEVICE;
+				wc_harvest *hvk = p->hv[k];
 				if ((rc = hv_enqueue(hvk, sk, u1 - u0, d_x + xo, x_length + u0, d_tpos + fo, d_f0 + fo, hv_full, nullptr, nullptr))) return rc;
 				if (k > 0) WC_HIP(hipEventRecord(p->he[k], sk));
 				for (int u = u0; u < u1; ++u) { xo += x_length[u]; fo += f_len[u]; }
@@ -673,14 +800,15 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 		if ((rc = syn_pulses(p->sy, s0, d_f0, d_sp, d_ap, d_y, d4c_end_positions(p->d4)))) return rc;
 		bool o1 = false, o2 = false;
 		if ((rc = syn_finish(p->sy, s0, rng_pos, &o2))) return rc;  // synchronises s0 (and, through E1/E2, s1 and s2)
-		bool ties = false;
+		std::vector<int> tied;
 		for (int k = 0; k < ns; ++k) {
 			bool ok = false, tie = false;
-			if ((rc = hv_overflowed(hv_exact[k] ? hv_exact_twin(p->hv[k]) : p->hv[k], s0, &ok, &tie))) return rc;  // s0 is already idle; the flag copies are tiny
+			std::vector<int> tg;
+			if ((rc = hv_overflowed(p->hv[k], s0, &ok, &tie, &tg))) return rc;  // s0 is already idle; the flag copies are tiny
 			o1 = o1 || ok;
-			if (tie && !hv_exact[k]) { hv_exact[k] = true; ties = true; }  // (like the groups of the chained schedule above)
+			for (int u : tg) tied.push_back((int)((long long)n_utt * k / ns) + u);  // (like the groups of the chained schedule above)
 		}
-		if (!o1 && !o2 && !ties) return WC_OK;
+		if (!o1 && !o2) return fix_up(tied);
 		hv_full = hv_full || o1;
 		syn_full = syn_full || o2;
 	}
@@ -747,14 +875,8 @@ int wc_pipeline_run_batch_host(wc_pipeline *p, int n_utt, const void *const *x, 
 		for (int g = 2; g <= kMaxGroups; ++g) ub[g] = n_utt;
 		if (p->mode == 1 && n_utt >= 4 && (sp || ap)) {
 			std::vector<int> pct;
-			if (const char *env = getenv("WC_PIPELINE_HOST_SPLITS")) {
-				for (const char *c = env; *c && (int)pct.size() < kMaxGroups - 1;) {
-					pct.push_back(atoi(c));
-					while (*c && *c != ',') ++c;
-					if (*c == ',') ++c;
-				}
-			} else if (const char *env1 = getenv("WC_PIPELINE_HOST_SPLIT")) {
-				pct.push_back(atoi(env1));
+			if (p->knobs->host_splits_set) {
+				pct = p->knobs->host_splits;
 			} else if (n_utt >= 32) {
 				pct = {5, 8, 12, 18, 25};  // round 5 (with Synthesis on streams of its own): 3 / 5 / 8 / 11 / 16 / 21 of 64 utterances
 			} else if (n_utt >= 20) {
@@ -777,7 +899,7 @@ int wc_pipeline_run_batch_host(wc_pipeline *p, int n_utt, const void *const *x, 
 			for (int g = 0; g <= ng; ++g) sink.ub[g] = ub[g];
 		}
 		const bool halves = ng >= 2 && x_is_pcm16 == 0;
-		bool pinned_in = halves && !(getenv("WC_PIPELINE_DIRECT") && getenv("WC_PIPELINE_DIRECT")[0] == '0');
+		bool pinned_in = halves && p->knobs->direct != 0;
 		for (int u = 0; u < n_utt && pinned_in; ++u) pinned_in = is_pinned(x[u]);
 		char *dst = static_cast<char *>(p->st_in.p);
 		long long xo = 0;
@@ -834,16 +956,14 @@ int wc_pipeline_run_batch_host(wc_pipeline *p, int n_utt, const void *const *x, 
 	// a caller who hands over page-locked rows (hipHostMalloc / hipHostRegister, a pinned torch tensor) gets them written by the
 	// copy engine directly: no staging copy, no host-side scatter of the 2 GB
 	{
-		const char *env = getenv("WC_PIPELINE_DIRECT");  // 0: always through the staging buffer (A/B)
-		sink.direct = (sp || ap) && !(env && env[0] == '0');
+		sink.direct = (sp || ap) && p->knobs->direct != 0;  // ("direct" = 0: always through the staging buffer, A/B)
 	}
 	for (int u = 0; u < n_utt && sink.direct; ++u)
 		sink.direct = (!sp || !sp[u] || is_pinned(sp[u])) && (!ap || !ap[u] || is_pinned(ap[u]));
 	{
-		const char *env = getenv("WC_PIPELINE_EAGER");  // 0: the device-resident schedule (A/B)
-		sink.eager = (sp || ap) && !(env && env[0] == '0');
+		sink.eager = (sp || ap) && p->knobs->eager != 0;  // ("eager" = 0: the device-resident schedule, A/B)
 	}
-	if (y && !y_is_pcm16 && p->mode == 1 && n_utt >= 2 && !(getenv("WC_PIPELINE_DIRECT") && getenv("WC_PIPELINE_DIRECT")[0] == '0')) {
+	if (y && !y_is_pcm16 && p->mode == 1 && n_utt >= 2 && p->knobs->direct != 0) {
 		bool all = true;
 		for (int u = 0; u < n_utt && all; ++u) all = !y[u] || is_pinned(y[u]);
 		if (all) {

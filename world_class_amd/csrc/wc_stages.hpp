@@ -1,6 +1,9 @@
 // Enqueue-only entry points of the four stages (no host synchronisation), used by the fused pipeline
 // (wc_pipeline.hip).  Each is defined next to its stage's kernels.
 #pragma once
+#include <utility>
+#include <vector>
+
 #include "wc_internal.hpp"
 
 // part: 3 = the whole chain, 1 = its front only, 2 = the tail behind a front that an earlier call with the same arguments enqueued;
@@ -8,8 +11,10 @@
 int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const int *x_length, double *d_tpos, double *d_f0,
 			   bool full, hipEvent_t mid_event, hipEvent_t start_after, int part = 3, hipEvent_t bp_done = nullptr,
 			   hipEvent_t tail_after = nullptr);
-int hv_overflowed(wc_harvest *h, hipStream_t s, bool *overflow, bool *tie = nullptr);
-// a batch whose refinement raised the tie flag is run again on this handle: the same options, band-pass as direct FIR sums
+int hv_overflowed(wc_harvest *h, hipStream_t s, bool *overflow, bool *tie = nullptr, std::vector<int> *tie_utts = nullptr);
+// stretches [u0, u1) of consecutive utterances out of a sorted list
+std::vector<std::pair<int, int>> hv_runs_of(const std::vector<int> &us);
+// the utterances whose refinement raised the tie flag are run again on this handle: the same options, band-pass as direct FIR sums
 wc_harvest *hv_exact_twin(wc_harvest *h);
 // Harvest in two parts (incremental streams): phases 1 = front (decimation .. refinement), 2 = tail (unreliable .. output), 3 = both
 void hv_set_phases(wc_harvest *h, int mask);
