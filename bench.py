@@ -377,6 +377,22 @@ WAVES_PER_SIMD = {"harvest_bandpass": 3, "harvest_raw": 7, "harvest_refine": 4, 
                   "d4c_bands": 2, "synthesis_pulses": 2}
 
 
+def tie_counts(L, reset=False):
+    """(utterances that went through a Harvest refinement, utterances flagged for a tie) since the last reset -- the library's
+    process-wide counters (wc_harvest_tie_counts, a development hook)"""
+    import ctypes as C
+    fn = L.wc_harvest_tie_counts
+    fn.restype = None
+    fn.argtypes = [C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.c_int]
+    a, b = C.c_ulonglong(0), C.c_ulonglong(0)
+    fn(C.byref(a), C.byref(b), 1 if reset else 0)
+    return int(a.value), int(b.value)
+
+
+def per_1000(seen, flagged):
+    return {"utterances": seen, "flagged": flagged, "per_1000_utterances": (1000.0 * flagged / seen) if seen else None}
+
+
 def load_issue_rates():
     """profiles/issue_rates.json (tools/issue_rate.hip on the GPU box) -> ns per wave-instruction and SIMD by wavefronts per SIMD:
     'fp64' = the v_fma_f64 stream, 'int32' = the cheaper of the v_add_u32 / v_mov_b32 streams, made non-increasing in the occupancy
@@ -557,12 +573,14 @@ def main():
         final_gather()  # one-time costs of the epilogue too (torch reduction kernels, RCCL channel set-up)
     L.wc_set_kernel_timing(1)
     barrier()
+    tie_counts(L, reset=True)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     final_gather()
     barrier()
     elapsed = time.perf_counter() - t0
+    ties = {"headline": per_1000(*tie_counts(L, reset=True))}
     if world > 1:
         from world_class_amd.shard import max_over_ranks, sum_over_ranks
         elapsed, gather_s[0] = max_over_ranks([elapsed, gather_s[0]], cdev)
@@ -570,6 +588,24 @@ def main():
     else:
         total_frames = frames
 
+    # What a tie costs (round-5 verdict, item 3): the same step with ONE of its utterances forced onto the tie flag -- that
+    # utterance goes through the whole path once more by itself, the band-pass as direct FIR sums; everything else stands
+    if rank == 0 and world == 1 and not a.no_extras:
+        try:
+            pipe.set_option("force_tie", str(n_utt // 3))
+            step(); barrier()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                step()
+            barrier()
+            ties["step_with_one_utterance_flagged_ms"] = (time.perf_counter() - t1) / 5 * 1e3
+            ties["plain_step_ms"] = elapsed / a.steps * 1e3
+            ties["ratio"] = ties["step_with_one_utterance_flagged_ms"] / ties["plain_step_ms"]
+        except Exception as e:
+            ties["step_with_one_utterance_flagged_ms"] = f"failed: {e}"
+        finally:
+            pipe.set_option("force_tie", None)
+            tie_counts(L, reset=True)
     # per-kernel time of the last timed step, HIP events on the library's own streams: what the kernels take INSIDE the overlapped
     # schedule (a kernel that shares the chip with the other half batch's is stretched by the sharing; the sum exceeds the step)
     kern_overlapped = {}
@@ -706,10 +742,13 @@ def main():
                             ("config5_streams_share", lambda: stage_config5(w, L, torch, dev))):
                 if key in os.environ.get("WC_BENCH_SKIP", "").split(","):  # (development aid: leave stages out)
                     continue
+                tie_counts(L, reset=True)
                 try:
                     st[key] = fn()
                 except Exception as e:
                     st[key] = {"error": str(e)}
+                if key in ("config2_16k_full_pipeline", "config5_streams_share"):
+                    ties[key.split("_")[0]] = per_1000(*tie_counts(L, reset=True))
                 torch.cuda.empty_cache()
             c3 = st.get("cheaptrick_config3", {})
             if "_k" in c3:
@@ -738,6 +777,7 @@ def main():
                     "cheaptrick_config3_ms": c3.get("ms"), "cheaptrick_config3_hbm_frac": c3.get("hbm_frac"),
                     "cheaptrick_config3_target_hbm_frac": c3.get("target_hbm_frac"),
                     "config2_ms": c2.get("ms"), "config4_ms": c4.get("ms")}
+            also["ties"] = ties
             out["config"]["also_measured"] = also
             if out["roofline"] is not None:
                 out["roofline"]["also_measured"] = also

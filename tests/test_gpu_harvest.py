@@ -182,23 +182,40 @@ def test_bandpass_with_eight_lanes_per_band_is_bit_identical(wca):
         assert sum(int((f > 0).sum()) for f in got["8"][0]) > 100
 
 
-def test_decimation_staged_through_lds_is_bit_identical(wca):
-    """the decimator that stages every lane's stream through LDS (default) against the one that reads the streams directly
-    (WC_HARVEST_DECIMATE=direct): same recursion, same chunk and warm-up boundaries, so the same bits -- at every
-    decimation ratio, for lengths that are not a multiple of anything, and for an utterance shorter than one chunk"""
+def test_decimation_formulations_agree(wca):
+    """decimate / FilterForDecimate (reference src/world_matlabfunctions.cpp:27-125, :184-210) three ways.  Rounds 1-5: the recursion
+    cut into 512-sample chunks that start 768 samples early from a zero state, every lane's stream staged through LDS
+    (WC_HARVEST_DECIMATE=chunks) or read directly (=direct): same recursion, same chunk and warm-up boundaries, so the same bits.
+    Round 6 (default): 32-sample chunks whose exact starting states come out of a scan of the chunks' own end states
+    (hv_decimate_scan_kernel) -- the reference's statements in the reference's order from a state that is exact up to rounding:
+    within 1e-13 of the signal's scale of the chunked kernels (measured: 2e-15 at a ratio of 6, 1.4e-14 at 12: a state of the narrower filter is a hundred times its output).  At every decimation ratio, for
+    lengths that are not a multiple of anything, for an utterance shorter than one chunk, and in a ragged batch."""
     import os
-    for fs, n in ((48000, 100003), (44100, 50001), (22050, 33333), (16000, 20011), (48000, 700)):
-        x = make_utterance(fs, (n + 10) / fs, 4321 + n)[:n]
-        a = wca.Harvest(fs)
-        a.compute(x)
-        ya = a.debug_fetch("y")
-        os.environ["WC_HARVEST_DECIMATE"] = "direct"
+
+    def harvest(mode):
+        if mode:
+            os.environ["WC_HARVEST_DECIMATE"] = mode
         try:
-            b = wca.Harvest(fs)
+            return wca.Harvest(fs)
         finally:
-            del os.environ["WC_HARVEST_DECIMATE"]
-        b.compute(x)
-        assert np.array_equal(ya, b.debug_fetch("y")), (fs, n)
+            os.environ.pop("WC_HARVEST_DECIMATE", None)
+
+    for fs, n in ((48000, 100003), (44100, 50001), (22050, 33333), (16000, 20011), (48000, 700), (96000, 77777)):
+        x = make_utterance(fs, (n + 10) / fs, 4321 + n)[:n]
+        ys = {}
+        for mode in (None, "chunks", "direct"):
+            h = harvest(mode)
+            h.compute(x)
+            ys[mode] = h.debug_fetch("y")
+        assert np.array_equal(ys["chunks"], ys["direct"]), (fs, n)
+        assert np.abs(ys[None] - ys["chunks"]).max() < 1e-13 * max(1.0, np.abs(x).max()), (fs, n, np.abs(ys[None] - ys["chunks"]).max())
+    fs = 48000
+    xs = [make_utterance(fs, sec, 900 + i) for i, sec in enumerate((0.7, 0.05, 1.3, 0.33))]
+    a, b = harvest(None), harvest("chunks")
+    a.compute_batch(xs)
+    b.compute_batch(xs)
+    for k in range(len(xs)):
+        assert np.abs(a.debug_fetch("y", k) - b.debug_fetch("y", k)).max() < 1e-13, k
 
 
 def test_smoothing_that_skips_settled_stretches_is_bit_identical(wca):

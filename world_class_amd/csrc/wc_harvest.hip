@@ -240,6 +240,142 @@ __global__ __launch_bounds__(64) void hv_decimate_lds_kernel(const HvUtt *__rest
 	}
 }
 
+// Round 6 (default): the same two passes with EXACT chunk states instead of warm-ups.  The recursion is linear: the state behind a
+// chunk is A^C times the state in front of it plus the state the chunk's own samples leave behind a zero state.  A thread
+// holds the DS_C samples of its chunk in registers, runs them through the recursion from a zero state, the workgroup scans those
+// end states with the constant matrices A^(C 2^j) (seven levels, no sample touched), and every thread runs its chunk once more
+// from the state the scan hands it -- the reference's statements in the reference's order, on a starting state that is
+// exact up to rounding (the chunked kernels above start 768 samples early instead and re-read those: 2.5 samples fetched
+// and stepped per sample kept at 512-sample chunks, far more at the small chunks a lone utterance would need to fill the
+// chip).  Only a workgroup's first DS_WARM threads are warm-up (their chunks start from a zero state, as the kernels above do
+// everywhere): 5 % more samples, and exactly zero at the start of an utterance.  Chunks of 32 samples: an utterance of 10 s is
+// 250 wavefronts per pass where the kernels above have 15.  Results within an ulp of the chunked kernels' (a starting state
+// rounds differently), not the same bits: tests/test_gpu_harvest.py holds the two to 1e-14 of the signal's scale.
+constexpr int DS_C = 32, DS_T = 512, DS_WARM = DEC_WARM / DS_C, DS_SPAN = (DS_T - DS_WARM) * DS_C;
+struct DecScan { double mp[7][9]; };  // A^(DS_C 2^j), row-major
+__device__ __forceinline__ void ds_madd(double (&s)[3], const double (&m)[9], const double (&t)[3]) {  // s += m t
+	s[0] += m[0] * t[0] + m[1] * t[1] + m[2] * t[2];
+	s[1] += m[3] * t[0] + m[4] * t[1] + m[5] * t[2];
+	s[2] += m[6] * t[0] + m[7] * t[1] + m[8] * t[2];
+}
+template <int PASS>
+__global__ __launch_bounds__(DS_T) void hv_decimate_scan_kernel(const HvUtt *__restrict__ utts, const double *__restrict__ x, double *__restrict__ buf,
+																 double *__restrict__ y, DecCoef c, DecScan ms, const double *__restrict__ ptab, int r, int lag) {
+	__shared__ double tot[DS_T / 64][3];
+	__shared__ double tiles[DS_T / 64][32 * 33];  // per wavefront: the chunks of 32 of its lanes on their way between memory order and lane order
+	const HvUtt u = utts[blockIdx.y];
+	const int nn = u.x_len + 2 * lag;
+	const int len = nn + 18;
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const long long span0 = (long long)blockIdx.x * DS_SPAN;
+	if (span0 >= len) return;
+	const double *__restrict__ xin = x + u.x_off;
+	double *__restrict__ b = buf + u.dec_off;
+	const int k0 = (int)span0 + (tid - DS_WARM) * DS_C;  // (negative in front of the signal: zeros into a zero state)
+	// A wavefront's 64 chunks are 2048 consecutive positions: fetched 64 consecutive ones per instruction (a lane reading its own
+	// chunk touches 64 cache lines per load) and handed to their lanes through LDS, the chunks of 32 lanes at a time
+	double *const tile = &tiles[wv][0];
+	const int kw0 = (int)span0 + (wv * 64 - DS_WARM) * DS_C;
+	double v[DS_C];
+#pragma unroll
+	for (int hf = 0; hf < 2; ++hf) {
+		double q[16];
+#pragma unroll
+		for (int i = 0; i < 16; ++i) {
+			const int k = kw0 + 1024 * hf + lane + 64 * i;
+			q[i] = 0.0;
+			if (k >= 0 && k < len) q[i] = (PASS == 0) ? xin[clampi(k - 9 - lag, 0, u.x_len - 1)] : b[len - 1 - k];
+		}
+#pragma unroll
+		for (int i = 0; i < 16; ++i) {
+			const int e = lane + 64 * i;
+			tile[(e >> 5) * 33 + (e & 31)] = q[i];
+		}
+		rq_fence();
+		if ((lane >> 5) == hf) {
+#pragma unroll
+			for (int j = 0; j < DS_C; ++j) v[j] = tile[(lane & 31) * 33 + j];
+		}
+		rq_fence();
+	}
+	// the state the chunk leaves behind a zero state
+	double st[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+	for (int j = 0; j < DS_C; ++j) {
+		const double wt = v[j] + c.a0 * st[0] + c.a1 * st[1] + c.a2 * st[2];
+		st[2] = st[1]; st[1] = st[0]; st[0] = wt;
+	}
+	// ... scanned: first inside the wavefront,
+#pragma unroll
+	for (int j = 0; j < 6; ++j) {
+		double t[3];
+#pragma unroll
+		for (int k = 0; k < 3; ++k) t[k] = __shfl_up(st[k], 1 << j, 64);
+		if (lane >= (1 << j)) ds_madd(st, ms.mp[j], t);
+	}
+	if (lane == 63) { tot[wv][0] = st[0]; tot[wv][1] = st[1]; tot[wv][2] = st[2]; }
+	__syncthreads();
+	// then the state in front of this wavefront from the totals of the ones before it,
+	double pre[3] = {0.0, 0.0, 0.0};
+	for (int w = 0; w < wv; ++w) {
+		double nx[3] = {tot[w][0], tot[w][1], tot[w][2]};
+		ds_madd(nx, ms.mp[6], pre);
+		pre[0] = nx[0]; pre[1] = nx[1]; pre[2] = nx[2];
+	}
+	// carried to every chunk's end (A^(C (lane + 1)) from a table), and the state in FRONT of the chunk is its neighbour's
+	{
+		double m[9];
+#pragma unroll
+		for (int k = 0; k < 9; ++k) m[k] = ptab[9 * lane + k];
+		ds_madd(st, m, pre);
+	}
+	double w0 = __shfl_up(st[0], 1, 64), w1 = __shfl_up(st[1], 1, 64), w2 = __shfl_up(st[2], 1, 64);
+	if (lane == 0) { w0 = pre[0]; w1 = pre[1]; w2 = pre[2]; }
+	// the chunk once more, from its own starting state (reference src/world_matlabfunctions.cpp:106-118, statement by statement)
+	const int nout = nn / r + 1;
+	const int nbeg = r - r * nout + nn;
+	const int first = nbeg + (lag / r) * r + 8;  // index (original order) of y[0]
+	const bool keep = tid >= DS_WARM;
+#pragma unroll
+	for (int j = 0; j < DS_C; ++j) {
+		const double wt = v[j] + c.a0 * w0 + c.a1 * w1 + c.a2 * w2;
+		const double o = c.b0 * wt + c.b1 * w0 + c.b1 * w1 + c.b0 * w2;
+		w2 = w1; w1 = w0; w0 = wt;
+		const int k = k0 + j;
+		if (PASS == 0) {
+			v[j] = o;  // (leaves through LDS below)
+		} else if (keep && k < len) {
+			const int p = len - 1 - k;  // position in the original order
+			const int d = p - first;
+			if (d >= 0 && d % r == 0) {
+				const int i = d / r;
+				// (The recursion's tail behind a stretch that ends in digital silence is carried exactly here -- the chunked kernels above cut
+				// it off 768 samples on, where a chunk's warm-up starts from zero -- and would go on down into the denormal numbers, where the
+				// sliding band-pass's reciprocal-based quotients of neighbouring outputs have no answer: 240 orders of magnitude below
+				// full scale the tail is set to the zero it becomes 0.1 s later anyway.)
+				if (i < u.y_len) y[u.y_off + i] = fabs(o) < 0x1p-800 ? 0.0 : o;
+			}
+		}
+	}
+	if (PASS == 0) {
+#pragma unroll
+		for (int hf = 0; hf < 2; ++hf) {
+			if ((lane >> 5) == hf) {
+#pragma unroll
+				for (int j = 0; j < DS_C; ++j) tile[(lane & 31) * 33 + j] = v[j];
+			}
+			rq_fence();
+#pragma unroll
+			for (int i = 0; i < 16; ++i) {
+				const int e = lane + 64 * i;
+				const int k = kw0 + 1024 * hf + e;
+				if (k >= (int)span0 && k < len) b[k] = tile[(e >> 5) * 33 + (e & 31)];
+			}
+			rq_fence();
+		}
+	}
+}
+
 // reference src/harvest.cpp:237-241: accumulate(y, y + n, 0) with an int accumulator truncates after every
 // addition, so the "mean" is 0 unless some abs(y) reaches 1.  Emulated exactly.
 __global__ void hv_dc_kernel(const HvUtt *__restrict__ utts, double *__restrict__ y) {
@@ -3334,6 +3470,9 @@ struct wc_harvest {
 	int refine_mode;        // WC_HARVEST_REFINE=slots: one wavefront per candidate slot (1); =packed: one wavefront per frame (2); default: frames in groups (0) (A/B and the bit-identity tests)
 	bool smooth_full_walk;  // WC_HARVEST_SMOOTH=full: the smoothing filter without the skipping of settled stretches (A/B and the bit-identity test)
 	bool direct_decimation;  // WC_HARVEST_DECIMATE=direct: every lane reads its own stream from memory (A/B and the bit-identity test)
+	bool chunked_decimation = false;  // WC_HARVEST_DECIMATE=chunks (or direct): the chunked kernels with warm-ups of rounds 1-5 instead of exact chunk states
+	DecScan dec_scan;
+	DevBuf d_dec_ptab;
 	DevBuf utts, dec, y, events, ev_count, overflow, tile_run, raw, cand0, cand1, score1, cand2, score2;
 	DevBuf base, s1, s2, s3, fixed, f0_1ms, sec, chan, smooth, ibuf, rawdesc;
 	DevBuf d_x, d_tpos, d_f0;
@@ -3557,7 +3696,11 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 				const DecCoef c = dec_coef(r);
 				const int chunks = (max_len + DEC_CHUNK - 1) / DEC_CHUNK;
 				dim3 grid((chunks + 63) / 64, n_utt);
-				if (h->direct_decimation) {
+				if (!h->chunked_decimation) {
+					const dim3 sgrid((max_len + DS_SPAN - 1) / DS_SPAN, n_utt);
+					hipLaunchKernelGGL(hv_decimate_scan_kernel<0>, sgrid, dim3(DS_T), 0, s, du, d_x, h->dec.as<double>(), h->y.as<double>(), c, h->dec_scan, h->d_dec_ptab.as<double>(), r, lag);
+					hipLaunchKernelGGL(hv_decimate_scan_kernel<1>, sgrid, dim3(DS_T), 0, s, du, d_x, h->dec.as<double>(), h->y.as<double>(), c, h->dec_scan, h->d_dec_ptab.as<double>(), r, lag);
+				} else if (h->direct_decimation) {
 					hipLaunchKernelGGL(hv_decimate_kernel<0>, grid, dim3(64), 0, s, du, d_x, h->dec.as<double>(), h->y.as<double>(), c, r, lag);
 					hipLaunchKernelGGL(hv_decimate_kernel<1>, grid, dim3(64), 0, s, du, d_x, h->dec.as<double>(), h->y.as<double>(), c, r, lag);
 				} else {
@@ -3924,6 +4067,37 @@ wc_harvest *wc_harvest_create(int fs, double f0_floor, double f0_ceil, double fr
 		h->debug_small_caps = getenv("WC_DEBUG_SMALL_CAPS") != nullptr;
 		const char *dm = getenv("WC_HARVEST_DECIMATE");
 		h->direct_decimation = dm && std::strcmp(dm, "direct") == 0;
+		h->chunked_decimation = dm && (std::strcmp(dm, "direct") == 0 || std::strcmp(dm, "chunks") == 0);
+		{
+			// powers of the recursion's state matrix A = [a0 a1 a2; 1 0 0; 0 1 0] (state = the last three values of the recursion's
+			// inner sequence, newest first), in extended precision: A^(C 2^j) for the scan's levels, A^(C (l + 1)) for the carry
+			const DecCoef dc_ = dec_coef(h->decim);
+			typedef long double LD;
+			auto mul = [](const LD (&a)[9], const LD (&b)[9], LD (&o)[9]) {
+				LD t[9];
+				for (int i = 0; i < 3; ++i)
+					for (int j = 0; j < 3; ++j) t[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+				for (int k = 0; k < 9; ++k) o[k] = t[k];
+			};
+			const LD A[9] = {(LD)dc_.a0, (LD)dc_.a1, (LD)dc_.a2, 1, 0, 0, 0, 1, 0};
+			LD AC[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+			for (int k = 0; k < DS_C; ++k) mul(AC, A, AC);  // A^C
+			LD P[9];
+			for (int k = 0; k < 9; ++k) P[k] = AC[k];
+			std::vector<double> ptab(64 * 9);
+			for (int l = 0; l < 64; ++l) {
+				for (int k = 0; k < 9; ++k) ptab[9 * l + k] = (double)P[k];
+				mul(P, AC, P);
+			}
+			LD Q[9];
+			for (int k = 0; k < 9; ++k) Q[k] = AC[k];
+			for (int j = 0; j < 7; ++j) {
+				for (int k = 0; k < 9; ++k) h->dec_scan.mp[j][k] = (double)Q[k];
+				mul(Q, Q, Q);
+			}
+			ok = ok && h->d_dec_ptab.reserve(sizeof(double) * ptab.size()) == 0 &&
+				 hipMemcpy(h->d_dec_ptab.p, ptab.data(), sizeof(double) * ptab.size(), hipMemcpyHostToDevice) == hipSuccess;
+		}
 		const char *sm = getenv("WC_HARVEST_SMOOTH");
 		h->smooth_full_walk = sm && std::strcmp(sm, "full") == 0;
 		const char *rfm = getenv("WC_HARVEST_REFINE");
@@ -3980,7 +4154,7 @@ void wc_harvest_destroy(wc_harvest *h) {
 	h->dev->quiesce();
 	if (h->exact_twin) wc_harvest_destroy(h->exact_twin);
 	h->dev->handle_gone();
-	for (DevBuf *b : {&h->d_cos_table, &h->d_sd_rot, &h->d_sd_p0, &h->d_slot_off, &h->d_slot_cap, &h->slots, &h->slot_count, &h->seam, &h->quiet, &h->bmax, &h->d_rot, &h->d_rot8, &h->d_taps, &h->d_tap_off, &h->d_half_len, &h->d_band_f0, &h->d_ev_band_off, &h->d_ev_cap, &h->utts, &h->dec, &h->y,
+	for (DevBuf *b : {&h->d_cos_table, &h->d_sd_rot, &h->d_sd_p0, &h->d_slot_off, &h->d_slot_cap, &h->slots, &h->slot_count, &h->seam, &h->quiet, &h->bmax, &h->d_rot, &h->d_rot8, &h->d_dec_ptab, &h->d_taps, &h->d_tap_off, &h->d_half_len, &h->d_band_f0, &h->d_ev_band_off, &h->d_ev_cap, &h->utts, &h->dec, &h->y,
 					  &h->events, &h->ev_count, &h->overflow, &h->tile_run, &h->raw, &h->cand0, &h->cand1, &h->score1, &h->cand2, &h->score2, &h->base,
 					  &h->s1, &h->s2, &h->s3, &h->fixed, &h->f0_1ms, &h->sec, &h->chan, &h->smooth, &h->ibuf, &h->rawdesc, &h->d_x, &h->d_tpos, &h->d_f0})
 		b->release();
