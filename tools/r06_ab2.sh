@@ -1,7 +1,4 @@
-python -m pytest tests/test_gpu_harvest.py -x -q 2>&1 | tail -3
-for mode in default chunks default chunks; do
-  echo "== WC_HARVEST_DECIMATE=$mode"
-  WC_HARVEST_DECIMATE=$mode python tools/microbench.py --utts 64 --iters 5 --stages h 2>&1 | grep "decimate"
-  WC_HARVEST_DECIMATE=$mode python tools/microbench.py --utts 32 --iters 5 --stages h 2>&1 | grep "decimate"
-  WC_HARVEST_DECIMATE=$mode python tools/microbench.py --utts 1 --iters 5 --stages h 2>&1 | grep "decimate"
+for v in 2 0 1 2 0 1; do
+  echo "== WC_PIPELINE_PRE_LANE=$v"
+  WC_PIPELINE_PRE_LANE=$v python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --no-serialised 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'])"
 done

@@ -3565,8 +3565,14 @@ static void launch_refine(const RefArgs &fa, hipStream_t s, int mode, bool table
 int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const int *x_length, double *d_tpos, double *d_f0,
 			   bool full, hipEvent_t mid_event, hipEvent_t start_after, int part, hipEvent_t bp_done, hipEvent_t tail_after) {
 	Device *dev = h->dev;
-	const int phases = h->phases & part;
-	const bool resume = part == 2;
+	// part, bits 0 / 1: front / tail.  Bit 2 (4): of the front only what needs nothing but the samples -- decimation, DC, the level
+	// marks and the seam values in front of the band-pass --; bit 3 (8): the front behind that (an earlier call with bit 2 has
+	// enqueued the rest, maybe on another stream: `start_after` orders the two).  Round 6: the pipeline's two-lane schedule puts the
+	// second group's decimation on its latency lane, underneath the first group's band-pass.
+	const bool pre_only = (part & 4) != 0, main_only = (part & 8) != 0;
+	const int phases = h->phases & part & 3;
+	const bool resume_tail = (part & 3) == 2;
+	const bool resume = resume_tail || main_only;  // (nothing is uploaded or cleared again)
 	const int r = h->decim;
 	const int lag = (r == 1) ? 0 : static_cast<int>(std::ceil(140.0 / r) * r);
 	std::vector<HvUtt> utts(n_utt);
@@ -3687,7 +3693,7 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 			WC_HIP(hipMemsetAsync(h->overflow.p, 0, (2 + (size_t)n_utt) * sizeof(int), s));
 		}
 		const HvUtt *du = h->utts.as<HvUtt>();
-		if (phases & 1) {
+		if ((phases & 1) && !main_only) {
 			WC_HIP(hipMemsetAsync(h->y.p, 0, sizeof(double) * yo, s));
 			if ((rc = dev->time_begin("harvest_decimate", s))) return rc;
 			if (r == 1) {
@@ -3721,8 +3727,9 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 		ba.half_len = h->d_half_len.as<int>(); ba.ev_band_off = h->d_ev_band_off.as<long long>(); ba.ev_cap = h->d_ev_cap.as<int>();
 		ba.events = h->events.as<double>(); ba.ev_count = h->ev_count.as<int>(); ba.overflow = h->overflow.as<int>(); ba.n_bands = nb;
 		ba.tile_run = h->tile_run.as<int>(); ba.n_tiles = n_tiles;
-		if ((rc = dev->time_begin("harvest_bandpass", s))) return rc;
+		if (!pre_only && (rc = dev->time_begin("harvest_bandpass", s))) return rc;
 		if (h->use_fir) {
+			if (pre_only) { h->last_utts = utts; return WC_OK; }
 			hipLaunchKernelGGL(hv_bandpass_kernel, dim3(nb, n_utt), dim3(BP_T), 0, s, ba);
 		} else {
 			SdArgs sa;
@@ -3735,9 +3742,16 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 			sa.n_blk = (max_ylen + 63) / 64;
 			sa.hl_max = *std::max_element(h->half_len.begin(), h->half_len.end());
 			sa.bmax = h->bmax.as<double>(); sa.quiet = h->quiet.as<int>();
-			hipLaunchKernelGGL(hv_blockmax_kernel, dim3((sa.n_blk + 3) / 4, n_utt), dim3(256), 0, s, sa, h->bmax.as<double>());
-			hipLaunchKernelGGL(hv_quiet_kernel, dim3(n_utt), dim3(64), 0, s, sa, h->quiet.as<int>(), h->no_quiet ? 0 : 1);
-			hipLaunchKernelGGL(hv_seam_kernel, dim3(nb, n_utt), dim3(64), 0, s, sa);
+			if (!main_only) {
+				hipLaunchKernelGGL(hv_blockmax_kernel, dim3((sa.n_blk + 3) / 4, n_utt), dim3(256), 0, s, sa, h->bmax.as<double>());
+				hipLaunchKernelGGL(hv_quiet_kernel, dim3(n_utt), dim3(64), 0, s, sa, h->quiet.as<int>(), h->no_quiet ? 0 : 1);
+				hipLaunchKernelGGL(hv_seam_kernel, dim3(nb, n_utt), dim3(64), 0, s, sa);
+			}
+			if (pre_only) {
+				WC_HIP(hipGetLastError());
+				h->last_utts = utts;
+				return WC_OK;
+			}
 			// small batches leave most of the chip idle with a lane per (band, chunk): eight lanes each then (same bits)
 			const long long waves1 = (long long)((nb * n_tiles + 63) / 64) * n_utt;
 			if (h->sdft_lanes == 8 || (h->sdft_lanes == 0 && waves1 * 8 <= 3072))
@@ -3818,7 +3832,7 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 	// places -- wants all (1.83 ms alone, 2.55 ms beside it): 27.8 -> 27.2 ms per 64 x 10 s.  Later still (behind the contour
 	// kernels, one wavefront per utterance or section) exposes their latency: 27.9 / 28.1 ms.  WC_HARVEST_MID_LATE=0..3 (A/B).
 	static const int mid_late = getenv("WC_HARVEST_MID_LATE") ? atoi(getenv("WC_HARVEST_MID_LATE")) : 1;
-	if (mid_event && !resume && !(mid_late && (phases & 2))) WC_HIP(hipEventRecord(mid_event, s));
+	if (mid_event && !resume_tail && !(mid_late && (phases & 2))) WC_HIP(hipEventRecord(mid_event, s));
 	if (!(phases & 2)) {
 		h->last_utts = utts;
 		return WC_OK;
@@ -3828,7 +3842,7 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 	const size_t unr_lds = sizeof(double) * (size_t)(3 * UNR_F + 2) * nc + sizeof(int) * (2 * UNR_F + 2) + (size_t)UNR_F * nc;
 	hipLaunchKernelGGL(hv_unreliable_kernel, dim3((unsigned)((max_L1 + UNR_F - 1) / UNR_F), n_utt), dim3(256), unr_lds, s, du, h->cand1.as<double>(),
 					   h->score1.as<double>(), h->cand2.as<double>(), h->score2.as<double>(), h->base.as<double>(), nc);
-	if (mid_event && !resume && mid_late == 1) WC_HIP(hipEventRecord(mid_event, s));
+	if (mid_event && !resume_tail && mid_late == 1) WC_HIP(hipEventRecord(mid_event, s));
 	CtrArgs ca;
 	ca.utts = du; ca.cand = h->cand2.as<double>(); ca.score = h->score2.as<double>(); ca.base = h->base.as<double>();
 	ca.s1 = h->s1.as<double>(); ca.s2 = h->s2.as<double>(); ca.s3 = h->s3.as<double>(); ca.fixed = h->fixed.as<double>();
@@ -3836,9 +3850,9 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 	ca.ibuf = h->ibuf.as<int>();
 	ca.nsec = h->ibuf.as<int>() + 4ll * max_sec * n_utt;
 	hipLaunchKernelGGL(hv_contour_kernel<0>, dim3(n_utt), dim3(64), 0, s, ca);
-	if (mid_event && !resume && mid_late == 2) WC_HIP(hipEventRecord(mid_event, s));
+	if (mid_event && !resume_tail && mid_late == 2) WC_HIP(hipEventRecord(mid_event, s));
 	hipLaunchKernelGGL(hv_contour_kernel<1>, dim3(96, n_utt), dim3(64), 0, s, ca);  // a 10 s utterance has 20-40 sections
-	if (mid_event && !resume && mid_late == 3) WC_HIP(hipEventRecord(mid_event, s));
+	if (mid_event && !resume_tail && mid_late == 3) WC_HIP(hipEventRecord(mid_event, s));
 	hipLaunchKernelGGL(hv_contour_kernel<2>, dim3(n_utt), dim3(64), 0, s, ca);
 	SmArgs sa;
 	sa.utts = du; sa.fixed = h->fixed.as<double>(); sa.f0_1ms = h->f0_1ms.as<double>(); sa.sec = h->sec.as<int>();

@@ -100,6 +100,7 @@ struct PipeKnobs {
 	int chain = 1;             // WC_PIPELINE_CHAIN / "chain"
 	int direct = 1;            // WC_PIPELINE_DIRECT / "direct"
 	int eager = 1;             // WC_PIPELINE_EAGER / "eager"
+	int pre_lane = 0;          // WC_PIPELINE_PRE_LANE / "pre_lane" (experiment, measured and not kept): the second group's decimation .. seam values on the latency lane (1) or a stream of their own (2)
 	int force_tie = -1;        // WC_PIPELINE_FORCE_TIE / "force_tie" (test hook): this utterance of every run counts as flagged for a tie
 	std::vector<int> host_splits;  // WC_PIPELINE_HOST_SPLITS "a,b,c" / WC_PIPELINE_HOST_SPLIT "a" / "host_splits": per cent of the utterances per group but the last
 	bool host_splits_set = false;
@@ -118,6 +119,7 @@ static void knob_set(PipeKnobs &k, const std::string &name, const char *v) {
 	else if (name == "direct") k.direct = val.empty() ? 1 : atoi(v);
 	else if (name == "eager") k.eager = val.empty() ? 1 : atoi(v);
 	else if (name == "force_tie") k.force_tie = val.empty() ? -1 : atoi(v);
+	else if (name == "pre_lane") k.pre_lane = val.empty() ? 0 : atoi(v);
 	else if (name == "host_splits") {
 		k.host_splits.clear();
 		k.host_splits_set = !val.empty();
@@ -200,7 +202,7 @@ wc_pipeline *wc_pipeline_create(int fs, double frame_period, double harvest_f0_f
 	p->c_floor = harvest_f0_floor; p->c_ceil = harvest_f0_ceil; p->c_q1 = q1; p->c_ct_floor = cheaptrick_f0_floor;
 	p->c_threshold = d4c_threshold; p->c_fft_size = fft_size;
 	p->knobs = new PipeKnobs();
-	for (const char *nm : {"UNCHAIN_BELOW", "SCHEDULE", "SIDE", "SYN_STREAMS", "CHAIN_MIN", "GROUPS", "TAIL_AFTER_BP", "CHAIN", "DIRECT", "EAGER", "FORCE_TIE", "HOST_SPLITS"}) {
+	for (const char *nm : {"UNCHAIN_BELOW", "SCHEDULE", "SIDE", "SYN_STREAMS", "CHAIN_MIN", "GROUPS", "TAIL_AFTER_BP", "CHAIN", "DIRECT", "EAGER", "FORCE_TIE", "HOST_SPLITS", "PRE_LANE"}) {
 		const std::string env = std::string("WC_PIPELINE_") + nm;
 		std::string low(nm);
 		for (char &c : low) c = (char)tolower(c);
@@ -339,7 +341,7 @@ void wc_pipeline_destroy(wc_pipeline *p) {
 int wc_pipeline_set_option(wc_pipeline *p, const char *name, const char *value) {
 	if (!p || !name) return fail(WC_ERR_INVALID, "pipeline option: null argument");
 	static const char *known[] = {"unchain_below", "schedule", "side", "syn_streams", "chain_min", "groups", "tail_after_bp", "chain", "direct", "eager",
-								  "host_splits", "force_tie"};
+								  "host_splits", "force_tie", "pre_lane"};
 	bool ok = false;
 	for (const char *k : known) ok = ok || std::strcmp(k, name) == 0;
 	if (!ok) return fail(WC_ERR_INVALID, "pipeline option: unknown name");
@@ -565,8 +567,27 @@ static int pipeline_run(wc_pipeline *p, int n_utt, const double *d_x, const int 
 				for (int g = 0; g < 2; ++g) {
 					hvg[g] = p->grp[g].hv;
 					dev->time_tag = g;
+					// Round 6, measured and NOT kept (option "pre_lane" = 1 / 2): what the second group's front needs nothing but the samples
+					// for -- decimation, DC, level marks, seam values: 0.45 ms of kernels that leave most of the chip idle between the two
+					// groups' full-grid kernels -- on the latency lane (or a stream of its own) behind the first group's band-pass.  Under
+					// rocprofv3's kernel trace the step is 0.24 ms shorter that way (the second band-pass starts 0.29 ms earlier); without
+					// the tracer, timed alternately in one process, it is 0.6 ms LONGER (27.00 / 27.05 against 26.39 ms,
+					// profiles/r06_b_pre_lane_ab.txt): the decimation's workgroups hold 67 KB of LDS each and take the places of two of the
+					// refinement's four workgroups on the CUs they land on.
+					const bool pre_on_s = g == 1 && p->knobs->pre_lane != 0;
+					if (pre_on_s) {
+						// (behind the first group's band-pass: that kernel is one round of long-lived wavefronts on nearly every place of
+						// the chip, and whatever takes places beside it pushes some of them into a second round -- 26.7 against 26.3 ms)
+						const hipStream_t P = p->knobs->pre_lane == 2 ? p->grp[1].aux : S;  // (2: a stream of its own)
+						if (P != S) WC_HIP(hipStreamWaitEvent(P, p->e1, 0));
+						WC_HIP(hipStreamWaitEvent(P, p->e2, 0));
+						if ((rc = hv_enqueue(hvg[g], P, sl[g].nu, d_x + sl[g].xo, x_length + sl[g].u0, d_tpos + sl[g].fo, d_f0 + sl[g].fo, full[g][0],
+											 nullptr, nullptr, 1 | 4, nullptr, nullptr)))
+							return rc;
+						WC_HIP(hipEventRecord(p->e_bp, P));
+					}
 					if ((rc = hv_enqueue(hvg[g], F, sl[g].nu, d_x + sl[g].xo, x_length + sl[g].u0, d_tpos + sl[g].fo, d_f0 + sl[g].fo, full[g][0],
-										 p->grp[g].e_mid, nullptr, 1, nullptr, nullptr)))
+										 p->grp[g].e_mid, pre_on_s ? p->e_bp : nullptr, pre_on_s ? (1 | 8) : 1, (g == 0 && p->knobs->pre_lane != 0) ? p->e2 : nullptr, nullptr)))
 						return rc;
 				}
 				for (int g = 0; g < 2; ++g) {
