@@ -393,6 +393,15 @@ def per_1000(seen, flagged):
     return {"utterances": seen, "flagged": flagged, "per_1000_utterances": (1000.0 * flagged / seen) if seen else None}
 
 
+def rate_at(table, waves):
+    """nanoseconds per instruction at `waves` wavefronts per SIMD: the measured occupancy, or the next one measured above it (the
+    tables are non-increasing in the occupancy, so that is a lower bound on the cost)"""
+    if waves in table:
+        return table[waves]
+    above = [k for k in table if k > waves]
+    return table[min(above)] if above else table[max(table)]
+
+
 def load_issue_rates():
     """profiles/issue_rates.json (tools/issue_rate.hip on the GPU box) -> ns per wave-instruction and SIMD by wavefronts per SIMD:
     'fp64' = the v_fma_f64 stream, 'int32' = the cheaper of the v_add_u32 / v_mov_b32 streams, made non-increasing in the occupancy
@@ -689,7 +698,7 @@ def main():
                         continue
                     n64 = sum((n_f64_all.get(k) or {}).values())
                     wv = WAVES_PER_SIMD[k]
-                    c64, c32 = rates["fp64"][wv], rates["int32"][wv]
+                    c64, c32 = rate_at(rates["fp64"], wv), rate_at(rates["int32"], wv)
                     t_issue = (n64 * c64 + max(0.0, n_valu - n64) * c32) * 1e-9 / 1024.0
                     issue[k] = t_issue / (kern[k] * 1e-3)
                     issue_detail[k] = {"waves_per_simd": wv, "valu_insts": n_valu, "fp64_insts": n64, "ns_fp64": c64, "ns_int32": c32,
@@ -765,7 +774,7 @@ def main():
                 if n_v and n_64 and rates:
                     byt = c3["frames"] * c3["bytes_per_frame"]
                     for tag, wv in (("at_2_waves_per_simd", 2), ("at_8_waves_per_simd", 8)):
-                        t_iss = (n_64 * rates["fp64"][wv] + (n_v - n_64) * rates["int32"][wv]) * 1e-9 / 1024.0
+                        t_iss = (n_64 * rate_at(rates["fp64"], wv) + (n_v - n_64) * rate_at(rates["int32"], wv)) * 1e-9 / 1024.0
                         c3["issue_floor_" + tag] = {"ms": t_iss * 1e3, "hbm_frac": byt / t_iss / (HBM_PEAK_GBS * 1e9)}
                     c3["issue_frac"] = c3["issue_floor_at_2_waves_per_simd"]["ms"] / c3["kernel_ms"]
             out["stages"] = st

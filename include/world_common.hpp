@@ -10,6 +10,10 @@
 #include "world_matlabfunctions.hpp"
 
 #ifdef __cplusplus
+#include <algorithm>
+#include <cmath>
+#include <complex>
+
 typedef struct ForwardRealFFT {
 	int fft_size;
 	double *waveform;
@@ -86,47 +90,28 @@ typedef struct MinimumPhaseAnalysis {
 		delete[] log_spectrum;
 		delete[] minimum_phase_spectrum;
 	}
-	// log_spectrum[0 .. fft_size/2] in, minimum_phase_spectrum[0 .. fft_size/2] out (reference src/world_common.cpp:196-233)
+	// log_spectrum[0 .. fft_size/2] in, minimum_phase_spectrum[0 .. fft_size/2] out: the causal part of the cepstrum of an even log
+	// spectrum, transformed back and exponentiated (what reference src/world_common.cpp:196-233 computes, in this header's own terms)
 	void compute() {
-		for (int i = fft_size / 2 + 1; i < fft_size; ++i) log_spectrum[i] = log_spectrum[fft_size - i];
+		const int half = fft_size / 2;
+		std::reverse_copy(log_spectrum + 1, log_spectrum + half, log_spectrum + half + 1);  // the even extension: bin N - i = bin i
 		fft_execute(inverse_fft);
-		cepstrum[0][1] *= -1.0;
-		for (int i = 1; i < fft_size / 2; ++i) {
-			cepstrum[i][0] *= 2.0;
-			cepstrum[i][1] *= -2.0;
+		// fold the two-sided cepstrum onto its causal half: weights 1, 2, .., 2, 1, 0, .., 0; the plan's e^{+i} convention leaves the
+		// conjugate of what the forward transform below expects
+		for (int i = 0; i < fft_size; ++i) {
+			const double w = (i == 0 || i == half) ? 1.0 : (i < half ? 2.0 : 0.0);
+			cepstrum[i][0] = i <= half ? w * cepstrum[i][0] : 0.0;
+			cepstrum[i][1] = i <= half ? -w * cepstrum[i][1] : 0.0;
 		}
-		cepstrum[fft_size / 2][1] *= -1.0;
-		for (int i = fft_size / 2 + 1; i < fft_size; ++i) cepstrum[i][0] = cepstrum[i][1] = 0.0;
 		fft_execute(forward_fft);
-		for (int i = 0; i <= fft_size / 2; ++i) {
-			const double mag = exp(minimum_phase_spectrum[i][0] / fft_size);
-			const double arg = minimum_phase_spectrum[i][1] / fft_size;
-			minimum_phase_spectrum[i][0] = mag * cos(arg);
-			minimum_phase_spectrum[i][1] = mag * sin(arg);
+		for (int i = 0; i <= half; ++i) {
+			const std::complex<double> z = std::polar(std::exp(minimum_phase_spectrum[i][0] / fft_size), minimum_phase_spectrum[i][1] / fft_size);
+			minimum_phase_spectrum[i][0] = z.real();
+			minimum_phase_spectrum[i][1] = z.imag();
 		}
 	}
 } MinimumPhaseAnalysis;
 
-// reference src/world_matlabfunctions.cpp:266-301: y = ifft(fft(x / N) .* fft(h / N)), fft_size points
-inline void fast_fftfilt(const double *x, int x_length, const double *h, int h_length, int fft_size,
-						 const ForwardRealFFT *forward_real_fft, const InverseRealFFT *inverse_real_fft, double *y) {
-	fft_complex *x_spectrum = new fft_complex[fft_size];
-	for (int i = 0; i < fft_size; ++i) forward_real_fft->waveform[i] = i < x_length ? x[i] / fft_size : 0.0;
-	fft_execute(forward_real_fft->forward_fft);
-	for (int i = 0; i <= fft_size / 2; ++i) {
-		x_spectrum[i][0] = forward_real_fft->spectrum[i][0];
-		x_spectrum[i][1] = forward_real_fft->spectrum[i][1];
-	}
-	for (int i = 0; i < fft_size; ++i) forward_real_fft->waveform[i] = i < h_length ? h[i] / fft_size : 0.0;
-	fft_execute(forward_real_fft->forward_fft);
-	for (int i = 0; i <= fft_size / 2; ++i) {
-		const double hr = forward_real_fft->spectrum[i][0], hi = forward_real_fft->spectrum[i][1];
-		inverse_real_fft->spectrum[i][0] = x_spectrum[i][0] * hr - x_spectrum[i][1] * hi;
-		inverse_real_fft->spectrum[i][1] = x_spectrum[i][0] * hi + x_spectrum[i][1] * hr;
-	}
-	fft_execute(inverse_real_fft->inverse_fft);
-	for (int i = 0; i < fft_size; ++i) y[i] = inverse_real_fft->waveform[i];
-	delete[] x_spectrum;
-}
+// (fast_fftfilt of reference src/world_matlabfunctions.cpp:266-301 is not provided: nothing in the reference calls it)
 #endif  // __cplusplus
 #endif

@@ -90,8 +90,9 @@ def test_fft_plan_api_conventions_match_the_reference(golden, h):
 
 
 def test_world_common_structs_compile_and_run(golden, tmp_path):
-    """include/world_common.hpp: MinimumPhaseAnalysis / ForwardRealFFT / InverseRealFFT / fast_fftfilt used the way the
-    reference's callers use them, compiled with plain g++ against the product library (host-only code: runs without a GPU)"""
+    """include/world_common.hpp: MinimumPhaseAnalysis / ForwardRealFFT / InverseRealFFT used the way the reference's callers use
+    them, compiled with plain g++ against the product library (host-only code: runs without a GPU); the minimum-phase spectrum
+    against the real reference's (minphase/* goldens), a forward / inverse real transform pair against numpy"""
     import os
     import subprocess
     from world_class_amd import build
@@ -114,12 +115,22 @@ int main(int argc, char **argv) {
 	fwrite(m.minimum_phase_spectrum, 16, n / 2 + 1, f);
 	fclose(f);
 	m.destroy();
-	// fast_fftfilt: convolution of two short sequences
+	// the real transform pair: a circular convolution of two short sequences through the spectra
 	ForwardRealFFT fw; InverseRealFFT iv;
 	fw.initialize(16); iv.initialize(16);
-	double x[4] = {1, 2, 3, 4}, hh[3] = {1, -1, 0.5}, y[16];
-	fast_fftfilt(x, 4, hh, 3, 16, &fw, &iv, y);
-	for (int i = 0; i < 6; ++i) printf("%.12f\n", y[i] * 16);  // the reference's scaling leaves a factor 1 / fft_size
+	const double x[4] = {1, 2, 3, 4}, hh[3] = {1, -1, 0.5};
+	double xs[9][2];
+	for (int i = 0; i < 16; ++i) fw.waveform[i] = i < 4 ? x[i] : 0.0;
+	fft_execute(fw.forward_fft);
+	for (int i = 0; i <= 8; ++i) { xs[i][0] = fw.spectrum[i][0]; xs[i][1] = fw.spectrum[i][1]; }
+	for (int i = 0; i < 16; ++i) fw.waveform[i] = i < 3 ? hh[i] : 0.0;
+	fft_execute(fw.forward_fft);
+	for (int i = 0; i <= 8; ++i) {
+		iv.spectrum[i][0] = xs[i][0] * fw.spectrum[i][0] - xs[i][1] * fw.spectrum[i][1];
+		iv.spectrum[i][1] = xs[i][0] * fw.spectrum[i][1] + xs[i][1] * fw.spectrum[i][0];
+	}
+	fft_execute(iv.inverse_fft);
+	for (int i = 0; i < 6; ++i) printf("%.12f\n", iv.waveform[i] / 16);  // (the inverse is unnormalised)
 	fw.destroy(); iv.destroy();
 	return 0;
 }
