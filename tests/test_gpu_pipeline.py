@@ -473,3 +473,27 @@ def test_only_the_utterances_on_a_tie_are_run_again(wca, monkeypatch):
             want = fir[u] if u in (k, j) else ign[u]
             assert all(np.array_equal(out[u][n], want[n]) for n in ("tpos", "f0", "sp", "ap")), ("host front-end", pinned, u)
             assert np.abs(out[u]["y"] - want["y"]).max() < 1e-10
+
+
+def test_two_lane_schedule_retries_after_an_overflow(wca, monkeypatch):
+    """Advice of round 5: the two-lane schedule (the default of resident batches of 500 s and more) has its own copy of the retry
+    logic; the small-caps and impulse-train tests all ran batches that take the side-by-side or chains path.  Here a batch goes
+    through the two lanes (option "unchain_below" = 0) with rate-bounded buffers sized to overflow (WC_DEBUG_SMALL_CAPS=1:
+    every group runs again with the hard bounds) and one utterance that raises the tie flag: the chains' bits in every output."""
+    from world_class_amd.synth import make_signal
+    fs = 16000
+    xs = [make_utterance(fs, 0.6 + 0.1 * (i % 4), 8300 + i) for i in range(8)]
+    xs[5] = make_signal(fs, 3.0, 1340043)  # an impulse train on a tie
+    monkeypatch.setenv("WC_DEBUG_SMALL_CAPS", "1")
+    outs = []
+    for schedule in ("lanes", "chains"):
+        p = wca.Pipeline(fs)
+        p.set_option("unchain_below", "0")
+        p.set_option("schedule", schedule)
+        outs.append(p.run_batch(xs, rng_pos=[0] * len(xs))[0])
+    monkeypatch.delenv("WC_DEBUG_SMALL_CAPS")
+    plain = wca.Pipeline(fs).run_batch(xs, rng_pos=[0] * len(xs))[0]
+    for u in range(len(xs)):
+        for n in ("tpos", "f0", "sp", "ap", "y"):
+            assert np.array_equal(outs[0][u][n], outs[1][u][n]), (u, n)
+            assert np.array_equal(outs[0][u][n], plain[u][n]), (u, n)

@@ -264,7 +264,13 @@ void Device::handle_gone() {
 	std::lock_guard<std::recursive_mutex> lk(mu);
 	if (--live_handles <= 0) {
 		live_handles = 0;
-		release_batch_staging();
+		// Round 6 (advice of round 5): the batch calls' staging is given back with the last handle only where it is large.  A
+		// caller that creates and destroys its stage objects per call -- Python objects going out of scope between batches do
+		// exactly that -- would otherwise re-allocate and re-pin it on every wc_*_compute_batch (hipHostMalloc of a gigabyte
+		// takes hundreds of milliseconds).  Up to 256 MB stay until wc_release_scratch() or the end of the process.
+		size_t held = 0;
+		for (const Staging &st : batch) held += st.h.cap + st.d.cap;
+		if (held > (size_t)256 << 20) release_batch_staging();
 	}
 }
 
