@@ -1,4 +1,4 @@
-for v in 2 0 1 2 0 1; do
-  echo "== WC_PIPELINE_PRE_LANE=$v"
-  WC_PIPELINE_PRE_LANE=$v python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --no-serialised 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'])"
+for mode in group group8 group group8; do
+  echo "== WC_HARVEST_REFINE=$mode"
+  WC_HARVEST_REFINE=$mode python tools/microbench.py --utts 64 --iters 5 --stages h 2>&1 | grep "refine"
 done

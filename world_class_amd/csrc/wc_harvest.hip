@@ -3547,6 +3547,9 @@ static void launch_refine(const RefArgs &fa, hipStream_t s, int mode, bool table
 	} else if (mode == 3 && small && !table) {  // (A/B: two frames per workgroup)
 		const int n_grp = (fa.max_l1 + 1) / 2;
 		hipLaunchKernelGGL((hv_refine_group_kernel<false, 2>), dim3((unsigned)(8 * ((n_grp + 7) / 8)), (unsigned)fa.n_utt), dim3(128), 0, s, fa);
+	} else if (mode == 4 && small && !table) {  // (A/B: eight frames per workgroup)
+		const int n_grp = (fa.max_l1 + 7) / 8;
+		hipLaunchKernelGGL((hv_refine_group_kernel<false, 8>), dim3((unsigned)(8 * ((n_grp + 7) / 8)), (unsigned)fa.n_utt), dim3(512), 0, s, fa);
 	} else {
 		if (table) {
 			if (small) hipLaunchKernelGGL((hv_refine_packed_kernel<true, 112>), dim3(frames), dim3(64), 0, s, fa);
@@ -4115,7 +4118,7 @@ wc_harvest *wc_harvest_create(int fs, double f0_floor, double f0_ceil, double fr
 		const char *sm = getenv("WC_HARVEST_SMOOTH");
 		h->smooth_full_walk = sm && std::strcmp(sm, "full") == 0;
 		const char *rfm = getenv("WC_HARVEST_REFINE");
-		h->refine_mode = !rfm ? 0 : std::strcmp(rfm, "slots") == 0 ? 1 : std::strcmp(rfm, "packed") == 0 ? 2 : std::strcmp(rfm, "group2") == 0 ? 3 : 0;
+		h->refine_mode = !rfm ? 0 : std::strcmp(rfm, "slots") == 0 ? 1 : std::strcmp(rfm, "packed") == 0 ? 2 : std::strcmp(rfm, "group2") == 0 ? 3 : std::strcmp(rfm, "group8") == 0 ? 4 : 0;
 		const char *rw = getenv("WC_HARVEST_RAW");
 		h->raw_from_lists = rw && std::strcmp(rw, "lists") == 0;
 		h->raw_mode = rw && std::strcmp(rw, "blocks") == 0 ? 1 : 0;

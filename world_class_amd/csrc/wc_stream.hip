@@ -189,6 +189,7 @@ wc_stream *wc_stream_create(int fs, int n_streams, double frame_period_ms, int c
 	s->hv_floor = harvest_f0_floor; s->hv_ceil = harvest_f0_ceil;
 	s->hv_front = s->hv_tail = nullptr;
 	s->hv = wc_harvest_create(fs, harvest_f0_floor, harvest_f0_ceil, frame_period_ms, 8000.0, 40.0, 0);
+	if (s->hv && !hv_exact_twin(s->hv)) { wc_harvest_destroy(s->hv); s->hv = nullptr; }  // (built now rather than inside the first push that meets a tie)
 	s->ct = s->hv ? wc_cheaptrick_create(fs, q1, cheaptrick_f0_floor, fft_size) : nullptr;
 	if (!s->ct) {
 		std::string err = wc_last_error();
@@ -245,6 +246,9 @@ int wc_stream_set_incremental(wc_stream *s, int context_ms) {
 	{
 		hv_set_phases(s->hv_front, 1);
 		hv_set_phases(s->hv_tail, 2);
+		// (the handle that re-runs windows on a tie with the band-pass as direct FIR sums: built here, not inside the first push that
+		// meets a tie -- its tables are milliseconds of host work and synchronous uploads, a latency spike in a real-time stream)
+		if (!hv_exact_twin(s->hv_front)) return fail(WC_ERR_DEVICE, "stream: the incremental mode's Harvest handles could not be created");
 	}
 	s->ctx_ms = context_ms;
 	// samples kept: what the front needs (chunk + 2 context) and what CheapTrick needs behind the oldest uncommitted frame
