@@ -3,7 +3,7 @@
 // classes (the demo's ParameterModification calls interp1, test/test.cpp:231).  Host functions of libworldclass_hip.so with the
 // reference's names, argument meaning and arithmetic; randn() draws from the same process-wide noise stream the stages
 // consume (wc_rng_get_position / wc_rng_set_position), as in the reference.
-// fast_fftfilt and the FFT buffer structs are in world_common.hpp, the plan API in world_fft.hpp.
+// The FFT buffer structs are in world_common.hpp, the plan API in world_fft.hpp (fast_fftfilt, which nothing in the reference calls, is not provided).
 #ifndef WORLD_MATLABFUNCTIONS_HPP
 #define WORLD_MATLABFUNCTIONS_HPP
 

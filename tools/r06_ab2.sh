@@ -1,4 +1,5 @@
-for mode in group group8 group group8; do
-  echo "== WC_HARVEST_REFINE=$mode"
-  WC_HARVEST_REFINE=$mode python tools/microbench.py --utts 64 --iters 5 --stages h 2>&1 | grep "refine"
+python -m pytest tests/test_gpu_cheaptrick.py -x -q 2>&1 | tail -2
+for lib in "" world_class_amd/_variants/ct_before.so "" world_class_amd/_variants/ct_before.so; do
+  echo "== lib=$lib"
+  WC_LIB_PATH=$lib python tools/microbench.py --stages c --utts 256 --iters 5 2>&1 | grep cheaptrick
 done
