@@ -63,6 +63,7 @@ _SIGNATURES = {
     "wc_pipeline_create": (_vp, [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_double]),
     "wc_pipeline_destroy": (None, [_vp]),
     "wc_pipeline_get_fft_size": (C.c_int, [_vp]),
+    "wc_pipeline_set_option": (C.c_int, [_vp, C.c_char_p, C.c_char_p]),
     "wc_pipeline_run_device": (C.c_int, [_vp, C.c_int, _vp, _ip, _vp, _vp, _vp, _vp, _vp, _u64p]),
     "wc_pipeline_run_batch_host": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.c_int, _ip, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp),
                                              C.POINTER(_vp), C.POINTER(_vp), C.c_int, _u64p]),

@@ -17,11 +17,7 @@ class Pipeline:
     def set_option(self, name, value=None):
         """wc_pipeline_set_option: a schedule knob of this handle ("unchain_below", "schedule", "host_splits", "force_tie", ...;
         None = the default).  The WC_PIPELINE_* environment variables are read once, when the handle is created."""
-        import ctypes as C
-        fn = lib().wc_pipeline_set_option
-        fn.restype = C.c_int
-        fn.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
-        _check(fn(self._h, name.encode(), None if value is None else str(value).encode()))
+        _check(lib().wc_pipeline_set_option(self._h, name.encode(), None if value is None else str(value).encode()))
 
     def lengths(self, x_lengths):
         fl = [get_samples(self.fs, n, self.frame_period) for n in x_lengths]
