@@ -54,6 +54,16 @@ def dev(a, b, rel=False):
     return float(d.max()) if d.size else 0.0
 
 
+def tie_counts():
+    """(utterances that went through a Harvest refinement, utterances of those that raised the tie flag) in this process so far"""
+    import ctypes as C
+    fn = w.lib().wc_harvest_tie_counts
+    fn.restype, fn.argtypes = None, [C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.c_int]
+    seen, flagged = C.c_ulonglong(0), C.c_ulonglong(0)
+    fn(C.byref(seen), C.byref(flagged), 0)
+    return int(seen.value), int(flagged.value)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=32)
@@ -82,6 +92,7 @@ def main():
     if a.dither > 0:
         xs = [x + a.dither * np.random.default_rng((a.first_seed + i * a.seed_step) + 10 ** 6).normal(size=len(x)) for i, x in enumerate(xs)]
     res = w.Pipeline(a.fs, frame_period=a.frame_period, harvest_f0_floor=a.floor).run_batch(xs)
+    ties = tie_counts()
     P = port.Port()
     P.set_threads(os.cpu_count() or 1)
     worst = dict(f0=0.0, sp=0.0, ap=0.0, y=0.0)
@@ -116,6 +127,7 @@ def main():
         if fl or e["f0"] > 1e-6 or e["sp"] > 1e-7 or e["ap"] > 1e-7 or e["y"] > 1e-8:
             print("seed", (a.first_seed + i * a.seed_step), kinds[((a.first_seed + i * a.seed_step)) % len(kinds)] if (a.zoo or a.zoo2) else "", "V/UV flips", fl, {k: "%.2e" % v for k, v in e.items()})
     print("fs", a.fs, "floor", a.floor, "hop", a.frame_period, "utterances", a.n, "V/UV flips", flips, "worst", {k: "%.2e" % v for k, v in worst.items()},
+          "; flagged for a tie (and run again with FIR sums): %d of %d" % (ties[1], ties[0]),
           ("; reference crashed on %d, its Synthesis on %d more (F0 only); non-finite aperiodicities from the checker: %d" % (crashed, harvest_only, nan_ref)) if a.checker == "ref" else "")
 
 

@@ -1115,6 +1115,186 @@ __global__ __launch_bounds__(64) void hv_bandpass_sdft8_kernel(SdArgs a) {
 	}
 }
 
+// The eight-lane kernel in blocks of 64 samples (round 6).  Above, every step of a group runs the recurrence, then gathers the seven
+// sums through quad exchanges, then runs the detectors in lane 0 with the other seven lanes looking on: ~50 instructions per
+// sample, every one on the critical path of a wavefront that has its SIMD to itself (one utterance: 0.55 ms of 2.1).  Here a
+// step is the recurrence and one LDS store of the lane's sum; after 64 steps the block's outputs and detectors are done ACROSS
+// the lanes -- lane r of a group takes samples 8 r .. 8 r + 7: the Nuttall sum in out()'s order from the seven rows, the two
+// preceding outputs from lane r - 1 (lane 0: the previous block's last two, or the seam's), the detectors as above; the edges go
+// to their slots in time order through a scan of the lanes' counts.  ~12 instructions per sample and wavefront in the steps,
+// ~5 in the blocks; the same values in the same slots.  Rows of 64 sums, one pad per eight, stride 73: the stores of a step and
+// the loads of a block are conflict-free.
+constexpr int SD8_ROW = 73;
+__global__ __launch_bounds__(64) void hv_bandpass_sdft8b_kernel(SdArgs a) {
+	__shared__ double X[64 * SD8_ROW];
+	const int lane = threadIdx.x, sub = lane & 7, grp = lane >> 3;
+	const HvUtt u = a.utts[blockIdx.y];
+	const int item = blockIdx.x * 8 + grp;
+	const bool valid = item < a.n_bands * a.n_chunks;
+	const int chunk = valid ? item / a.n_bands : 0;
+	const int band = valid ? item - chunk * a.n_bands : 0;
+	const int i0 = chunk * SD_CH;
+	const bool skip = valid && a.quiet[(long long)blockIdx.y * a.n_chunks + chunk] != 0;
+	const bool live = valid && i0 < u.y_len && !skip;
+	const bool head = sub == 0;
+	if (__ballot(live) == 0ull) {
+		if (valid && head && !skip) {
+			int *c = a.slot_count + (((long long)blockIdx.y * a.n_bands + band) * a.n_chunks + chunk) * 4;
+			c[0] = c[1] = c[2] = c[3] = 0;
+		}
+		return;
+	}
+	const int hl = live ? a.half_len[band] : 0;
+	const double *__restrict__ y = a.y + u.y_off;
+	const int ylen = u.y_len;
+	const int v = sub == 0 ? 0 : sub - 1;  // (lane 1 idles on a copy of v = 0; its row is never read)
+	const double2 R = a.rot[band * 7 + v];
+	double2 D = make_double2(0.0, 0.0);
+	const double2 P = a.p0[band];
+	int hlmax = hl;
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) hlmax = max(hlmax, __shfl_xor(hlmax, o, 64));
+	const int qb = live ? i0 + 1 + hl - 2 * hlmax : 0;
+	for (int sidx = 0; sidx <= 2 * hlmax; ++sidx) {
+		const int q = qb + sidx;
+		const double yv = (live && sidx >= 2 * (hlmax - hl)) ? y[q] : 0.0;
+		const double ux = yv * P.x, uy = yv * P.y;
+		const double nx = fma(R.x, D.x, fma(-R.y, D.y, ux));
+		const double ny = fma(R.x, D.y, fma(R.y, D.x, uy));
+		D = make_double2(nx, ny);
+	}
+	auto quot = [](double n, double d) -> double {
+		double r = __builtin_amdgcn_rcp(d);
+		r = fma(fma(-d, r, 1.0), r, r);
+		r = fma(fma(-d, r, 1.0), r, r);
+		const double q = n * r;
+		return fma(fma(-d, q, n), r, q);
+	};
+	auto slide = [&](double yn, double yo) {
+		const double ux = yn * P.x, uy = yn * P.y;
+		const double vx = yo * P.x, vy = -(yo * P.y);
+		const double tx = D.x - vx, ty = D.y - vy;
+		const double nx = fma(R.x, tx, fma(-R.y, ty, ux));
+		const double ny = fma(R.x, ty, fma(R.y, tx, uy));
+		D = make_double2(nx, ny);
+	};
+	const double *__restrict__ pn = y + (live ? i0 + 2 + hl : 0), *__restrict__ po = y + (live ? i0 + 1 - hl : 0);
+	slide(pn[0], po[0]);
+	// the chunk's first two outputs and its two outputs of lookahead (the next chunk's first two) from hv_seam_kernel: see there
+	const double *__restrict__ sm = a.seam + (((long long)blockIdx.y * a.n_bands + band) * (a.n_chunks + 1) + chunk) * 2;
+	double c0 = live ? sm[0] : 0.0, c1 = live ? sm[1] : 0.0;  // the two outputs in front of the block
+	const double fn0 = live ? sm[2] : 0.0, fn1 = live ? sm[3] : 0.0;
+	const int cap = a.slot_cap[band];
+	double *__restrict__ slot = a.slots + blockIdx.y * a.slots_per_utt + a.slot_off[band] + (long long)chunk * 4 * cap;
+	int cnt[4] = {0, 0, 0, 0};
+	const int i_end = live ? min(i0 + SD_CH, ylen) : i0;
+	int steps = i_end - i0;
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) steps = max(steps, __shfl_xor(steps, o, 64));
+	constexpr int U = 8;
+	double *__restrict__ xw = X + lane * SD8_ROW;              // this lane's row, written a step at a time
+	const double *__restrict__ xr = X + grp * 8 * SD8_ROW + 9 * sub;  // the group's rows at this lane's eight samples
+	double yn[U], yo[U];
+#pragma unroll
+	for (int k = 0; k < U; ++k) { yn[k] = pn[1 + k]; yo[k] = po[1 + k]; }
+	for (int st = 0; st < steps; st += 64) {
+#pragma unroll
+		for (int t = 0; t < 64 / U; ++t) {
+			double cn[U], co[U];
+#pragma unroll
+			for (int k = 0; k < U; ++k) { cn[k] = yn[k]; co[k] = yo[k]; }
+#pragma unroll
+			for (int k = 0; k < U; ++k) { yn[k] = pn[st + t * U + U + 1 + k]; yo[k] = po[st + t * U + U + 1 + k]; }
+#pragma unroll
+			for (int k = 0; k < U; ++k) {
+				slide(cn[k], co[k]);
+				xw[t * 9 + k] = D.x;
+			}
+		}
+		rq_fence();
+		double o[10];
+#pragma unroll
+		for (int jj = 0; jj < 8; ++jj) {
+			const double d0 = xr[jj];
+			const double p2 = xr[2 * SD8_ROW + jj] + xr[3 * SD8_ROW + jj];
+			const double p4 = xr[4 * SD8_ROW + jj] + xr[5 * SD8_ROW + jj];
+			const double p6 = xr[6 * SD8_ROW + jj] + xr[7 * SD8_ROW + jj];
+			double f = 0.355768 * d0;
+			f = fma(-0.243698, p2, f);
+			f = fma(0.072116, p4, f);
+			f = fma(-0.006302, p6, f);
+			o[2 + jj] = f;
+		}
+		rq_fence();
+		if (live && st + 64 == SD_CH && sub == 7) { o[8] = fn0; o[9] = fn1; }  // (the next chunk's first two outputs: hv_seam_kernel)
+		{
+			const double b0 = __shfl_up(o[8], 1, 64), b1 = __shfl_up(o[9], 1, 64);
+			o[0] = head ? c0 : b0;
+			o[1] = head ? c1 : b1;
+			c0 = __shfl(o[8], lane | 7, 64);
+			c1 = __shfl(o[9], lane | 7, 64);
+		}
+		unsigned m_neg = 0, m_pos = 0, m_pk = 0, m_dp = 0;
+		const int ib = i0 + st + 8 * sub;
+#pragma unroll
+		for (int jj = 0; jj < 8; ++jj) {
+			const int i = ib + jj;
+			const double s0 = o[jj], s1 = o[jj + 1], s2 = o[jj + 2];
+			const double d0 = s1 - s0, d1 = s2 - s1;
+			const bool in1 = i < i_end && i + 1 < ylen, in2 = i < i_end && i + 2 < ylen;
+			const bool neg = in1 && 0.0 < s0 && s1 <= 0.0, pos = in1 && 0.0 < -s0 && -s1 <= 0.0;
+			const bool pk = in2 && 0.0 < d0 && d1 <= 0.0, dp = in2 && 0.0 < -d0 && -d1 <= 0.0;
+			m_neg |= (neg ? 1u : 0u) << jj;
+			m_pos |= (pos ? 1u : 0u) << jj;
+			m_pk |= (pk ? 1u : 0u) << jj;
+			m_dp |= (dp ? 1u : 0u) << jj;
+		}
+		const unsigned mine = __popc(m_neg) | (__popc(m_pos) << 8) | (__popc(m_pk) << 16) | (__popc(m_dp) << 24);
+		if (__ballot(mine != 0u) != 0ull) {
+			unsigned inc = mine;  // counts of 0..8 per byte: a group's sums stay below 256
+#pragma unroll
+			for (int d = 1; d < 8; d <<= 1) {
+				const unsigned t = __shfl_up(inc, d, 8);
+				if (sub >= d) inc += t;
+			}
+			const unsigned before = inc - mine, total = __shfl(inc, 7, 8);
+			int at[4];
+#pragma unroll
+			for (int ty = 0; ty < 4; ++ty) at[ty] = cnt[ty] + (int)((before >> (8 * ty)) & 255u);
+			if (mine != 0u) {
+#pragma unroll
+				for (int jj = 0; jj < 8; ++jj) {
+					const int i = ib + jj;
+					const double s0 = o[jj], s1 = o[jj + 1], s2 = o[jj + 2];
+					const double d0 = s1 - s0, d1 = s2 - s1;
+					const bool neg = (m_neg >> jj) & 1u, pos = (m_pos >> jj) & 1u, pk = (m_pk >> jj) & 1u, dp = (m_dp >> jj) & 1u;
+					if (neg || pos) {
+						const double fine = (i + 1) - quot(s0, d0);
+						const int c = neg ? at[0] : at[1];
+						if (c < cap) slot[(neg ? 0 : cap) + c] = fine;
+						at[0] += neg ? 1 : 0;
+						at[1] += pos ? 1 : 0;
+					}
+					if (pk || dp) {
+						const double fine = (i + 1) - quot(d0, d1 - d0);
+						const int c = pk ? at[2] : at[3];
+						if (c < cap) slot[(pk ? 2 * cap : 3 * cap) + c] = fine;
+						at[2] += pk ? 1 : 0;
+						at[3] += dp ? 1 : 0;
+					}
+				}
+			}
+#pragma unroll
+			for (int ty = 0; ty < 4; ++ty) cnt[ty] += (int)((total >> (8 * ty)) & 255u);
+		}
+	}
+	if (valid && head && !skip) {
+		int *c = a.slot_count + (((long long)blockIdx.y * a.n_bands + band) * a.n_chunks + chunk) * 4;
+#pragma unroll
+		for (int ty = 0; ty < 4; ++ty) c[ty] = cnt[ty];
+	}
+}
+
 struct CpArgs {
 	const HvUtt *utts;
 	const long long *slot_off;
@@ -3454,6 +3634,7 @@ struct wc_harvest {
 	bool tables_valid;  // the capacity tables on the device are those of (tables_ylen, tables_full, tables_tiles)
 	int tables_ylen, tables_full, tables_tiles;
 	hipStream_t tables_stream = nullptr;  // the stream those uploads were enqueued on
+	long long sdft8_max;  // eight lanes per (band, chunk) while that makes at most this many wavefronts (WC_HARVEST_SDFT8_MAX)
 	int sdft_lanes;  // WC_HARVEST_SDFT_LANES=1 / 8: lanes per (band, chunk) of the sliding band-pass (default 0: eight for small batches; A/B and the bit-identity test)
 	bool use_fir;  // WC_HARVEST_BANDPASS=fir: the direct FIR band-pass instead of the sliding DFT (A/B and tests)
 	bool use_cos_table;  // HarvestOption::use_cos_table
@@ -3757,8 +3938,12 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 			}
 			// small batches leave most of the chip idle with a lane per (band, chunk): eight lanes each then (same bits)
 			const long long waves1 = (long long)((nb * n_tiles + 63) / 64) * n_utt;
-			if (h->sdft_lanes == 8 || (h->sdft_lanes == 0 && waves1 * 8 <= 3072))
-				hipLaunchKernelGGL(hv_bandpass_sdft8_kernel, dim3((nb * n_tiles + 7) / 8, n_utt), dim3(64), 0, s, sa);
+			if (h->sdft_lanes == 8 || h->sdft_lanes == 9 || (h->sdft_lanes == 0 && waves1 * 8 <= h->sdft8_max)) {
+				if (h->sdft_lanes == 9)  // (the step-by-step form of the eight-lane kernel: A/B and the bit-identity test)
+					hipLaunchKernelGGL(hv_bandpass_sdft8_kernel, dim3((nb * n_tiles + 7) / 8, n_utt), dim3(64), 0, s, sa);
+				else
+					hipLaunchKernelGGL(hv_bandpass_sdft8b_kernel, dim3((nb * n_tiles + 7) / 8, n_utt), dim3(64), 0, s, sa);
+			}
 			else
 				hipLaunchKernelGGL(hv_bandpass_sdft_kernel, dim3((nb * n_tiles + 63) / 64, n_utt), dim3(64), 0, s, sa);
 			if (!h->no_quiet) hipLaunchKernelGGL(hv_bandpass_quiet_kernel, dim3(nb, n_utt), dim3(BP_T), 0, s, sa);
@@ -4080,6 +4265,8 @@ wc_harvest *wc_harvest_create(int fs, double f0_floor, double f0_ceil, double fr
 		h->no_quiet = qu && std::strcmp(qu, "sliding") == 0;
 		const char *sl = getenv("WC_HARVEST_SDFT_LANES");
 		h->sdft_lanes = sl ? atoi(sl) : 0;
+		const char *sm8 = getenv("WC_HARVEST_SDFT8_MAX");
+		h->sdft8_max = sm8 ? atoll(sm8) : 3072;
 		h->tables_valid = false;
 		h->debug_small_caps = getenv("WC_DEBUG_SMALL_CAPS") != nullptr;
 		const char *dm = getenv("WC_HARVEST_DECIMATE");

@@ -1358,6 +1358,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_SYN_WAVE_
 	__shared__ __attribute__((aligned(16))) double P[1024];
 #endif
 	const int lane = threadIdx.x;
+#ifdef WC_SYN_LDS_PAD  // (development builds: fewer wavefronts per SIMD, to see what one of them does alone)
+	__shared__ double PAD[WC_SYN_LDS_PAD];
+	if (a.fs < 0) PAD[lane] = 0.0;
+#endif
 	const long long total_p = a.pulse_prefix[a.n_utt];
 	if ((long long)blockIdx.x >= 8 * ((total_p + 7) / 8)) return;
 	const long long gp = xcd_frame(blockIdx.x, total_p);
