@@ -56,10 +56,9 @@ int pack_rows_up(Staging &st, int n, const double *const *const *rows, const int
 	long long o = 0;
 	for (int u = 0; u < n; ++u) {
 		if (f0_length[u] > 0 && !rows[u]) return fail(WC_ERR_INVALID, "batch: null row table");
-		rows_copy(const_cast<double *const *>(rows[u]), f0_length[u], bins, st.h.as<double>() + o * bins, false);
+		if ((rc = rows_up(s, rows[u], f0_length[u], bins, st.h.as<double>() + o * bins, st.d.as<double>() + o * bins))) return rc;
 		o += f0_length[u];
 	}
-	WC_HIP(hipMemcpyAsync(st.d.p, st.h.p, sizeof(double) * frames * bins, hipMemcpyHostToDevice, s));
 	return st.h.mark(s);
 }
 // one packed device array -> the caller's arrays
@@ -82,19 +81,14 @@ int unpack_down(Staging &st, int n, double *const *dst, const int *len, hipStrea
 }
 int unpack_rows_down(Staging &st, int n, double *const *const *rows, const int *f0_length, int bins, hipStream_t s) {
 	long long frames = 0;
-	for (int u = 0; u < n; ++u) frames += f0_length[u];
+	for (int u = 0; u < n; ++u) {
+		if (f0_length[u] > 0 && !rows[u]) return fail(WC_ERR_INVALID, "batch: null row table");
+		frames += f0_length[u];
+	}
 	if (frames == 0) return WC_OK;
 	int rc;
 	if ((rc = st.h.reserve(sizeof(double) * frames * bins))) return rc;
-	WC_HIP(hipMemcpyAsync(st.h.p, st.d.p, sizeof(double) * frames * bins, hipMemcpyDeviceToHost, s));
-	WC_HIP(hipStreamSynchronize(s));
-	long long o = 0;
-	for (int u = 0; u < n; ++u) {
-		if (f0_length[u] > 0 && !rows[u]) return fail(WC_ERR_INVALID, "batch: null row table");
-		rows_copy(rows[u], f0_length[u], bins, st.h.as<double>() + o * bins, true);
-		o += f0_length[u];
-	}
-	return WC_OK;
+	return rows_down_many(s, n, rows, f0_length, bins, st.d.as<double>(), st.h.as<double>());
 }
 
 }  // namespace

@@ -1278,7 +1278,7 @@ struct wc_cheaptrick {
 	double q1, f0_floor_opt, f0_floor;
 	Device *dev;
 	DevBuf utts, cnt, uidx, rare, off, endpos, d_x, d_tpos, d_f0, d_sp;
-	HostBuf h_stage, h_rows;
+	HostBuf h_stage, h_rows, h_x;
 	double f0_bound = 0.0;  // (a caller's promise about the contour's highest F0: no longer relied on -- the frames the wavefront kernels leave out are listed on the device)
 };
 
@@ -1459,6 +1459,7 @@ void wc_cheaptrick_destroy(wc_cheaptrick *c) {
 	c->utts.release(); c->cnt.release(); c->uidx.release(); c->rare.release(); c->off.release(); c->endpos.release();
 	c->d_x.release(); c->d_tpos.release(); c->d_f0.release(); c->d_sp.release();
 	c->h_stage.release();
+	c->h_x.release();
 	c->h_rows.release();
 	delete c;
 }
@@ -1489,7 +1490,7 @@ int wc_cheaptrick_compute(wc_cheaptrick *c, const double *x, int x_length, const
 	if ((rc = c->d_tpos.reserve(sizeof(double) * f0_length))) return rc;
 	if ((rc = c->d_f0.reserve(sizeof(double) * f0_length))) return rc;
 	if ((rc = c->d_sp.reserve(sizeof(double) * (size_t)f0_length * bins))) return rc;
-	WC_HIP(hipMemcpyAsync(c->d_x.p, x, sizeof(double) * x_length, hipMemcpyHostToDevice, s));
+	if ((rc = array_up(s, x, (size_t)x_length, c->h_x, c->d_x.as<double>()))) return rc;
 	WC_HIP(hipMemcpyAsync(c->d_tpos.p, temporal_positions, sizeof(double) * f0_length, hipMemcpyHostToDevice, s));
 	WC_HIP(hipMemcpyAsync(c->d_f0.p, f0, sizeof(double) * f0_length, hipMemcpyHostToDevice, s));
 	uint64_t pos = global_rng_position();
@@ -1501,10 +1502,7 @@ int wc_cheaptrick_compute(wc_cheaptrick *c, const double *x, int x_length, const
 	// vector per call is 4096 page faults) and go to the caller's rows by a few threads
 	const size_t n_sp = (size_t)f0_length * bins;
 	if ((rc = c->h_rows.reserve(sizeof(double) * n_sp))) return rc;
-	WC_HIP(hipMemcpyAsync(c->h_rows.p, c->d_sp.p, sizeof(double) * n_sp, hipMemcpyDeviceToHost, s));
-	WC_HIP(hipStreamSynchronize(s));
-	rows_copy(spectrogram, f0_length, bins, c->h_rows.as<double>(), true);
-	return WC_OK;
+	return rows_down(s, spectrogram, f0_length, bins, c->d_sp.as<double>(), c->h_rows.as<double>());
 }
 
 }  // extern "C"

@@ -1844,7 +1844,7 @@ struct wc_d4c {
 	Device *dev;
 	double f0_bound = 0.0;  // (a caller's promise about the contour's highest F0: no longer relied on -- the frames the wavefront kernels leave out are listed on the device)
 	DevBuf nuttall, utts, cnt, uidx, long_list, rare_list, off, endpos, endpos2, ap0, sgd, coarse, d_x, d_tpos, d_f0, d_ap;
-	HostBuf h_stage, h_rows;
+	HostBuf h_stage, h_rows, h_x;
 };
 
 template <int N>
@@ -2087,7 +2087,7 @@ void wc_d4c_destroy(wc_d4c *d) {
 	d->dev->quiesce();
 	d->dev->handle_gone();
 	d->nuttall.release(); d->utts.release(); d->cnt.release(); d->uidx.release(); d->long_list.release(); d->rare_list.release(); d->off.release(); d->endpos.release(); d->endpos2.release();
-	d->ap0.release(); d->sgd.release(); d->coarse.release(); d->d_x.release(); d->d_tpos.release(); d->d_f0.release(); d->d_ap.release(); d->h_stage.release(); d->h_rows.release();
+	d->ap0.release(); d->sgd.release(); d->coarse.release(); d->d_x.release(); d->d_tpos.release(); d->d_f0.release(); d->d_ap.release(); d->h_stage.release(); d->h_rows.release(); d->h_x.release();
 	delete d;
 }
 
@@ -2114,7 +2114,7 @@ int wc_d4c_compute(wc_d4c *d, const double *x, int x_length, const double *tempo
 	if ((rc = d->d_tpos.reserve(sizeof(double) * f0_length))) return rc;
 	if ((rc = d->d_f0.reserve(sizeof(double) * f0_length))) return rc;
 	if ((rc = d->d_ap.reserve(sizeof(double) * (size_t)f0_length * bins))) return rc;
-	WC_HIP(hipMemcpyAsync(d->d_x.p, x, sizeof(double) * x_length, hipMemcpyHostToDevice, s));
+	if ((rc = array_up(s, x, (size_t)x_length, d->h_x, d->d_x.as<double>()))) return rc;
 	WC_HIP(hipMemcpyAsync(d->d_tpos.p, temporal_positions, sizeof(double) * f0_length, hipMemcpyHostToDevice, s));
 	WC_HIP(hipMemcpyAsync(d->d_f0.p, f0, sizeof(double) * f0_length, hipMemcpyHostToDevice, s));
 	uint64_t pos = global_rng_position();
@@ -2124,10 +2124,7 @@ int wc_d4c_compute(wc_d4c *d, const double *x, int x_length, const double *tempo
 	set_global_rng_position(pos);
 	const size_t n_ap = (size_t)f0_length * bins;  // (page-locked staging, rows handed over by a few threads: see wc_cheaptrick_compute)
 	if ((rc = d->h_rows.reserve(sizeof(double) * n_ap))) return rc;
-	WC_HIP(hipMemcpyAsync(d->h_rows.p, d->d_ap.p, sizeof(double) * n_ap, hipMemcpyDeviceToHost, s));
-	WC_HIP(hipStreamSynchronize(s));
-	rows_copy(aperiodicity, f0_length, bins, d->h_rows.as<double>(), true);
-	return WC_OK;
+	return rows_down(s, aperiodicity, f0_length, bins, d->d_ap.as<double>(), d->h_rows.as<double>());
 }
 
 }  // extern "C"

@@ -44,6 +44,7 @@
 #include "wc_device.hpp"
 #include "wc_internal.hpp"
 #include "wc_frames.hpp"
+#include "wc_hostcopy.hpp"
 
 namespace wc {
 
@@ -2470,9 +2471,11 @@ __global__ __launch_bounds__(64, RF_NP > 112 ? 2 : WC_REFINE_WAVES) void hv_refi
 #ifndef WC_RQ_PC
 #define WC_RQ_PC 8   // passes whose start phases are staged together: 8 KB, one stretch for up to 64 keys
 #endif
-template <bool TABLE, int F>
+// NP: candidate positions per frame the LDS is sized for: 112 (15 slots: the reference's default floor of 71 Hz; four workgroups per
+// CU) or 128 (18 slots: the 40 Hz floor of the reference's demo; three per CU); wider rows take the kernel above
+template <bool TABLE, int F, int NP = 112>
 __global__ __launch_bounds__(64 * F, WC_REFINE_WAVES) void hv_refine_group_kernel(RefArgs a) {
-	constexpr int NP = 112;  // candidate positions per frame (7 S <= 112; wider rows take the kernel above)
+	static_assert(NP <= 128, "positions are gathered in two rounds of 64 and travel as seven bits");
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	const int grp = lane >> 3, sub = lane & 7;
 	// a workgroup per F consecutive frames of ONE utterance (blockIdx.y), the groups of an utterance XCD by XCD (see above)
@@ -3657,7 +3660,7 @@ struct wc_harvest {
 	DevBuf utts, dec, y, events, ev_count, overflow, tile_run, raw, cand0, cand1, score1, cand2, score2;
 	DevBuf base, s1, s2, s3, fixed, f0_1ms, sec, chan, smooth, ibuf, rawdesc;
 	DevBuf d_x, d_tpos, d_f0;
-	HostBuf h_stage;
+	HostBuf h_stage, h_x;  // (h_x: the samples of a host-pointer call on their way up)
 	std::vector<HvUtt> last_utts;
 	RefArgs last_refine;       // arguments of the most recent refinement launch (wc_harvest_debug_refine)
 	bool last_refine_valid = false;
@@ -3700,13 +3703,18 @@ static inline int h_mround(double x) { return x > 0 ? static_cast<int>(x + 0.5) 
 // Enqueue-only (no host synchronisation), shared with the fused pipeline.  `full` selects the hard bound for the
 // zero-crossing buffers; with the rate bound an overflow is reported through h->overflow (device) and handled by
 // the caller (hv_overflowed) by re-running with full == true.
-// mode: 0 = frames in groups (hv_refine_group_kernel; rows wider than 112 positions take the packed kernel), 1 = slots, 2 = packed
+// mode: 0 = frames in groups (hv_refine_group_kernel; rows wider than 128 positions take the packed kernel), 1 = slots, 2 = packed
 static void launch_refine(const RefArgs &fa, hipStream_t s, int mode, bool table) {
 	const unsigned frames = (unsigned)(8 * ((fa.total_frames + 7) / 8));  // (the packed kernel deals frames to the XCDs in eighths)
 	const bool small = 7 * fa.p.S <= 112;
 	if (mode == 1) {
 		if (table) hipLaunchKernelGGL(hv_refine_kernel<true>, dim3(frames), dim3(256), 0, s, fa);
 		else hipLaunchKernelGGL(hv_refine_kernel<false>, dim3(frames), dim3(256), 0, s, fa);
+	} else if (mode == 0 && !small && 7 * fa.p.S <= 128) {
+		const int n_grp = (fa.max_l1 + WC_RQ_F - 1) / WC_RQ_F;
+		const dim3 blocks((unsigned)(8 * ((n_grp + 7) / 8)), (unsigned)fa.n_utt);
+		if (table) hipLaunchKernelGGL((hv_refine_group_kernel<true, WC_RQ_F, 128>), blocks, dim3(64 * WC_RQ_F), 0, s, fa);
+		else hipLaunchKernelGGL((hv_refine_group_kernel<false, WC_RQ_F, 128>), blocks, dim3(64 * WC_RQ_F), 0, s, fa);
 	} else if (mode == 0 && small) {
 		const int n_grp = (fa.max_l1 + WC_RQ_F - 1) / WC_RQ_F;
 		const dim3 blocks((unsigned)(8 * ((n_grp + 7) / 8)), (unsigned)fa.n_utt);
@@ -4363,6 +4371,7 @@ void wc_harvest_destroy(wc_harvest *h) {
 					  &h->s1, &h->s2, &h->s3, &h->fixed, &h->f0_1ms, &h->sec, &h->chan, &h->smooth, &h->ibuf, &h->rawdesc, &h->d_x, &h->d_tpos, &h->d_f0})
 		b->release();
 	h->h_stage.release();
+	h->h_x.release();
 	delete h;
 }
 
@@ -4384,7 +4393,7 @@ int wc_harvest_compute(wc_harvest *h, const double *x, int x_length, double *tem
 	if ((rc = h->d_x.reserve(sizeof(double) * x_length))) return rc;
 	if ((rc = h->d_tpos.reserve(sizeof(double) * L))) return rc;
 	if ((rc = h->d_f0.reserve(sizeof(double) * L))) return rc;
-	WC_HIP(hipMemcpyAsync(h->d_x.p, x, sizeof(double) * x_length, hipMemcpyHostToDevice, s));
+	if ((rc = array_up(s, x, (size_t)x_length, h->h_x, h->d_x.as<double>()))) return rc;
 	if ((rc = hv_run_device(h, 1, h->d_x.as<double>(), &x_length, h->d_tpos.as<double>(), h->d_f0.as<double>()))) return rc;
 	WC_HIP(hipMemcpyAsync(temporal_positions, h->d_tpos.p, sizeof(double) * L, hipMemcpyDeviceToHost, s));
 	WC_HIP(hipMemcpyAsync(f0, h->d_f0.p, sizeof(double) * L, hipMemcpyDeviceToHost, s));

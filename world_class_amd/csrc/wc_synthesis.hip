@@ -2449,11 +2449,9 @@ int wc_synthesis_compute(wc_synthesis *s, const double *f0, int f0_length, const
 	const size_t n_rows = (size_t)f0_length * bins;
 	if ((rc = s->h_rows.reserve(sizeof(double) * (2 * n_rows + (size_t)out_length)))) return rc;
 	double *hsp = s->h_rows.as<double>(), *hap = hsp + n_rows, *hy = hap + n_rows;
-	rows_copy(const_cast<double *const *>(spectrogram), f0_length, bins, hsp, false);
-	rows_copy(const_cast<double *const *>(aperiodicity), f0_length, bins, hap, false);
 	WC_HIP(hipMemcpyAsync(s->d_f0.p, f0, sizeof(double) * f0_length, hipMemcpyHostToDevice, st));
-	WC_HIP(hipMemcpyAsync(s->d_sp.p, hsp, sizeof(double) * n_rows, hipMemcpyHostToDevice, st));
-	WC_HIP(hipMemcpyAsync(s->d_ap.p, hap, sizeof(double) * n_rows, hipMemcpyHostToDevice, st));
+	if ((rc = rows_up(st, spectrogram, f0_length, bins, hsp, s->d_sp.as<double>()))) return rc;
+	if ((rc = rows_up(st, aperiodicity, f0_length, bins, hap, s->d_ap.as<double>()))) return rc;
 	uint64_t pos = global_rng_position();
 	rc = syn_run_device(s, 1, s->d_f0.as<double>(), &f0_length, s->d_sp.as<double>(), s->d_ap.as<double>(), &out_length,
 						s->d_out.as<double>(), &pos);
