@@ -796,6 +796,13 @@ __global__ __launch_bounds__(BP_T, 3) void hv_bandpass_quiet_kernel(SdArgs a) {
 #ifndef WC_SDFT_RING
 #define WC_SDFT_RING 1   // edges leave for their slots in whole 32-byte sectors (below)
 #endif
+// DEFER (round 6, default): the detectors' work is split.  Some lane of a wavefront has an edge at almost every sample, so the
+// two blocks that turn an edge into its interpolated position and file it (quotient, counters, ring: ~34 instructions each) ran
+// at almost every step with a lane or two active -- 68 of the 127 vector instructions of a step.  Now a step only marks its edges
+// in a bit mask and stores its output (LDS, a row of 64 per step); after eight steps every lane walks its own marks: as many
+// trips as the busiest lane has edges (one to five), each reading the three outputs around the edge back from LDS.  The same
+// quotients of the same values filed in the same order: the same bits (test_bandpass_with_eight_lanes_per_band_is_bit_identical).
+template <bool DEFER>
 __global__ __launch_bounds__(64, WC_SDFT_WAVES) void hv_bandpass_sdft_kernel(SdArgs a) {
 	const int lane = threadIdx.x;
 	const HvUtt u = a.utts[blockIdx.y];
@@ -879,13 +886,13 @@ __global__ __launch_bounds__(64, WC_SDFT_WAVES) void hv_bandpass_sdft_kernel(SdA
 	// 32-byte sector when edge 4 m + 3 arrives; what is left at the end of the chunk follows then.  (cap is a multiple of 4 and
 	// the slots are 32-byte aligned.)  WC_SDFT_RING=0: every edge stored as it appears.
 #if WC_SDFT_RING
-	__shared__ double ring[16 * 64];  // [type][c & 3][lane]
+	__shared__ double ring[12 * 64];  // [type][c & 3 < 3][lane] (the fourth edge of a sector leaves with the three parked ones)
 	auto put = [&](int ty, int c, double fine) {
 		const int k = c & 3;
 		if (k != 3) {
-			ring[(ty * 4 + k) * 64 + lane] = fine;
+			ring[(ty * 3 + k) * 64 + lane] = fine;
 		} else {
-			const double e0 = ring[(ty * 4 + 0) * 64 + lane], e1 = ring[(ty * 4 + 1) * 64 + lane], e2 = ring[(ty * 4 + 2) * 64 + lane];
+			const double e0 = ring[(ty * 3 + 0) * 64 + lane], e1 = ring[(ty * 3 + 1) * 64 + lane], e2 = ring[(ty * 3 + 2) * 64 + lane];
 			double2 *dst = reinterpret_cast<double2 *>(slot + (long long)ty * cap + (c - 3));
 			dst[0] = make_double2(e0, e1);
 			dst[1] = make_double2(e2, fine);
@@ -904,6 +911,76 @@ __global__ __launch_bounds__(64, WC_SDFT_WAVES) void hv_bandpass_sdft_kernel(SdA
 	double yn[U], yo[U];
 #pragma unroll
 	for (int k = 0; k < U; ++k) { yn[k] = pn[1 + k]; yo[k] = po[1 + k]; }
+	if constexpr (DEFER) {
+		static_assert(U == 4 && SD_CH % 8 == 0, "blocks of two trips");
+		__shared__ double O[10 * 64];  // [output of the block, two in front of it][lane]
+		// the signs of the newest output and difference are looked at once (three compares each) and serve the two steps that use
+		// them: "0 < s0 && s1 <= 0" is pos(s0) && (neg(s1) || zero(s1)), written so that a NaN still marks nothing
+		bool p_a = 0.0 < s0, n_a = s0 < 0.0;                                    // s0
+		bool p_b = 0.0 < s1, n_b = s1 < 0.0, z_b = s1 == 0.0;                     // s1
+		double dprev = s1 - s0;
+		bool p_d = 0.0 < dprev, n_d = dprev < 0.0;                              // d0
+		unsigned long long cnt4 = 0ull;  // the four counts, sixteen bits each (a chunk has 2048 samples)
+		for (int st = 0; st < steps; st += 8) {
+			O[lane] = s0;
+			O[64 + lane] = s1;
+			unsigned mask = 0u;  // bit k: a zero crossing at step k of the block, bit 8 + k: an extremum
+#pragma unroll
+			for (int half = 0; half < 2; ++half) {
+				double cn[U], co[U];
+#pragma unroll
+				for (int k = 0; k < U; ++k) { cn[k] = yn[k]; co[k] = yo[k]; }
+#pragma unroll
+				for (int k = 0; k < U; ++k) { yn[k] = pn[st + 4 * half + U + 1 + k]; yo[k] = po[st + 4 * half + U + 1 + k]; }
+				const bool last_trip = live && st + 4 * half + U == SD_CH;
+#pragma unroll
+				for (int k = 0; k < U; ++k) {
+					const int kk = 4 * half + k;
+					slide(cn[k], co[k]);
+					double s2 = out();
+					if (k == U - 2) s2 = last_trip ? fn0 : s2;
+					if (k == U - 1) s2 = last_trip ? fn1 : s2;
+					O[(kk + 2) * 64 + lane] = s2;
+					const double d1 = s2 - s1;
+					const bool p_e = 0.0 < d1, n_e = d1 < 0.0, z_e = d1 == 0.0;
+					const bool zc = (p_a && (n_b || z_b)) || (n_a && (p_b || z_b));
+					const bool ex = (p_d && (n_e || z_e)) || (n_d && (p_e || z_e));
+					mask |= (zc ? 1u << kk : 0u) | (ex ? 0x100u << kk : 0u);
+					p_a = p_b; n_a = n_b;
+					p_b = 0.0 < s2; n_b = s2 < 0.0; z_b = s2 == 0.0;
+					p_d = p_e; n_d = n_e;
+					s0 = s1;
+					s1 = s2;
+				}
+			}
+			{
+				// the steps of the block that lie inside the chunk and have their one / two outputs of lookahead inside the signal
+				const int ib = i0 + st;
+				const int n1 = min(8, max(0, min(i_end, ylen - 1) - ib)), n2 = min(8, max(0, min(i_end, ylen - 2) - ib));
+				mask &= ((1u << n1) - 1u) | (((1u << n2) - 1u) << 8);
+			}
+			rq_fence();
+			while (__ballot(mask != 0u) != 0ull) {
+				if (mask != 0u) {
+					const int b = __ffs((int)mask) - 1;
+					mask &= mask - 1u;
+					const bool is_ex = b >= 8;
+					const int kk = b & 7;
+					const double a0 = O[kk * 64 + lane], a1 = O[(kk + 1) * 64 + lane], a2 = O[(kk + 2) * 64 + lane];
+					const double d0 = a1 - a0, d1 = a2 - a1;
+					const double num = is_ex ? d0 : a0, den = is_ex ? d1 - d0 : d0;
+					const double fine = (i0 + st + kk + 1) - quot(num, den);
+					const int ty = (is_ex ? 2 : 0) + (0.0 < num ? 0 : 1);  // negative-going, positive-going, peak, dip
+					const int c = (int)(cnt4 >> (16 * ty)) & 0xffff;
+					if (c < cap) put(ty, c, fine);
+					cnt4 += 1ull << (16 * ty);
+				}
+			}
+			rq_fence();
+		}
+#pragma unroll
+		for (int ty = 0; ty < 4; ++ty) cnt[ty] = (int)(cnt4 >> (16 * ty)) & 0xffff;
+	} else
 	for (int st = 0; st < steps; st += U) {
 		double cn[U], co[U];
 #pragma unroll
@@ -951,7 +1028,7 @@ __global__ __launch_bounds__(64, WC_SDFT_WAVES) void hv_bandpass_sdft_kernel(SdA
 #pragma unroll
 		for (int ty = 0; ty < 4; ++ty) {
 			const int stored = min(cnt[ty], cap), rem = stored & 3;
-			for (int k = 0; k < rem; ++k) slot[(long long)ty * cap + (stored - rem) + k] = ring[(ty * 4 + k) * 64 + lane];
+			for (int k = 0; k < rem; ++k) slot[(long long)ty * cap + (stored - rem) + k] = ring[(ty * 3 + k) * 64 + lane];
 		}
 	}
 #endif
@@ -3638,7 +3715,7 @@ struct wc_harvest {
 	int tables_ylen, tables_full, tables_tiles;
 	hipStream_t tables_stream = nullptr;  // the stream those uploads were enqueued on
 	long long sdft8_max;  // eight lanes per (band, chunk) while that makes at most this many wavefronts (WC_HARVEST_SDFT8_MAX)
-	int sdft_lanes;  // WC_HARVEST_SDFT_LANES=1 / 8: lanes per (band, chunk) of the sliding band-pass (default 0: eight for small batches; A/B and the bit-identity test)
+	int sdft_lanes;  // WC_HARVEST_SDFT_LANES=1 / 8: lanes per (band, chunk) of the sliding band-pass (default 0: eight for small batches); 7 / 9: the same with the detectors at every step (rounds 3-5; A/B and the bit-identity test)
 	bool use_fir;  // WC_HARVEST_BANDPASS=fir: the direct FIR band-pass instead of the sliding DFT (A/B and tests)
 	bool use_cos_table;  // HarvestOption::use_cos_table
 	DevBuf d_cos_table;
@@ -3951,9 +4028,11 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 					hipLaunchKernelGGL(hv_bandpass_sdft8_kernel, dim3((nb * n_tiles + 7) / 8, n_utt), dim3(64), 0, s, sa);
 				else
 					hipLaunchKernelGGL(hv_bandpass_sdft8b_kernel, dim3((nb * n_tiles + 7) / 8, n_utt), dim3(64), 0, s, sa);
+			} else if (h->sdft_lanes == 7) {  // (the one-lane kernel with its detectors at every step: A/B and the bit-identity test)
+				hipLaunchKernelGGL(hv_bandpass_sdft_kernel<false>, dim3((nb * n_tiles + 63) / 64, n_utt), dim3(64), 0, s, sa);
+			} else {
+				hipLaunchKernelGGL(hv_bandpass_sdft_kernel<true>, dim3((nb * n_tiles + 63) / 64, n_utt), dim3(64), 0, s, sa);
 			}
-			else
-				hipLaunchKernelGGL(hv_bandpass_sdft_kernel, dim3((nb * n_tiles + 63) / 64, n_utt), dim3(64), 0, s, sa);
 			if (!h->no_quiet) hipLaunchKernelGGL(hv_bandpass_quiet_kernel, dim3(nb, n_utt), dim3(BP_T), 0, s, sa);
 			CpArgs ca;
 			ca.utts = du; ca.slot_off = sa.slot_off; ca.slot_cap = sa.slot_cap; ca.slots_per_utt = slots_per_utt; ca.slots = sa.slots;
