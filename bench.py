@@ -461,8 +461,8 @@ def serialised_kernels(w, L, d_x, x_len, d_t, d_f, f_len, d_sp, d_ap, y_len, d_y
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--utts", type=int, default=64, help="utterances per GPU")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic utterances per GPU (tiled to --utts)")
     ap.add_argument("--gather", choices=("f0", "y"), default="f0", help="what the final RCCL all-gather collects besides the checksums")
