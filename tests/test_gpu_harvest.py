@@ -336,7 +336,7 @@ def test_raw_candidates_from_the_band_pass_slots_are_bit_identical(wca):
         assert sum(int((a.debug_fetch("raw", k) != 0).sum()) for k in range(len(batch))) > 10000
         # round 6: the blocks' slices come from hv_rawdesc_kernel (a thread per (utterance, band, block, type)) and the frames' interval
         # counts from a running maximum instead of a bisection; WC_HARVEST_RAW=blocks lets every block work its slice out itself
-        for mode in ("blocks",):
+        for mode in ("blocks", "four"):
             os.environ.update(env)
             os.environ["WC_HARVEST_RAW"] = mode
             try:

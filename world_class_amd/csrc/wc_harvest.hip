@@ -1773,6 +1773,189 @@ __global__ __launch_bounds__(RAW_T) void hv_raw_kernel(RawArgs a) {
 	RQ_FLUSH();
 }
 
+// The same block of 256 frames by ONE wavefront (round 6, default for the sliding band-pass's slots).  Above, four wavefronts stage a
+// type each, meet at a barrier, and a thread per frame reads all four: a chain of scalar loads, edge loads, LDS round trips and the
+// barrier per block with ~300 instructions per wavefront to show for it -- 0.52 of the kernel's time is issue, seven blocks per
+// CU (19.5 KB of LDS each) do not cover the chain.  Here a wavefront takes the four types in turn through ONE 4.9 KB buffer: the
+// next type's edges are requested before the current type is worked on (registers), no barrier, a lane owns frames 4 lane .. 4 lane
+// + 3 (their counts come out of raw_frame_counts' scan in registers) and adds the types up in the reference's order.  The same
+// arithmetic per (frame, type): the same bits.
+__device__ __forceinline__ void raw_frame_counts4(const double *__restrict__ Xs, unsigned short *__restrict__ lo_, int len, int i0, int lane, int (&m)[4]) {
+	*reinterpret_cast<uint2 *>(&lo_[4 * lane]) = make_uint2(0u, 0u);
+	rq_fence();
+	for (int j0 = 0; j0 < len; j0 += 64) {
+		const int j = j0 + lane;
+		int rel = RAW_T;
+		if (j < len) {
+			const double x = Xs[j];
+			int f = (int)ceil(x * 1000.0);
+			while (f > 0 && div_const((double)(f - 1), 1000.0, 1.0 / 1000.0) >= x) --f;   // the first frame with f / 1000.0 >= x, exactly
+			while (div_const((double)f, 1000.0, 1.0 / 1000.0) < x) ++f;
+			rel = max(f - i0, 0);
+		}
+		bool pending = rel < RAW_T;
+		while (__ballot(pending) != 0ull) {
+			if (pending) lo_[rel] = (unsigned short)(j + 1);
+			rq_fence();
+			pending = pending && lo_[rel] < j + 1;
+		}
+	}
+	rq_fence();
+	const uint2 w2 = *reinterpret_cast<const uint2 *>(&lo_[4 * lane]);
+	int m0 = (int)(w2.x & 0xFFFFu), m1 = (int)(w2.x >> 16), m2 = (int)(w2.y & 0xFFFFu), m3 = (int)(w2.y >> 16);
+	m1 = max(m1, m0); m2 = max(m2, m1); m3 = max(m3, m2);
+	int inc = m3;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const int t = __shfl_up(inc, o, 64);
+		if (lane >= o) inc = max(inc, t);
+	}
+	int ex = __shfl_up(inc, 1, 64);
+	if (lane == 0) ex = 0;
+	m[0] = max(m0, ex); m[1] = max(m1, ex); m[2] = max(m2, ex); m[3] = max(m3, ex);
+}
+
+__global__ __launch_bounds__(64) void hv_raw_wave_kernel(RawArgs a) {
+	__shared__ double X[RAW_LDS], Y[RAW_LDS + 1];  // (Y holds the slice's edges first, as above)
+	__shared__ __attribute__((aligned(8))) unsigned short LO[RAW_T];
+	const int lane = threadIdx.x;
+	const int band = blockIdx.y;
+	const HvUtt u = a.utts[blockIdx.z];
+	const int i0 = blockIdx.x * RAW_T;
+	if (i0 >= u.L1) return;
+	const int *cnt = a.ev_count + ((long long)blockIdx.z * a.n_bands + band) * 4;
+	const double fb = a.band_f0[band];
+	const int scap = a.slot_cap[band];
+	const double *__restrict__ slot = a.slots + blockIdx.z * a.slots_per_utt + a.slot_off[band];
+	const int *__restrict__ trun_b = a.tile_run + ((long long)blockIdx.z * a.n_bands + band) * (a.n_tiles + 1) * 4;
+	auto edge = [&](int ty, int q) -> double {  // edge q of the list of type ty, wherever it lies (the fallback's look-ups)
+		int lo = 0, hi = a.n_tiles;
+		while (hi - lo > 1) {
+			const int mid = (lo + hi) >> 1;
+			if (trun_b[mid * 4 + ty] <= q) lo = mid; else hi = mid;
+		}
+		return slot[((long long)lo * 4 + ty) * scap + min(q - trun_b[lo * 4 + ty], scap - 1)];
+	};
+	double *__restrict__ out = a.raw + u.l1_off * a.n_bands + (long long)band * u.L1;
+	const int fi = i0 + 4 * lane;  // this lane's first frame
+	int n[4];
+	bool ok = true;
+#pragma unroll
+	for (int ty = 0; ty < 4; ++ty) {
+		const int ce = cnt[ty];
+		n[ty] = ce < 2 ? 0 : ce - 1;
+		ok = ok && n[ty] > 2;
+	}
+	if (!ok) {
+#pragma unroll
+		for (int m = 0; m < 4; ++m) if (fi + m < u.L1) out[fi + m] = 0.0;
+		return;
+	}
+	const double fs = a.fs_d;
+	const int4 *__restrict__ dp = a.desc + ((((long long)blockIdx.z * a.n_bands + band) * a.desc_blocks + blockIdx.x) * 4) * 2;
+	int4 d0[4], d1[4];
+#pragma unroll
+	for (int ty = 0; ty < 4; ++ty) { d0[ty] = dp[2 * ty]; d1[ty] = dp[2 * ty + 1]; }
+	// the edges of a slice within four chunks (mode 0), elements lane + 64 k <= len <= RAW_LDS, straight from their slots
+	auto fetch = [&](int ty, double (&pe)[5]) {
+		const int base = d0[ty].x, len = d0[ty].y - base - 1, c0 = d0[ty].z;
+		const int t0 = d1[ty].x, t1 = d1[ty].y, t2 = d1[ty].z, t3 = d1[ty].w;
+		const double *__restrict__ sl0 = slot + ((long long)c0 * 4 + ty) * scap;
+#pragma unroll
+		for (int k = 0; k < 5; ++k) {
+			const int j = lane + 64 * k;
+			pe[k] = 0.0;
+			if (d0[ty].w == 0 && j <= len) {
+				const int q = base + j;
+				const int kq = (q >= t1 ? 1 : 0) + (q >= t2 ? 1 : 0) + (q >= t3 ? 1 : 0);
+				const int tk = kq == 0 ? t0 : (kq == 1 ? t1 : (kq == 2 ? t2 : t3));
+				pe[k] = sl0[kq * 4 * scap + min(q - tk, scap - 1)];
+			}
+		}
+	};
+	static_assert(RAW_LDS < 5 * 64, "five edges per lane cover a staged slice");
+	double tt[4], s[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+	for (int m = 0; m < 4; ++m) tt[m] = div_const((double)((fi + m) * 1), 1000.0, 1.0 / 1000.0);  // i * 1 / 1000.0
+	double pe[5];
+	fetch(0, pe);
+#pragma unroll
+	for (int ty = 0; ty < 4; ++ty) {
+		const int base = d0[ty].x, end = d0[ty].y, c0 = d0[ty].z, mode = d0[ty].w;
+		const int len = end - base - 1;
+		const bool staged_ty = mode != 1;
+		int lo4[4] = {0, 0, 0, 0};
+		if (staged_ty) {
+			double *__restrict__ E = Y;
+			if (mode == 0) {
+#pragma unroll
+				for (int k = 0; k < 5; ++k) if (lane + 64 * k <= len) E[lane + 64 * k] = pe[k];
+			} else {
+				for (int c = c0; c < a.n_tiles && trun_b[c * 4 + ty] < end; ++c) {
+					const int tc = trun_b[c * 4 + ty];
+					const int lo = max(base, tc), hi = min(end, trun_b[(c + 1) * 4 + ty]);
+					const double *__restrict__ src = slot + ((long long)c * 4 + ty) * scap;
+					for (int q = lo + lane; q < hi; q += 64) E[q - base] = src[min(q - tc, scap - 1)];
+				}
+			}
+		}
+		if (ty < 3) fetch(ty + 1, pe);  // (in flight while this type is worked on)
+		if (staged_ty) {
+			rq_fence();
+			for (int j0 = 0; j0 < len; j0 += 64) {  // (the reads of a trip precede its writes)
+				const int j = j0 + lane;
+				double ea = 0.0, eb = 1.0;
+				if (j < len) { ea = Y[j]; eb = Y[j + 1]; }
+				if (j < len) {
+					X[j] = div_const((ea + eb) / 2.0, fs, a.r_fs_d);
+					Y[j] = fs / (eb - ea);
+				}
+			}
+			raw_frame_counts4(X, LO, len, i0, lane, lo4);
+		}
+#pragma unroll
+		for (int m = 0; m < 4; ++m) {
+			const int i = fi + m;
+			if (i >= u.L1) continue;
+			const double t = tt[m];
+			double x0, x1, y0, y1;
+			bool staged = false;
+			if (staged_ty) {
+				const int lo = lo4[m];  // #{j < len : X[j] <= t}
+				const int c = base + lo;
+				if ((lo > 0 || base == 0) && (lo < len || base + len == n[ty])) {
+					const int k = min(max(c, 1), n[ty] - 1) - base;  // interp1 between intervals k - 1 and k
+					if (k >= 1 && k < len) {
+						x0 = X[k - 1]; x1 = X[k];
+						y0 = Y[k - 1]; y1 = Y[k];
+						staged = true;
+					}
+				}
+			}
+			if (!staged) {
+				auto eg = [&](int q) { return edge(ty, q); };
+				const int c = hv_count_le(eg, 0, n[ty], fs, t);
+				const int k = min(max(c, 1), n[ty] - 1);
+				const double e0 = eg(k - 1), e1 = eg(k), e2 = eg(k + 1);
+				x0 = div_const((e0 + e1) / 2.0, fs, a.r_fs_d); x1 = div_const((e1 + e2) / 2.0, fs, a.r_fs_d);
+				y0 = fs / (e1 - e0); y1 = fs / (e2 - e1);
+			}
+			const double sl = (t - x0) / (x1 - x0);
+			const double v = y0 + sl * (y1 - y0);
+			s[m] = (ty == 0) ? v : s[m] + v;  // (a + b + c + d) in the reference's order: negative-going, positive-going, peaks, dips
+		}
+		rq_fence();  // (the buffer is the next type's)
+	}
+#pragma unroll
+	for (int m = 0; m < 4; ++m) {
+		const int i = fi + m;
+		if (i >= u.L1) continue;
+		double v = s[m] / 4.0;
+		if (v > fb * 1.1 || v < fb * 0.9 || v > a.f0_ceil || v < a.f0_floor) v = 0.0;
+		out[i] = v;
+	}
+}
+
 // ------------------------------------------------------------------------------------------------
 // per-frame candidate detection (reference :1005-1083)
 // ------------------------------------------------------------------------------------------------
@@ -3725,7 +3908,7 @@ struct wc_harvest {
 	int force_tie = -1;        // WC_HARVEST_FORCE_TIE=u (test hook, read at creation): utterance u of every stage call counts as flagged
 	wc_harvest *exact_twin = nullptr;  // the same options with the band-pass as a direct FIR sum: re-runs of batches that raised the tie flag (hv_exact_twin)
 	int use_cos_table_opt = 0;
-	int raw_mode = 0;       // WC_HARVEST_RAW=blocks: every block of frames works out its own slice (1, round 5); default 0: slices from hv_rawdesc_kernel
+	int raw_mode = 0;       // WC_HARVEST_RAW=blocks: every block of frames works out its own slice (1, round 5); =four: slices from hv_rawdesc_kernel, four wavefronts per block (2); default 0: one wavefront per block (hv_raw_wave_kernel)
 	bool raw_from_lists;    // WC_HARVEST_RAW=lists: the edges packed into per-band lists before hv_raw reads them (A/B and the bit-identity test)
 	long long slots_per_utt = 0;
 	int refine_mode;        // WC_HARVEST_REFINE=slots: one wavefront per candidate slot (1); =packed: one wavefront per frame (2); default: frames in groups (0) (A/B and the bit-identity tests)
@@ -4067,7 +4250,8 @@ int hv_enqueue(wc_harvest *h, hipStream_t s, int n_utt, const double *d_x, const
 		ra.desc_blocks = nblk;
 		const long long nd = 4ll * nblk * nb * n_utt;
 		hipLaunchKernelGGL(hv_rawdesc_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, s, ra, h->rawdesc.as<int4>(), nblk, n_utt);
-		hipLaunchKernelGGL((hv_raw_kernel<true, true>), dim3(nblk, nb, n_utt), dim3(256), 0, s, ra);
+		if (h->raw_mode == 2) hipLaunchKernelGGL((hv_raw_kernel<true, true>), dim3(nblk, nb, n_utt), dim3(256), 0, s, ra);
+		else hipLaunchKernelGGL(hv_raw_wave_kernel, dim3(nblk, nb, n_utt), dim3(64), 0, s, ra);
 	}
 #if WC_RQ_PROF
 	{
@@ -4395,7 +4579,7 @@ wc_harvest *wc_harvest_create(int fs, double f0_floor, double f0_ceil, double fr
 		h->refine_mode = !rfm ? 0 : std::strcmp(rfm, "slots") == 0 ? 1 : std::strcmp(rfm, "packed") == 0 ? 2 : std::strcmp(rfm, "group2") == 0 ? 3 : std::strcmp(rfm, "group8") == 0 ? 4 : 0;
 		const char *rw = getenv("WC_HARVEST_RAW");
 		h->raw_from_lists = rw && std::strcmp(rw, "lists") == 0;
-		h->raw_mode = rw && std::strcmp(rw, "blocks") == 0 ? 1 : 0;
+		h->raw_mode = rw && std::strcmp(rw, "blocks") == 0 ? 1 : rw && std::strcmp(rw, "four") == 0 ? 2 : 0;
 	}
 	{
 		std::vector<double2> rot(2 * (RF_MAXHW + 1));
