@@ -1969,16 +1969,25 @@ __global__ void hv_detect_kernel(const HvUtt *__restrict__ utts, const double *_
 	int nc = 0, st = 0;
 	int prev = 0;
 	double sum = 0.0;
-	for (int j = 1; j < n_bands; ++j) {
-		const double v = r[(long long)j * u.L1];
-		const int cur = (j == n_bands - 1) ? 0 : (v > 0 ? 1 : 0);
-		if (cur - prev == 1) { st = j; sum = 0.0; }
-		if (cur - prev == -1) {
-			const int ed = j;
-			if (ed - st >= 10 && nc < S) out[nc++] = sum / (ed - st);
+	constexpr int B = 8;  // bands whose values are requested together (a load per band and thread, each a round trip if left in the loop's order)
+	for (int j0 = 1; j0 < n_bands; j0 += B) {
+		double vv[B];
+#pragma unroll
+		for (int b = 0; b < B; ++b) vv[b] = r[(long long)min(j0 + b, n_bands - 1) * u.L1];
+#pragma unroll
+		for (int b = 0; b < B; ++b) {
+			const int j = j0 + b;
+			if (j >= n_bands) break;
+			const double v = vv[b];
+			const int cur = (j == n_bands - 1) ? 0 : (v > 0 ? 1 : 0);
+			if (cur - prev == 1) { st = j; sum = 0.0; }
+			if (cur - prev == -1) {
+				const int ed = j;
+				if (ed - st >= 10 && nc < S) out[nc++] = sum / (ed - st);
+			}
+			if (cur) sum += v;
+			prev = cur;
 		}
-		if (cur) sum += v;
-		prev = cur;
 	}
 	for (int k = nc; k < S; ++k) out[k] = 0.0;
 }
