@@ -334,8 +334,10 @@ def test_raw_candidates_from_the_band_pass_slots_are_bit_identical(wca):
             assert np.array_equal(a.debug_fetch("raw", k), b.debug_fetch("raw", k)), (opts, env, k)
             assert np.array_equal(ra[k][1], rb[k][1])
         assert sum(int((a.debug_fetch("raw", k) != 0).sum()) for k in range(len(batch))) > 10000
-        # round 6: the blocks' slices come from hv_rawdesc_kernel (a thread per (utterance, band, block, type)) and the frames' interval
-        # counts from a running maximum instead of a bisection; WC_HARVEST_RAW=blocks lets every block work its slice out itself
+        # round 6: the blocks' slices come from hv_rawdesc_kernel (a thread per (utterance, band, block, type)), the frames' interval
+        # counts from a running maximum instead of a bisection, and one wavefront takes a block's four edge types in turn
+        # (hv_raw_wave_kernel); WC_HARVEST_RAW=blocks lets every block work its slice out itself (round 5), =four is the round-6
+        # kernel with a wavefront per type and a barrier
         for mode in ("blocks", "four"):
             os.environ.update(env)
             os.environ["WC_HARVEST_RAW"] = mode

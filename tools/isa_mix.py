@@ -13,7 +13,7 @@ from collections import Counter
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = "/opt/rocm/lib/llvm/bin"
-DEFAULT = ["ct_wave_kernel", "d4c2_", "syn_pulse_wave_kernel", "hv_refine_group", "hv_bandpass_sdft", "hv_raw_kernel", "hv_decimate_scan", "ct_frames_kernel<2048",
+DEFAULT = ["ct_wave_kernel", "d4c2_", "syn_pulse_wave_kernel", "hv_refine_group", "hv_bandpass_sdft", "hv_raw_kernel", "hv_raw_wave_kernel", "hv_decimate_scan", "ct_frames_kernel<2048",
            "d4c_frames_kernel<4096, 512, true", "d4c_band_kernel<4096", "syn_pulse_kernel<2048"]
 F64 = re.compile(r"^v_(add|mul|fma|fmac|max|min|rcp|rsq|sqrt|div_scale|div_fmas|div_fixup|ldexp|frexp_mant|rndne|floor|fract|trig_preop|ceil|trunc)_f64")
 

@@ -23,7 +23,7 @@ KERNELS = {  # substring of the kernel symbol -> name bench.py uses
     "ct_wave_kernel": "cheaptrick_frames", "d4c2_frames_kernel": "d4c_frames", "d4c2_band_kernel": "d4c_bands", "d4c2_lovetrain_kernel": "d4c_lovetrain",
     "syn_pulse_wave_kernel": "synthesis_pulses", "syn_overlap_add_kernel": "synthesis_pulses",
     "hv_refine_kernel": "harvest_refine", "hv_refine_packed_kernel": "harvest_refine", "hv_refine_group_kernel": "harvest_refine", "hv_bandpass_kernel": "harvest_bandpass", "hv_bandpass_sdft_kernel": "harvest_bandpass",
-    "hv_compact_kernel": "harvest_bandpass", "hv_raw_kernel": "harvest_raw", "hv_rawdesc_kernel": "harvest_raw", "hv_detect_kernel": "harvest_raw",
+    "hv_compact_kernel": "harvest_bandpass", "hv_raw_kernel": "harvest_raw", "hv_raw_wave_kernel": "harvest_raw", "hv_rawdesc_kernel": "harvest_raw", "hv_detect_kernel": "harvest_raw",
     "hv_decimate_scan_kernel": "harvest_decimate", "hv_seam_kernel": "harvest_bandpass", "hv_bandpass_quiet_kernel": "harvest_bandpass",
     "hv_contour_kernel": "harvest_contour", "syn_pulse_kernel": "synthesis_pulses", "syn_timebase_kernel": "synthesis_timebase",
 }
