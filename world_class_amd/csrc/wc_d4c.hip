@@ -1306,6 +1306,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_D4C2_OCC,
 #ifndef WC_D4C2_BRACKET
 #define WC_D4C2_BRACKET 1
 #endif
+#ifndef WC_D4C2_HI32
+#define WC_D4C2_HI32 1  // the selection's search on the keys' high words first (0: 64-bit compares throughout, rounds 3-5)
+#endif
 #ifndef WC_D4C2_BRACKET_FIRST
 #define WC_D4C2_BRACKET_FIRST 0x1p-14
 #endif
@@ -1398,7 +1401,40 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_D4C2_BAND
 	mx = uniform_d(mx);
 	long long lo = -1, hi = __double_as_longlong(mx);
 	unsigned int c_lo = 0;
-#if WC_D4C2_BRACKET
+#if WC_D4C2_HI32
+	{
+		// The same search on the keys' HIGH words first (round 6): a threshold (h, 0xFFFFFFFF) has a key at or below it exactly when the
+		// key's high word is at most h -- a 32-bit compare per key and step instead of a 64-bit one, on registers that are there anyway.
+		// It ends with exactly K keys below a threshold (nearly always: two neighbours of the ranking share a high word only when they
+		// are within 1e-6 of each other) or with the one high word the K-th key has, where the 64-bit search below takes over.
+		auto count_hi = [&](int h) {
+			unsigned int c = (unsigned int)__popcll(__ballot(lane == 0 && __double2hiint(keyM) <= h));
+#pragma unroll
+			for (int s = 0; s < 16; ++s) {
+				c += (unsigned int)__popcll(__ballot(__double2hiint(key[0][s]) <= h));
+				c += (unsigned int)__popcll(__ballot(__double2hiint(key[1][s]) <= h));
+			}
+			return c;
+		};
+		int lo_h = -1, hi_h = __double2hiint(mx);
+#pragma unroll 1
+		for (int tr = 0; tr < 2; ++tr) {  // (the bracket of the 64-bit search: 2^-14, else 2^-40 below the largest key)
+			const int cand = __double2hiint(mx * (tr == 0 ? WC_D4C2_BRACKET_FIRST : 0x1p-40)) - 1;
+			if (cand < 0) continue;
+			const unsigned int c = count_hi(cand);
+			if (c <= K) { lo_h = cand; c_lo = c; break; }
+			hi_h = cand;
+		}
+		while (hi_h - lo_h > 1 && c_lo != K) {
+			const int mid = lo_h + ((hi_h - lo_h) >> 1);
+			const unsigned int c = count_hi(mid);
+			if (c >= K) hi_h = mid;
+			if (c <= K) { lo_h = mid; c_lo = c; }
+		}
+		lo = lo_h < 0 ? -1ll : (((long long)lo_h << 32) | 0xFFFFFFFFll);
+		hi = min(hi, ((long long)hi_h << 32) | 0xFFFFFFFFll);
+	}
+#elif WC_D4C2_BRACKET
 	{
 		// The keys left out of the sum are the boundary + 1 largest of a smooth spectrum (the main lobe of its strongest line,
 		// mostly): they lie within a few binades of the largest one, so the search starts from a threshold 2^-14 below it where
@@ -1796,7 +1832,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_D4C1_BAND
 		for (int s = 0; s < 16; ++s) c += (unsigned int)__popcll(__ballot(__double_as_longlong(key[s]) <= t));
 		return c;
 	};
-#if WC_D4C2_BRACKET
+#if WC_D4C2_HI32
+	{
+		// (the search on the keys' high words first: see d4c2_band_kernel)
+		auto count_hi = [&](int h) {
+			unsigned int c = (unsigned int)__popcll(__ballot(lane == 0 && __double2hiint(keyM) <= h));
+#pragma unroll
+			for (int s = 0; s < 16; ++s) c += (unsigned int)__popcll(__ballot(__double2hiint(key[s]) <= h));
+			return c;
+		};
+		int lo_h = -1, hi_h = __double2hiint(mx);
+#pragma unroll 1
+		for (int tr = 0; tr < 2; ++tr) {
+			const int cand = __double2hiint(mx * (tr == 0 ? WC_D4C2_BRACKET_FIRST : 0x1p-40)) - 1;
+			if (cand < 0) continue;
+			const unsigned int c = count_hi(cand);
+			if (c <= K) { lo_h = cand; c_lo = c; break; }
+			hi_h = cand;
+		}
+		while (hi_h - lo_h > 1 && c_lo != K) {
+			const int mid = lo_h + ((hi_h - lo_h) >> 1);
+			const unsigned int c = count_hi(mid);
+			if (c >= K) hi_h = mid;
+			if (c <= K) { lo_h = mid; c_lo = c; }
+		}
+		lo = lo_h < 0 ? -1ll : (((long long)lo_h << 32) | 0xFFFFFFFFll);
+		hi = min(hi, ((long long)hi_h << 32) | 0xFFFFFFFFll);
+	}
+#elif WC_D4C2_BRACKET
 #pragma unroll 1
 	for (int tr = 0; tr < 2; ++tr) {
 		const long long cand = __double_as_longlong(mx * (tr == 0 ? WC_D4C2_BRACKET_FIRST : 0x1p-40));
