@@ -92,6 +92,35 @@ def test_d4c_edges(wca, port):
     port.rng_reset()
 
 
+@pytest.mark.parametrize("fs", [16000, 24000, 48000])
+def test_d4c_band_selection_on_high_words_is_bit_identical(wca, port, fs, monkeypatch):
+    """The band kernels need the sum of the K smallest powers of a band (reference src/d4c.cpp:466-503 sorts them) and find the
+    threshold by bisecting the keys' bit patterns: since round 6 on the keys' high words first (a 32-bit compare per key and step),
+    with 64-bit compares only where neighbours of the ranking share a high word; WC_D4C_SELECT=64 is the search of rounds 3-5.  The K
+    smallest keys are the same set whichever threshold separates them, so the rows are the same bit for bit -- on speech, on an
+    impulse train (runs of equal powers) and on a signal with digital silence (all powers zero)."""
+    from world_class_amd.synth import make_signal
+    fft = wca.cheaptrick_fft_size(fs)
+    gaps = make_utterance(fs, 1.2, 99)
+    gaps[len(gaps) // 3: len(gaps) // 2] = 0.0
+    gated = 0
+    for x in (make_utterance(fs, 1.0, 4321), make_signal(fs, 1.0, 40003), gaps):
+        tpos, f0 = port.harvest(x, fs)
+        if not (f0 > 0).any():
+            f0 = np.where(np.arange(len(f0)) % 7 < 5, 150.0, 0.0)
+        wca.rng_set_position(0)
+        a = wca.D4C(fs).compute(x, tpos, f0, fft)
+        monkeypatch.setenv("WC_D4C_SELECT", "64")
+        d = wca.D4C(fs)
+        monkeypatch.delenv("WC_D4C_SELECT")
+        wca.rng_set_position(0)
+        b = d.compute(x, tpos, f0, fft)
+        assert np.array_equal(a, b, equal_nan=True)
+        gated += int((a < 0.999).any(axis=1).sum())  # frames that went through the band kernels
+    assert gated > 100
+    wca.rng_set_position(0)
+
+
 @pytest.mark.parametrize("fs", [16000, 48000])
 def test_d4c_fused_and_split_schedules_agree(wca, port, fs, monkeypatch):
     """workgroup-per-frame kernels (WC_D4C_IMPL=block): frames / band / rows kernels against WC_D4C_SPLIT=0, one fused kernel.

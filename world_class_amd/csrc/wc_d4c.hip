@@ -48,6 +48,7 @@ struct D4cArgs {
 	const double *nuttall;  // window_length_ entries
 	long long total_frames;
 	int fs, fft_size_out, n_ap, window_length;
+	int select64;  // the band kernels' selection with 64-bit compares throughout (WC_D4C_SELECT=64: rounds 3-5; A/B and the bit-identity test)
 	double threshold;
 	long long sgd_stride;  // doubles per frame in sgd
 	int *long_list, *long_cnt;  // gated frames whose windows exceed 2048 samples: left by d4c2_frames_kernel<false>, done by <true>
@@ -1306,9 +1307,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_D4C2_OCC,
 #ifndef WC_D4C2_BRACKET
 #define WC_D4C2_BRACKET 1
 #endif
-#ifndef WC_D4C2_HI32
-#define WC_D4C2_HI32 1  // the selection's search on the keys' high words first (0: 64-bit compares throughout, rounds 3-5)
-#endif
 #ifndef WC_D4C2_BRACKET_FIRST
 #define WC_D4C2_BRACKET_FIRST 0x1p-14
 #endif
@@ -1401,8 +1399,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_D4C2_BAND
 	mx = uniform_d(mx);
 	long long lo = -1, hi = __double_as_longlong(mx);
 	unsigned int c_lo = 0;
-#if WC_D4C2_HI32
-	{
+	if (!a.select64) {
 		// The same search on the keys' HIGH words first (round 6): a threshold (h, 0xFFFFFFFF) has a key at or below it exactly when the
 		// key's high word is at most h -- a 32-bit compare per key and step instead of a 64-bit one, on registers that are there anyway.
 		// It ends with exactly K keys below a threshold (nearly always: two neighbours of the ranking share a high word only when they
@@ -1433,9 +1430,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_D4C2_BAND
 		}
 		lo = lo_h < 0 ? -1ll : (((long long)lo_h << 32) | 0xFFFFFFFFll);
 		hi = min(hi, ((long long)hi_h << 32) | 0xFFFFFFFFll);
-	}
-#elif WC_D4C2_BRACKET
-	{
+	} else {
 		// The keys left out of the sum are the boundary + 1 largest of a smooth spectrum (the main lobe of its strongest line,
 		// mostly): they lie within a few binades of the largest one, so the search starts from a threshold 2^-14 below it where
 		// that holds (at most K keys at or below it), else from 2^-40 -- seven steps fewer than from the whole range of bit patterns.
@@ -1456,7 +1451,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_D4C2_BAND
 			hi = cand > 0 && c >= K ? cand : hi;  // (more than K below: the K-th smallest is at or below cand)
 		}
 	}
-#endif
 	for (int it = 0; it < 64 && hi - lo > 1 && c_lo != K; ++it) {
 		const long long mid = lo + ((hi - lo) >> 1);
 		unsigned int c = (unsigned int)__popcll(__ballot(lane == 0 && __double_as_longlong(keyM) <= mid));
@@ -1832,8 +1826,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_D4C1_BAND
 		for (int s = 0; s < 16; ++s) c += (unsigned int)__popcll(__ballot(__double_as_longlong(key[s]) <= t));
 		return c;
 	};
-#if WC_D4C2_HI32
-	{
+	if (!a.select64) {
 		// (the search on the keys' high words first: see d4c2_band_kernel)
 		auto count_hi = [&](int h) {
 			unsigned int c = (unsigned int)__popcll(__ballot(lane == 0 && __double2hiint(keyM) <= h));
@@ -1858,16 +1851,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WC_D4C1_BAND
 		}
 		lo = lo_h < 0 ? -1ll : (((long long)lo_h << 32) | 0xFFFFFFFFll);
 		hi = min(hi, ((long long)hi_h << 32) | 0xFFFFFFFFll);
-	}
-#elif WC_D4C2_BRACKET
+	} else {
 #pragma unroll 1
-	for (int tr = 0; tr < 2; ++tr) {
-		const long long cand = __double_as_longlong(mx * (tr == 0 ? WC_D4C2_BRACKET_FIRST : 0x1p-40));
-		const unsigned int c = count_le(cand);
-		if (c <= K && cand > 0) { lo = cand; c_lo = c; break; }
-		hi = cand > 0 && c >= K ? cand : hi;  // (more than K below: the K-th smallest is at or below cand)
+		for (int tr = 0; tr < 2; ++tr) {
+			const long long cand = __double_as_longlong(mx * (tr == 0 ? WC_D4C2_BRACKET_FIRST : 0x1p-40));
+			const unsigned int c = count_le(cand);
+			if (c <= K && cand > 0) { lo = cand; c_lo = c; break; }
+			hi = cand > 0 && c >= K ? cand : hi;  // (more than K below: the K-th smallest is at or below cand)
+		}
 	}
-#endif
 	for (int it = 0; it < 64 && hi - lo > 1 && c_lo != K; ++it) {
 		const long long mid = lo + ((hi - lo) >> 1);
 		const unsigned int c = count_le(mid);
@@ -1902,6 +1894,7 @@ using namespace wc;
 struct wc_d4c {
 	int fs, fft_size_d4c, fft_size_lt, n_ap, window_length;
 	double threshold;
+	bool select64 = false;  // WC_D4C_SELECT=64 (D4cArgs::select64)
 	bool split;  // band loop and row output as separate kernels (default; WC_D4C_SPLIT=0: one fused kernel)
 	bool wave2;  // 4096-point transforms by two wavefronts per frame (d4c2_*; default where they apply, WC_D4C_IMPL=block: never)
 	Device *dev;
@@ -1992,7 +1985,7 @@ int d4c_enqueue(wc_d4c *d, hipStream_t s, int n_utt, const double *d_x, const in
 	a.tw = dev->twiddle; a.ap = d_ap; a.ap0 = d->ap0.as<double>(); a.cnt = d->cnt.as<uint32_t>(); a.uidx = d->uidx.as<int>(); a.long_cnt = d->long_list.as<int>(); a.long_list = d->long_list.as<int>();
 	a.sgd = d->sgd.as<double>(); a.coarse = d->coarse.as<double>();
 	a.nuttall = d->nuttall.as<double>(); a.total_frames = total; a.fs = d->fs; a.fft_size_out = fft_size;
-	a.n_ap = d->n_ap; a.window_length = d->window_length; a.threshold = d->threshold;
+	a.n_ap = d->n_ap; a.window_length = d->window_length; a.threshold = d->threshold; a.select64 = d->select64 ? 1 : 0;
 	a.rare_only = 0;
 	a.rare_list = d->rare_list.as<int>();
 	a.sgd_stride = main2 ? row2 : (long long)(d->fft_size_d4c / 2 + 1);
@@ -2115,6 +2108,8 @@ wc_d4c *wc_d4c_create(int fs, double threshold) {
 	{
 		const char *sp = getenv("WC_D4C_SPLIT");  // default: split schedule; WC_D4C_SPLIT=0 runs the single fused kernel
 		d->split = !(sp && sp[0] == '0');
+		const char *sel = getenv("WC_D4C_SELECT");
+		d->select64 = sel && std::strcmp(sel, "64") == 0;
 		const char *impl = getenv("WC_D4C_IMPL");
 		d->wave2 = !(impl && std::strcmp(impl, "block") == 0);
 	}
