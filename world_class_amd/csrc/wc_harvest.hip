@@ -1773,6 +1773,29 @@ __global__ __launch_bounds__(RAW_T) void hv_raw_kernel(RawArgs a) {
 	RQ_FLUSH();
 }
 
+// A frame whose interval does not lie strictly inside the staged slice (or whose slice was too long to stage) takes its three edges
+// from the slots themselves: a bisection of the running counts per edge.  Rare, and long: kept out of line, so that the sixteen places
+// of hv_raw_wave_kernel that may need it share one copy (inlined, they made 90 KB of code).
+struct RawQuad { double x0, x1, y0, y1; };
+__device__ __attribute__((noinline)) RawQuad raw_fallback(const double *slot, const int *trun_b, int scap, int n_tiles, double fs, double r_fs_d, int ty,
+														  int n_ty, double t) {
+	auto eg = [&](int q) -> double {
+		int lo = 0, hi = n_tiles;
+		while (hi - lo > 1) {
+			const int mid = (lo + hi) >> 1;
+			if (trun_b[mid * 4 + ty] <= q) lo = mid; else hi = mid;
+		}
+		return slot[((long long)lo * 4 + ty) * scap + min(q - trun_b[lo * 4 + ty], scap - 1)];
+	};
+	const int c = hv_count_le(eg, 0, n_ty, fs, t);
+	const int k = min(max(c, 1), n_ty - 1);
+	const double e0 = eg(k - 1), e1 = eg(k), e2 = eg(k + 1);
+	RawQuad r;
+	r.x0 = div_const((e0 + e1) / 2.0, fs, r_fs_d); r.x1 = div_const((e1 + e2) / 2.0, fs, r_fs_d);
+	r.y0 = fs / (e1 - e0); r.y1 = fs / (e2 - e1);
+	return r;
+}
+
 // The same block of 256 frames by ONE wavefront (round 6, default for the sliding band-pass's slots).  Above, four wavefronts stage a
 // type each, meet at a barrier, and a thread per frame reads all four: a chain of scalar loads, edge loads, LDS round trips and the
 // barrier per block with ~300 instructions per wavefront to show for it -- 0.52 of the kernel's time is issue, seven blocks per
@@ -1828,14 +1851,6 @@ __global__ __launch_bounds__(64) void hv_raw_wave_kernel(RawArgs a) {
 	const int scap = a.slot_cap[band];
 	const double *__restrict__ slot = a.slots + blockIdx.z * a.slots_per_utt + a.slot_off[band];
 	const int *__restrict__ trun_b = a.tile_run + ((long long)blockIdx.z * a.n_bands + band) * (a.n_tiles + 1) * 4;
-	auto edge = [&](int ty, int q) -> double {  // edge q of the list of type ty, wherever it lies (the fallback's look-ups)
-		int lo = 0, hi = a.n_tiles;
-		while (hi - lo > 1) {
-			const int mid = (lo + hi) >> 1;
-			if (trun_b[mid * 4 + ty] <= q) lo = mid; else hi = mid;
-		}
-		return slot[((long long)lo * 4 + ty) * scap + min(q - trun_b[lo * 4 + ty], scap - 1)];
-	};
 	double *__restrict__ out = a.raw + u.l1_off * a.n_bands + (long long)band * u.L1;
 	const int fi = i0 + 4 * lane;  // this lane's first frame
 	int n[4];
@@ -1933,12 +1948,8 @@ __global__ __launch_bounds__(64) void hv_raw_wave_kernel(RawArgs a) {
 				}
 			}
 			if (!staged) {
-				auto eg = [&](int q) { return edge(ty, q); };
-				const int c = hv_count_le(eg, 0, n[ty], fs, t);
-				const int k = min(max(c, 1), n[ty] - 1);
-				const double e0 = eg(k - 1), e1 = eg(k), e2 = eg(k + 1);
-				x0 = div_const((e0 + e1) / 2.0, fs, a.r_fs_d); x1 = div_const((e1 + e2) / 2.0, fs, a.r_fs_d);
-				y0 = fs / (e1 - e0); y1 = fs / (e2 - e1);
+				const RawQuad r = raw_fallback(slot, trun_b, scap, a.n_tiles, fs, a.r_fs_d, ty, n[ty], t);
+				x0 = r.x0; x1 = r.x1; y0 = r.y0; y1 = r.y1;
 			}
 			const double sl = (t - x0) / (x1 - x0);
 			const double v = y0 + sl * (y1 - y0);
