@@ -914,12 +914,19 @@ __global__ __launch_bounds__(64, WC_SDFT_WAVES) void hv_bandpass_sdft_kernel(SdA
 	if constexpr (DEFER) {
 		static_assert(U == 4 && SD_CH % 8 == 0, "blocks of two trips");
 		__shared__ double O[10 * 64];  // [output of the block, two in front of it][lane]
-		// the signs of the newest output and difference are looked at once (three compares each) and serve the two steps that use
-		// them: "0 < s0 && s1 <= 0" is pos(s0) && (neg(s1) || zero(s1)), written so that a NaN still marks nothing
-		bool p_a = 0.0 < s0, n_a = s0 < 0.0;                                    // s0
-		bool p_b = 0.0 < s1, n_b = s1 < 0.0, z_b = s1 == 0.0;                     // s1
-		double dprev = s1 - s0;
-		bool p_d = 0.0 < dprev, n_d = dprev < 0.0;                              // d0
+		// The signs of the newest output and difference are looked at once -- x <= 0 and x >= 0, two compares each, kept as lane masks in
+		// scalar registers -- and serve the two steps that use them: "0 < s0" is (s0 >= 0) and not (s0 <= 0), so that a NaN (neither)
+		// still marks nothing; the masks are combined by scalar instructions and come back as a per-lane select.
+		typedef unsigned long long LaneMask;
+		LaneMask le_b = __ballot(s0 <= 0.0), ge_b = __ballot(s0 >= 0.0);
+		LaneMask p_a = ge_b & ~le_b, n_a = le_b & ~ge_b;                           // s0
+		le_b = __ballot(s1 <= 0.0); ge_b = __ballot(s1 >= 0.0);                    // s1
+		LaneMask p_d, n_d;                                                         // d0
+		{
+			const double dprev = s1 - s0;
+			const LaneMask le = __ballot(dprev <= 0.0), ge = __ballot(dprev >= 0.0);
+			p_d = ge & ~le; n_d = le & ~ge;
+		}
 		unsigned long long cnt4 = 0ull;  // the four counts, sixteen bits each (a chunk has 2048 samples)
 		for (int st = 0; st < steps; st += 8) {
 			O[lane] = s0;
@@ -942,13 +949,13 @@ __global__ __launch_bounds__(64, WC_SDFT_WAVES) void hv_bandpass_sdft_kernel(SdA
 					if (k == U - 1) s2 = last_trip ? fn1 : s2;
 					O[(kk + 2) * 64 + lane] = s2;
 					const double d1 = s2 - s1;
-					const bool p_e = 0.0 < d1, n_e = d1 < 0.0, z_e = d1 == 0.0;
-					const bool zc = (p_a && (n_b || z_b)) || (n_a && (p_b || z_b));
-					const bool ex = (p_d && (n_e || z_e)) || (n_d && (p_e || z_e));
+					const LaneMask le_e = __ballot(d1 <= 0.0), ge_e = __ballot(d1 >= 0.0);
+					const bool zc = __builtin_amdgcn_inverse_ballot_w64((p_a & le_b) | (n_a & ge_b));
+					const bool ex = __builtin_amdgcn_inverse_ballot_w64((p_d & le_e) | (n_d & ge_e));
 					mask |= (zc ? 1u << kk : 0u) | (ex ? 0x100u << kk : 0u);
-					p_a = p_b; n_a = n_b;
-					p_b = 0.0 < s2; n_b = s2 < 0.0; z_b = s2 == 0.0;
-					p_d = p_e; n_d = n_e;
+					p_a = ge_b & ~le_b; n_a = le_b & ~ge_b;
+					le_b = __ballot(s2 <= 0.0); ge_b = __ballot(s2 >= 0.0);
+					p_d = ge_e & ~le_e; n_d = le_e & ~ge_e;
 					s0 = s1;
 					s1 = s2;
 				}
