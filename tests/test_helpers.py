@@ -145,3 +145,24 @@ int main(int argc, char **argv) {
     assert np.abs(got - golden["minphase/out_1024"][:513]).max() < 1e-12
     conv = np.array([float(v) for v in out.split()])
     assert np.abs(conv - np.convolve([1, 2, 3, 4], [1, -1, 0.5])).max() < 1e-9
+
+
+def test_host_copy_threads_hand_over_fork_and_serve_two_callers(tmp_path):
+    """The host-pointer entry points move rows between the caller's arrays and page-locked staging with a set of threads that is
+    started once per process and woken per copy (world_class_amd/csrc/wc_hostcopy.hpp, round 6).  Host code only: a hundred
+    scatters in a row, rows that do not lie one behind the other, a forked child (it has none of the parent's threads) and two
+    calling threads at once -- tests/cpp/hostcopy_pool.cpp, built against the library as a host program."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, "world_class_amd")
+    if not os.path.exists(os.path.join(lib_dir, "libworldclass_hip.so")) or not shutil.which("hipcc"):
+        pytest.skip("needs the built library and hipcc")
+    exe = str(tmp_path / "hostcopy_pool")
+    subprocess.run(["hipcc", "-x", "hip", "--offload-arch=gfx950", "-O2", "-std=c++17", "-pthread", "-w", "-I" + os.path.join(lib_dir, "csrc"),
+                    "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "hostcopy_pool.cpp"), "-L" + lib_dir, "-lworldclass_hip",
+                    "-Wl,-rpath," + lib_dir, "-o", exe], check=True)
+    out = subprocess.run([exe], check=True, stdout=subprocess.PIPE, text=True, timeout=300).stdout
+    assert out.strip().endswith("ok"), out
+
